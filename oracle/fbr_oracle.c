@@ -1,0 +1,559 @@
+/*
+ * fbr_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C restatement of the arithmetic of FloBaRoID's regressor hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the shipped
+ * path (flobaroid_amd/) never does and fails loudly when its HIP library is missing.
+ *
+ * PARITY STATUS: "parity unpinned" at the iDynTree boundary.  The per-sample arithmetic of
+ * the reference is iDynTree 15.0.0 (git robotology/idyntree tag v15.0.0 @ 2388e5ea, pinned in
+ * /root/reference/pyproject.toml:12,42 and uv.lock:585-590), which is neither vendored nor
+ * installable here, and the reference's tests hold no golden regressor entries
+ * (tests/test_regressors.py:118-126 is a property test).  What IS pinned (tests/golden/):
+ * link order, the 10-parameter convention and the a-priori vector (documentation/TUTORIAL.md:60-160),
+ * the structurally-zero column set non_id={0..18,20,22}, the base-parameter counts
+ * 24/43(+21=64)/59/213, and regressor == inverse dynamics (the reference's own property).
+ *
+ * The functions below follow the published algorithms the reference calls:
+ *   orc_kinematics            KinDynComputations::setRobotState + ForwardVelAccKinematics
+ *                             (called at identification/model.py:435,441,731,737; 278,283)
+ *   orc_regressor             KinDynComputations::inverseDynamicsInertialParametersRegressor
+ *                             (model.py:446,742): per link SpatialInertia::momentumDerivativeRegressor,
+ *                             adjoint-wrench propagation to every ancestor joint, base rows in the
+ *                             MIXED representation; friction column blocks model.py:459-503,755-799;
+ *                             gravity-only column deletion model.py:455-457
+ *   orc_inverse_dynamics      KinDynComputations::inverseDynamics (RNEA) + friction torques,
+ *                             Model.simulateDynamicsIDynTree model.py:239-331
+ *   orc_contact_torques       getFrameFreeFloatingJacobian + J^T w, model.py:535-555
+ *   orc_gram                  R += A^T A, model.py:803-806 (raw sum, never normalised)
+ *
+ * Spatial vectors are ordered [linear(3); angular(3)] like iDynTree.  All arithmetic is fp64.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#define ORC_MAX_LINKS 256
+
+typedef struct {
+    int L;               /* links */
+    int n;               /* dofs */
+    const int *order;    /* [L] traversal order, parents first */
+    const int *parent;   /* [L] parent link index, -1 base */
+    const int *dof;      /* [L] dof index of the joint to the parent, -1 if fixed/base */
+    const double *restR; /* [L][9] child orientation in parent frame at q=0 (row-major) */
+    const double *restp; /* [L][3] child origin in parent frame */
+    const double *axis;  /* [L][3] unit joint axis in child frame */
+    int floating;        /* 1: rows = 6+n, state has base twist/acc/rpy ; 0: rows = n */
+    double gravity[3];   /* world gravity, reference uses (0,0,-9.81) model.py:182-187 */
+} orc_model;
+
+/* ---------------------------------------------------------------- small helpers */
+static void cross3(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void mat3_mul(const double *A, const double *B, double *C)
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static void mat3_vec(const double *A, const double *x, double *y)
+{
+    for (int i = 0; i < 3; i++) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+static void mat3T_vec(const double *A, const double *x, double *y)
+{
+    for (int i = 0; i < 3; i++) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+/* Rodrigues: rotation by angle q about unit axis s */
+static void axis_angle(const double *s, double q, double *R)
+{
+    double c = cos(q), sn = sin(q), v = 1.0 - c;
+    R[0] = c + s[0] * s[0] * v;
+    R[1] = s[0] * s[1] * v - s[2] * sn;
+    R[2] = s[0] * s[2] * v + s[1] * sn;
+    R[3] = s[1] * s[0] * v + s[2] * sn;
+    R[4] = c + s[1] * s[1] * v;
+    R[5] = s[1] * s[2] * v - s[0] * sn;
+    R[6] = s[2] * s[0] * v - s[1] * sn;
+    R[7] = s[2] * s[1] * v + s[0] * sn;
+    R[8] = c + s[2] * s[2] * v;
+}
+/* Rz(y) Ry(p) Rx(r), iDynTree Rotation::RPY */
+static void rpy_matrix(const double *rpy, double *R)
+{
+    double cr = cos(rpy[0]), sr = sin(rpy[0]);
+    double cp = cos(rpy[1]), sp = sin(rpy[1]);
+    double cy = cos(rpy[2]), sy = sin(rpy[2]);
+    R[0] = cy * cp;
+    R[1] = cy * sp * sr - sy * cr;
+    R[2] = cy * sp * cr + sy * sr;
+    R[3] = sy * cp;
+    R[4] = sy * sp * sr + cy * cr;
+    R[5] = sy * sp * cr - cy * sr;
+    R[6] = -sp;
+    R[7] = cp * sr;
+    R[8] = cp * cr;
+}
+
+/* per-link kinematic state */
+typedef struct {
+    double R[9];  /* A_R_link: link orientation in the absolute (world-aligned, base-origin) frame */
+    double p[3];  /* link origin in A */
+    double pRc[9]; /* parent_R_link (this link's orientation in its parent) */
+    double pj[3];  /* link origin in the parent frame */
+    double v[6];  /* body-fixed twist  [lin; ang] in link coordinates */
+    double a[6];  /* body-fixed PROPER spatial acceleration [lin; ang] */
+} link_state;
+
+/* motion-vector transform child <- parent for pose (pRc = parent_R_child, pj = origin of child in parent) */
+static void xform_motion_to_child(const double *pRc, const double *pj, const double *vp, double *vc)
+{
+    /* v_child.lin = R^T (v.lin + w x pj) ; v_child.ang = R^T w */
+    double t[3], u[3];
+    cross3(vp + 3, pj, t);
+    for (int i = 0; i < 3; i++) u[i] = vp[i] + t[i];
+    mat3T_vec(pRc, u, vc);
+    mat3T_vec(pRc, vp + 3, vc + 3);
+}
+/* wrench transform parent <- child */
+static void xform_wrench_to_parent(const double *pRc, const double *pj, const double *fc, double *fp)
+{
+    /* f_p = R f ; n_p = R n + pj x (R f) */
+    double t[3];
+    mat3_vec(pRc, fc, fp);
+    mat3_vec(pRc, fc + 3, fp + 3);
+    cross3(pj, fp, t);
+    for (int i = 0; i < 3; i++) fp[3 + i] += t[i];
+}
+
+/*
+ * Forward kinematics of one sample.  base_vel / base_acc are MIXED-representation 6-vectors
+ * [linear; angular] (model.py:434-439), rpy as stored in the samples (world_T_base =
+ * Transform(RPY(rpy),0).inverse(), model.py:429-432).  Fixed base: pass NULLs.
+ */
+static void orc_kinematics(const orc_model *m, const double *q, const double *dq, const double *ddq,
+                           const double *base_vel, const double *base_acc, const double *rpy, link_state *st)
+{
+    for (int k = 0; k < m->L; k++) {
+        int l = m->order[k];
+        int par = m->parent[l];
+        link_state *s = &st[l];
+        if (par < 0) {
+            double Rrpy[9];
+            if (m->floating) {
+                rpy_matrix(rpy, Rrpy);
+                /* world_R_base = RPY(rpy)^T */
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) s->R[3 * i + j] = Rrpy[3 * j + i];
+            } else {
+                memset(s->R, 0, sizeof(s->R));
+                s->R[0] = s->R[4] = s->R[8] = 1.0;
+            }
+            s->p[0] = s->p[1] = s->p[2] = 0.0;
+            double g_b[3];
+            mat3T_vec(s->R, m->gravity, g_b);
+            if (m->floating) {
+                /* mixed -> body-fixed */
+                mat3T_vec(s->R, base_vel, s->v);
+                mat3T_vec(s->R, base_vel + 3, s->v + 3);
+                double al[3], wxv[3];
+                mat3T_vec(s->R, base_acc, al);
+                cross3(s->v + 3, s->v, wxv);
+                for (int i = 0; i < 3; i++) s->a[i] = al[i] - wxv[i];
+                mat3T_vec(s->R, base_acc + 3, s->a + 3);
+            } else {
+                memset(s->v, 0, sizeof(s->v));
+                memset(s->a, 0, sizeof(s->a));
+            }
+            /* proper acceleration: subtract gravity expressed in the base frame */
+            for (int i = 0; i < 3; i++) s->a[i] -= g_b[i];
+            continue;
+        }
+        const link_state *ps = &st[par];
+        int d = m->dof[l];
+        const double *ax = m->axis + 3 * l;
+        if (d >= 0) {
+            double Rq[9];
+            axis_angle(ax, q[d], Rq);
+            mat3_mul(m->restR + 9 * l, Rq, s->pRc);
+        } else {
+            memcpy(s->pRc, m->restR + 9 * l, sizeof(s->pRc));
+        }
+        memcpy(s->pj, m->restp + 3 * l, sizeof(s->pj));
+        mat3_mul(ps->R, s->pRc, s->R);
+        double t[3];
+        mat3_vec(ps->R, s->pj, t);
+        for (int i = 0; i < 3; i++) s->p[i] = ps->p[i] + t[i];
+        xform_motion_to_child(s->pRc, s->pj, ps->v, s->v);
+        xform_motion_to_child(s->pRc, s->pj, ps->a, s->a);
+        if (d >= 0) {
+            /* S = [0; axis] in the child frame (revolute about the child origin) */
+            double vj[6] = {0, 0, 0, ax[0] * dq[d], ax[1] * dq[d], ax[2] * dq[d]};
+            for (int i = 0; i < 6; i++) s->v[i] += vj[i];
+            /* a += S ddq + v x S dq   (motion cross product, [lin;ang]) */
+            double c1[3], c2[3];
+            cross3(s->v + 3, vj, c1);     /* w x vj.lin (=0) */
+            cross3(s->v, vj + 3, c2);     /* v.lin x vj.ang */
+            double c3[3];
+            cross3(s->v + 3, vj + 3, c3); /* w x vj.ang */
+            for (int i = 0; i < 3; i++) {
+                s->a[i] += c1[i] + c2[i];
+                s->a[3 + i] += ax[i] * ddq[d] + c3[i];
+            }
+        }
+    }
+}
+
+/* momentum regressor: M(v) pi = I(pi) v, 6x10 row-major, pi = [m, h(3), Ixx Ixy Ixz Iyy Iyz Izz] */
+static void momentum_regressor(const double *v, double *M)
+{
+    const double *vl = v, *w = v + 3;
+    memset(M, 0, 60 * sizeof(double));
+    /* lin: m*vl + w x h */
+    for (int i = 0; i < 3; i++) M[10 * i + 0] = vl[i];
+    /* w x h = [w]x h */
+    M[10 * 0 + 2] = -w[2]; M[10 * 0 + 3] = w[1];
+    M[10 * 1 + 1] = w[2];  M[10 * 1 + 3] = -w[0];
+    M[10 * 2 + 1] = -w[1]; M[10 * 2 + 2] = w[0];
+    /* ang: h x vl + Ibar w ; h x vl = -[vl]x h */
+    M[10 * 3 + 2] = vl[2];  M[10 * 3 + 3] = -vl[1];
+    M[10 * 4 + 1] = -vl[2]; M[10 * 4 + 3] = vl[0];
+    M[10 * 5 + 1] = vl[1];  M[10 * 5 + 2] = -vl[0];
+    M[10 * 3 + 4] = w[0]; M[10 * 3 + 5] = w[1]; M[10 * 3 + 6] = w[2];
+    M[10 * 4 + 5] = w[0]; M[10 * 4 + 7] = w[1]; M[10 * 4 + 8] = w[2];
+    M[10 * 5 + 6] = w[0]; M[10 * 5 + 8] = w[1]; M[10 * 5 + 9] = w[2];
+}
+/* Y = M(a) + v x* M(v)   (SpatialInertia::momentumDerivativeRegressor) */
+static void momentum_derivative_regressor(const double *v, const double *a, double *Y)
+{
+    double Mv[60];
+    momentum_regressor(a, Y);
+    momentum_regressor(v, Mv);
+    const double *vl = v, *w = v + 3;
+    for (int c = 0; c < 10; c++) {
+        double f[3] = {Mv[c], Mv[10 + c], Mv[20 + c]};
+        double n[3] = {Mv[30 + c], Mv[40 + c], Mv[50 + c]};
+        double wf[3], vf[3], wn[3];
+        cross3(w, f, wf);
+        cross3(vl, f, vf);
+        cross3(w, n, wn);
+        for (int i = 0; i < 3; i++) {
+            Y[10 * i + c] += wf[i];
+            Y[10 * (3 + i) + c] += vf[i] + wn[i];
+        }
+    }
+}
+
+/* options describing the identified-column layout (model.py:134-168) */
+typedef struct {
+    int fric;        /* identifyFrictionSimultaneously */
+    int fric_sym;    /* identifySymmetricVelFriction */
+    int grav_only;   /* identifyGravityParamsOnly */
+    double stribeck; /* stribeckVelocity (>0 enables the Fs block) */
+} orc_layout;
+
+int orc_num_cols(int L, int n, const orc_layout *lay)
+{
+    int P = lay->grav_only ? 4 * L : 10 * L;
+    if (lay->fric) {
+        P += n;
+        if (!lay->grav_only) {
+            P += lay->fric_sym ? n : 2 * n;
+            P += n;
+            if (lay->stribeck > 0) P += n;
+        }
+    }
+    return P;
+}
+
+/*
+ * Standard regressor of ONE sample: Y (rows x P_id) row-major, rows = n (+6 floating).
+ * sign = Coulomb sign term for this sample (n values; tanh-smoothed series for data regressors
+ * model.py:462, tanh(dq/thr) for random ones model.py:757-758), may be NULL when !fric.
+ */
+static void orc_regressor_sample(const orc_model *m, const orc_layout *lay, const link_state *st,
+                                 const double *dq, const double *sign, double *Y)
+{
+    const int fb = m->floating ? 6 : 0;
+    const int rows = m->n + fb;
+    const int P = orc_num_cols(m->L, m->n, lay);
+    const int cpl = lay->grav_only ? 4 : 10; /* columns kept per link */
+    memset(Y, 0, (size_t)rows * P * sizeof(double));
+    for (int l = 0; l < m->L; l++) {
+        double Yl[60], W[60];
+        momentum_derivative_regressor(st[l].v, st[l].a, Yl);
+        /* base rows: A_X*_l Y_l  (A = world-aligned frame at the base origin == MIXED representation
+           because world_T_base has zero position, model.py:431-432) */
+        if (m->floating) {
+            for (int c = 0; c < cpl; c++) {
+                double f[6] = {Yl[c], Yl[10 + c], Yl[20 + c], Yl[30 + c], Yl[40 + c], Yl[50 + c]}, g[6];
+                xform_wrench_to_parent(st[l].R, st[l].p, f, g);
+                for (int i = 0; i < 6; i++) Y[(size_t)i * P + cpl * l + c] = g[i];
+            }
+        }
+        /* walk up to the base: at every movable joint take S^T of the wrench expressed in the child frame */
+        memcpy(W, Yl, sizeof(W));
+        int cur = l;
+        while (m->parent[cur] >= 0) {
+            int d = m->dof[cur];
+            if (d >= 0) {
+                const double *ax = m->axis + 3 * cur;
+                for (int c = 0; c < cpl; c++)
+                    Y[(size_t)(fb + d) * P + cpl * l + c] =
+                        ax[0] * W[30 + c] + ax[1] * W[40 + c] + ax[2] * W[50 + c];
+            }
+            for (int c = 0; c < 10; c++) {
+                double f[6] = {W[c], W[10 + c], W[20 + c], W[30 + c], W[40 + c], W[50 + c]}, g[6];
+                xform_wrench_to_parent(st[cur].pRc, st[cur].pj, f, g);
+                for (int i = 0; i < 6; i++) W[10 * i + c] = g[i];
+            }
+            cur = m->parent[cur];
+        }
+    }
+    if (lay->fric) {
+        int c0 = cpl * m->L;
+        const int n = m->n;
+        for (int j = 0; j < n; j++) Y[(size_t)(fb + j) * P + c0 + j] = sign[j];
+        c0 += n;
+        if (!lay->grav_only) {
+            if (lay->fric_sym) {
+                for (int j = 0; j < n; j++) Y[(size_t)(fb + j) * P + c0 + j] = dq[j];
+                c0 += n;
+            } else {
+                for (int j = 0; j < n; j++) {
+                    Y[(size_t)(fb + j) * P + c0 + j] = dq[j] < 0 ? 0.0 : dq[j];
+                    Y[(size_t)(fb + j) * P + c0 + n + j] = dq[j] > 0 ? 0.0 : dq[j];
+                }
+                c0 += 2 * n;
+            }
+            for (int j = 0; j < n; j++) Y[(size_t)(fb + j) * P + c0 + j] = 1.0;
+            c0 += n;
+            if (lay->stribeck > 0) {
+                for (int j = 0; j < n; j++) {
+                    double sg = (dq[j] > 0) - (dq[j] < 0);
+                    Y[(size_t)(fb + j) * P + c0 + j] = exp(-fabs(dq[j]) / lay->stribeck) * sg;
+                }
+            }
+        }
+    }
+}
+
+/* spatial inertia times motion vector from the 10 parameters: f = I(pi) v */
+static void inertia_apply(const double *pi, const double *v, double *f)
+{
+    const double m = pi[0], *h = pi + 1;
+    const double *vl = v, *w = v + 3;
+    double wxh[3], hxv[3];
+    cross3(w, h, wxh);
+    cross3(h, vl, hxv);
+    for (int i = 0; i < 3; i++) f[i] = m * vl[i] + wxh[i];
+    f[3] = hxv[0] + pi[4] * w[0] + pi[5] * w[1] + pi[6] * w[2];
+    f[4] = hxv[1] + pi[5] * w[0] + pi[7] * w[1] + pi[8] * w[2];
+    f[5] = hxv[2] + pi[6] * w[0] + pi[8] * w[1] + pi[9] * w[2];
+}
+
+/* RNEA for one sample: tau (rows) = [base wrench(6, mixed) ;] joint torques */
+static void orc_rnea_sample(const orc_model *m, const link_state *st, const double *x_inertial, double *f_links,
+                            double *tau)
+{
+    const int fb = m->floating ? 6 : 0;
+    for (int l = 0; l < m->L; l++) {
+        double Ia[6], Iv[6];
+        inertia_apply(x_inertial + 10 * l, st[l].a, Ia);
+        inertia_apply(x_inertial + 10 * l, st[l].v, Iv);
+        const double *vl = st[l].v, *w = st[l].v + 3;
+        double wf[3], vf[3], wn[3];
+        cross3(w, Iv, wf);
+        cross3(vl, Iv, vf);
+        cross3(w, Iv + 3, wn);
+        for (int i = 0; i < 3; i++) {
+            f_links[6 * l + i] = Ia[i] + wf[i];
+            f_links[6 * l + 3 + i] = Ia[3 + i] + vf[i] + wn[i];
+        }
+    }
+    for (int k = m->L - 1; k >= 0; k--) {
+        int l = m->order[k];
+        int par = m->parent[l];
+        if (par < 0) {
+            if (m->floating) xform_wrench_to_parent(st[l].R, st[l].p, f_links + 6 * l, tau);
+            continue;
+        }
+        int d = m->dof[l];
+        if (d >= 0) {
+            const double *ax = m->axis + 3 * l;
+            tau[fb + d] = ax[0] * f_links[6 * l + 3] + ax[1] * f_links[6 * l + 4] + ax[2] * f_links[6 * l + 5];
+        }
+        double g[6];
+        xform_wrench_to_parent(st[l].pRc, st[l].pj, f_links + 6 * l, g);
+        for (int i = 0; i < 6; i++) f_links[6 * par + i] += g[i];
+    }
+}
+
+/* =============================================================== exported batch entry points */
+
+typedef struct {
+    const double *q, *dq, *ddq;               /* [S][n] */
+    const double *base_vel, *base_acc, *rpy;  /* [S][6],[S][6],[S][3] or NULL (fixed base) */
+} orc_states;
+
+static void make_model(orc_model *m, int L, int n, const int *order, const int *parent, const int *dof,
+                       const double *restR, const double *restp, const double *axis, int floating,
+                       const double *gravity)
+{
+    m->L = L; m->n = n; m->order = order; m->parent = parent; m->dof = dof;
+    m->restR = restR; m->restp = restp; m->axis = axis; m->floating = floating;
+    m->gravity[0] = gravity[0]; m->gravity[1] = gravity[1]; m->gravity[2] = gravity[2];
+}
+
+/* Y_out: [S][rows][P_id] row-major (== the reference's regressor_stack, model.py:349-354,520-523) */
+int orc_regressor_batch(int L, int n, const int *order, const int *parent, const int *dof, const double *restR,
+                        const double *restp, const double *axis, int floating, const double *gravity,
+                        int fric, int fric_sym, int grav_only, double stribeck,
+                        long S, const double *q, const double *dq, const double *ddq, const double *base_vel,
+                        const double *base_acc, const double *rpy, const double *sign, double *Y_out)
+{
+    if (L > ORC_MAX_LINKS) return -1;
+    orc_model m;
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, floating, gravity);
+    orc_layout lay = {fric, fric_sym, grav_only, stribeck};
+    const int rows = n + (floating ? 6 : 0);
+    const int P = orc_num_cols(L, n, &lay);
+    link_state st[ORC_MAX_LINKS];
+    for (long s = 0; s < S; s++) {
+        orc_kinematics(&m, q + s * n, dq + s * n, ddq + s * n, floating ? base_vel + 6 * s : NULL,
+                       floating ? base_acc + 6 * s : NULL, floating ? rpy + 3 * s : NULL, st);
+        orc_regressor_sample(&m, &lay, st, dq + s * n, sign ? sign + s * n : NULL, Y_out + (size_t)s * rows * P);
+    }
+    return 0;
+}
+
+/*
+ * tau_out [S][rows].  x_std = full standard vector (10L inertial + friction slots in the
+ * layout of model.py:134-168, friction part used only when fric != 0):
+ *   tau += sign*Fc ; tau += Fv*dq ; tau += off ; tau += Fs*exp(-|vel_sign|/vs)*sign(sign)
+ * exactly as model.py:299-326 (note: only the first n viscous slots are used even in the
+ * asymmetric layout, model.py:310-315).
+ */
+int orc_inverse_dynamics_batch(int L, int n, const int *order, const int *parent, const int *dof,
+                               const double *restR, const double *restp, const double *axis, int floating,
+                               const double *gravity, int fric, int fric_sym, int grav_only, double stribeck,
+                               long S, const double *q, const double *dq, const double *ddq,
+                               const double *base_vel, const double *base_acc, const double *rpy,
+                               const double *sign, const double *vel_sign, const double *x_std, double *tau_out)
+{
+    if (L > ORC_MAX_LINKS) return -1;
+    orc_model m;
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, floating, gravity);
+    const int fb = floating ? 6 : 0;
+    const int rows = n + fb;
+    link_state st[ORC_MAX_LINKS];
+    double f_links[6 * ORC_MAX_LINKS];
+    /* friction_params_start: model.py:164-168 */
+    const int fstart = grav_only ? 4 * L : 10 * L;
+    (void)fric_sym;
+    for (long s = 0; s < S; s++) {
+        double *tau = tau_out + (size_t)s * rows;
+        orc_kinematics(&m, q + s * n, dq + s * n, ddq + s * n, floating ? base_vel + 6 * s : NULL,
+                       floating ? base_acc + 6 * s : NULL, floating ? rpy + 3 * s : NULL, st);
+        orc_rnea_sample(&m, st, x_std, f_links, tau);
+        if (fric) {
+            for (int j = 0; j < n; j++) {
+                double sg = sign[s * n + j];
+                double t = sg * x_std[fstart + j];
+                if (!grav_only) {
+                    t += x_std[fstart + n + j] * dq[s * n + j];
+                    int poff = fstart + 2 * n;
+                    t += x_std[poff + j];
+                    if (stribeck > 0) {
+                        double vs = vel_sign[s * n + j];
+                        double sgn = (sg > 0) - (sg < 0);
+                        t += x_std[poff + n + j] * exp(-fabs(vs) / stribeck) * sgn;
+                    }
+                }
+                tau[fb + j] += t;
+            }
+        }
+    }
+    return 0;
+}
+
+/*
+ * J^T w for a frame rigidly attached to link `flink` with pose (fR, fp) in that link,
+ * w = 6D wrench [force; torque] per sample, MIXED representation of the frame (world axes,
+ * frame origin) -- getFrameFreeFloatingJacobian, model.py:542-549.  out [S][rows]
+ * (the last `rows` entries of J^T w, model.py:552-555).
+ */
+int orc_contact_torques(int L, int n, const int *order, const int *parent, const int *dof, const double *restR,
+                        const double *restp, const double *axis, int floating, const double *gravity, long S,
+                        const double *q, const double *rpy, int flink, const double *fR, const double *fp,
+                        const double *wrench, double *out)
+{
+    if (L > ORC_MAX_LINKS) return -1;
+    (void)fR;
+    orc_model m;
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, floating, gravity);
+    const int fb = floating ? 6 : 0;
+    const int rows = n + fb;
+    link_state st[ORC_MAX_LINKS];
+    double zeros6[6] = {0, 0, 0, 0, 0, 0};
+    for (long s = 0; s < S; s++) {
+        double zq[ORC_MAX_LINKS];
+        memset(zq, 0, sizeof(double) * n);
+        orc_kinematics(&m, q + s * n, zq, zq, floating ? zeros6 : NULL, floating ? zeros6 : NULL,
+                       floating ? rpy + 3 * s : NULL, st);
+        const double *w = wrench + 6 * s;
+        double *o = out + (size_t)s * rows;
+        memset(o, 0, sizeof(double) * rows);
+        /* frame origin in A */
+        double t[3], pf[3];
+        mat3_vec(st[flink].R, fp, t);
+        for (int i = 0; i < 3; i++) pf[i] = st[flink].p[i] + t[i];
+        /* wrench moved to the base origin (A axes): n_O = n + pf x f */
+        double pxf[3];
+        cross3(pf, w, pxf);
+        if (floating) {
+            for (int i = 0; i < 3; i++) {
+                o[i] = w[i];
+                o[3 + i] = w[3 + i] + pxf[i];
+            }
+        }
+        int cur = flink;
+        while (m.parent[cur] >= 0) {
+            int d = m.dof[cur];
+            if (d >= 0) {
+                /* axis in A, moment of the wrench about the joint origin */
+                double sA[3], r[3], rxf[3];
+                mat3_vec(st[cur].R, m.axis + 3 * cur, sA);
+                for (int i = 0; i < 3; i++) r[i] = pf[i] - st[cur].p[i];
+                cross3(r, w, rxf);
+                o[fb + d] = sA[0] * (w[3] + rxf[0]) + sA[1] * (w[4] + rxf[1]) + sA[2] * (w[5] + rxf[2]);
+            }
+            cur = m.parent[cur];
+        }
+    }
+    return 0;
+}
+
+/* G (P x P, row-major) += sum_s A_s^T A_s over a stacked regressor A [M][P]  (model.py:803-806).
+   rhs [M][k] optional: G_aug = [A|rhs]^T [A|rhs] of size (P+k)^2. */
+int orc_gram(long M, int P, const double *A, int k, const double *rhs, double *G)
+{
+    const int Pa = P + k;
+    for (long r = 0; r < M; r++) {
+        const double *a = A + (size_t)r * P;
+        const double *b = rhs ? rhs + (size_t)r * k : NULL;
+        for (int i = 0; i < Pa; i++) {
+            double ai = i < P ? a[i] : b[i - P];
+            if (ai == 0.0) continue;
+            double *g = G + (size_t)i * Pa;
+            for (int j = 0; j < P; j++) g[j] += ai * a[j];
+            for (int j = 0; j < k; j++) g[P + j] += ai * b[j];
+        }
+    }
+    return 0;
+}
