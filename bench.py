@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- regressor samples/s of the fused hot path on MI355X (contract: see the task statement).
+
+A step = one pass of the hot path over this rank's batch of synthetic WALK-MAN floating-base samples
+that are already resident in HBM: link kinematics + fused regressor -> [Y|tau]^T[Y|tau] Gram (fp64 MFMA),
+reduced deterministically on the device, then (N > 1) an RCCL all-reduce of the (P+1)^2 Gram.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # vendor dense fp64 matrix peak of MI355X; not in MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_states(topo, S, seed, floating=True):
+    """Synthetic inputs of SURVEY.md §8(d): seeded, the distributions of model.py:696-725."""
+    rng = np.random.default_rng(seed)
+    n = topo.num_dofs
+    lo = np.array([topo.limits[j]["lower"] for j in topo.dof_names])
+    hi = np.array([topo.limits[j]["upper"] for j in topo.dof_names])
+    vm = np.array([topo.limits[j]["velocity"] for j in topo.dof_names])
+    st = dict(q=lo + (hi - lo) * rng.random((S, n)), dq=(rng.random((S, n)) - 0.5) * 2 * vm,
+              ddq=(rng.random((S, n)) - 0.5) * 2 * np.pi)
+    if floating:
+        st.update(base_vel=np.pi * rng.random((S, 6)), base_acc=np.pi * rng.random((S, 6)), rpy=0.1 * rng.random((S, 3)))
+    return st, rng
+
+
+def cpu_baseline(topo, budget_s=15.0):
+    """Oracle (C restatement, 1 thread) timed on the host: per-sample regressor + RNEA torques + the
+    A^T A accumulation of the stacked block with NumPy (BLAS pinned to 1 thread)."""
+    from oracle.oracle import OracleModel
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    om = OracleModel(topo, floating=True)
+    x = topo.x_std()
+    block = 256
+    st, _ = synth_states(topo, block, 1234)
+    done = 0
+    G = np.zeros((om.P + 1, om.P + 1))
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    t0 = time.perf_counter()
+    while True:
+        Y = om.regressor(st)
+        tau = om.inverse_dynamics(st, x).reshape(-1, 1)
+        Ya = np.hstack([Y, tau])
+        G += Ya.T @ Ya
+        done += block
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    if ctx is not None:
+        ctx.unregister() if hasattr(ctx, "unregister") else None
+    return {"value": done / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{done} WALK-MAN floating-base samples: oracle regressor + RNEA (C, 1 thread) + NumPy A^T A (1 BLAS thread), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=1_000_000, help="samples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from flobaroid_amd._lib import Engine
+    from flobaroid_amd.topology import Topology
+
+    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "walkman_apriori.topology.json"))
+    eng = Engine(topo, floating=True, device=local)
+    eng.use_torch_stream()
+    S = args.samples
+    st_np, rng = synth_states(topo, S, 42 + rank)
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
+    # tau = ID(state; xStdModel) + N(0, 0.05^2)  (tests/test_identification.py:79), computed on the device
+    tau = eng.inverse_dynamics(st, topo.x_std())
+    tau += 0.05 * torch.randn(tau.shape, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(7 + rank))
+    rhs = tau.reshape(-1, 1).contiguous()
+    Pa = eng.cols + 1
+    G = torch.zeros((Pa, Pa), dtype=torch.float64, device=dev)
+
+    def step():
+        eng.gram(st, rhs=rhs, out=G)
+        if world > 1:
+            dist.all_reduce(G)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile_enable(True)
+    eng.profile_get()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_get()
+    eng.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * S / (dt / args.steps)
+    rows, P = eng.rows, eng.cols
+    info = eng.gram_program_info(1)
+    gram_ms, gram_n = prof["gram"]
+    samples_per_launch = S * args.steps / max(gram_n, 1)
+    # symmetric Gram count rows*P*(P+1) + 2*rows*P per rhs column, per sample
+    alg_flop_per_sample = rows * P * (P + 1) + 2 * rows * P * 1
+    avg_launch_s = gram_ms / max(gram_n, 1) * 1e-3
+    achieved = alg_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+    executed_flop_per_sample = info["mfma_per_sample"] * 2 * 16 * 16 * 4
+    out = {
+        "metric": "regressor samples/s (fused regressor->Gram pass), WALK-MAN float-base",
+        "value": value,
+        "unit": "samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"walkman_apriori floating base (29 DOF, 48 links, {rows}x{P} regressor block), "
+                        f"{S} samples per GPU per step, fused kinematics + [Y|tau]^T[Y|tau] Gram"
+                        + (" + RCCL all-reduce" if world > 1 else ""),
+            "samples_per_gpu": S,
+            "rhs_columns": 1,
+            "parallelism": f"samples sharded over {world} GPU(s)",
+        },
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "fbr_gram_kernel",
+            "achieved": achieved,
+            "peak": PEAK_FP64_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            "traffic": None,
+            "algorithmic_flop_per_sample": alg_flop_per_sample,
+            "executed_mfma_flop_per_sample": executed_flop_per_sample,
+            "avg_launch_ms": avg_launch_s * 1e3,
+            "launches": gram_n,
+            "samples_per_launch": samples_per_launch,
+        },
+        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(topo)
+    elif world == 1:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,403 @@
+"""Thin ctypes layer over the C-ABI in ``include/fbr.h`` (``libfbr.so``, HIP, gfx950).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is usable the calls
+raise.  Arrays may be NumPy (host) or torch CUDA tensors (device, float64, contiguous); all state
+arrays of one call must live in the same memory space.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Any
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfbr.so")
+
+FBR_HOST = 0
+FBR_DEVICE = 1
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+
+
+class FbrError(RuntimeError):
+    pass
+
+
+class fbr_topology(ctypes.Structure):
+    _fields_ = [
+        ("num_links", ctypes.c_int32),
+        ("num_dofs", ctypes.c_int32),
+        ("parent", _ip),
+        ("dof_index", _ip),
+        ("rest_R", _dp),
+        ("rest_p", _dp),
+        ("axis", _dp),
+        ("floating_base", ctypes.c_int32),
+        ("gravity", ctypes.c_double * 3),
+        ("friction", ctypes.c_int32),
+        ("friction_symmetric", ctypes.c_int32),
+        ("gravity_only", ctypes.c_int32),
+        ("stribeck_velocity", ctypes.c_double),
+    ]
+
+
+class fbr_states(ctypes.Structure):
+    _fields_ = [
+        ("num_samples", ctypes.c_int64),
+        ("mem", ctypes.c_int32),
+        ("q", ctypes.c_void_p),
+        ("dq", ctypes.c_void_p),
+        ("ddq", ctypes.c_void_p),
+        ("base_vel", ctypes.c_void_p),
+        ("base_acc", ctypes.c_void_p),
+        ("base_rpy", ctypes.c_void_p),
+        ("sign", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+
+# name -> (restype, argtypes); also the list of symbols tests check against include/fbr.h
+_SIGNATURES = {
+    "fbr_version": (ctypes.c_int, []),
+    "fbr_device_count": (ctypes.c_int, []),
+    "fbr_last_error": (ctypes.c_char_p, []),
+    "fbr_model_create": (ctypes.c_int, [ctypes.POINTER(fbr_topology), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "fbr_model_destroy": (None, [ctypes.c_void_p]),
+    "fbr_model_dims": (ctypes.c_int, [ctypes.c_void_p, _ip, _ip]),
+    "fbr_model_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "fbr_regressor_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32]),
+    "fbr_inverse_dynamics_batch": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), _dp, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32],
+    ),
+    "fbr_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(fbr_states), _dp, ctypes.c_void_p, ctypes.c_int32]),
+    "fbr_contact_torques": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_int32, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32],
+    ),
+    "fbr_gram_accumulate": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_int32, ctypes.c_int32],
+    ),
+    "fbr_tsqr": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_int32],
+    ),
+    "fbr_tsqr_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "fbr_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "fbr_profile_get": (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.POINTER(ctypes.c_int64)]),
+    "fbr_gram_program_info": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, _ip, _ip, ctypes.POINTER(ctypes.c_int64), _ip],
+    ),
+}
+
+
+def load_library():
+    """Load libfbr.so (fails loudly; never substitutes a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FbrError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  flobaroid_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    return int(load_library().fbr_device_count())
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().fbr_last_error()
+        raise FbrError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def _is_torch(x: Any) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class _Ref:
+    """Pointer + memory space of one array argument (keeps the backing object alive)."""
+
+    def __init__(self, x: Any, shape: tuple | None = None, name: str = "array"):
+        self.obj = None
+        self.ptr = None
+        self.mem = None
+        if x is None:
+            return
+        if _is_torch(x):
+            import torch
+
+            if x.dtype != torch.float64:
+                raise TypeError(f"{name}: torch tensors must be float64")
+            if x.device.type == "cuda":
+                t = x.contiguous()
+                self.obj, self.ptr, self.mem = t, t.data_ptr(), FBR_DEVICE
+                got = tuple(t.shape)
+            else:
+                a = np.ascontiguousarray(x.numpy(), dtype=np.float64)
+                self.obj, self.ptr, self.mem = a, a.ctypes.data, FBR_HOST
+                got = a.shape
+        else:
+            a = np.ascontiguousarray(x, dtype=np.float64)
+            self.obj, self.ptr, self.mem = a, a.ctypes.data, FBR_HOST
+            got = a.shape
+        if shape is not None and tuple(got) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(got)}")
+
+
+def _same_space(refs: list[_Ref]) -> int:
+    mems = {r.mem for r in refs if r.mem is not None}
+    if len(mems) > 1:
+        raise ValueError("all arrays of one call must live in the same memory space (all NumPy or all CUDA tensors)")
+    return mems.pop() if mems else FBR_HOST
+
+
+class Engine:
+    """One ``fbr_model`` handle: device tables of a robot + identified-column layout."""
+
+    def __init__(self, topo, floating=False, friction=False, friction_symmetric=True, gravity_only=False,
+                 stribeck_velocity=0.0, gravity=(0.0, 0.0, -9.81), device: int = 0):
+        lib = load_library()
+        self._lib = lib
+        self.topo = topo
+        self._parent = np.array(topo.parent, dtype=np.int32)
+        self._dof = np.array(topo.dof_index, dtype=np.int32)
+        self._restR = np.ascontiguousarray(topo.rest_R, dtype=np.float64).reshape(-1)
+        self._restp = np.ascontiguousarray(topo.rest_p, dtype=np.float64).reshape(-1)
+        self._axis = np.ascontiguousarray(topo.axis, dtype=np.float64).reshape(-1)
+        t = fbr_topology()
+        t.num_links = topo.num_links
+        t.num_dofs = topo.num_dofs
+        t.parent = self._parent.ctypes.data_as(_ip)
+        t.dof_index = self._dof.ctypes.data_as(_ip)
+        t.rest_R = self._restR.ctypes.data_as(_dp)
+        t.rest_p = self._restp.ctypes.data_as(_dp)
+        t.axis = self._axis.ctypes.data_as(_dp)
+        t.floating_base = int(bool(floating))
+        t.gravity = (ctypes.c_double * 3)(*[float(g) for g in gravity])
+        t.friction = int(bool(friction))
+        t.friction_symmetric = int(bool(friction_symmetric))
+        t.gravity_only = int(bool(gravity_only))
+        t.stribeck_velocity = float(stribeck_velocity)
+        h = ctypes.c_void_p()
+        _check(lib.fbr_model_create(ctypes.byref(t), int(device), ctypes.byref(h)), "fbr_model_create")
+        self._h = h
+        r, c = ctypes.c_int32(), ctypes.c_int32()
+        _check(lib.fbr_model_dims(h, ctypes.byref(r), ctypes.byref(c)), "fbr_model_dims")
+        self.rows, self.cols = int(r.value), int(c.value)
+        self.n = topo.num_dofs
+        self.L = topo.num_links
+        self.floating = bool(floating)
+        self.friction = bool(friction)
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.fbr_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def set_stream(self, stream_ptr: int | None) -> None:
+        _check(self._lib.fbr_model_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), "fbr_model_set_stream")
+
+    def use_torch_stream(self) -> None:
+        import torch
+
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _states(self, st: dict, need_vel: bool = True):
+        q = _Ref(st["q"], name="q")
+        S = q.obj.shape[0]
+        n = self.n
+        if tuple(q.obj.shape) != (S, n):
+            raise ValueError(f"q: expected (S,{n}), got {tuple(q.obj.shape)}")
+        refs = [q]
+        dq = _Ref(st.get("dq"), (S, n), "dq") if need_vel or st.get("dq") is not None else _Ref(None)
+        ddq = _Ref(st.get("ddq"), (S, n), "ddq") if need_vel or st.get("ddq") is not None else _Ref(None)
+        bv = ba = rpy = sg = _Ref(None)
+        if self.floating:
+            rpy = _Ref(st.get("rpy", st.get("base_rpy")), (S, 3), "base_rpy")
+            if need_vel:
+                bv = _Ref(st.get("base_vel", st.get("base_velocity")), (S, 6), "base_vel")
+                ba = _Ref(st.get("base_acc", st.get("base_acceleration")), (S, 6), "base_acc")
+        if self.friction and need_vel:
+            sg = _Ref(st.get("sign"), (S, n), "sign")
+        refs += [dq, ddq, bv, ba, rpy, sg]
+        mem = _same_space(refs)
+        s = fbr_states()
+        s.num_samples = S
+        s.mem = mem
+        s.q, s.dq, s.ddq = q.ptr, dq.ptr, ddq.ptr
+        s.base_vel, s.base_acc, s.base_rpy, s.sign = bv.ptr, ba.ptr, rpy.ptr, sg.ptr
+        return s, refs, S, mem
+
+    def _out(self, out, shape, mem):
+        if out is not None:
+            if _is_torch(out):
+                import torch
+
+                if out.dtype != torch.float64 or not out.is_contiguous():
+                    raise ValueError("out must be a contiguous float64 tensor")
+            elif not (isinstance(out, np.ndarray) and out.flags.c_contiguous and out.dtype == np.float64):
+                raise ValueError("out must be a C-contiguous float64 ndarray")
+            return _Ref(out, shape, "out"), out
+        if mem == FBR_DEVICE:
+            import torch
+
+            t = torch.empty(shape, dtype=torch.float64, device=f"cuda:{self.device}")
+            return _Ref(t), t
+        a = np.empty(shape, dtype=np.float64)
+        return _Ref(a), a
+
+    # ------------------------------------------------------------------ C-ABI calls
+    def regressor(self, st: dict, out=None):
+        """Stacked standard regressor (S*rows, cols)."""
+        s, keep, S, mem = self._states(st)
+        r, ret = self._out(out, (S * self.rows, self.cols), mem)
+        _check(self._lib.fbr_regressor_batch(self._h, ctypes.byref(s), r.ptr, r.mem), "fbr_regressor_batch")
+        return ret
+
+    def inverse_dynamics(self, st: dict, x_std, vel_sign=None, out=None):
+        s, keep, S, mem = self._states(st)
+        x = np.ascontiguousarray(x_std, dtype=np.float64)
+        vs = _Ref(vel_sign, (S, self.n), "vel_sign") if vel_sign is not None else _Ref(None)
+        if vs.mem is not None and vs.mem != mem:
+            raise ValueError("vel_sign must live in the same memory space as the states")
+        r, ret = self._out(out, (S, self.rows), mem)
+        _check(
+            self._lib.fbr_inverse_dynamics_batch(self._h, ctypes.byref(s), x.ctypes.data_as(_dp), int(x.size), vs.ptr,
+                                                 r.ptr, r.mem),
+            "fbr_inverse_dynamics_batch",
+        )
+        return ret
+
+    def predict(self, st: dict, x, out=None):
+        s, keep, S, mem = self._states(st)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.size != self.cols:
+            raise ValueError(f"x must have {self.cols} entries")
+        r, ret = self._out(out, (S, self.rows), mem)
+        _check(self._lib.fbr_predict(self._h, ctypes.byref(s), x.ctypes.data_as(_dp), r.ptr, r.mem), "fbr_predict")
+        return ret
+
+    def contact_torques(self, st: dict, frame: str, wrench, out=None):
+        t = self.topo
+        if frame in t.frames:
+            link, fR, fp = t.frames[frame]["link"], t.frames[frame]["R"], t.frames[frame]["p"]
+        elif frame in t.link_names:
+            link, fR, fp = t.link_names.index(frame), np.eye(3), np.zeros(3)
+        else:
+            raise KeyError(f"unknown frame '{frame}'")
+        s, keep, S, mem = self._states(st, need_vel=False)
+        w = _Ref(wrench, (S, 6), "wrench")
+        if w.mem != mem:
+            raise ValueError("wrench must live in the same memory space as the states")
+        fR = np.ascontiguousarray(fR, dtype=np.float64).reshape(-1)
+        fp = np.ascontiguousarray(fp, dtype=np.float64).reshape(-1)
+        r, ret = self._out(out, (S, self.rows), mem)
+        _check(
+            self._lib.fbr_contact_torques(self._h, ctypes.byref(s), int(link), fR.ctypes.data_as(_dp),
+                                          fp.ctypes.data_as(_dp), w.ptr, r.ptr, r.mem),
+            "fbr_contact_torques",
+        )
+        return ret
+
+    def _rhs(self, rhs, w, S, mem):
+        k = 0
+        rr = _Ref(None)
+        if rhs is not None:
+            if _is_torch(rhs):
+                rhs2 = rhs.reshape(S * self.rows, -1)
+            else:
+                rhs2 = np.asarray(rhs, dtype=np.float64).reshape(S * self.rows, -1)
+            k = int(rhs2.shape[1])
+            rr = _Ref(rhs2, (S * self.rows, k), "rhs")
+            if rr.mem != mem:
+                raise ValueError("rhs must live in the same memory space as the states")
+        wr = _Ref(None)
+        if w is not None:
+            w2 = w.reshape(S * self.rows) if _is_torch(w) else np.asarray(w, dtype=np.float64).reshape(S * self.rows)
+            wr = _Ref(w2, (S * self.rows,), "w")
+            if wr.mem != mem:
+                raise ValueError("w must live in the same memory space as the states")
+        return rr, wr, k
+
+    def gram(self, st: dict, rhs=None, w=None, out=None, accumulate: bool = False):
+        """Raw Gram [Y|rhs]^T diag(w)^2 [Y|rhs], shape (cols+k, cols+k)."""
+        s, keep, S, mem = self._states(st)
+        rr, wr, k = self._rhs(rhs, w, S, mem)
+        Pa = self.cols + k
+        r, ret = self._out(out, (Pa, Pa), mem)
+        _check(
+            self._lib.fbr_gram_accumulate(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, r.ptr, r.mem, int(bool(accumulate))),
+            "fbr_gram_accumulate",
+        )
+        return ret
+
+    def tsqr(self, st: dict, rhs=None, w=None, R_in=None, out=None):
+        """Upper-triangular R with R^T R = [Y|rhs]^T [Y|rhs] (blocked Householder TSQR)."""
+        s, keep, S, mem = self._states(st)
+        rr, wr, k = self._rhs(rhs, w, S, mem)
+        Pa = self.cols + k
+        r, ret = self._out(out, (Pa, Pa), mem)
+        rin = _Ref(R_in, (Pa, Pa), "R_in") if R_in is not None else _Ref(None)
+        if rin.mem is not None and rin.mem != r.mem:
+            raise ValueError("R_in must live in the same memory space as the output")
+        _check(self._lib.fbr_tsqr(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, rin.ptr, r.ptr, r.mem), "fbr_tsqr")
+        return ret
+
+    def tsqr_merge(self, R_a, R_b, out=None):
+        a = _Ref(R_a, name="R_a")
+        n = a.obj.shape[0]
+        b = _Ref(R_b, (n, n), "R_b")
+        if a.mem != b.mem:
+            raise ValueError("R_a and R_b must live in the same memory space")
+        r, ret = self._out(out, (n, n), a.mem)
+        _check(self._lib.fbr_tsqr_merge(self._h, n, a.ptr, b.ptr, r.ptr, a.mem), "fbr_tsqr_merge")
+        return ret
+
+    PROF_CLASSES = ("kin", "regressor", "gram", "reduce", "id", "tsqr")
+
+    def profile_enable(self, on: bool = True) -> None:
+        _check(self._lib.fbr_profile_enable(self._h, int(bool(on))), "fbr_profile_enable")
+
+    def profile_get(self) -> dict:
+        """{class: (device ms, launches)} since the last call (resets the counters)."""
+        n = len(self.PROF_CLASSES)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int64 * n)()
+        _check(self._lib.fbr_profile_get(self._h, ms, cnt), "fbr_profile_get")
+        return {c: (float(ms[i]), int(cnt[i])) for i, c in enumerate(self.PROF_CLASSES)}
+
+    def gram_program_info(self, k: int = 0) -> dict:
+        nt, npairs, parts = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        mf = ctypes.c_int64()
+        _check(
+            self._lib.fbr_gram_program_info(self._h, int(k), ctypes.byref(nt), ctypes.byref(npairs), ctypes.byref(mf),
+                                            ctypes.byref(parts)),
+            "fbr_gram_program_info",
+        )
+        return {"tiles": nt.value, "pairs": npairs.value, "mfma_per_sample": mf.value, "parts": parts.value}

@@ -1,0 +1,780 @@
+// fbr_api.hip -- C-ABI of libfbr (see include/fbr.h).  Host side: device tables, workspace, launches.
+// gfx950 only; there is deliberately no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/fbr.h"
+#include "fbr_kernels.h"
+#include "fbr_tsqr.h"
+
+static thread_local std::string g_err;
+static void set_err(const std::string &s) { g_err = s; }
+
+#define HIPCHK(call)                                                                            \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            set_err(std::string(#call) + ": " + hipGetErrorString(e__));                        \
+            return FBR_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return FBR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) {
+            set_err(std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
+            return FBR_E_HIP;
+        }
+        bytes = need;
+        return FBR_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+
+template <class T> static int upload(std::vector<DevBuf> &pool, const std::vector<T> &v, const T **out)
+{
+    pool.emplace_back();
+    DevBuf &b = pool.back();
+    size_t n = std::max<size_t>(v.size(), 1) * sizeof(T);
+    int rc = b.ensure(n);
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)b.p;
+    return FBR_OK;
+}
+
+struct GramHolder {
+    FbrGramProgram prog;
+    DevGram dev;
+    std::vector<DevBuf> pool;
+    size_t lds_bytes = 0;
+};
+
+struct fbr_model {
+    FbrHostModel hm;
+    DevModel dm;
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<DevBuf> tables;
+    std::map<int, std::unique_ptr<GramHolder>> gram;
+    // workspace
+    DevBuf st_q, st_dq, st_ddq, st_bv, st_ba, st_rpy, st_sign, st_aux, st_aux2, st_x;
+    DevBuf rec, partial, out_tmp, g_tmp;
+    FbrTsqrWork tsqr;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
+    double prof_ms[FBR_PROF_COUNT] = {0};
+    int64_t prof_n[FBR_PROF_COUNT] = {0};
+};
+
+// Bracket a launch with events (no-op unless profiling is on).
+struct ProfScope {
+    fbr_model *m;
+    int idx = -1;
+    ProfScope(fbr_model *m_, int cls) : m(m_)
+    {
+        if (!m->prof) return;
+        size_t i = m->ev_used.size();
+        if (i >= m->ev_pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            m->ev_pool.emplace_back(a, b);
+        }
+        idx = (int)i;
+        m->ev_used.emplace_back(cls, idx);
+        (void)hipEventRecord(m->ev_pool[idx].first, m->stream);
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(m->ev_pool[idx].second, m->stream);
+    }
+};
+static void prof_collect(fbr_model *m)
+{
+    for (auto &u : m->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->ev_pool[u.second].first, m->ev_pool[u.second].second) == hipSuccess) {
+            m->prof_ms[u.first] += ms;
+            m->prof_n[u.first] += 1;
+        }
+    }
+    m->ev_used.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int fbr_version(void) { return 100; }
+
+extern "C" int fbr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *fbr_last_error(void) { return g_err.c_str(); }
+
+extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **out)
+{
+    if (!t || !out) {
+        set_err("null argument");
+        return FBR_E_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err("no HIP device available (libfbr has no CPU fallback)");
+        return FBR_E_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_err("device index out of range");
+        return FBR_E_INVALID;
+    }
+    std::unique_ptr<fbr_model> m(new fbr_model());
+    try {
+        m->hm.build(t->num_links, t->num_dofs, t->parent, t->dof_index, t->rest_R, t->rest_p, t->axis, t->floating_base,
+                    t->gravity, t->friction, t->friction_symmetric, t->gravity_only, t->stribeck_velocity);
+    } catch (const std::exception &e) {
+        set_err(std::string("invalid topology: ") + e.what());
+        return FBR_E_INVALID;
+    }
+    m->device = device;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    m->num_cus = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+    m->stream = m->own_stream;
+
+    const FbrHostModel &hm = m->hm;
+    DevModel &dm = m->dm;
+    memset(&dm, 0, sizeof(dm));
+    dm.L = hm.L; dm.n = hm.n; dm.fb = hm.fb; dm.rows = hm.rows; dm.cols = hm.cols; dm.cpl = hm.cpl;
+    dm.floating = hm.floating; dm.rec = hm.rec_size(); dm.maxd = std::max(hm.maxdepth, 1);
+    dm.nw = std::max(1, (hm.n + 31) / 32);
+    dm.fric = hm.fric; dm.grav_only = hm.grav_only; dm.fstart = hm.friction_start();
+    for (int i = 0; i < 3; i++) dm.g[i] = hm.gravity[i];
+    dm.stribeck = hm.stribeck;
+    std::vector<int> pathlen(hm.L), pathtab((size_t)hm.L * dm.maxd, 0);
+    std::vector<unsigned> anc((size_t)hm.L * dm.nw, 0u);
+    std::vector<std::vector<int>> sub(std::max(hm.n, 1));
+    std::vector<int> dof_link(std::max(hm.n, 1), 0);
+    for (int l = 0; l < hm.L; l++) {
+        pathlen[l] = (int)hm.path[l].size();
+        for (size_t j = 0; j < hm.path[l].size(); j++) {
+            int d = hm.path[l][j];
+            pathtab[(size_t)l * dm.maxd + j] = d;
+            anc[(size_t)l * dm.nw + (d >> 5)] |= 1u << (d & 31);
+            sub[d].push_back(l);
+        }
+        if (hm.dof[l] >= 0) dof_link[hm.dof[l]] = l;
+    }
+    std::vector<int> sub_begin(hm.n + 1, 0), sub_links;
+    for (int d = 0; d < hm.n; d++) {
+        sub_begin[d] = (int)sub_links.size();
+        sub_links.insert(sub_links.end(), sub[d].begin(), sub[d].end());
+    }
+    sub_begin[hm.n] = (int)sub_links.size();
+    std::vector<int4> cd(hm.cols);
+    for (int c = 0; c < hm.cols; c++) cd[c] = make_int4(hm.coldesc[c].kind, hm.coldesc[c].link, hm.coldesc[c].pidx, hm.coldesc[c].joint);
+    int rc = 0;
+    m->tables.reserve(32);
+    if ((rc = upload(m->tables, hm.order, &dm.order))) return rc;
+    if ((rc = upload(m->tables, hm.parent, &dm.parent))) return rc;
+    if ((rc = upload(m->tables, hm.dof, &dm.dof))) return rc;
+    if ((rc = upload(m->tables, hm.restR, &dm.restR))) return rc;
+    if ((rc = upload(m->tables, hm.restp, &dm.restp))) return rc;
+    if ((rc = upload(m->tables, hm.axis, &dm.axis))) return rc;
+    if ((rc = upload(m->tables, pathlen, &dm.pathlen))) return rc;
+    if ((rc = upload(m->tables, pathtab, &dm.pathtab))) return rc;
+    if ((rc = upload(m->tables, anc, &dm.ancmask))) return rc;
+    if ((rc = upload(m->tables, cd, &dm.coldesc))) return rc;
+    if ((rc = upload(m->tables, sub_begin, &dm.sub_begin))) return rc;
+    if ((rc = upload(m->tables, sub_links, &dm.sub_links))) return rc;
+    if ((rc = upload(m->tables, dof_link, &dm.dof_link))) return rc;
+    *out = m.release();
+    return FBR_OK;
+}
+
+extern "C" void fbr_model_destroy(fbr_model *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (auto &b : m->tables) b.release();
+    for (auto &kv : m->gram)
+        for (auto &b : kv.second->pool) b.release();
+    DevBuf *bufs[] = {&m->st_q, &m->st_dq, &m->st_ddq, &m->st_bv, &m->st_ba, &m->st_rpy, &m->st_sign, &m->st_aux,
+                      &m->st_aux2, &m->st_x, &m->rec, &m->partial, &m->out_tmp, &m->g_tmp};
+    for (DevBuf *b : bufs) b->release();
+    m->tsqr.release();
+    for (auto &e : m->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    delete m;
+}
+
+extern "C" int fbr_model_dims(const fbr_model *m, int32_t *rows, int32_t *cols)
+{
+    if (!m) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    if (rows) *rows = m->hm.rows;
+    if (cols) *cols = m->hm.cols;
+    return FBR_OK;
+}
+
+extern "C" int fbr_model_set_stream(fbr_model *m, void *s)
+{
+    if (!m) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    m->stream = s ? (hipStream_t)s : m->own_stream;
+    return FBR_OK;
+}
+
+extern "C" int fbr_profile_enable(fbr_model *m, int32_t on)
+{
+    if (!m) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    m->prof = on != 0;
+    return FBR_OK;
+}
+
+extern "C" int fbr_profile_get(fbr_model *m, double *ms_out, int64_t *launches_out)
+{
+    if (!m) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    for (int i = 0; i < FBR_PROF_COUNT; i++) {
+        if (ms_out) ms_out[i] = m->prof_ms[i];
+        if (launches_out) launches_out[i] = m->prof_n[i];
+        m->prof_ms[i] = 0;
+        m->prof_n[i] = 0;
+    }
+    return FBR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state staging
+// ------------------------------------------------------------------------------------------------
+struct DevStates {
+    long S = 0;
+    const double *q = nullptr, *dq = nullptr, *ddq = nullptr, *bv = nullptr, *ba = nullptr, *rpy = nullptr, *sign = nullptr;
+};
+
+static int stage_one(fbr_model *m, DevBuf &buf, const double *src, size_t count, int mem, const double **dst)
+{
+    if (!src) {
+        *dst = nullptr;
+        return FBR_OK;
+    }
+    if (mem == FBR_DEVICE) {
+        *dst = src;
+        return FBR_OK;
+    }
+    int rc = buf.ensure(std::max<size_t>(count, 1) * sizeof(double));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    *dst = (const double *)buf.p;
+    return FBR_OK;
+}
+
+static int stage_states(fbr_model *m, const fbr_states *st, DevStates *d, bool need_vel = true)
+{
+    if (!m || !st) {
+        set_err("null argument");
+        return FBR_E_INVALID;
+    }
+    if (st->num_samples < 0 || (st->mem != FBR_HOST && st->mem != FBR_DEVICE)) {
+        set_err("bad fbr_states header");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    if (!st->q || (need_vel && (!st->dq || !st->ddq))) {
+        set_err("q/dq/ddq must not be NULL");
+        return FBR_E_INVALID;
+    }
+    if (hm.floating && (!st->base_rpy || (need_vel && (!st->base_vel || !st->base_acc)))) {
+        set_err("floating base model needs base_vel/base_acc/base_rpy");
+        return FBR_E_INVALID;
+    }
+    if (need_vel && hm.fric && !st->sign) {
+        set_err("friction layout needs the Coulomb sign series (fbr_states.sign)");
+        return FBR_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(m->device));
+    const size_t S = (size_t)st->num_samples;
+    d->S = (long)S;
+    int rc;
+    if ((rc = stage_one(m, m->st_q, st->q, S * hm.n, st->mem, &d->q))) return rc;
+    if ((rc = stage_one(m, m->st_dq, st->dq ? st->dq : st->q, S * hm.n, st->mem, &d->dq))) return rc;
+    if ((rc = stage_one(m, m->st_ddq, st->ddq ? st->ddq : st->q, S * hm.n, st->mem, &d->ddq))) return rc;
+    if (hm.floating) {
+        if ((rc = stage_one(m, m->st_rpy, st->base_rpy, S * 3, st->mem, &d->rpy))) return rc;
+        // without velocities (contact Jacobian only) the twist inputs are irrelevant: reuse any valid buffer
+        if ((rc = stage_one(m, m->st_bv, st->base_vel, S * 6, st->mem, &d->bv))) return rc;
+        if ((rc = stage_one(m, m->st_ba, st->base_acc, S * 6, st->mem, &d->ba))) return rc;
+    }
+    if (hm.fric && st->sign)
+        if ((rc = stage_one(m, m->st_sign, st->sign, S * hm.n, st->mem, &d->sign))) return rc;
+    return FBR_OK;
+}
+
+static long chunk_size(const fbr_model *m, long S)
+{
+    const size_t per = (size_t)m->hm.rec_size() * sizeof(double);
+    long ch = (long)((size_t)(768u << 20) / per);
+    if (ch < 1024) ch = 1024;
+    return std::min(S, ch);
+}
+
+static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, bool zero_twist = false)
+{
+    const FbrHostModel &hm = m->hm;
+    int rc = m->rec.ensure((size_t)cs * hm.rec_size() * sizeof(double));
+    if (rc) return rc;
+    (void)zero_twist;
+    const int threads = 256;
+    const int blocks = (int)((cs + threads - 1) / threads);
+    ProfScope ps(m, FBR_PROF_KIN);
+    hipLaunchKernelGGL(fbr_kin_kernel, dim3(blocks), dim3(threads), 0, m->stream, m->dm, cs, d.q + s0 * hm.n,
+                       d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
+                       d.rpy ? d.rpy + s0 * 3 : nullptr, m->rec.as<double>());
+    HIPCHK(hipGetLastError());
+    return FBR_OK;
+}
+
+static int finish_output(fbr_model *m, double *dev_src, double *user_dst, size_t count, int out_mem)
+{
+    if (out_mem == FBR_HOST)
+        HIPCHK(hipMemcpyAsync(user_dst, dev_src, count * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    prof_collect(m);
+    return FBR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y_out, int32_t out_mem)
+{
+    DevStates d;
+    int rc = stage_states(m, st, &d);
+    if (rc) return rc;
+    if (!Y_out) {
+        set_err("Y_out is NULL");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    const size_t per = (size_t)hm.rows * hm.cols;
+    const long S = d.S;
+    if (S == 0) return FBR_OK;
+    long ch = chunk_size(m, S);
+    if (out_mem == FBR_HOST) {
+        // bound the device staging buffer of the output to ~1 GiB
+        long och = (long)((size_t)(1u << 30) / (per * sizeof(double)));
+        ch = std::max(1L, std::min(ch, och));
+        if ((rc = m->out_tmp.ensure((size_t)ch * per * sizeof(double)))) return rc;
+    }
+    const size_t lds = (size_t)hm.rec_size() * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (long s0 = 0; s0 < S; s0 += ch) {
+        const long cs = std::min(ch, S - s0);
+        if ((rc = run_kin(m, d, s0, cs))) return rc;
+        double *dst = (out_mem == FBR_HOST) ? m->out_tmp.as<double>() : Y_out + (size_t)s0 * per;
+        const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
+        {
+            ProfScope ps(m, FBR_PROF_REGRESSOR);
+            hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
+                               d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst);
+        }
+        HIPCHK(hipGetLastError());
+        if (out_mem == FBR_HOST) {
+            HIPCHK(hipMemcpyAsync(Y_out + (size_t)s0 * per, dst, (size_t)cs * per * sizeof(double), hipMemcpyDeviceToHost,
+                                  m->stream));
+            HIPCHK(hipStreamSynchronize(m->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    prof_collect(m);
+    return FBR_OK;
+}
+
+static int run_id(fbr_model *m, const fbr_states *st, const double *x, int nx, const double *vel_sign, int mode,
+                  double *tau_out, int32_t out_mem)
+{
+    DevStates d;
+    int rc = stage_states(m, st, &d);
+    if (rc) return rc;
+    const FbrHostModel &hm = m->hm;
+    if (!x || !tau_out) {
+        set_err("null x / tau_out");
+        return FBR_E_INVALID;
+    }
+    const int need = (mode == 0) ? (hm.fric ? hm.friction_start() + (hm.cols - hm.cpl * hm.L) : 10 * hm.L) : hm.cols;
+    if (mode == 0 && nx < std::max(need, 10 * hm.L)) {
+        set_err("x_std too short for this model layout");
+        return FBR_E_INVALID;
+    }
+    const long S = d.S;
+    if (S == 0) return FBR_OK;
+    if ((rc = m->st_x.ensure((size_t)std::max(nx, 1) * sizeof(double)))) return rc;
+    HIPCHK(hipMemcpyAsync(m->st_x.p, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    const double *dvs = nullptr;
+    if (mode == 0 && hm.fric && hm.stribeck > 0) {
+        if (!vel_sign) {
+            set_err("Stribeck model needs vel_sign");
+            return FBR_E_INVALID;
+        }
+        if ((rc = stage_one(m, m->st_aux, vel_sign, (size_t)S * hm.n, st->mem, &dvs))) return rc;
+    }
+    double *dst = tau_out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->out_tmp.ensure((size_t)S * hm.rows * sizeof(double)))) return rc;
+        dst = m->out_tmp.as<double>();
+    }
+    const int waves = 4;
+    const size_t lds = (size_t)waves * (hm.rec_size() + 6 * hm.L) * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void *)fbr_id_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long ch = chunk_size(m, S);
+    for (long s0 = 0; s0 < S; s0 += ch) {
+        const long cs = std::min(ch, S - s0);
+        if ((rc = run_kin(m, d, s0, cs))) return rc;
+        const int blocks = (int)std::min<long>((cs + waves - 1) / waves, (long)m->num_cus * 8);
+        ProfScope ps(m, FBR_PROF_ID);
+        hipLaunchKernelGGL(fbr_id_kernel, dim3(blocks), dim3(64 * waves), lds, m->stream, m->dm, cs, m->rec.as<double>(),
+                           d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dvs ? dvs + s0 * hm.n : nullptr,
+                           m->st_x.as<double>(), mode, dst + (size_t)s0 * hm.rows);
+        HIPCHK(hipGetLastError());
+    }
+    return finish_output(m, dst, tau_out, (size_t)S * hm.rows, out_mem);
+}
+
+extern "C" int fbr_inverse_dynamics_batch(fbr_model *m, const fbr_states *st, const double *x_std, int32_t num_x,
+                                          const double *vel_sign, double *tau_out, int32_t out_mem)
+{
+    return run_id(m, st, x_std, num_x, vel_sign, 0, tau_out, out_mem);
+}
+
+extern "C" int fbr_predict(fbr_model *m, const fbr_states *st, const double *x, double *tau_out, int32_t out_mem)
+{
+    if (!m) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    return run_id(m, st, x, m->hm.cols, nullptr, 1, tau_out, out_mem);
+}
+
+extern "C" int fbr_contact_torques(fbr_model *m, const fbr_states *st, int32_t link, const double *frame_R,
+                                   const double *frame_p, const double *wrench, double *out, int32_t out_mem)
+{
+    (void)frame_R;
+    if (!m || !st) {
+        set_err("null argument");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    if (link < 0 || link >= hm.L || !frame_p || !wrench || !out) {
+        set_err("bad contact frame / null pointer");
+        return FBR_E_INVALID;
+    }
+    fbr_states s2 = *st;
+    // only q and rpy matter for the Jacobian: feed q as velocity placeholders (never read into the result)
+    s2.dq = st->q;
+    s2.ddq = st->q;
+    if (hm.floating) {
+        s2.base_vel = nullptr;
+        s2.base_acc = nullptr;
+    }
+    s2.sign = nullptr;
+    DevStates d;
+    int rc = stage_states(m, &s2, &d, false);
+    if (rc) return rc;
+    const long S = d.S;
+    if (S == 0) return FBR_OK;
+    if (hm.floating) {
+        // zero twist / acceleration buffers
+        if ((rc = m->st_bv.ensure((size_t)S * 6 * sizeof(double)))) return rc;
+        HIPCHK(hipMemsetAsync(m->st_bv.p, 0, (size_t)S * 6 * sizeof(double), m->stream));
+        d.bv = d.ba = m->st_bv.as<double>();
+    }
+    const double *dw = nullptr;
+    if ((rc = stage_one(m, m->st_aux, wrench, (size_t)S * 6, st->mem, &dw))) return rc;
+    double *dst = out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->out_tmp.ensure((size_t)S * hm.rows * sizeof(double)))) return rc;
+        dst = m->out_tmp.as<double>();
+    }
+    const long ch = chunk_size(m, S);
+    for (long s0 = 0; s0 < S; s0 += ch) {
+        const long cs = std::min(ch, S - s0);
+        if ((rc = run_kin(m, d, s0, cs))) return rc;
+        hipLaunchKernelGGL(fbr_contact_kernel, dim3((unsigned)((cs + 255) / 256)), dim3(256), 0, m->stream, m->dm, cs,
+                           m->rec.as<double>(), link, frame_p[0], frame_p[1], frame_p[2], dw + s0 * 6,
+                           dst + (size_t)s0 * hm.rows);
+        HIPCHK(hipGetLastError());
+    }
+    return finish_output(m, dst, out, (size_t)S * hm.rows, out_mem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused Gram
+// ------------------------------------------------------------------------------------------------
+static int get_gram(fbr_model *m, int k, GramHolder **out)
+{
+    auto it = m->gram.find(k);
+    if (it != m->gram.end()) {
+        *out = it->second.get();
+        return FBR_OK;
+    }
+    std::unique_ptr<GramHolder> h(new GramHolder());
+    try {
+        h->prog.build(m->hm, k);
+    } catch (const std::exception &e) {
+        set_err(std::string("gram program: ") + e.what());
+        return FBR_E_INVALID;
+    }
+    FbrGramProgram &gp = h->prog;
+    DevGram &dg = h->dev;
+    memset(&dg, 0, sizeof(dg));
+    dg.T = gp.T; dg.NT = gp.NT; dg.k = gp.k; dg.Pa = gp.Pa; dg.image_doubles = gp.image_doubles;
+    dg.rid_stride = 0;
+    if (gp.image_doubles > 1023 * 64 || m->hm.rows > 255) {
+        set_err("model too large for the fused Gram tile image");
+        return FBR_E_UNSUPPORTED;
+    }
+    // image row -> global regressor row (identity inside dense tiles, path rows inside chain tiles)
+    std::vector<int> rowid((size_t)gp.image_doubles / FBR_TILE, 0);
+    for (int t = 0; t < gp.NT; t++)
+        for (size_t j = 0; j < gp.tiles[t].rowid.size(); j++) rowid[(size_t)gp.tiles[t].off / FBR_TILE + j] = gp.tiles[t].rowid[j];
+    dg.ntab = (int)rowid.size();
+    std::vector<int4> items;
+    std::vector<int> item_begin(gp.T + 1, 0);
+    for (int t = 0; t < gp.T; t++) {
+        item_begin[t] = (int)items.size();
+        for (auto &it2 : gp.items[t]) items.push_back(make_int4(it2.off, it2.kind, it2.a, it2.b));
+    }
+    item_begin[gp.T] = (int)items.size();
+    const size_t nslots = gp.slots.size();
+    std::vector<int> meta(nslots, 0);
+    std::vector<int> slot_tiles(2 * nslots, -1);
+    for (size_t s = 0; s < nslots; s++) {
+        int pi = gp.slots[s].pair;
+        if (pi < 0) continue;
+        const FbrPair &p = gp.pairs[pi];
+        const int offA = gp.tiles[p.I].off, offB = gp.tiles[p.J].off;
+        meta[s] = (offA / 64) | ((offB / 64) << 10) | (p.common << 20) | ((p.mode == 1 ? 1 : 0) << 28);
+        slot_tiles[2 * s] = p.I;
+        slot_tiles[2 * s + 1] = p.J;
+    }
+    std::vector<int> tilecol((size_t)gp.NT * FBR_TILE);
+    for (int t = 0; t < gp.NT; t++)
+        for (int s = 0; s < FBR_TILE; s++) tilecol[(size_t)t * FBR_TILE + s] = gp.tiles[t].col[s];
+    int rc;
+    h->pool.reserve(16);
+    if ((rc = upload(h->pool, items, &dg.items))) return rc;
+    if ((rc = upload(h->pool, item_begin, &dg.item_begin))) return rc;
+    if ((rc = upload(h->pool, meta, &dg.slotmeta))) return rc;
+    if ((rc = upload(h->pool, rowid, &dg.rowid))) return rc;
+    if ((rc = upload(h->pool, slot_tiles, &dg.slot_tiles))) return rc;
+    if ((rc = upload(h->pool, tilecol, &dg.tilecol))) return rc;
+    h->lds_bytes = ((size_t)gp.image_doubles + ((m->hm.rec_size() + 1) & ~1)) * sizeof(double) + ((size_t)dg.ntab + FBR_WPB * FBR_NPW) * sizeof(int);
+    if (h->lds_bytes > 160 * 1024) {
+        set_err("model too large: fused Gram needs more than 160 KiB of LDS");
+        return FBR_E_UNSUPPORTED;
+    }
+    *out = h.get();
+    m->gram[k] = std::move(h);
+    return FBR_OK;
+}
+
+extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *num_tiles, int32_t *num_pairs,
+                                     int64_t *mfma_per_sample, int32_t *num_parts)
+{
+    if (!mc) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    fbr_model *m = const_cast<fbr_model *>(mc);
+    HIPCHK(hipSetDevice(m->device));
+    GramHolder *h = nullptr;
+    int rc = get_gram(m, k, &h);
+    if (rc) return rc;
+    if (num_tiles) *num_tiles = h->prog.NT;
+    if (num_pairs) *num_pairs = (int32_t)h->prog.pairs.size();
+    if (mfma_per_sample) *mfma_per_sample = h->prog.mfma_per_sample;
+    if (num_parts) *num_parts = h->prog.T;
+    return FBR_OK;
+}
+
+extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
+                                   double *G_out, int32_t out_mem, int32_t accumulate)
+{
+    DevStates d;
+    int rc = stage_states(m, st, &d);
+    if (rc) return rc;
+    if (!G_out || k < 0 || k > FBR_MAX_RHS || (k > 0 && !rhs)) {
+        set_err("bad rhs / G_out arguments");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    GramHolder *h = nullptr;
+    if ((rc = get_gram(m, k, &h))) return rc;
+    const int Pa = h->prog.Pa;
+    const size_t gcount = (size_t)Pa * Pa;
+    const long S = d.S;
+    const double *drhs = nullptr, *dw = nullptr;
+    if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
+    if ((rc = stage_one(m, m->st_aux2, w, (size_t)S * hm.rows, st->mem, &dw))) return rc;
+    double *G = G_out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure(gcount * sizeof(double)))) return rc;
+        G = m->g_tmp.as<double>();
+        if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, gcount * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    }
+    if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
+    if (S > 0) {
+        const int T = h->prog.T;
+        const int blocks_per_cu = (h->lds_bytes <= 80 * 1024) ? 2 : 1;
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes));
+        const long ch = chunk_size(m, S);
+        for (long s0 = 0; s0 < S; s0 += ch) {
+            const long cs = std::min(ch, S - s0);
+            if ((rc = run_kin(m, d, s0, cs))) return rc;
+            int NS = std::max(1, (m->num_cus * blocks_per_cu) / T);
+            if ((long)NS > cs) NS = (int)cs;
+            const size_t pcount = (size_t)NS * T * FBR_WPB * FBR_NPW * 256;
+            if ((rc = m->partial.ensure(pcount * sizeof(double)))) return rc;
+            {
+            ProfScope ps(m, FBR_PROF_GRAM);
+            hipLaunchKernelGGL(fbr_gram_kernel, dim3(T * NS), dim3(256), h->lds_bytes, m->stream, h->dev, m->dm, cs, NS,
+                               m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                               drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
+                               m->partial.as<double>());
+            }
+            HIPCHK(hipGetLastError());
+            {
+            ProfScope ps(m, FBR_PROF_REDUCE);
+            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW), dim3(256), 0, m->stream, h->dev, NS,
+                               m->partial.as<double>(), G);
+            }
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return finish_output(m, G, G_out, gcount, out_mem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TSQR (fbr_tsqr.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
+                        const double *R_in, double *R_out, int32_t out_mem)
+{
+    DevStates d;
+    int rc = stage_states(m, st, &d);
+    if (rc) return rc;
+    if (!R_out || k < 0 || k > FBR_MAX_RHS || (k > 0 && !rhs)) {
+        set_err("bad rhs / R_out arguments");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    const int Pa = hm.cols + k;
+    const size_t rcount = (size_t)Pa * Pa;
+    const long S = d.S;
+    const double *drhs = nullptr, *dw = nullptr;
+    if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
+    if ((rc = stage_one(m, m->st_aux2, w, (size_t)S * hm.rows, st->mem, &dw))) return rc;
+    double *R = R_out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure(rcount * sizeof(double)))) return rc;
+        R = m->g_tmp.as<double>();
+    }
+    if (R_in) {
+        HIPCHK(hipMemcpyAsync(R, R_in, rcount * sizeof(double),
+                              out_mem == FBR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, m->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(R, 0, rcount * sizeof(double), m->stream));
+    }
+    if (S > 0) {
+        // materialise [Y | rhs] chunk by chunk (K1 + K2) and fold each chunk into R with the blocked
+        // Householder kernels of fbr_tsqr.h
+        const size_t per = (size_t)hm.rows * hm.cols;
+        long ch = fbr_tsqr_chunk_samples(hm.rows, Pa);
+        ch = std::min(ch, chunk_size(m, S));
+        const size_t lds = (size_t)hm.rec_size() * sizeof(double);
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if ((rc = m->out_tmp.ensure((size_t)ch * per * sizeof(double)))) return rc;
+        for (long s0 = 0; s0 < S; s0 += ch) {
+            const long cs = std::min(ch, S - s0);
+            if ((rc = run_kin(m, d, s0, cs))) return rc;
+            const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
+            hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
+                               d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, m->out_tmp.as<double>());
+            HIPCHK(hipGetLastError());
+            ProfScope ps(m, FBR_PROF_TSQR);
+            rc = fbr_tsqr_fold(m->tsqr, m->stream, cs * hm.rows, hm.cols, m->out_tmp.as<double>(), k,
+                               drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr, R,
+                               m->num_cus);
+            if (rc) {
+                set_err(std::string("tsqr fold: ") + fbr_tsqr_error());
+                return rc;
+            }
+        }
+    }
+    return finish_output(m, R, R_out, rcount, out_mem);
+}
+
+extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem)
+{
+    if (!m || n <= 0 || !R_a || !R_b || !R_out) {
+        set_err("bad arguments");
+        return FBR_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(m->device));
+    const size_t cnt = (size_t)n * n;
+    int rc;
+    const double *da = nullptr, *db = nullptr;
+    if ((rc = stage_one(m, m->st_aux, R_a, cnt, mem, &da))) return rc;
+    if ((rc = stage_one(m, m->st_aux2, R_b, cnt, mem, &db))) return rc;
+    double *R = R_out;
+    if (mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
+        R = m->g_tmp.as<double>();
+    }
+    if (R != da) HIPCHK(hipMemcpyAsync(R, da, cnt * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
+    // fold the n rows of R_b (a dense n x n block; its zero lower triangle costs nothing extra in accuracy)
+    rc = fbr_tsqr_fold(m->tsqr, m->stream, n, n, db, 0, nullptr, nullptr, R, m->num_cus);
+    if (rc) {
+        set_err(std::string("tsqr merge: ") + fbr_tsqr_error());
+        return rc;
+    }
+    return finish_output(m, R, R_out, cnt, mem);
+}

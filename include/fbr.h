@@ -1,0 +1,174 @@
+/*
+ * fbr.h -- C-ABI of libfbr (FloBaRoID regressor hot path on MI355X / gfx950).
+ *
+ * The reference has no FFI of its own for this path: its per-sample arithmetic is reached through
+ * iDynTree's SWIG bindings and its reductions through NumPy/SciPy.  Every entry point below names
+ * the reference call site(s) it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; int return: 0 = OK, negative = error (fbr_last_error()).
+ *   - All numeric data is IEEE fp64, C-contiguous, row-major.
+ *   - Every data pointer carries a memory-space flag: FBR_HOST (pageable/pinned host memory; the call
+ *     stages it through the device) or FBR_DEVICE (HIP device memory on the model's device).
+ *   - Calls are blocking: results are complete (and the model's stream synchronised) on return.
+ *   - A model handle may be used from one host thread at a time; handles are per-process and must be
+ *     created after fork() (the reference's multiprocessing users build one Model per worker,
+ *     excitation/analyticalGradient.py:188-210).
+ *   - There is NO CPU fallback: without a usable HIP device every compute call fails with FBR_E_NODEVICE.
+ */
+#ifndef FBR_H
+#define FBR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBR_OK 0
+#define FBR_E_INVALID (-1)   /* bad argument */
+#define FBR_E_NODEVICE (-2)  /* no HIP device / HIP runtime failure at init */
+#define FBR_E_HIP (-3)       /* HIP runtime error during the call */
+#define FBR_E_UNSUPPORTED (-4)
+
+#define FBR_HOST 0
+#define FBR_DEVICE 1
+
+typedef struct fbr_model fbr_model; /* opaque */
+
+/*
+ * Kinematic tree + identified-column layout.  Replaces what the reference pulls out of
+ * iDynTree::ModelLoader / Model (identification/model.py:60-68,112-131) and the layout logic of
+ * Model.__init__ (model.py:134-168).  Links are indexed in URDF document order after fake-link
+ * removal; columns of the regressor are link-major, 10 per link
+ * [m, m*cx, m*cy, m*cz, Ixx, Ixy, Ixz, Iyy, Iyz, Izz] (model.py:220-231), followed by the friction
+ * blocks Fc | Fv (or Fv+,Fv-) | off | Fs (model.py:459-503).
+ */
+typedef struct {
+    int32_t num_links;
+    int32_t num_dofs;
+    const int32_t *parent;    /* [L] parent link, -1 for the base */
+    const int32_t *dof_index; /* [L] DOF of the joint to the parent, -1 when fixed / base */
+    const double *rest_R;     /* [L][9] child orientation in the parent frame at q = 0 */
+    const double *rest_p;     /* [L][3] child origin in the parent frame */
+    const double *axis;       /* [L][3] unit revolute axis in the child frame */
+    int32_t floating_base;    /* opt['floatingBase']: rows per sample = num_dofs + 6 */
+    double gravity[3];        /* reference: (0, 0, -9.81), model.py:182-187 */
+    int32_t friction;           /* opt['identifyFrictionSimultaneously'] */
+    int32_t friction_symmetric; /* opt['identifySymmetricVelFriction'] */
+    int32_t gravity_only;       /* opt['identifyGravityParamsOnly'] (keeps 4 columns per link) */
+    double stribeck_velocity;   /* opt['stribeckVelocity'] (> 0 adds the Fs block) */
+} fbr_topology;
+
+/*
+ * A batch of trajectory samples = what Model.computeRegressors reads per sample_index
+ * (model.py:374-394, 425-439, 462).  All arrays share the same memory space.
+ */
+typedef struct {
+    int64_t num_samples;
+    int32_t mem;            /* FBR_HOST or FBR_DEVICE */
+    const double *q;        /* [S][n] positions */
+    const double *dq;       /* [S][n] velocities */
+    const double *ddq;      /* [S][n] accelerations */
+    const double *base_vel; /* [S][6] base twist [lin; ang], mixed representation (floating base) */
+    const double *base_acc; /* [S][6] its time derivative */
+    const double *base_rpy; /* [S][3] rpy with world_T_base = Transform(RPY(rpy),0).inverse() */
+    const double *sign;     /* [S][n] Coulomb sign term (helpers.getFrictionSignSeries); NULL unless friction */
+} fbr_states;
+
+/* ---- library / device ------------------------------------------------------------------------- */
+int fbr_version(void);
+int fbr_device_count(void);        /* number of visible HIP devices (0 if none / no runtime) */
+const char *fbr_last_error(void);  /* thread-local message of the last failing call */
+
+/* ---- model ------------------------------------------------------------------------------------ */
+/* Builds device tables for `topo` on HIP device `device`.  Replaces ModelLoader.loadModelFromFile +
+   KinDynComputations.loadRobotModel (model.py:60-68). */
+int fbr_model_create(const fbr_topology *topo, int device, fbr_model **out);
+void fbr_model_destroy(fbr_model *m);
+/* rows per sample (N_OUT, model.py:102-105) and identified columns (num_identified_params, model.py:138-168) */
+int fbr_model_dims(const fbr_model *m, int32_t *rows_per_sample, int32_t *num_cols);
+/* Run subsequent calls on this hipStream_t (e.g. torch's current stream); NULL = the model's own stream. */
+int fbr_model_set_stream(fbr_model *m, void *hip_stream);
+
+/* ---- per-sample kernels ----------------------------------------------------------------------- */
+/*
+ * Stacked standard regressor, Y_out [S*rows][cols] -- the reference's regressor_stack
+ * (model.py:349-354, 435-523: setRobotState + inverseDynamicsInertialParametersRegressor + friction
+ * column blocks + gravity-only column deletion, one Python iteration per sample).
+ */
+int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y_out, int32_t out_mem);
+
+/*
+ * Generalized torques [base wrench(6); joint torques] per sample, tau_out [S][rows], from the full
+ * standard parameter vector x_std (host pointer; 10 per link + friction slots laid out as in
+ * model.py:134-168) -- Model.simulateDynamicsIDynTree (model.py:239-331): KinDynComputations.
+ * inverseDynamics plus the friction model sign*Fc + Fv*dq + off (+ Stribeck with vel_sign, may be NULL).
+ */
+int fbr_inverse_dynamics_batch(fbr_model *m, const fbr_states *st, const double *x_std, int32_t num_x,
+                               const double *vel_sign, double *tau_out, int32_t out_mem);
+
+/*
+ * tau_out [S][rows] = Y_s . x for an identified-parameter vector x (host, length cols) WITHOUT
+ * materialising Y -- Identification.estimateRegressorTorques' np.dot(YStd, x) (identifier.py:135-141).
+ */
+int fbr_predict(fbr_model *m, const fbr_states *st, const double *x, double *tau_out, int32_t out_mem);
+
+/*
+ * out [S][rows] = J_frame^T w per sample for a frame rigidly attached to `link` at (frame_R, frame_p)
+ * (host, 9 and 3 doubles); wrench [S][6] in st->mem.  getFrameFreeFloatingJacobian + J^T w
+ * (model.py:542-555).  Uses st->q and st->base_rpy only.
+ */
+int fbr_contact_torques(fbr_model *m, const fbr_states *st, int32_t link, const double *frame_R,
+                        const double *frame_p, const double *wrench, double *out, int32_t out_mem);
+
+/* ---- fused reductions (Y is never materialised) ----------------------------------------------- */
+/*
+ * G_out [(cols+k)][(cols+k)] (+)= [Y | rhs]^T diag(w)^2 [Y | rhs], the raw (un-normalised) Gram of the
+ * stacked regressor augmented with k right-hand-side columns rhs [S*rows][k] (tau, contact forces, ...),
+ * row weights w [S*rows] optional (NULL = 1; a 0/1 mask selects e.g. the base-wrench rows of
+ * identifier.py:617-681).  accumulate != 0 adds to the existing content of G_out.
+ * Serves: R += A^T A of getRandomRegressor (model.py:803-806), YBase^T YBase = G[ic,ic]
+ * (identifier.py:361, trajectoryOptimizer.py:263), YBase^T tau, and the OLS normal equations.
+ * rhs / w live in st->mem; G_out in out_mem.
+ */
+int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
+                        double *G_out, int32_t out_mem, int32_t accumulate);
+
+/*
+ * R_out [(cols+k)][(cols+k)] upper triangular with R^T R = [Y|rhs]^T [Y|rhs], by blocked Householder
+ * TSQR over sample blocks (no Gram squaring of the condition number).  If R_in != NULL it is an
+ * existing triangular factor (same shape, out_mem space) that is folded in first (streaming / tree
+ * reduction across calls and ranks).  Serves la.qr(YBase) (sdp.py:470), sla.qr(YStd, pivoting) column
+ * norms / pivots (model.py:841) and lstsq (identifier.py:712) through the small host problems.
+ */
+int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
+             const double *R_in, double *R_out, int32_t out_mem);
+
+/* R_out = R factor of [R_a; R_b] (both n x n upper triangular, row-major) -- one node of the TSQR tree. */
+int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem);
+
+/* ---- profiling ---------------------------------------------------------------------------------- */
+#define FBR_PROF_KIN 0       /* link kinematics kernel */
+#define FBR_PROF_REGRESSOR 1 /* materialising regressor kernel */
+#define FBR_PROF_GRAM 2      /* fused regressor->Gram MFMA kernel */
+#define FBR_PROF_REDUCE 3    /* slice reduction / scatter of the Gram partials */
+#define FBR_PROF_ID 4        /* inverse dynamics / predict kernel */
+#define FBR_PROF_TSQR 5      /* TSQR fold kernels (whole fold) */
+#define FBR_PROF_COUNT 6
+/* When enabled, every kernel launch is bracketed by hipEvents on the launch stream; fbr_profile_get
+   returns, per kernel class, the summed device time in ms and the launch count since the last reset
+   (the counters are reset by the call).  Used by bench.py for the live roofline figures. */
+int fbr_profile_enable(fbr_model *m, int32_t on);
+int fbr_profile_get(fbr_model *m, double *ms_out /*[FBR_PROF_COUNT]*/, int64_t *launches_out /*[FBR_PROF_COUNT]*/);
+
+/* ---- introspection (tests, tooling) ------------------------------------------------------------ */
+/* Tile program of the fused Gram kernel: counts of padded column tiles / tile pairs / MFMA k-steps per
+   sample, so tests and bench.py can report executed vs algorithmic flops. */
+int fbr_gram_program_info(const fbr_model *m, int32_t k, int32_t *num_tiles, int32_t *num_pairs,
+                          int64_t *mfma_per_sample, int32_t *num_parts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBR_H */

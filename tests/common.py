@@ -1,0 +1,54 @@
+"""Shared helpers for the test-suite."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from flobaroid_amd.topology import Topology
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROBOTS = os.path.join(ROOT, "flobaroid_amd", "robots")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_topo(name: str) -> Topology:
+    return Topology.load(os.path.join(ROBOTS, name + ".topology.json"))
+
+
+def random_states(topo, S, rng, floating, use_limits=False):
+    """Random states with the reference's distributions.
+
+    use_limits=False: tests/test_regressors.py:50-66 (U(-pi,pi), base pi*U(0,1), rpy 0.1*U(0,1)).
+    use_limits=True : Model.getRandomRegressor, model.py:696-725 (joint limits from the URDF)."""
+    n = topo.num_dofs
+    if use_limits:
+        lo = np.array([topo.limits[j]["lower"] for j in topo.dof_names])
+        hi = np.array([topo.limits[j]["upper"] for j in topo.dof_names])
+        vm = np.array([topo.limits[j]["velocity"] for j in topo.dof_names])
+        st = dict(q=lo + (hi - lo) * rng.random((S, n)), dq=(rng.random((S, n)) - 0.5) * 2 * vm,
+                  ddq=(rng.random((S, n)) - 0.5) * 2 * np.pi)
+    else:
+        st = dict(q=(rng.random((S, n)) * 2 - 1) * np.pi, dq=(rng.random((S, n)) * 2 - 1) * np.pi,
+                  ddq=(rng.random((S, n)) * 2 - 1) * np.pi)
+    if floating:
+        st.update(base_vel=np.pi * rng.random((S, 6)), base_acc=np.pi * rng.random((S, 6)), rpy=0.1 * rng.random((S, 3)))
+    return st
+
+
+# (robot, floating, friction, friction_symmetric, gravity_only, stribeck)
+CONFIGS = [
+    ("threeLinks", 1, 0, 1, 0, 0.0),
+    ("threeLinks", 0, 1, 0, 0, 0.1),
+    ("kuka_lwr4", 0, 0, 1, 0, 0.0),
+    ("kuka_lwr4", 0, 1, 1, 0, 0.0),
+    ("kuka_lwr4", 1, 1, 0, 0, 0.05),
+    ("kuka_lwr4", 0, 1, 1, 1, 0.0),
+    ("walkman_left_arm", 1, 1, 1, 0, 0.0),
+    ("walkman_apriori", 1, 0, 1, 0, 0.0),
+    ("walkman_apriori", 0, 1, 1, 0, 0.0),
+]
+
+
+def cfg_id(c):
+    return f"{c[0]}-fb{c[1]}-fr{c[2]}{'s' if c[3] else 'a'}-g{c[4]}-st{c[5]}"

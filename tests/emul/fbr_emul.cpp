@@ -1,0 +1,264 @@
+// fbr_emul.cpp -- CPU emulation of the HIP kernels' data flow (TEST ONLY, built by tests/conftest.py with g++).
+//
+// It compiles the SAME headers the kernels use (csrc/fbr_math.h, csrc/fbr_program.h) and mirrors the
+// kernels' indexing (records, packed tile image, pair slots, MFMA lane mapping), so table / index bugs
+// show up in the CPU test-suite instead of costing a GPU round trip.  Nothing here is shipped or used
+// by the product path.
+#include <cstring>
+#include <vector>
+
+#include "../../flobaroid_amd/csrc/fbr_math.h"
+#include "../../flobaroid_amd/csrc/fbr_program.h"
+
+extern "C" {
+
+struct EmulTopo {
+    int L, n;
+    const int32_t *parent, *dof;
+    const double *restR, *restp, *axis;
+    int floating;
+    double gravity[3];
+    int fric, fric_sym, grav_only;
+    double stribeck;
+};
+
+static void make(const EmulTopo *t, FbrHostModel &hm)
+{
+    hm.build(t->L, t->n, t->parent, t->dof, t->restR, t->restp, t->axis, t->floating, t->gravity, t->fric,
+             t->fric_sym, t->grav_only, t->stribeck);
+}
+
+// mirrors fbr_kin_kernel: one "lane" per sample, links in traversal order, AoS record
+static void kin_sample(const FbrHostModel &hm, const double *q, const double *dq, const double *ddq, const double *bv,
+                       const double *ba, const double *rpy, double *rec)
+{
+    for (int l : hm.order) {
+        double *r = rec + 21 * l;
+        if (hm.parent[l] < 0) {
+            fbr_kin_base(hm.floating, hm.gravity, bv, ba, rpy, r);
+        } else {
+            int d = hm.dof[l];
+            fbr_kin_child(rec + 21 * hm.parent[l], &hm.restR[9 * l], &hm.restp[3 * l], &hm.axis[3 * l], d >= 0,
+                          d >= 0 ? q[d] : 0.0, d >= 0 ? dq[d] : 0.0, d >= 0 ? ddq[d] : 0.0, r,
+                          d >= 0 ? rec + 21 * hm.L + 6 * d : nullptr);
+        }
+    }
+}
+
+int emul_dims(const EmulTopo *t, int *rows, int *cols, int *rec)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    *rows = hm.rows; *cols = hm.cols; *rec = hm.rec_size();
+    return 0;
+}
+
+int emul_kin(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv,
+             const double *ba, const double *rpy, double *rec_out)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    const int REC = hm.rec_size();
+    for (long s = 0; s < S; s++)
+        kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
+                   hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec_out + s * REC);
+    return 0;
+}
+
+// mirrors fbr_regressor_kernel: one thread per column, rows emitted in order
+int emul_regressor(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv,
+                   const double *ba, const double *rpy, const double *sign, double *Y)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    const int REC = hm.rec_size();
+    std::vector<double> rec(REC);
+    for (long s = 0; s < S; s++) {
+        kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
+                   hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
+        double *Ys = Y + (size_t)s * hm.rows * hm.cols;
+        for (int c = 0; c < hm.cols; c++) {
+            const FbrCol &cd = hm.coldesc[c];
+            for (int r = 0; r < hm.rows; r++) Ys[(size_t)r * hm.cols + c] = 0.0;
+            if (cd.kind == 0) {
+                double w6[6];
+                fbr_unit_wrench(&rec[21 * cd.link], cd.pidx, w6);
+                for (int r = 0; r < hm.fb; r++) Ys[(size_t)r * hm.cols + c] = w6[r];
+                for (int d : hm.path[cd.link])
+                    Ys[(size_t)(hm.fb + d) * hm.cols + c] = fbr_dot6(&rec[21 * hm.L + 6 * d], w6);
+            } else {
+                int j = cd.joint;
+                Ys[(size_t)(hm.fb + j) * hm.cols + c] =
+                    fbr_friction_value(cd.pidx, dq[s * hm.n + j], sign ? sign[s * hm.n + j] : 0.0, hm.stribeck);
+            }
+        }
+    }
+    return 0;
+}
+
+// mirrors fbr_id_kernel: per link net wrench in frame A, subtree sums, S^T projection, friction model
+// mode 0: x is the full standard vector (10 per link + friction slots, model.py:299-326 semantics)
+// mode 1: x is an identified-parameter vector (cols), tau = Y x   (predict)
+int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv,
+            const double *ba, const double *rpy, const double *sign, const double *vel_sign, const double *x, int mode,
+            double *tau)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    const int REC = hm.rec_size();
+    std::vector<double> rec(REC), F(6 * hm.L);
+    for (long s = 0; s < S; s++) {
+        kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
+                   hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
+        double *ts = tau + (size_t)s * hm.rows;
+        for (int r = 0; r < hm.rows; r++) ts[r] = 0.0;
+        for (int l = 0; l < hm.L; l++) {
+            double pi[10] = {0};
+            if (mode == 0) {
+                for (int p = 0; p < 10; p++) pi[p] = x[10 * l + p];
+            } else {
+                for (int p = 0; p < hm.cpl; p++) pi[p] = x[hm.cpl * l + p];
+            }
+            fbr_link_wrench(&rec[21 * l], pi, &F[6 * l]);
+            for (int r = 0; r < hm.fb; r++) ts[r] += F[6 * l + r];
+            for (int d : hm.path[l]) ts[hm.fb + d] += fbr_dot6(&rec[21 * hm.L + 6 * d], &F[6 * l]);
+        }
+        if (hm.fric) {
+            const int n = hm.n;
+            if (mode == 0) {
+                const int f0 = hm.friction_start();
+                for (int j = 0; j < n; j++) {
+                    double sg = sign[s * n + j];
+                    double v = sg * x[f0 + j];
+                    if (!hm.grav_only) {
+                        v += x[f0 + n + j] * dq[s * n + j];
+                        const int poff = f0 + 2 * n;
+                        v += x[poff + j];
+                        if (hm.stribeck > 0) {
+                            double sgn = (sg > 0) - (sg < 0);
+                            v += x[poff + n + j] * exp(-fabs(vel_sign[s * n + j]) / hm.stribeck) * sgn;
+                        }
+                    }
+                    ts[hm.fb + j] += v;
+                }
+            } else {
+                for (int c = hm.cpl * hm.L; c < hm.cols; c++) {
+                    const FbrCol &cd = hm.coldesc[c];
+                    ts[hm.fb + cd.joint] +=
+                        x[c] * fbr_friction_value(cd.pidx, dq[s * n + cd.joint], sign[s * n + cd.joint], hm.stribeck);
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma, int *T, int *image_doubles,
+                      int *items_total)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrGramProgram gp;
+    gp.build(hm, k);
+    *NT = gp.NT; *npairs = (int)gp.pairs.size(); *mfma = gp.mfma_per_sample; *T = gp.T;
+    *image_doubles = gp.image_doubles;
+    int it = 0;
+    for (auto &v : gp.items) it += (int)v.size();
+    *items_total = it;
+    return 0;
+}
+
+// mirrors fbr_gram_kernel + fbr_gram_reduce_kernel: per part, per sample: producer fills the packed image,
+// each (wave, slot) runs its k-steps with the 16x16x4 MFMA lane mapping, results scattered into G.
+int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv,
+              const double *ba, const double *rpy, const double *sign, const double *rhs, int k, const double *wts,
+              double *G)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrGramProgram gp;
+    gp.build(hm, k);
+    const int REC = hm.rec_size();
+    const int Pa = gp.Pa;
+    std::vector<double> rec(REC), img(gp.image_doubles);
+    std::vector<double> acc((size_t)gp.T * FBR_WPB * FBR_NPW * 256, 0.0);
+    for (int part = 0; part < gp.T; part++) {
+        for (long s = 0; s < S; s++) {
+            kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
+                       hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
+            if (s == 0) std::fill(img.begin(), img.end(), 0.0);  // image zeroed once per block
+            const double *ws = wts ? wts + (size_t)s * hm.rows : nullptr;
+            for (const FbrItem &it : gp.items[part]) {
+                if (it.kind == 0) {
+                    double w6[6];
+                    fbr_unit_wrench(&rec[21 * it.a], it.b, w6);
+                    for (int r = 0; r < hm.fb; r++) img[it.off + r * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
+                    int j = 0;
+                    for (int d : hm.path[it.a]) {
+                        img[it.off + (hm.fb + j) * FBR_TILE] =
+                            fbr_dot6(&rec[21 * hm.L + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
+                        j++;
+                    }
+                } else if (it.kind == 1) {
+                    int r = hm.fb + it.a;
+                    img[it.off + r * FBR_TILE] =
+                        fbr_friction_value(it.b, dq[s * hm.n + it.a], sign ? sign[s * hm.n + it.a] : 0.0, hm.stribeck) *
+                        (ws ? ws[r] : 1.0);
+                } else {
+                    for (int r = 0; r < hm.rows; r++)
+                        img[it.off + r * FBR_TILE] = rhs[((size_t)s * hm.rows + r) * k + it.a] * (ws ? ws[r] : 1.0);
+                }
+            }
+            for (int w = 0; w < FBR_WPB; w++)
+                for (int sl = 0; sl < FBR_NPW; sl++) {
+                    int pi = gp.slots[((size_t)part * FBR_WPB + w) * FBR_NPW + sl].pair;
+                    if (pi < 0) continue;
+                    const FbrPair &p = gp.pairs[pi];
+                    const FbrTile &ta = gp.tiles[p.I], &tb = gp.tiles[p.J];
+                    double *a4 = &acc[(((size_t)part * FBR_WPB + w) * FBR_NPW + sl) * 256];
+                    for (int ks = 0; ks < p.nk4(); ks++) {
+                        // D[i][j] += sum_kk A[i][kk] B[kk][j]; lane = kk*16 + i supplies A[i][kk], B[kk][j=lane&15]
+                        double A[16][4], B[4][16];
+                        for (int lane = 0; lane < 64; lane++) {
+                            int i = lane & 15, kk = lane >> 4;
+                            int pos = 4 * ks + kk;
+                            double a = img[ta.off + pos * FBR_TILE + i];
+                            if (pos >= p.common) a = 0.0;
+                            int posb = pos;
+                            if (p.mode == 1) posb = (pos < (int)ta.rowid.size()) ? ta.rowid[pos] : 0;
+                            double b = img[tb.off + posb * FBR_TILE + i];
+                            A[i][kk] = a;
+                            B[kk][i] = b;
+                        }
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int reg = 0; reg < 4; reg++) {
+                                int row = (lane >> 4) + 4 * reg, col = lane & 15;
+                                double sum = 0;
+                                for (int kk = 0; kk < 4; kk++) sum += A[row][kk] * B[kk][col];
+                                a4[reg * 64 + lane] += sum;
+                            }
+                    }
+                }
+        }
+    }
+    // reduce / scatter
+    for (int part = 0; part < gp.T; part++)
+        for (int w = 0; w < FBR_WPB; w++)
+            for (int sl = 0; sl < FBR_NPW; sl++) {
+                int pi = gp.slots[((size_t)part * FBR_WPB + w) * FBR_NPW + sl].pair;
+                if (pi < 0) continue;
+                const FbrPair &p = gp.pairs[pi];
+                const double *a4 = &acc[(((size_t)part * FBR_WPB + w) * FBR_NPW + sl) * 256];
+                for (int lane = 0; lane < 64; lane++)
+                    for (int reg = 0; reg < 4; reg++) {
+                        int row = (lane >> 4) + 4 * reg, col = lane & 15;
+                        int ci = gp.tiles[p.I].col[row], cj = gp.tiles[p.J].col[col];
+                        if (ci < 0 || cj < 0) continue;
+                        double v = a4[reg * 64 + lane];
+                        G[(size_t)ci * Pa + cj] += v;
+                        if (p.I != p.J) G[(size_t)cj * Pa + ci] += v;
+                    }
+            }
+    return 0;
+}
+}

@@ -1,0 +1,105 @@
+"""ctypes loader for the CPU emulation of the HIP kernels (tests/emul/fbr_emul.cpp) -- test-only."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "emul", "fbr_emul.cpp")
+_OUT = os.path.join(_HERE, "emul", "_build", "libfbr_emul.so")
+_CSRC = os.path.join(_HERE, "..", "flobaroid_amd", "csrc")
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+
+
+class EmulTopo(ctypes.Structure):
+    _fields_ = [("L", ctypes.c_int), ("n", ctypes.c_int), ("parent", _ip), ("dof", _ip), ("restR", _dp),
+                ("restp", _dp), ("axis", _dp), ("floating", ctypes.c_int), ("gravity", ctypes.c_double * 3),
+                ("fric", ctypes.c_int), ("fric_sym", ctypes.c_int), ("grav_only", ctypes.c_int),
+                ("stribeck", ctypes.c_double)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h")]
+        if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
+            os.makedirs(os.path.dirname(_OUT), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _OUT, _SRC])
+        _lib = ctypes.CDLL(_OUT)
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Emul:
+    def __init__(self, topo, floating=False, fric=False, fric_sym=True, grav_only=False, stribeck=0.0):
+        self.keep = [np.array(topo.parent, dtype=np.int32), np.array(topo.dof_index, dtype=np.int32),
+                     np.ascontiguousarray(topo.rest_R, dtype=np.float64).reshape(-1),
+                     np.ascontiguousarray(topo.rest_p, dtype=np.float64).reshape(-1),
+                     np.ascontiguousarray(topo.axis, dtype=np.float64).reshape(-1)]
+        self.t = EmulTopo(topo.num_links, topo.num_dofs, self.keep[0].ctypes.data_as(_ip),
+                          self.keep[1].ctypes.data_as(_ip), _d(self.keep[2]), _d(self.keep[3]), _d(self.keep[4]),
+                          int(floating), (ctypes.c_double * 3)(0.0, 0.0, -9.81), int(fric), int(fric_sym),
+                          int(grav_only), float(stribeck))
+        r, c, rec = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib().emul_dims(ctypes.byref(self.t), ctypes.byref(r), ctypes.byref(c), ctypes.byref(rec))
+        self.rows, self.cols, self.rec = r.value, c.value, rec.value
+        self.n = topo.num_dofs
+        self.floating = bool(floating)
+
+    def _st(self, st):
+        c = lambda k: np.ascontiguousarray(st[k], dtype=np.float64) if (k in st and st[k] is not None) else None
+        q = c("q")
+        return q.shape[0], q, c("dq"), c("ddq"), c("base_vel"), c("base_acc"), c("rpy")
+
+    def kin(self, st):
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        out = np.zeros((S, self.rec))
+        lib().emul_kin(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(out))
+        return out
+
+    def regressor(self, st, sign=None):
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        sign = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+        Y = np.zeros((S * self.rows, self.cols))
+        lib().emul_regressor(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy),
+                             _d(sign), _d(Y))
+        return Y
+
+    def inverse_dynamics(self, st, x, sign=None, vel_sign=None, mode=0):
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        sign = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+        vel_sign = None if vel_sign is None else np.ascontiguousarray(vel_sign, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        tau = np.zeros((S, self.rows))
+        lib().emul_id(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
+                      _d(vel_sign), _d(x), int(mode), _d(tau))
+        return tau
+
+    def program_info(self, k):
+        NT, npairs, T, img, items = (ctypes.c_int() for _ in range(5))
+        mfma = ctypes.c_long()
+        lib().emul_program_info(ctypes.byref(self.t), int(k), ctypes.byref(NT), ctypes.byref(npairs), ctypes.byref(mfma),
+                                ctypes.byref(T), ctypes.byref(img), ctypes.byref(items))
+        return dict(NT=NT.value, npairs=npairs.value, mfma=mfma.value, T=T.value, image_doubles=img.value,
+                    items=items.value)
+
+    def gram(self, st, rhs=None, sign=None, w=None):
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        sign = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+        k = 0
+        if rhs is not None:
+            rhs = np.ascontiguousarray(rhs, dtype=np.float64).reshape(S * self.rows, -1)
+            k = rhs.shape[1]
+        w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        G = np.zeros((self.cols + k, self.cols + k))
+        lib().emul_gram(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
+                        _d(rhs), int(k), _d(w), _d(G))
+        return G
