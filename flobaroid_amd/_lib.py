@@ -109,6 +109,13 @@ def load_library():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  flobaroid_amd has no CPU fallback."
         )
+    # torch ships its own libamdhip64; if libfbr pulled in /opt/rocm's copy first, a later torch.cuda
+    # initialisation in the same process would see "No HIP GPUs".  Load torch's runtime first when torch
+    # is installed so both share one HIP runtime (torch is plumbing here, not a dependency of the C-ABI).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -717,15 +717,22 @@ extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, i
         if ((rc = m->g_tmp.ensure(rcount * sizeof(double)))) return rc;
         R = m->g_tmp.as<double>();
     }
+    const double *Rin_dev = nullptr;
     if (R_in) {
-        HIPCHK(hipMemcpyAsync(R, R_in, rcount * sizeof(double),
-                              out_mem == FBR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, m->stream));
-    } else {
-        HIPCHK(hipMemsetAsync(R, 0, rcount * sizeof(double), m->stream));
+        if (out_mem == FBR_HOST) {
+            HIPCHK(hipMemcpyAsync(R, R_in, rcount * sizeof(double), hipMemcpyHostToDevice, m->stream));
+            Rin_dev = R;
+        } else {
+            Rin_dev = R_in;
+        }
     }
+    auto tsqr_fail = [&](int code, const char *what) {
+        set_err(std::string(what) + ": " + fbr_tsqr_error());
+        return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
+    };
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
     if (S > 0) {
-        // materialise [Y | rhs] chunk by chunk (K1 + K2) and fold each chunk into R with the blocked
-        // Householder kernels of fbr_tsqr.h
+        // materialise Y chunk by chunk (K1 + K2) and fold each chunk into the per-workgroup factors
         const size_t per = (size_t)hm.rows * hm.cols;
         long ch = fbr_tsqr_chunk_samples(hm.rows, Pa);
         ch = std::min(ch, chunk_size(m, S));
@@ -736,18 +743,21 @@ extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, i
             const long cs = std::min(ch, S - s0);
             if ((rc = run_kin(m, d, s0, cs))) return rc;
             const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
-            hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                               d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, m->out_tmp.as<double>());
+            {
+                ProfScope ps(m, FBR_PROF_REGRESSOR);
+                hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
+                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, m->out_tmp.as<double>());
+            }
             HIPCHK(hipGetLastError());
             ProfScope ps(m, FBR_PROF_TSQR);
-            rc = fbr_tsqr_fold(m->tsqr, m->stream, cs * hm.rows, hm.cols, m->out_tmp.as<double>(), k,
-                               drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr, R,
-                               m->num_cus);
-            if (rc) {
-                set_err(std::string("tsqr fold: ") + fbr_tsqr_error());
-                return rc;
-            }
+            rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, cs * hm.rows, hm.cols, m->out_tmp.as<double>(), k,
+                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr);
+            if (rc) return tsqr_fail(rc, "tsqr fold");
         }
+    }
+    {
+        ProfScope ps(m, FBR_PROF_TSQR);
+        if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
     }
     return finish_output(m, R, R_out, rcount, out_mem);
 }
@@ -769,12 +779,10 @@ extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const 
         if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
         R = m->g_tmp.as<double>();
     }
-    if (R != da) HIPCHK(hipMemcpyAsync(R, da, cnt * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
-    // fold the n rows of R_b (a dense n x n block; its zero lower triangle costs nothing extra in accuracy)
-    rc = fbr_tsqr_fold(m->tsqr, m->stream, n, n, db, 0, nullptr, nullptr, R, m->num_cus);
-    if (rc) {
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, n, da, m->num_cus, n)) || (rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, n, n, db, 0, nullptr, nullptr)) ||
+        (rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) {
         set_err(std::string("tsqr merge: ") + fbr_tsqr_error());
-        return rc;
+        return rc == -4 ? FBR_E_UNSUPPORTED : (rc == -3 ? FBR_E_HIP : FBR_E_INVALID);
     }
     return finish_output(m, R, R_out, cnt, mem);
 }

@@ -1,0 +1,121 @@
+"""Estimators fed by the fused GPU reductions (consumer side of the hot path).
+
+The reference solves its least-squares problems on the materialised tall matrix
+(``identifier.py:683-737``, ``sdp.py:456-487``).  Every quantity it derives there is a function of the
+small reductions the GPU pass returns:
+
+    G_aug = [YStd | tau | cf]^T [YStd | tau | cf]           (fbr_gram_accumulate)
+    R_aug with R_aug^T R_aug = G_aug, computed without squaring (fbr_tsqr)
+
+so the functions below reproduce the reference's results from (P+k) x (P+k) inputs, with the same
+LAPACK semantics (cut-offs relative to the TALL row count, sign conventions of numpy.linalg.qr).
+"""
+from __future__ import annotations
+
+import numpy as np
+import numpy.linalg as la
+import scipy.linalg as sla
+
+
+def select_aug(M_aug: np.ndarray, cols, P: int) -> np.ndarray:
+    """Rows/columns of an augmented (P+k) matrix for the identified columns ``cols`` plus all k rhs columns."""
+    k = M_aug.shape[0] - P
+    sel = np.concatenate((np.asarray(cols, dtype=np.int64), np.arange(P, P + k)))
+    return M_aug[np.ix_(sel, sel)]
+
+
+def r_from_gram(G: np.ndarray) -> np.ndarray:
+    """Upper-triangular R with R^T R = G for a (possibly rank-deficient) PSD Gram, via eigen-decomposition
+    + QR (no Cholesky breakdown).  Accuracy is limited to sqrt(eps)*||Y|| -- prefer the TSQR factor."""
+    w, V = la.eigh((G + G.T) * 0.5)
+    w = np.clip(w, 0.0, None)
+    return la.qr((V * np.sqrt(w)).T, mode="r")
+
+
+def qr_subset(R_aug: np.ndarray, cols, P: int) -> np.ndarray:
+    """R factor (positive diagonal) of [YStd[:, cols] | rhs] from the full augmented factor:
+    qr(R_aug[:, subset]) -- a (P+k) x (nb+k) host problem."""
+    k = R_aug.shape[0] - P
+    sel = np.concatenate((np.asarray(cols, dtype=np.int64), np.arange(P, P + k)))
+    R = la.qr(R_aug[:, sel], mode="r")
+    sgn = np.sign(np.diag(R))
+    sgn[sgn == 0] = 1.0
+    return R * sgn[:, None]
+
+
+def lstsq_from_R(Rb_aug: np.ndarray, nb: int, rhs_col: int, num_rows: int):
+    """``numpy.linalg.lstsq(YBase, tau)`` (identifier.py:712) from the factor of [YBase | rhs...].
+
+    rcond follows NumPy's default on the TALL problem: eps * max(M, N) with M = num_rows."""
+    R1 = Rb_aug[:nb, :nb]
+    z = Rb_aug[:nb, nb + rhs_col]
+    U, s, Vt = la.svd(R1)
+    rcond = np.finfo(np.float64).eps * max(num_rows, nb)
+    keep = s > rcond * s[0]
+    x = Vt[keep].T @ ((U[:, keep].T @ z) / s[keep])
+    return x, s
+
+
+def pinv_apply_from_R(Rb_aug: np.ndarray, nb: int, rhs_col: int):
+    """``numpy.linalg.pinv(YBase).dot(v)`` (identifier.py:709,718) for a rhs column v of the augmented matrix
+    (pinv default cut-off: 1e-15 * s_max)."""
+    R1 = Rb_aug[:nb, :nb]
+    z = Rb_aug[:nb, nb + rhs_col]
+    U, s, Vt = la.svd(R1)
+    keep = s > 1e-15 * s[0]
+    return Vt[keep].T @ ((U[:, keep].T @ z) / s[keep])
+
+
+def identify_base_parameters(R_aug: np.ndarray, independent_cols, P: int, num_rows: int, add_contacts: bool = True):
+    """xBase exactly as ``Identification.identifyBaseParameters`` computes it (identifier.py:709-718) from the
+    augmented factor of [YStd | tau | contactForcesSum]."""
+    nb = len(independent_cols)
+    Rb = qr_subset(R_aug, independent_cols, P)
+    xBase, s = lstsq_from_R(Rb, nb, 0, num_rows)
+    if add_contacts and Rb.shape[1] > nb + 1:
+        xBase = xBase - pinv_apply_from_R(Rb, nb, 1)
+    return xBase, Rb, s
+
+
+def residual_sq_from_R(Rb_aug: np.ndarray, nb: int, x: np.ndarray, rhs_cols=(0,), signs=(1.0,)) -> float:
+    """|| sum_i signs[i]*rhs_i - YBase x ||^2 from the augmented factor (used for rho2, sdp.py:482-485, and for
+    sigma_rho, identifier.py:357-358): the norm of R_aug [ -x ; signs ]."""
+    k = Rb_aug.shape[1] - nb
+    v = np.zeros(nb + k)
+    v[:nb] = -np.asarray(x)
+    for c, sg in zip(rhs_cols, signs):
+        v[nb + c] = sg
+    return float(np.sum((Rb_aug @ v) ** 2))
+
+
+def std_dev_for_params(Rb_aug: np.ndarray, nb: int, xBase: np.ndarray, rho: float, num_rows: int) -> np.ndarray:
+    """Relative standard deviations p_sigma_x (identifier.py:343-370): C_xx = sigma_rho * pinv(YBase^T YBase)."""
+    sigma_rho = rho / (num_rows - nb)
+    R1 = Rb_aug[:nb, :nb]
+    C = sigma_rho * sla.pinv(R1.T @ R1)
+    p = np.sqrt(np.diag(C))
+    nz = xBase != 0
+    p[nz] /= np.abs(xBase[nz])
+    return p
+
+
+def sdp_inputs(R_aug: np.ndarray, independent_cols, K: np.ndarray, P: int, xBase: np.ndarray):
+    """What ``SDP.identifyFeasibleStandardParameters`` derives from ``la.qr(YBase)`` (sdp.py:470-487):
+    R1 (sign-normalised, the objective is invariant to row sign flips), rho1 = Q1^T tau,
+    contactForces = Q1^T cf, rho2_norm_sqr = ||tau - cf - YBase xBase||^2 and R1 @ K."""
+    nb = len(independent_cols)
+    Rb = qr_subset(R_aug, independent_cols, P)
+    R1 = Rb[:nb, :nb].copy()
+    rho1 = Rb[:nb, nb].copy()
+    k = Rb.shape[1] - nb
+    cf = Rb[:nb, nb + 1].copy() if k > 1 else np.zeros(nb)
+    if k > 1:
+        rho2 = residual_sq_from_R(Rb, nb, xBase, rhs_cols=(0, 1), signs=(1.0, -1.0))
+    else:
+        rho2 = residual_sq_from_R(Rb, nb, xBase)
+    return {"R1": R1, "rho1": rho1, "contactForces": cf, "rho2_norm_sqr": rho2, "R1_K": R1 @ K}
+
+
+def find_std_from_base(K: np.ndarray, xBase: np.ndarray) -> np.ndarray:
+    """``findStdFromBaseParameters`` (identifier.py:328-341): xStd = pinv(K) xBase."""
+    return la.pinv(K).dot(xBase)

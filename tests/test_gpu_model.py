@@ -1,0 +1,151 @@
+"""GPU tests of the Model/Data work-alikes: the drop-in surface against a reference-shaped pipeline built
+from the oracle (per-sample loop semantics of identification/model.py:333-632)."""
+import os
+
+import numpy as np
+import numpy.linalg as la
+import pytest
+
+from common import ROBOTS, load_topo, random_states
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(**kw):
+    o = dict(floatingBase=0, identifyFrictionSimultaneously=0, identifySymmetricVelFriction=1, identifyGravityParamsOnly=0,
+             simulateTorques=0, useAPriori=0, useStructuralRegressor=1, skipSamples=0, startOffset=0, verbose=0, showTiming=0,
+             filterRegressor=0, estimateWith="std", randomSamples=2000, minTol=1e-4, selectBlocksFromMeasurements=0)
+    o.update(kw)
+    return o
+
+
+def _synth(topo, S, seed, floating, noise=0.05):
+    """tests/test_identification.py:25-93 shaped generator (rng seed, limits, noise) on the oracle."""
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(seed)
+    st = random_states(topo, S, rng, floating, use_limits=True)
+    om = OracleModel(topo, floating=floating)
+    tau = om.inverse_dynamics(st, topo.x_std())
+    tau = tau + rng.normal(0, noise, tau.shape)
+    d = {"positions": st["q"], "velocities": st["dq"], "accelerations": st["ddq"], "torques": tau[:, 6:] if floating else tau,
+         "times": np.arange(S) / 200.0}
+    if floating:
+        d.update(base_velocity=st["base_vel"], base_acceleration=st["base_acc"], base_rpy=st["rpy"])
+    return d, st, tau
+
+
+def test_kuka_ols_pipeline_matches_reference_thresholds(tmp_path):
+    """The reference's own end-to-end pin (tests/test_identification.py:141-164): OLS on 2000 seeded synthetic
+    KUKA samples, base-parameter error < 5 %, torque residual < 1 %; plus parity of every array against the
+    oracle-built pipeline."""
+    from flobaroid_amd import estimation as est
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model
+    from oracle.oracle import OracleModel
+
+    path = str(tmp_path / "kuka_lwr4.topology.json")
+    topo = load_topo("kuka_lwr4")
+    topo.save_json(path)
+    opt = _opt(randomSamples=5000)
+    np.random.seed(123)
+    model = Model(opt, path)
+    assert model.num_base_params == 43 and model.num_links == 8 and model.N_OUT == 7
+    assert os.path.exists(path + ".regressor.npz")
+    assert model.non_id == list(range(19)) + [20, 22]
+    meas, st, tau_full = _synth(topo, 2000, 42, 0)
+    data = Data(opt)
+    data.init_from_data(meas)
+    model.computeRegressors(data)
+    om = OracleModel(topo)
+    Yo = om.regressor(st)
+    assert np.abs(model.YStd - Yo).max() <= 1e-11 * np.abs(Yo).max()
+    assert np.array_equal(model.YBase, model.YStd[:, model.independent_cols])
+    assert np.allclose(model.YBase, model.YStd @ model.Pb, rtol=0, atol=0)
+    assert np.array_equal(model.tau, meas["torques"].reshape(-1))
+    # reference estimator on the materialised matrices
+    xBase_ref = la.lstsq(model.YBase, model.tau, rcond=None)[0]
+    xBaseModel = model.K.dot(model.xStdModel[model.identified_params])
+    rel = la.norm(xBase_ref - xBaseModel) / la.norm(xBaseModel)
+    assert rel < 0.05
+    xStd = la.pinv(model.K).dot(xBase_ref)
+    tauEst = model.YStd.dot(xStd)
+    resid = la.norm(tauEst - model.tau) * 100 / la.norm(model.tau)
+    assert resid < 1.0
+    # same numbers from the fused reductions (no tall matrix)
+    A = np.column_stack([Yo, model.tau, model.contactForcesSum])
+    assert la.norm(model.G_aug - A.T @ A) <= 1e-11 * la.norm(A.T @ A)
+    R_aug = model.engine.tsqr(model._states, rhs=np.stack((model.tau, model.contactForcesSum), axis=1))
+    xB, Rb, s = est.identify_base_parameters(R_aug, model.independent_cols, model.num_identified_params, Yo.shape[0])
+    assert la.norm(xB - xBase_ref) <= 1e-9 * la.norm(xBase_ref)
+    xStd2 = est.find_std_from_base(model.K, xB)
+    assert la.norm(xStd2 - xStd) <= 1e-6 * la.norm(xStd)  # north_star tolerance on identified standard parameters
+    pred = model.engine.predict(model._states, xStd2).reshape(-1)
+    assert la.norm(pred - tauEst) <= 1e-9 * la.norm(tauEst)
+
+
+def test_threelinks_floating_data_driven_base(tmp_path):
+    """configs/threeLinks.yaml shape: floating base, useStructuralRegressor=0 (pivoted QR of the data regressor,
+    model.py:598-601, 841), simulated base wrench prepended to joint-only torques (model.py:398-413)."""
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model
+    from oracle.oracle import OracleModel, lin_deps_qr
+
+    path = str(tmp_path / "threeLinks.topology.json")
+    topo = load_topo("threeLinks")
+    topo.save_json(path)
+    opt = _opt(floatingBase=1, useStructuralRegressor=0, minTol=1e-4, randomSamples=2000)
+    np.random.seed(5)
+    model = Model(opt, path)
+    assert model.num_base_params == 24
+    meas, st, tau_full = _synth(topo, 2000, 7, 1, noise=0.0)
+    data = Data(opt)
+    data.init_from_data(meas)
+    model.computeRegressors(data)
+    om = OracleModel(topo, floating=1)
+    Yo = om.regressor(st)
+    assert np.abs(model.YStd - Yo).max() <= 1e-11 * np.abs(Yo).max()
+    assert la.norm(model.tauMeasured - tau_full) <= 1e-10 * la.norm(tau_full)
+    d = lin_deps_qr(Yo, opt["minTol"])
+    # bit-exact base-parameter index set vs the reference algorithm on the oracle's matrix
+    assert model.num_base_params == d["r"]
+    assert sorted(model.independent_cols.tolist()) == sorted(d["independent_cols"].tolist())
+    assert np.array_equal(model.independent_cols, d["independent_cols"])
+
+
+def test_walkman_floating_contacts_and_friction(tmp_path):
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model
+    from oracle.oracle import OracleModel
+
+    path = str(tmp_path / "walkman_left_arm.topology.json")
+    topo = load_topo("walkman_left_arm")
+    topo.save_json(path)
+    opt = _opt(floatingBase=1, identifyFrictionSimultaneously=1, randomSamples=1500, skipSamples=1)
+    np.random.seed(9)
+    model = Model(opt, path)
+    assert model.num_identified_params == 90 + 21
+    S = 400
+    rng = np.random.default_rng(3)
+    st = random_states(topo, S, rng, 1, use_limits=True)
+    frame = list(topo.frames)[1]
+    cw = rng.standard_normal((S, 6))
+    meas = {"positions": st["q"], "velocities": st["dq"], "accelerations": st["ddq"], "torques": rng.standard_normal((S, 7)),
+            "base_velocity": st["base_vel"], "base_acceleration": st["base_acc"], "base_rpy": st["rpy"],
+            "times": np.arange(S) / 100.0, "contacts": np.array({frame: cw})}
+    data = Data(opt)
+    data.init_from_data(meas)
+    assert data.num_used_samples == S // 2
+    model.computeRegressors(data)
+    idx = np.arange(S // 2) * 2
+    sub = {k: v[idx] for k, v in st.items()}
+    sign = np.tanh(sub["dq"] / 0.02)
+    om = OracleModel(topo, floating=1, fric=1, fric_sym=1)
+    Yo = om.regressor(sub, sign)
+    assert np.abs(model.YStd - Yo).max() <= 1e-11 * np.abs(Yo).max()
+    cf = om.contact_torques(sub, frame, cw[idx]).reshape(-1)
+    assert la.norm(model.contactForcesSum - cf) <= 1e-11 * la.norm(cf)
+    sim = om.inverse_dynamics(sub, model.xStdModel, sign, sub["dq"])
+    expect = np.concatenate((sim[:, :6], meas["torques"][idx]), axis=1)
+    expect[:, :6] += cf.reshape(-1, 13)[:, :6]
+    assert la.norm(model.tauMeasured - expect) <= 1e-10 * la.norm(expect)

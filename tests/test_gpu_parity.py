@@ -116,3 +116,74 @@ def test_device_pointers_and_chunking():
     assert np.linalg.norm(G.cpu().numpy() - Go) <= 1e-11 * np.linalg.norm(Go)
     Y = eng.regressor(dst)
     assert np.abs(Y.cpu().numpy() - Yo).max() <= 1e-11 * np.abs(Yo).max()
+
+
+def _aug(om, st, rhs, w=None):
+    Yo = om.regressor(st, st["sign"])
+    A = Yo if rhs is None else np.hstack([Yo, rhs])
+    if w is not None:
+        A = A * w[:, None]
+    return A
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[3], CONFIGS[6], CONFIGS[7]], ids=cfg_id)
+def test_tsqr_matches_householder_reference(cfg):
+    """R^T R = A^T A to rounding, R upper triangular, and on a full-rank column subset R agrees with
+    numpy.linalg.qr of the materialised matrix (the reference's la.qr(YBase), sdp.py:470) up to row signs."""
+    from flobaroid_amd import estimation as est
+    from oracle.oracle import lin_deps_qr
+
+    t, eng, om = _engine_oracle(cfg)
+    S = 700 if t.num_links > 10 else 1500
+    st, rng = _states(t, cfg, S, 11)
+    rhs = rng.standard_normal((S * om.rows, 2))
+    A = _aug(om, st, rhs)
+    R = eng.tsqr(st, rhs=rhs)
+    assert np.all(np.tril(R, -1) == 0.0)
+    G = A.T @ A
+    assert np.linalg.norm(R.T @ R - G) <= 1e-12 * np.linalg.norm(G)
+    # full-rank subset: the structural base columns + the rhs columns
+    d = lin_deps_qr(G[: om.P, : om.P], 1e-6 * np.abs(G).max())
+    ic = d["independent_cols"]
+    Rb = est.qr_subset(R, ic, om.P)
+    Rn = np.linalg.qr(A[:, np.concatenate((ic, [om.P, om.P + 1]))], mode="r")
+    Rn = Rn * np.where(np.diag(Rn) < 0, -1.0, 1.0)[:, None]
+    assert np.linalg.norm(Rb - Rn) <= 1e-9 * np.linalg.norm(Rn)
+
+
+def test_tsqr_streaming_weights_and_merge():
+    cfg = CONFIGS[3]
+    t, eng, om = _engine_oracle(cfg)
+    S = 900
+    st, rng = _states(t, cfg, S, 12)
+    w = rng.random(S * om.rows) + 0.5
+    A = _aug(om, st, None, w)
+    G = A.T @ A
+    half = S // 2
+    st1 = {k: v[:half] for k, v in st.items()}
+    st2 = {k: v[half:] for k, v in st.items()}
+    R1 = eng.tsqr(st1, w=w[: half * om.rows])
+    R12 = eng.tsqr(st2, w=w[half * om.rows:], R_in=R1)
+    assert np.linalg.norm(R12.T @ R12 - G) <= 1e-12 * np.linalg.norm(G)
+    R2 = eng.tsqr(st2, w=w[half * om.rows:])
+    Rm = eng.tsqr_merge(R1, R2)
+    assert np.all(np.tril(Rm, -1) == 0.0)
+    assert np.linalg.norm(Rm.T @ Rm - G) <= 1e-12 * np.linalg.norm(G)
+
+
+def test_tsqr_keeps_small_singular_directions():
+    """The reason TSQR exists: a column that is nearly dependent (1e-9 relative) keeps its tiny pivot in R,
+    while the Gram route loses it (sqrt(eps) * ||A||)."""
+    cfg = CONFIGS[2]
+    t, eng, om = _engine_oracle(cfg)
+    S = 600
+    st, rng = _states(t, cfg, S, 13)
+    Yo = om.regressor(st, st["sign"])
+    base = Yo[:, 29]
+    rhs = (base + 1e-9 * rng.standard_normal(base.shape) * np.abs(base).max()).reshape(-1, 1)
+    R = eng.tsqr(st, rhs=rhs)
+    A = np.hstack([Yo, rhs])
+    sel = [29, om.P]
+    Rs = np.linalg.qr(R[:, sel], mode="r")
+    Rn = np.linalg.qr(A[:, sel], mode="r")
+    assert abs(abs(Rs[1, 1]) - abs(Rn[1, 1])) <= 1e-4 * abs(Rn[1, 1])
