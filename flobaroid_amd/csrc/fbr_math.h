@@ -9,7 +9,7 @@
 // angular velocity/acceleration and the PROPER linear acceleration of the link origin in link axes.
 //
 // The functions are __host__ __device__ so tests can compile this header with g++ and check the
-// device arithmetic on the CPU against the oracle (tests/emul/).
+// device arithmetic on the CPU (tests/emul/).
 #pragma once
 
 #if defined(__HIPCC__)

@@ -1,0 +1,58 @@
+"""CPU emulation of the HIP kernels' data flow (same headers as the kernels) against the oracle (no GPU)."""
+import numpy as np
+import pytest
+
+from common import CONFIGS, cfg_id, load_topo, random_states
+from emul_lib import Emul
+from oracle.oracle import OracleModel
+
+
+def _setup(cfg, S, seed):
+    name, fl, fr, sym, grav, strb = cfg
+    t = load_topo(name)
+    om = OracleModel(t, floating=fl, fric=fr, fric_sym=sym, grav_only=grav, stribeck=strb)
+    em = Emul(t, floating=fl, fric=fr, fric_sym=sym, grav_only=grav, stribeck=strb)
+    rng = np.random.default_rng(seed)
+    st = random_states(t, S, rng, fl)
+    sign = np.tanh(st["dq"] / 0.02)
+    return t, om, em, st, sign, rng
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=cfg_id)
+def test_device_math_matches_oracle(cfg):
+    t, om, em, st, sign, rng = _setup(cfg, 25, 1)
+    assert (em.rows, em.cols) == (om.rows, om.P)
+    Y = om.regressor(st, sign)
+    Ye = em.regressor(st, sign)
+    assert np.abs(Y - Ye).max() <= 1e-13 * np.abs(Y).max()
+    x = np.concatenate([t.x_std(), rng.random(om.P + 4 * t.num_dofs)])
+    tau = om.inverse_dynamics(st, x, sign, 0.9 * st["dq"])
+    te = em.inverse_dynamics(st, x, sign, 0.9 * st["dq"])
+    assert np.abs(tau - te).max() <= 1e-13 * np.abs(tau).max()
+    xi = rng.standard_normal(om.P)
+    tp = em.inverse_dynamics(st, xi, sign, mode=1)
+    assert np.abs(tp.reshape(-1) - Y @ xi).max() <= 1e-12 * np.abs(Y @ xi).max()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=cfg_id)
+@pytest.mark.parametrize("k", [0, 3])
+def test_tile_program_reproduces_gram(cfg, k):
+    t, om, em, st, sign, rng = _setup(cfg, 12, 2)
+    Y = om.regressor(st, sign)
+    rhs = rng.standard_normal((Y.shape[0], k)) if k else None
+    w = rng.random(Y.shape[0]) + 0.5
+    A = (Y if rhs is None else np.hstack([Y, rhs])) * w[:, None]
+    G = em.gram(st, rhs, sign, w)
+    assert np.linalg.norm(G - A.T @ A) <= 1e-13 * np.linalg.norm(A.T @ A)
+    info = em.program_info(k)
+    dense = ((om.P + k + 15) // 16) * ((om.P + k + 15) // 16 + 1) // 2 * ((om.rows + 3) // 4)
+    assert info["mfma"] <= dense * 1.35  # the chain packing must never cost much more than the dense tiling
+    assert info["image_doubles"] * 8 <= 120 * 1024
+
+
+def test_walkman_program_is_sparse():
+    t = load_topo("walkman_apriori")
+    em = Emul(t, floating=True)
+    info = em.program_info(1)
+    assert info["mfma"] < 0.4 * 4185  # vs 31*32/2 tiles x 9 k-steps of the dense tiling
+    assert info["T"] * 80 >= info["npairs"]

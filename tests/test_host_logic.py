@@ -1,0 +1,174 @@
+"""Host logic of the drop-in layer that needs no GPU: Data container, friction helpers, parameter layout,
+base-parameter reduction on a given regressor, estimators from the small reductions."""
+import json
+import os
+
+import numpy as np
+import numpy.linalg as la
+import pytest
+
+from common import GOLDEN, ROBOTS, load_topo, random_states
+from flobaroid_amd import estimation as est
+from flobaroid_amd import helpers
+from flobaroid_amd.data import Data
+from flobaroid_amd.model import Model
+from oracle.oracle import OracleModel, lin_deps_qr
+
+
+def _opt(**kw):
+    o = dict(floatingBase=0, identifyFrictionSimultaneously=0, identifySymmetricVelFriction=1, identifyGravityParamsOnly=0,
+             simulateTorques=0, useAPriori=0, useStructuralRegressor=1, skipSamples=0, startOffset=0, verbose=0, showTiming=0,
+             filterRegressor=0, estimateWith="std", randomSamples=100, minTol=1e-4, selectBlocksFromMeasurements=0)
+    o.update(kw)
+    return o
+
+
+def _meas(S, n, rng, t0=0.0):
+    return {"positions": rng.random((S, n)), "velocities": rng.random((S, n)), "accelerations": rng.random((S, n)),
+            "torques": rng.random((S, n)), "times": t0 + np.arange(S) * 0.01, "frequency": np.array(100.0)}
+
+
+def test_data_container(tmp_path):
+    """file_boundaries == [0, n] / [0, n, 2n] (tests/test_data.py:23-45), startOffset, skipSamples, times re-basing."""
+    rng = np.random.default_rng(0)
+    f1, f2 = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    np.savez(f1, **_meas(50, 3, rng))
+    np.savez(f2, **_meas(50, 3, rng))
+    d = Data(_opt())
+    d.init_from_files([[f1]])
+    assert d.file_boundaries == [0, 50] and d.num_loaded_samples == 50 and d.num_used_samples == 50 and d.inited
+    d2 = Data(_opt(startOffset=5, skipSamples=1))
+    d2.init_from_files([[f1, f2]])
+    assert d2.file_boundaries == [0, 45, 90] and d2.num_loaded_samples == 90 and d2.num_used_samples == 45
+    assert np.all(np.diff(d2.samples["times"]) > 0)
+    d3 = Data(_opt(skipSamples=2))
+    d3.init_from_data(_meas(10, 3, rng))
+    assert d3.num_used_samples == 3
+    with pytest.raises(KeyError, match="missing required key"):
+        Data(_opt()).init_from_data({"positions": np.zeros((3, 2))})
+
+
+def test_friction_sign_helpers():
+    """tests/test_friction_helpers.py:27-83: tanh(v/thr) identity, caching, raw-velocity filtering, fallbacks."""
+    rng = np.random.default_rng(1)
+    S = 400
+    t = np.arange(S) / 200.0
+    v = np.column_stack([np.sin(2 * np.pi * 1.0 * t), np.cos(2 * np.pi * 0.5 * t)])
+    raw = v + 0.05 * rng.standard_normal(v.shape)
+    opt = {"frictionSignThreshold": 0.05, "frictionVelocityCutoff": 10.0}
+    s = {"velocities": v.copy(), "velocities_raw": raw, "frequency": np.array(200.0)}
+    sign = helpers.getFrictionSignSeries(s, opt)
+    assert "velocities_for_sign" in s and "friction_sign_series" in s
+    assert np.array_equal(sign, np.tanh(s["velocities_for_sign"] / 0.05))
+    # the low-pass of the raw signal is closer to the truth than the raw signal itself
+    assert np.sqrt(np.mean((s["velocities_for_sign"] - v) ** 2)) < 0.6 * np.sqrt(np.mean((raw - v) ** 2))
+    assert helpers.getFrictionSignSeries(s, opt) is sign  # cached
+    s2 = {"velocities": v.copy()}
+    assert np.array_equal(helpers.getFrictionSignSeries(s2, opt), np.tanh(v / 0.05))  # no raw data -> pipeline velocities
+    s3 = {"velocities": v.copy(), "velocities_raw": raw, "frequency": np.array(15.0)}
+    assert helpers.getFrictionSignVelocities(s3, opt) is s3["velocities"]  # cutoff above Nyquist
+
+
+def test_model_layout_and_apriori_vector():
+    g = json.load(open(os.path.join(GOLDEN, "kuka_tutorial_apriori.json")))
+    path = os.path.join(ROBOTS, "kuka_lwr4.topology.json")
+    m = Model(_opt(identifyFrictionSimultaneously=1), path, regressor_init=False)
+    assert (m.num_dofs, m.num_links, m.N_OUT) == (7, 8, 7)
+    assert (m.num_model_params, m.num_all_params, m.num_identified_params, m.friction_params_start) == (80, 101, 101, 80)
+    assert np.abs(m.xStdModel - np.array(g["xStdModel"])).max() <= 5e-9  # all 101 entries of the TUTORIAL table
+    assert m.jointNames == [f"lwr_{i}_joint" for i in range(7)]
+    assert m.getDescriptionOfParameters().splitlines()[13] == "Parameter 13: first moment of mass (z) of link lwr_1_link"
+    m2 = Model(_opt(identifyFrictionSimultaneously=1, identifySymmetricVelFriction=0, stribeckVelocity=0.1, floatingBase=1),
+               path, regressor_init=False)
+    assert (m2.num_all_params, m2.num_identified_params, m2.N_OUT) == (80 + 5 * 7, 80 + 5 * 7, 13)
+    assert np.allclose(m2.xStdModel[80 + 4 * 7:], 0.6 * np.abs(m2.xStdModel[80:87]))
+    m3 = Model(_opt(identifyFrictionSimultaneously=1, identifyGravityParamsOnly=1), path, regressor_init=False)
+    assert (m3.num_identified_params, m3.friction_params_start, m3.num_all_params) == (32 + 7, 32, 87)
+    w = Model(_opt(floatingBase=1), os.path.join(ROBOTS, "walkman_apriori.topology.json"), regressor_init=False)
+    assert (w.num_links, w.num_model_params, w.N_OUT) == (48, 480, 35)
+
+
+def test_lin_deps_qr_on_given_regressor_matches_reference_algorithm():
+    """computeRegressorLinDepsQR(regressor) = model.py:841-894 on the oracle's data regressor: bit-exact index set."""
+    path = os.path.join(ROBOTS, "kuka_lwr4.topology.json")
+    t = load_topo("kuka_lwr4")
+    rng = np.random.default_rng(4)
+    st = random_states(t, 300, rng, 0, use_limits=True)
+    om = OracleModel(t, fric=1, fric_sym=True)
+    Y = om.regressor(st, np.tanh(st["dq"] / 0.02))
+    m = Model(_opt(identifyFrictionSimultaneously=1), path, regressor_init=False)
+    m.computeRegressorLinDepsQR(Y)
+    d = lin_deps_qr(Y, 1e-4)
+    assert m.num_base_params == d["r"] == 64 and m.num_base_inertial_params == 57
+    assert np.array_equal(m.independent_cols, d["independent_cols"]) and np.array_equal(m.P, d["P"])
+    assert np.array_equal(m.K, d["K"]) and np.array_equal(m.Pb, d["Pb"]) and np.array_equal(m.linear_deps, d["linear_deps"])
+    assert m.non_id == list(range(19)) + [20, 22]
+    assert m.identifiable == [p for p in range(101) if p not in m.non_id]
+    assert len(m.identified_params) == 101
+    assert np.allclose(Y @ m.Pb, Y[:, m.independent_cols], rtol=0, atol=0)
+    # the lazily built symbolic bookkeeping agrees with the numeric non_id rule (model.py:1041-1052)
+    deps = m.base_deps
+    syms = set()
+    for i in range(deps.shape[0]):
+        syms |= deps[i].free_symbols
+    assert [p for p in range(m.num_all_params) if m.param_syms[p] not in syms] == m.non_id
+
+
+def test_estimators_from_small_reductions_match_the_tall_problem():
+    t = load_topo("walkman_left_arm")
+    rng = np.random.default_rng(5)
+    st = random_states(t, 500, rng, 1, use_limits=True)
+    om = OracleModel(t, floating=1)
+    Y = om.regressor(st)
+    tau = om.inverse_dynamics(st, t.x_std()).reshape(-1) + 0.05 * rng.standard_normal(Y.shape[0])
+    cf = 0.3 * rng.standard_normal(Y.shape[0])
+    d = lin_deps_qr(Y.T @ Y, 1e-4)
+    ic, K = d["independent_cols"], d["K"]
+    nb = len(ic)
+    assert nb == 59
+    YB = Y[:, ic]
+    x_ref = la.lstsq(YB, tau, rcond=None)[0] - la.pinv(YB).dot(cf)
+    R_aug = la.qr(np.column_stack([Y, tau, cf]), mode="r")
+    xB, Rb, s = est.identify_base_parameters(R_aug, ic, 90, Y.shape[0])
+    assert la.norm(xB - x_ref) <= 1e-10 * la.norm(x_ref)
+    assert np.allclose(s, la.svd(YB, compute_uv=False), rtol=1e-10)
+    Q, R = la.qr(YB)
+    sg = np.where(np.diag(R) < 0, -1.0, 1.0)
+    si = est.sdp_inputs(R_aug, ic, K, 90, xB)
+    assert la.norm(si["R1"] - R * sg[:, None]) <= 1e-10 * la.norm(R)
+    assert la.norm(si["rho1"] - (Q.T @ tau) * sg) <= 1e-10 * la.norm(tau)
+    assert la.norm(si["contactForces"] - (Q.T @ cf) * sg) <= 1e-9 * la.norm(cf)
+    assert abs(si["rho2_norm_sqr"] - la.norm(tau - cf - YB @ xB) ** 2) <= 1e-9 * la.norm(tau) ** 2
+    assert la.norm(si["R1_K"] - (R * sg[:, None]) @ K) <= 1e-10 * la.norm(R @ K)
+    rho = la.norm(tau - YB @ xB) ** 2
+    p = est.std_dev_for_params(Rb, nb, xB, rho, Y.shape[0])
+    import scipy.linalg as sla
+
+    C = rho / (Y.shape[0] - nb) * sla.pinv(YB.T @ YB)
+    pref = np.sqrt(np.diag(C)) / np.abs(xB)
+    assert np.allclose(p, pref, rtol=1e-6)
+    xStd = est.find_std_from_base(K, xB)
+    assert np.allclose(K @ xStd, xB, atol=1e-9 * la.norm(xB))
+    Rg = est.r_from_gram(R_aug.T @ R_aug)
+    xg, _, _ = est.identify_base_parameters(Rg, ic, 90, Y.shape[0])
+    assert la.norm(xg - x_ref) <= 1e-6 * la.norm(x_ref)
+
+
+def test_random_state_generator_follows_reference_call_order():
+    """getRandomRegressor draws per sample rand(n) x3 [, rand(6), rand(6), ranf(3)] from the GLOBAL numpy RNG
+    (model.py:696-725): same seed -> same states."""
+    path = os.path.join(ROBOTS, "threeLinks.topology.json")
+    m = Model(_opt(floatingBase=1), path, regressor_init=False)
+    np.random.seed(77)
+    st = m._random_states(3)
+    np.random.seed(77)
+    lim = m.limits
+    lo = np.array([lim[j]["lower"] for j in m.jointNames]); hi = np.array([lim[j]["upper"] for j in m.jointNames])
+    vm = np.array([lim[j]["velocity"] for j in m.jointNames])
+    for i in range(3):
+        q = lo + (hi - lo) * np.random.rand(2)
+        dq = (np.random.rand(2) - 0.5) * 2 * vm
+        ddq = (np.random.rand(2) - 0.5) * 2 * np.pi
+        bv = np.pi * np.random.rand(6); ba = np.pi * np.random.rand(6); rpy = np.random.ranf(3) * 0.1
+        assert np.array_equal(st["q"][i], q) and np.array_equal(st["dq"][i], dq) and np.array_equal(st["ddq"][i], ddq)
+        assert np.array_equal(st["base_vel"][i], bv) and np.array_equal(st["base_acc"][i], ba) and np.array_equal(st["rpy"][i], rpy)

@@ -1,0 +1,77 @@
+"""Topology extractor against the documented known answers (no GPU)."""
+import json
+import os
+
+import numpy as np
+
+from common import GOLDEN, load_topo
+from flobaroid_amd.topology import Topology, parse_urdf
+
+_URDF = """<robot name="t">
+  <link name="world_box"/>
+  <joint name="fix0" type="fixed"><origin xyz="1 2 3" rpy="0 0 0.5"/><origin xyz="9 9 9"/><parent link="world_box"/><child link="a"/></joint>
+  <link name="a"><inertial><mass value="2"/><origin xyz="0.1 0 0" rpy="0 0 1.5707963267948966"/>
+     <inertia ixx="1" ixy="0" ixz="0" iyy="2" iyz="0" izz="3"/></inertial></link>
+  <link name="sensor"/>
+  <joint name="sj" type="fixed"><parent link="b"/><child link="sensor"/><origin xyz="0 0 0.1"/></joint>
+  <joint name="j2" type="revolute"><origin xyz="0 0 1"/><axis xyz="0 1 0.5"/><parent link="a"/><child link="b"/>
+     <limit effort="1" lower="-1" upper="2" velocity="3"/><dynamics damping="0.7" friction="0.2"/></joint>
+  <link name="b"><inertial><mass value="1"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial></link>
+  <joint name="j1" type="continuous"><parent link="a"/><child link="c"/></joint>
+  <link name="c"><inertial><mass value="0.5"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial></link>
+</robot>"""
+
+
+def test_parse_rules(tmp_path):
+    p = tmp_path / "t.urdf"
+    p.write_text(_URDF)
+    t = parse_urdf(str(p))
+    # fake root and fake leaf removed, document order kept, DOFs in document order of the movable joints
+    assert t.link_names == ["a", "b", "c"]
+    assert t.parent == [-1, 0, 0]
+    assert t.dof_names == ["j2", "j1"] and t.dof_index == [-1, 0, 1]
+    assert set(t.frames) == {"world_box", "sensor"} and t.frames["sensor"]["link"] == 1
+    assert np.allclose(np.linalg.norm(t.axis[1]), 1.0) and np.allclose(t.axis[1], np.array([0, 1, 0.5]) / np.sqrt(1.25))
+    assert np.allclose(t.axis[2], [1, 0, 0])  # URDF default axis
+    # inertial origin rpy rotates the inertia (90 deg about z swaps xx/yy), parallel axis to the link origin
+    assert np.allclose(t.params[0], [2, 0.2, 0, 0, 2, 0, 0, 1 + 2 * 0.01, 0, 3 + 2 * 0.01])
+    assert t.limits["j2"] == {"torque": 1.0, "lower": -1.0, "upper": 2.0, "velocity": 3.0}
+    assert "j1" not in t.limits  # only 'revolute' joints carry limits in the reference (helpers.py:907)
+    assert t.friction["j2"] == {"f_constant": 0.2, "f_velocity": 0.7}
+    # first <origin> wins; the fake root frame is the inverse of the joint origin
+    f = t.frames["world_box"]
+    assert f["link"] == 0 and np.allclose(f["R"] @ np.array([1, 2, 3.0]) + f["p"], 0)
+    t2 = Topology.from_dict(json.loads(json.dumps(t.to_dict())))
+    assert t2.link_names == t.link_names and np.array_equal(t2.params, t.params)
+    t3 = t.reordered_dofs(["j1", "j2"])
+    assert t3.dof_index == [-1, 1, 0]
+
+
+def test_kuka_apriori_vector_matches_tutorial_table():
+    """F9: documentation/TUTORIAL.md:60-160 prints xStdModel[0:101] to 8 decimals."""
+    g = json.load(open(os.path.join(GOLDEN, "kuka_tutorial_apriori.json")))
+    t = load_topo("kuka_lwr4")
+    x = t.x_std()
+    ref = np.array(g["xStdModel"])
+    assert x.shape == (80,)
+    assert np.abs(x - ref[:80]).max() <= 5.0e-9
+    fc = [t.friction[j]["f_constant"] for j in t.dof_names]
+    fv = [t.friction[j]["f_velocity"] for j in t.dof_names]
+    assert np.allclose(fc, ref[80:87]) and np.allclose(fv, ref[87:94]) and np.all(ref[94:] == 0)
+    assert t.link_names == ["lwr_base_link"] + [f"lwr_{i}_link" for i in range(1, 8)]
+    assert t.dof_names == [f"lwr_{i}_joint" for i in range(7)]
+    assert abs(t.params[:, 0].sum() - g["apriori_mass"]) < 1e-12
+
+
+def test_structure_counts():
+    s = json.load(open(os.path.join(GOLDEN, "structure.json")))
+    for name in ("threeLinks", "kuka_lwr4", "walkman_left_arm", "walkman_apriori"):
+        t = load_topo(name)
+        assert t.num_links == s[name]["links"] and t.num_dofs == s[name]["dofs"]
+        order = t.traversal()
+        pos = {l: i for i, l in enumerate(order)}
+        assert all(t.parent[l] < 0 or pos[t.parent[l]] < pos[l] for l in range(t.num_links))
+    w = load_topo("walkman_apriori")
+    assert abs(w.params[:, 0].sum() - s["walkman_apriori"]["mass"]) < 0.01
+    anc = w.ancestors_dofs()
+    assert sum(len(a) for a in anc) == 228 and max(len(a) for a in anc) == 10
