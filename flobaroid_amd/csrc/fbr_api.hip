@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -67,7 +68,9 @@ struct GramHolder {
     FbrGramProgram prog;
     DevGram dev;
     std::vector<DevBuf> pool;
-    size_t lds_bytes = 0;
+    DevBuf pimg;              // packed tile images of one chunk of samples (zeroed when (re)allocated)
+    size_t lds_bytes = 0;     // streaming Gram kernel
+    size_t pack_lds_bytes = 0;
 };
 
 struct fbr_model {
@@ -177,7 +180,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
     dm.fric = hm.fric; dm.grav_only = hm.grav_only; dm.fstart = hm.friction_start();
     for (int i = 0; i < 3; i++) dm.g[i] = hm.gravity[i];
     dm.stribeck = hm.stribeck;
-    std::vector<int> pathlen(hm.L), pathtab((size_t)hm.L * dm.maxd, 0);
+    std::vector<int> pathlen(hm.L), pathtab((size_t)hm.L * dm.maxd, 0), pathpos((size_t)hm.L * dm.maxd, 0);
     std::vector<unsigned> anc((size_t)hm.L * dm.nw, 0u);
     std::vector<std::vector<int>> sub(std::max(hm.n, 1));
     std::vector<int> dof_link(std::max(hm.n, 1), 0);
@@ -186,6 +189,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
         for (size_t j = 0; j < hm.path[l].size(); j++) {
             int d = hm.path[l][j];
             pathtab[(size_t)l * dm.maxd + j] = d;
+            pathpos[(size_t)l * dm.maxd + j] = hm.ppos[l][j];
             anc[(size_t)l * dm.nw + (d >> 5)] |= 1u << (d & 31);
             sub[d].push_back(l);
         }
@@ -209,6 +213,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
     if ((rc = upload(m->tables, hm.axis, &dm.axis))) return rc;
     if ((rc = upload(m->tables, pathlen, &dm.pathlen))) return rc;
     if ((rc = upload(m->tables, pathtab, &dm.pathtab))) return rc;
+    if ((rc = upload(m->tables, pathpos, &dm.pathpos))) return rc;
     if ((rc = upload(m->tables, anc, &dm.ancmask))) return rc;
     if ((rc = upload(m->tables, cd, &dm.coldesc))) return rc;
     if ((rc = upload(m->tables, sub_begin, &dm.sub_begin))) return rc;
@@ -223,8 +228,10 @@ extern "C" void fbr_model_destroy(fbr_model *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     for (auto &b : m->tables) b.release();
-    for (auto &kv : m->gram)
+    for (auto &kv : m->gram) {
         for (auto &b : kv.second->pool) b.release();
+        kv.second->pimg.release();
+    }
     DevBuf *bufs[] = {&m->st_q, &m->st_dq, &m->st_ddq, &m->st_bv, &m->st_ba, &m->st_rpy, &m->st_sign, &m->st_aux,
                       &m->st_aux2, &m->st_x, &m->rec, &m->partial, &m->out_tmp, &m->g_tmp};
     for (DevBuf *b : bufs) b->release();
@@ -565,48 +572,74 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     DevGram &dg = h->dev;
     memset(&dg, 0, sizeof(dg));
     dg.T = gp.T; dg.NT = gp.NT; dg.k = gp.k; dg.Pa = gp.Pa; dg.image_doubles = gp.image_doubles;
-    dg.rid_stride = 0;
-    if (gp.image_doubles > 1023 * 64 || m->hm.rows > 255) {
+    dg.part_image_max = gp.part_image_max;
+    dg.nitems = (int)gp.items.size();
+    if (gp.part_image_max > 1023 * 64 || m->hm.rows > 255) {
         set_err("model too large for the fused Gram tile image");
         return FBR_E_UNSUPPORTED;
     }
-    // image row -> global regressor row (identity inside dense tiles, path rows inside chain tiles)
-    std::vector<int> rowid((size_t)gp.image_doubles / FBR_TILE, 0);
-    for (int t = 0; t < gp.NT; t++)
-        for (size_t j = 0; j < gp.tiles[t].rowid.size(); j++) rowid[(size_t)gp.tiles[t].off / FBR_TILE + j] = gp.tiles[t].rowid[j];
-    dg.ntab = (int)rowid.size();
     std::vector<int4> items;
-    std::vector<int> item_begin(gp.T + 1, 0);
+    for (auto &it2 : gp.items) items.push_back(make_int4(it2.off, it2.kind, it2.a, it2.b));
+    // per part: DMA pieces and the part-image-row -> regressor-row map (identity in dense tiles)
+    std::vector<int2> pieces;
+    std::vector<int> piece_begin(gp.T + 1, 0), rid_begin(gp.T + 1, 0), ridl;
     for (int t = 0; t < gp.T; t++) {
-        item_begin[t] = (int)items.size();
-        for (auto &it2 : gp.items[t]) items.push_back(make_int4(it2.off, it2.kind, it2.a, it2.b));
+        piece_begin[t] = (int)pieces.size();
+        for (auto &pc : gp.pieces[t]) pieces.push_back(make_int2(pc.goff, pc.loff | (pc.half << 30)));
+        rid_begin[t] = (int)ridl.size();
+        std::vector<int> rl((size_t)gp.part_image_max / FBR_TILE, 0);
+        for (int ti : gp.part_tiles[t])
+            for (size_t j = 0; j < gp.tiles[ti].rowid.size(); j++) rl[(size_t)gp.part_tile_off[t][ti] / FBR_TILE + j] = gp.tiles[ti].rowid[j];
+        ridl.insert(ridl.end(), rl.begin(), rl.end());
     }
-    item_begin[gp.T] = (int)items.size();
+    piece_begin[gp.T] = (int)pieces.size();
+    rid_begin[gp.T] = (int)ridl.size();
     const size_t nslots = gp.slots.size();
-    std::vector<int> meta(nslots, 0);
+    std::vector<int> meta((size_t)gp.T * FBR_WPB * FBR_NSEG * 8, 0);
     std::vector<int> slot_tiles(2 * nslots, -1);
-    for (size_t s = 0; s < nslots; s++) {
-        int pi = gp.slots[s].pair;
-        if (pi < 0) continue;
-        const FbrPair &p = gp.pairs[pi];
-        const int offA = gp.tiles[p.I].off, offB = gp.tiles[p.J].off;
-        meta[s] = (offA / 64) | ((offB / 64) << 10) | (p.common << 20) | ((p.mode == 1 ? 1 : 0) << 28);
-        slot_tiles[2 * s] = p.I;
-        slot_tiles[2 * s + 1] = p.J;
-    }
+    for (int part = 0; part < gp.T; part++)
+        for (int w = 0; w < FBR_WPB; w++)
+            for (int sg = 0; sg < FBR_NSEG; sg++) {
+                int *mm = &meta[(((size_t)part * FBR_WPB + w) * FBR_NSEG + sg) * 8];
+                int cnt = 0, nkmax = 0, offA = 0;
+                for (int j = 0; j < FBR_SEGW; j++) {
+                    const size_t s = ((size_t)part * FBR_WPB + w) * FBR_NPW + sg * FBR_SEGW + j;
+                    const int pi = gp.slots[s].pair;
+                    if (pi < 0) continue;
+                    const FbrPair &p = gp.pairs[pi];
+                    offA = gp.part_tile_off[part][p.I];
+                    const int offB = gp.part_tile_off[part][p.J];
+                    mm[1 + j] = (offB / 64) | (p.common << 10) | ((p.mode == 1 ? 1 : 0) << 18);
+                    nkmax = std::max(nkmax, p.nk4());
+                    cnt++;
+                    slot_tiles[2 * s] = p.I;
+                    slot_tiles[2 * s + 1] = p.J;
+                }
+                mm[0] = (offA / 64) | (cnt << 10) | (nkmax << 14);
+            }
     std::vector<int> tilecol((size_t)gp.NT * FBR_TILE);
     for (int t = 0; t < gp.NT; t++)
         for (int s = 0; s < FBR_TILE; s++) tilecol[(size_t)t * FBR_TILE + s] = gp.tiles[t].col[s];
     int rc;
     h->pool.reserve(16);
     if ((rc = upload(h->pool, items, &dg.items))) return rc;
-    if ((rc = upload(h->pool, item_begin, &dg.item_begin))) return rc;
     if ((rc = upload(h->pool, meta, &dg.slotmeta))) return rc;
-    if ((rc = upload(h->pool, rowid, &dg.rowid))) return rc;
+    if ((rc = upload(h->pool, piece_begin, &dg.piece_begin))) return rc;
+    if ((rc = upload(h->pool, pieces, &dg.pieces))) return rc;
+    if ((rc = upload(h->pool, rid_begin, &dg.rid_begin))) return rc;
+    if ((rc = upload(h->pool, ridl, &dg.ridl))) return rc;
     if ((rc = upload(h->pool, slot_tiles, &dg.slot_tiles))) return rc;
     if ((rc = upload(h->pool, tilecol, &dg.tilecol))) return rc;
-    h->lds_bytes = ((size_t)gp.image_doubles + ((m->hm.rec_size() + 1) & ~1)) * sizeof(double) + ((size_t)dg.ntab + FBR_WPB * FBR_NPW) * sizeof(int);
-    if (h->lds_bytes > 160 * 1024) {
+    size_t max_pieces = 0;
+    for (auto &v : gp.pieces) max_pieces = std::max(max_pieces, v.size());
+    h->lds_bytes = (size_t)2 * gp.part_image_max * sizeof(double) +
+                   ((size_t)gp.part_image_max / FBR_TILE + FBR_WPB * FBR_NSEG * 8 + 2 * max_pieces) * sizeof(int);
+    {
+        const int stage = m->hm.rec_size() + m->hm.rows * gp.k + m->hm.rows + 2 * m->hm.n;
+        h->pack_lds_bytes = (size_t)((stage + 1) & ~1) * sizeof(double) +
+                            ((size_t)m->hm.L + (size_t)2 * m->hm.L * std::max(m->hm.maxdepth, 1)) * sizeof(int);
+    }
+    if (h->lds_bytes > 160 * 1024 || h->pack_lds_bytes > 160 * 1024) {
         set_err("model too large: fused Gram needs more than 160 KiB of LDS");
         return FBR_E_UNSUPPORTED;
     }
@@ -662,29 +695,75 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
     if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
     if (S > 0) {
         const int T = h->prog.T;
-        const int blocks_per_cu = (h->lds_bytes <= 80 * 1024) ? 2 : 1;
-        HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const int blocks_per_cu = 1;  // 8 waves = 2 per SIMD; the register budget admits one workgroup per CU
+        const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes));
-        const long ch = chunk_size(m, S);
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes));
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->pack_lds_bytes));
+        const size_t img_bytes = (size_t)h->prog.image_doubles * sizeof(double);
+        long ch = chunk_size(m, S);
+        ch = std::max(1L, std::min(ch, (long)((size_t)6 * 1024 * 1024 * 1024 / img_bytes)));
+        if ((size_t)ch * img_bytes > h->pimg.bytes) {
+            if ((rc = h->pimg.ensure((size_t)ch * img_bytes))) return rc;
+            HIPCHK(hipMemsetAsync(h->pimg.p, 0, h->pimg.bytes, m->stream));  // structural zeros / padding are never rewritten
+        }
         for (long s0 = 0; s0 < S; s0 += ch) {
             const long cs = std::min(ch, S - s0);
             if ((rc = run_kin(m, d, s0, cs))) return rc;
+            {
+                ProfScope ps(m, FBR_PROF_REGRESSOR);
+                const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
+                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, m->stream, h->dev, m->dm, cs,
+                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
+                                   h->pimg.as<double>());
+            }
+            HIPCHK(hipGetLastError());
             int NS = std::max(1, (m->num_cus * blocks_per_cu) / T);
+            if (NS >= 8) NS &= ~7;  // multiple of 8: the parts of a slice share an XCD
             if ((long)NS > cs) NS = (int)cs;
             const size_t pcount = (size_t)NS * T * FBR_WPB * FBR_NPW * 256;
             if ((rc = m->partial.ensure(pcount * sizeof(double)))) return rc;
+            unsigned long long *dbg = nullptr;
+            if (timing) {
+                if ((rc = m->st_x.ensure((size_t)T * NS * FBR_WPB * 8 * sizeof(unsigned long long)))) return rc;
+                dbg = m->st_x.as<unsigned long long>();
+            }
             {
-            ProfScope ps(m, FBR_PROF_GRAM);
-            hipLaunchKernelGGL(fbr_gram_kernel, dim3(T * NS), dim3(256), h->lds_bytes, m->stream, h->dev, m->dm, cs, NS,
-                               m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
-                               drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
-                               m->partial.as<double>());
+                ProfScope ps(m, FBR_PROF_GRAM);
+                if (timing)
+                    hipLaunchKernelGGL(fbr_gram_kernel<true>, dim3(T * NS), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, h->dev, cs, NS,
+                                       h->pimg.as<double>(), m->partial.as<double>(), dbg);
+                else
+                    hipLaunchKernelGGL(fbr_gram_kernel<false>, dim3(T * NS), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, h->dev, cs, NS,
+                                       h->pimg.as<double>(), m->partial.as<double>(), dbg);
             }
             HIPCHK(hipGetLastError());
+            if (timing) {
+                std::vector<unsigned long long> hb((size_t)T * NS * FBR_WPB * 8);
+                HIPCHK(hipMemcpyAsync(hb.data(), dbg, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+                HIPCHK(hipStreamSynchronize(m->stream));
+                static const char *names[3] = {"wait_dma+barrier", "dma_issue", "mfma"};
+                std::vector<double> sum((size_t)T * 3, 0.0), ns(T, 0.0);
+                for (size_t e = 0; e + 8 <= hb.size(); e += 8) {
+                    const int part = (int)hb[e + 6];
+                    if (part < 0 || part >= T) continue;
+                    for (int i = 0; i < 3; i++) sum[(size_t)part * 3 + i] += (double)hb[e + i];
+                    ns[part] += (double)hb[e + 7];
+                }
+                for (int part = 0; part < T; part++) {
+                    fprintf(stderr, "[fbr gram timing] part %d (cycles per sample per wave):", part);
+                    for (int i = 0; i < 3; i++) fprintf(stderr, " %s=%.0f", names[i], sum[(size_t)part * 3 + i] / std::max(ns[part], 1.0));
+                    fprintf(stderr, "\n");
+                }
+            }
             {
-            ProfScope ps(m, FBR_PROF_REDUCE);
-            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW), dim3(256), 0, m->stream, h->dev, NS,
-                               m->partial.as<double>(), G);
+                ProfScope ps(m, FBR_PROF_REDUCE);
+                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW), dim3(256), 0, m->stream, h->dev, NS,
+                                   m->partial.as<double>(), G);
             }
             HIPCHK(hipGetLastError());
         }

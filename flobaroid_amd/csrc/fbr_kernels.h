@@ -16,6 +16,7 @@ struct DevModel {
     const int *order, *parent, *dof;
     const double *restR, *restp, *axis;
     const int *pathlen, *pathtab;     // [L], [L*maxd]  movable joints root -> link
+    const int *pathpos;               // [L*maxd] packed image row of each joint of the path (FbrHostModel::ppos)
     const unsigned *ancmask;          // [L*nw] bit d set <=> dof d is an ancestor joint of link
     const int4 *coldesc;              // [cols] kind, link, pidx/fkind, joint
     const int *sub_begin, *sub_links; // [n+1], [sum]  links in the subtree of each dof
@@ -23,13 +24,16 @@ struct DevModel {
 };
 
 struct DevGram {
-    int T, NT, k, Pa, image_doubles, rid_stride, ntab;
-    const int4 *items;      // off, kind, a, b
-    const int *item_begin;  // [T+1]
-    const int *slotmeta;    // [T*WPB*NPW]: offA/64 | (offB/64)<<10 | common<<20 | lookup<<28   (0 = unused slot)
-    const int *rowid;       // [ntab = image rows] image row -> global regressor row (chain tiles)
-    const int *slot_tiles;  // [T*WPB*NPW*2] tile I, tile J (or -1)
-    const int *tilecol;     // [NT*16] augmented column of each slot, -1 = padding
+    int T, NT, k, Pa, image_doubles, part_image_max, nitems;
+    const int4 *items;        // every real column: image offset, kind, a, b
+    const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | nkmax<<14 ;
+                              //   [1+j] = offB_j/64 | common_j<<10 | lookup_j<<18   (part-local offsets)
+    const int *piece_begin;   // [T+1]
+    const int2 *pieces;       // x = offset in the global image, y = offset in the part image | half<<30  (doubles)
+    const int *rid_begin;     // [T+1]
+    const int *ridl;          // per part: part-image row -> regressor row (chain tiles)
+    const int *slot_tiles;    // [T*WPB*NPW*2] tile I, tile J (or -1)
+    const int *tilecol;       // [NT*16] augmented column of each slot, -1 = padding
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -225,125 +229,201 @@ __global__ __launch_bounds__(256) void fbr_contact_kernel(DevModel m, long S, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: fused regressor -> Gram.  Workgroup = (part of the tile-pair list, slice of the samples).
-// Per sample: all 4 waves build the packed tile image of [Y_s | rhs_s] in LDS (VALU), then every wave
-// runs its <= FBR_NPW accumulators over that image with v_mfma_f64_16x16x4_f64.  Two workgroups share
-// a CU so one's VALU phase overlaps the other's MFMA phase.  Bound: fp64 MFMA.
+// K5a: packed tile image of [Y_s | rhs_s] (row weights applied), one workgroup per sample (grid-stride),
+// one thread per real column.  pimg[s][image_doubles]; structural zeros and padding are never written
+// (the buffer is zeroed once when it is allocated).  Bound: HBM write of the non-zero entries.
 // ------------------------------------------------------------------------------------------------
 typedef double fbr_d4 __attribute__((ext_vector_type(4)));
-#define FBR_NPF 6  // record prefetch registers per thread (covers rec <= 1536 doubles)
 
-__global__ __launch_bounds__(256, 2) void fbr_gram_kernel(DevGram g, DevModel m, long S, int NS,
-                                                           const double *__restrict__ rec,
-                                                           const double *__restrict__ dq,
-                                                           const double *__restrict__ sign,
-                                                           const double *__restrict__ rhs,
-                                                           const double *__restrict__ wts, double *__restrict__ partial)
+struct FbrStage {
+    int o_rhs, o_w, o_dq, o_sign, total;
+};
+__device__ __forceinline__ double fbr_stage_load(const FbrStage &sg, int i, long s, int rec_n, int rows, int k, int n,
+                                                 const double *__restrict__ rec, const double *__restrict__ rhs,
+                                                 const double *__restrict__ wts, const double *__restrict__ dq,
+                                                 const double *__restrict__ sign)
+{
+    if (i < sg.o_rhs) return rec[s * (long)rec_n + i];
+    if (i < sg.o_w) return rhs[s * (long)rows * k + (i - sg.o_rhs)];
+    if (i < sg.o_dq) return wts[s * (long)rows + (i - sg.o_w)];
+    if (i < sg.o_sign) return dq[s * (long)n + (i - sg.o_dq)];
+    if (i < sg.total) return sign[s * (long)n + (i - sg.o_sign)];
+    return 0.0;
+}
+
+__global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, long S, const double *__restrict__ rec,
+                                                        const double *__restrict__ dq, const double *__restrict__ sign,
+                                                        const double *__restrict__ rhs, const double *__restrict__ wts,
+                                                        double *__restrict__ pimg)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *img = smem;                                   // [image_doubles]
-    double *rs = smem + g.image_doubles;                  // [rec]
-    int *rid = (int *)(rs + ((m.rec + 1) & ~1));          // [ntab]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int part = blockIdx.x % g.T, slice = blockIdx.x / g.T;
-    const long s0 = (S * slice) / NS, s1 = (S * (slice + 1)) / NS;
-
-    for (int i = tid; i < g.image_doubles; i += 256) img[i] = 0.0;
-    for (int i = tid; i < g.ntab; i += 256) rid[i] = g.rowid[i];
-
-    fbr_d4 acc[FBR_NPW];
-#pragma unroll
-    for (int p = 0; p < FBR_NPW; p++) acc[p] = (fbr_d4){0.0, 0.0, 0.0, 0.0};
-
-    // accumulator-slot metadata (wave-uniform) lives in LDS behind the row map
-    int *mslot = rid + g.ntab;  // [WPB*NPW]
-    for (int i = tid; i < FBR_WPB * FBR_NPW; i += 256) mslot[i] = g.slotmeta[(long)part * FBR_WPB * FBR_NPW + i];
-    const int *mymeta = mslot + wave * FBR_NPW;
-    const int it0 = g.item_begin[part], it1 = g.item_begin[part + 1];
-    const int li = lane & 15, kk = lane >> 4;
-
-    double pre[FBR_NPF];
-    if (s0 < s1) {
-#pragma unroll
-        for (int j = 0; j < FBR_NPF; j++) {
-            const int i = tid + 256 * j;
-            pre[j] = (i < m.rec) ? rec[s0 * (long)m.rec + i] : 0.0;
-        }
+    FbrStage sg;
+    sg.o_rhs = m.rec;
+    sg.o_w = sg.o_rhs + m.rows * g.k;
+    sg.o_dq = sg.o_w + (wts ? m.rows : 0);
+    sg.o_sign = sg.o_dq + (m.fric ? m.n : 0);
+    sg.total = sg.o_sign + ((m.fric && sign) ? m.n : 0);
+    double *rs = smem;                                  // [stage]
+    int *plen = (int *)(rs + ((sg.total + 1) & ~1));    // [L]
+    int *ptab = plen + m.L;                             // [L*maxd] dof of each path joint
+    int *ppos = ptab + m.L * m.maxd;                    // [L*maxd] packed image row of each path joint
+    const int tid = threadIdx.x;
+    for (int i = tid; i < m.L; i += 256) plen[i] = m.pathlen[i];
+    for (int i = tid; i < m.L * m.maxd; i += 256) {
+        ptab[i] = m.pathtab[i];
+        ppos[i] = m.pathpos[i];
     }
-    for (long s = s0; s < s1; s++) {
-        // ---- stage this sample's link records (prefetched), then prefetch the next one
-#pragma unroll
-        for (int j = 0; j < FBR_NPF; j++) {
-            const int i = tid + 256 * j;
-            if (i < m.rec) rs[i] = pre[j];
-        }
-        for (int i = tid + 256 * FBR_NPF; i < m.rec; i += 256) rs[i] = rec[s * (long)m.rec + i];
-        __syncthreads();  // records visible; every wave is done reading the previous image
-        if (s + 1 < s1) {
-#pragma unroll
-            for (int j = 0; j < FBR_NPF; j++) {
-                const int i = tid + 256 * j;
-                pre[j] = (i < m.rec) ? rec[(s + 1) * (long)m.rec + i] : 0.0;
-            }
-        }
-        // ---- producer: one real column per item
-        const double *ws = wts ? wts + s * m.rows : nullptr;
-        for (int it = it0 + tid; it < it1; it += 256) {
+    const double *ws = wts ? rs + sg.o_w : nullptr;
+    for (long s = blockIdx.x; s < S; s += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < sg.total; i += 256) rs[i] = fbr_stage_load(sg, i, s, m.rec, m.rows, g.k, m.n, rec, rhs, wts, dq, sign);
+        __syncthreads();
+        double *img = pimg + s * (long)g.image_doubles;
+        for (int it = tid; it < g.nitems; it += 256) {
             const int4 d = g.items[it];
             if (d.y == 0) {
                 double w6[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * d.z, d.w, w6);
                 for (int r = 0; r < m.fb; r++) img[d.x + r * FBR_TILE] = ws ? w6[r] * ws[r] : w6[r];
-                const int len = m.pathlen[d.z];
+                const int len = plen[d.z];
                 for (int j = 0; j < len; j++) {
-                    const int dd = m.pathtab[d.z * m.maxd + j];
+                    const int dd = ptab[d.z * m.maxd + j];
                     double v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd, w6);
                     if (ws) v *= ws[m.fb + dd];
-                    img[d.x + (m.fb + j) * FBR_TILE] = v;
+                    img[d.x + ppos[d.z * m.maxd + j] * FBR_TILE] = v;
                 }
             } else if (d.y == 1) {
                 const int r = m.fb + d.z;
-                double v = fbr_friction_value(d.w, dq[s * m.n + d.z], sign ? sign[s * m.n + d.z] : 0.0, m.stribeck);
+                double v = fbr_friction_value(d.w, rs[sg.o_dq + d.z], sign ? rs[sg.o_sign + d.z] : 0.0, m.stribeck);
                 if (ws) v *= ws[r];
                 img[d.x + r * FBR_TILE] = v;
             } else {
                 for (int r = 0; r < m.rows; r++) {
-                    double v = rhs[(s * m.rows + r) * g.k + d.z];
+                    double v = rs[sg.o_rhs + r * g.k + d.z];
                     if (ws) v *= ws[r];
                     img[d.x + r * FBR_TILE] = v;
                 }
             }
         }
-        __syncthreads();  // image complete
-        // ---- MFMA phase
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5b: streaming Gram.  Workgroup = (part of the tile-pair list, slice of the samples).  Per sample the part's
+// tiles are copied global -> LDS by LDS-DMA (global_load_lds, no VGPRs) into one of two buffers while every
+// wave runs its <= FBR_NPW accumulators over the other buffer with v_mfma_f64_16x16x4_f64; operands of the
+// next k-step (and of the next accumulator's first k-step) are fetched before the current MFMA issues.
+// The parts of one slice share an XCD so that a sample's image is read from HBM once.  Bound: fp64 MFMA.
+// TIMING: diagnostic instantiation (s_memtime cycles per phase and wave into dbg[block][wave][8]).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *fbr_lds_ptr;
+typedef const __attribute__((address_space(1))) void *fbr_glb_ptr;
+
+template <bool TIMING>
+__global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, long S, int NS, const double *__restrict__ pimg,
+                                                           double *__restrict__ partial, unsigned long long *__restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *buf0 = smem, *buf1 = smem + g.part_image_max;
+    int *ridl = (int *)(smem + 2 * g.part_image_max);   // [part image rows]
+    int *mslot = ridl + g.part_image_max / FBR_TILE;    // [WPB*NSEG*8] row-segment metadata of this part
+    int *pcs = mslot + FBR_WPB * FBR_NSEG * 8;          // [2*pieces] DMA pieces of this part
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware mapping: workgroup b runs on XCD b % 8; the T parts of a slice are consecutive workgroups of one XCD
+    int part, slice;
+    if ((NS & 7) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        part = j % g.T;
+        slice = (j / g.T) * 8 + x;
+    } else {
+        part = blockIdx.x % g.T;
+        slice = blockIdx.x / g.T;
+    }
+    const long s0 = (S * slice) / NS, s1 = (S * (slice + 1)) / NS;
+    const int pc0 = g.piece_begin[part], npc = g.piece_begin[part + 1] - pc0;
+    const int rb0 = g.rid_begin[part], nrid = g.rid_begin[part + 1] - rb0;
+
+    for (int i = tid; i < 2 * g.part_image_max; i += FBR_WPB * 64) smem[i] = 0.0;
+    for (int i = tid; i < nrid; i += FBR_WPB * 64) ridl[i] = g.ridl[rb0 + i];
+    for (int i = tid; i < FBR_WPB * FBR_NSEG * 8; i += FBR_WPB * 64) mslot[i] = g.slotmeta[(long)part * FBR_WPB * FBR_NSEG * 8 + i];
+    for (int i = tid; i < npc; i += FBR_WPB * 64) {
+        const int2 pc = g.pieces[pc0 + i];
+        pcs[2 * i] = pc.x;
+        pcs[2 * i + 1] = pc.y;
+    }
+
+    fbr_d4 acc[FBR_NPW];
 #pragma unroll
-        for (int p = 0; p < FBR_NPW; p++) {
-            const int mt = __builtin_amdgcn_readfirstlane(mymeta[p]);
-            const int common = (mt >> 20) & 0xff;
-            const int nk4 = (common + 3) >> 2;
-            const int oA = (mt & 0x3ff) << 6, oB = ((mt >> 10) & 0x3ff) << 6;
-            const double *pa = img + oA + lane;
-            if (!((mt >> 28) & 1)) {
-                const double *pb = img + oB + lane;
-                for (int ks = 0; ks < nk4; ks++) {
-                    double a = pa[64 * ks];
-                    const double b = pb[64 * ks];
-                    a = (4 * ks + kk < common) ? a : 0.0;
-                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[p], 0, 0, 0);
-                }
+    for (int p = 0; p < FBR_NPW; p++) acc[p] = (fbr_d4){0.0, 0.0, 0.0, 0.0};
+    const int *wmeta = mslot + wave * FBR_NSEG * 8;
+    const int li = lane & 15, kk = lane >> 4;
+    unsigned long long tacc[3] = {0, 0, 0}, t0 = 0;
+
+    // LDS-DMA of sample s into buf: wave w issues pieces w, w+WPB, ...
+    auto dma = [&](long s, double *buf) {
+        const double *src = pimg + s * (long)g.image_doubles + 2 * lane;
+        for (int i = wave; i < npc; i += FBR_WPB) {
+            const int gx = __builtin_amdgcn_readfirstlane(pcs[2 * i]);
+            const int ly = __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]);
+            const int loff = ly & 0x3fffffff;
+            if (ly >> 30) {
+                if (lane < 32)
+                    __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + loff), 16, 0, 0);
             } else {
-                const int *pr = rid + (oA >> 4) + kk;
-                const double *pb = img + oB + li;
-                for (int ks = 0; ks < nk4; ks++) {
-                    double a = pa[64 * ks];
-                    const int posb = pr[4 * ks];
-                    const double b = pb[posb * FBR_TILE];
-                    a = (4 * ks + kk < common) ? a : 0.0;
-                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[p], 0, 0, 0);
+                __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + loff), 16, 0, 0);
+            }
+        }
+    };
+    __syncthreads();  // tables and zeroed buffers visible before the first DMA lands
+    if (s0 < s1) dma(s0, buf0);
+    if (TIMING) t0 = __builtin_readcyclecounter();
+    for (long s = s0; s < s1; s++) {
+        double *img = ((s - s0) & 1) ? buf1 : buf0;
+        __syncthreads();  // this sample's image has landed (vmcnt(0) of every wave) and the other buffer is free
+        if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
+        if (s + 1 < s1) dma(s + 1, ((s - s0) & 1) ? buf0 : buf1);
+        if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
+        // ---- MFMA phase: per row segment the A fragment of (I, ks) is loaded once and feeds up to SEGW
+        //      independent accumulators (tiles J, sorted by k-steps descending)
+#pragma unroll
+        for (int sgi = 0; sgi < FBR_NSEG; sgi++) {
+            const int mv = wmeta[sgi * 8 + (lane & 7)];
+            const int m0 = __builtin_amdgcn_readlane(mv, 0);
+            const int cnt = (m0 >> 10) & 15;
+            if (cnt == 0) continue;
+            const int oA = (m0 & 0x3ff) << 6, nkmax = (m0 >> 14) & 15;
+            int mj[FBR_SEGW];
+#pragma unroll
+            for (int j = 0; j < FBR_SEGW; j++) mj[j] = __builtin_amdgcn_readlane(mv, 1 + j);
+            const double *pa = img + oA + lane;
+            const int *pr = ridl + (oA >> 4) + kk;
+            for (int ks = 0; ks < nkmax; ks++) {
+                const double a = pa[64 * ks];
+                const int vlk = pr[4 * ks] * FBR_TILE + li;   // operand row through the row map (chain x dense pairs)
+                const int vpos = 64 * ks + lane;
+                double b[FBR_SEGW];
+#pragma unroll
+                for (int j = 0; j < FBR_SEGW; j++) {
+                    const int common = (mj[j] >> 10) & 0xff;
+                    if (4 * ks < common) b[j] = img[((mj[j] & 0x3ff) << 6) + (((mj[j] >> 18) & 1) ? vlk : vpos)];
+                }
+#pragma unroll
+                for (int j = 0; j < FBR_SEGW; j++) {
+                    const int common = (mj[j] >> 10) & 0xff;
+                    // no operand masking: rows past `common` are zero in at least one tile (aligned packing)
+                    if (4 * ks < common)
+                        acc[sgi * FBR_SEGW + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[sgi * FBR_SEGW + j], 0, 0, 0);
                 }
             }
         }
+        if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[2] += t1 - t0; t0 = t1; }
+    }
+    if (TIMING && lane == 0) {
+        unsigned long long *d = dbg + ((long)blockIdx.x * FBR_WPB + wave) * 8;
+        d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2];
+        d[6] = (unsigned long long)part;
+        d[7] = (unsigned long long)(s1 - s0);
     }
     // ---- write this workgroup's accumulators: partial[slice][part][wave][slot][reg][lane]
     double *pp = partial + ((((long)slice * g.T + part) * FBR_WPB + wave) * FBR_NPW) * 256;

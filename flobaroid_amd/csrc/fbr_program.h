@@ -18,8 +18,10 @@
 #include <vector>
 
 #define FBR_TILE 16
-#define FBR_WPB 4         // waves per workgroup of the Gram kernel
-#define FBR_NPW 20        // tile pairs (MFMA accumulators) per wave
+#define FBR_WPB 8         // waves per workgroup of the Gram kernel (2 per SIMD, one workgroup per CU)
+#define FBR_SEGW 6        // tile pairs per row segment (same tile I, up to SEGW different tiles J)
+#define FBR_NSEG 3        // row segments per wave
+#define FBR_NPW (FBR_SEGW * FBR_NSEG)  // tile pairs (MFMA accumulators) per wave
 #define FBR_MAX_RHS 16
 
 struct FbrCol {
@@ -37,6 +39,8 @@ struct FbrHostModel {
     std::vector<int> order, parent, dof;
     std::vector<double> restR, restp, axis;
     std::vector<std::vector<int>> path;  // per link: movable joints root -> link
+    std::vector<std::vector<int>> ppos;  // per link: PACKED row position of each joint of its path (see FbrTile)
+    std::vector<int> pdepth;             // per link: packed rows used (last position + 1)
     std::vector<FbrCol> coldesc;         // identified columns
     int maxdepth = 0;
 
@@ -96,6 +100,33 @@ struct FbrHostModel {
         }
         for (int d = 0; d < n; d++)
             if (!seen[d]) throw std::runtime_error("dof without a joint");
+        // packed row positions: base rows first, then the joints of the path in order; after every prefix from
+        // which two or more different movable joints continue (a branch point of the joint tree) the next position
+        // is rounded up to a multiple of 4, so two diverging chains always share a whole number of MFMA k-steps
+        // and no operand masking is needed (the rounding gaps are structural zero rows).
+        {
+            std::vector<int> pdof(std::max(n, 1), -1), nchild(n + 1, 0);  // nchild[n] = children of the empty prefix
+            for (int l = 0; l < L; l++) {
+                const auto &p = path[l];
+                if (!p.empty() && dof[l] == p.back()) pdof[p.back()] = p.size() >= 2 ? p[p.size() - 2] : n;
+            }
+            for (int d = 0; d < n; d++)
+                if (pdof[d] >= 0) nchild[pdof[d]]++;
+            ppos.assign(L, {});
+            pdepth.assign(L, 0);
+            for (int l = 0; l < L; l++) {
+                int cur = fb;
+                if (nchild[n] >= 2) cur = (cur + 3) & ~3;
+                int depth = fb;
+                for (int d : path[l]) {
+                    ppos[l].push_back(cur);
+                    depth = cur + 1;
+                    cur++;
+                    if (nchild[d] >= 2) cur = (cur + 3) & ~3;
+                }
+                pdepth[l] = depth;
+            }
+        }
         // identified columns (model.py:134-168, 459-503)
         coldesc.clear();
         for (int l = 0; l < L; l++)
@@ -128,6 +159,7 @@ struct FbrTile {
     int col[FBR_TILE];            // augmented column id per slot, -1 = padding
     std::vector<int> rowid;       // chain: global row of each packed position
     std::vector<int> tpath;       // chain: dof path of the deepest link
+    std::vector<int> tpos;        // chain: packed position of each joint of tpath
 };
 struct FbrPair {
     int I, J, common, mode;  // mode 0: both packed by position; 1: B rows looked up through rowid_I; 2: dense x dense
@@ -143,16 +175,28 @@ struct FbrSlot {  // one accumulator of one wave
     int pair;     // -1 = unused
 };
 
+struct FbrPiece {  // one LDS-DMA piece of a part's per-sample image: 128 doubles (1 KiB, whole wave) or 64 (half wave)
+    int goff;      // offset (doubles) inside the global per-sample image
+    int loff;      // offset (doubles) inside the part-local LDS image
+    int half;      // 1: 64 doubles (lanes 0..31 only)
+};
+
 struct FbrGramProgram {
     int k = 0, Pa = 0, NT = 0, T = 0;
     int rows_pad = 0;        // rows rounded up to a multiple of 4
-    int image_doubles = 0;   // per-sample LDS image size (all tiles) incl. tail padding
+    int image_doubles = 0;   // global per-sample image size (all tiles), multiple of 64
+    int part_image_max = 0;  // largest part-local LDS image (doubles, incl. one spare k-step of tail padding)
     int maxrow = 0;          // max tile depth
     std::vector<FbrTile> tiles;
     std::vector<FbrPair> pairs;
-    std::vector<std::vector<FbrItem>> items;  // per part
-    std::vector<FbrSlot> slots;               // [T][WPB][NPW]
+    std::vector<FbrItem> items;                   // every real column of every tile (pack kernel work list)
+    std::vector<FbrSlot> slots;                   // [T][WPB][NPW]
+    std::vector<std::vector<int>> part_tiles;     // per part: tiles it needs, in image order
+    std::vector<std::vector<int>> part_tile_off;  // per part: local LDS offset (doubles) of each tile, -1 if absent
+    std::vector<std::vector<FbrPiece>> pieces;    // per part: DMA pieces
+    std::vector<int> part_image;                  // per part: local image size (doubles)
     int64_t mfma_per_sample = 0;
+    int64_t mfma_uniform = 0;  // k-steps that run in row segments whose pairs all share `common` and the operand mode
 
     static bool nested(const std::vector<int> &a, const std::vector<int> &b)
     {
@@ -194,20 +238,26 @@ struct FbrGramProgram {
                         cur = FbrTile();
                         cur.type = 0;
                         cur.tpath = hm.path[l];
+                        cur.tpos = hm.ppos[l];
+                        cur.depth = hm.pdepth[l];
                         fill = 0;
                         open = true;
                     }
-                    if (hm.path[l].size() > cur.tpath.size()) cur.tpath = hm.path[l];
+                    if (hm.path[l].size() > cur.tpath.size()) {
+                        cur.tpath = hm.path[l];
+                        cur.tpos = hm.ppos[l];
+                        cur.depth = hm.pdepth[l];
+                    }
                     cur.col[fill++] = hm.cpl * l + p;
                 }
             }
             close();
         }
         for (auto &t : tiles) {
-            t.depth = hm.fb + (int)t.tpath.size();
-            t.rowid.clear();
-            for (int i = 0; i < hm.fb; i++) t.rowid.push_back(i);
-            for (int d : t.tpath) t.rowid.push_back(hm.fb + d);
+            // packed position -> regressor row (alignment gaps map to row 0; their image rows are zero)
+            t.rowid.assign(t.depth, 0);
+            for (int i = 0; i < hm.fb; i++) t.rowid[i] = i;
+            for (size_t j = 0; j < t.tpath.size(); j++) t.rowid[t.tpos[j]] = hm.fb + t.tpath[j];
         }
         // ---- dense tiles: friction columns then rhs columns
         {
@@ -226,103 +276,189 @@ struct FbrGramProgram {
         for (auto &t : tiles) {
             t.off = off;
             int dp = (t.depth + 3) / 4 * 4;
-            off += dp * FBR_TILE;
+            off += dp * FBR_TILE;  // multiple of 64 doubles
             maxrow = std::max(maxrow, dp);
         }
-        image_doubles = off + 4 * FBR_TILE;  // tail padding: masked lanes may read one k-step past a tile
-        // ---- pairs (I <= J)
-        mfma_per_sample = 0;
-        for (int I = 0; I < NT; I++)
-            for (int J = I; J < NT; J++) {
-                const FbrTile &a = tiles[I], &b = tiles[J];
-                FbrPair p{I, J, 0, 0};
-                if (a.type == 0 && b.type == 0) {
-                    p.common = hm.fb + common_prefix(a.tpath, b.tpath);
-                    p.mode = 0;
-                } else if (a.type == 0 && b.type == 1) {
-                    p.common = a.depth;
-                    p.mode = 1;
-                } else if (a.type == 1 && b.type == 1) {
-                    p.common = hm.rows;
-                    p.mode = 2;
+        image_doubles = off;
+        // ---- pack-kernel work list: every real column of every tile
+        items.clear();
+        for (int ti = 0; ti < NT; ti++)
+            for (int s = 0; s < FBR_TILE; s++) {
+                int c = tiles[ti].col[s];
+                if (c < 0) continue;
+                FbrItem it;
+                it.off = tiles[ti].off + s;
+                if (c >= hm.cols) {
+                    it.kind = 2; it.a = c - hm.cols; it.b = 0;
+                } else if (hm.coldesc[c].kind == 0) {
+                    it.kind = 0; it.a = hm.coldesc[c].link; it.b = hm.coldesc[c].pidx;
                 } else {
-                    throw std::runtime_error("dense tile before chain tile");
+                    it.kind = 1; it.a = hm.coldesc[c].joint; it.b = hm.coldesc[c].pidx;
                 }
-                if (p.common == 0) continue;  // structurally zero block (fixed base, disjoint branches)
-                pairs.push_back(p);
-                mfma_per_sample += p.nk4();
+                items.push_back(it);
             }
-        // ---- parts: contiguous chunks of the row-major pair list, balanced by k-steps
+        // ---- pairs (I <= J), enumerated in square blocks of the (I, J) triangle so that a contiguous chunk
+        //      of the list touches few distinct tiles (small part images, little DMA traffic)
         const int PPB = FBR_WPB * FBR_NPW;
+        int BE = 1;
+        while ((BE + 1) * (BE + 1) <= PPB) BE++;
+        mfma_per_sample = 0;
+        mfma_uniform = 0;
+        const int NB = (NT + BE - 1) / BE;
+        for (int bi = 0; bi < NB; bi++)
+            for (int bj = bi; bj < NB; bj++)
+                for (int I = bi * BE; I < std::min(NT, (bi + 1) * BE); I++)
+                    for (int J = std::max(I, bj * BE); J < std::min(NT, (bj + 1) * BE); J++) {
+                        const FbrTile &a = tiles[I], &b = tiles[J];
+                        FbrPair p{I, J, 0, 0};
+                        if (a.type == 0 && b.type == 0) {
+                            // nested chains: the shallower tile's rows (the deeper one's extra rows meet zero padding);
+                            // diverging chains: the shared prefix, whose end is 4-aligned by construction
+                            const int cp = common_prefix(a.tpath, b.tpath);
+                            if (cp == (int)std::min(a.tpath.size(), b.tpath.size()))
+                                p.common = std::min(a.depth, b.depth);
+                            else
+                                p.common = a.tpos[cp];
+                            p.mode = 0;
+                        } else if (a.type == 0 && b.type == 1) {
+                            p.common = a.depth;
+                            p.mode = 1;
+                        } else if (a.type == 1 && b.type == 1) {
+                            p.common = hm.rows;
+                            p.mode = 2;
+                        } else {
+                            throw std::runtime_error("dense tile before chain tile");
+                        }
+                        if (p.common == 0) continue;  // structurally zero block (fixed base, disjoint branches)
+                        pairs.push_back(p);
+                        mfma_per_sample += p.nk4();
+                    }
+        // ---- parts: contiguous chunks of the pair list.  Inside a part the pairs are grouped into ROW SEGMENTS
+        //      (same tile I, <= SEGW tiles J, sorted by k-steps descending): a wave loads the A fragment of (I, ks)
+        //      once and feeds up to SEGW independent accumulators with it.  A part holds <= WPB*NSEG segments.
         const int np = (int)pairs.size();
-        T = std::max(1, (np + PPB - 1) / PPB);
-        std::vector<int> part_begin(T + 1, 0);
-        {
-            int64_t total = 0;
-            for (auto &p : pairs) total += p.nk4();
+        const int SEGCAP = FBR_WPB * FBR_NSEG;
+        // a part must fit its row segments in WPB*NSEG slots and two copies of its tile image in the LDS
+        const int IMG_BUDGET = 9472;  // doubles per image buffer (2 x 74 KiB + tables < 160 KiB)
+        auto seg_count = [&](int b, int e) {
+            std::vector<int> cnt(NT, 0);
+            std::vector<char> need(NT, 0);
+            for (int i = b; i < e; i++) {
+                cnt[pairs[i].I]++;
+                need[pairs[i].I] = need[pairs[i].J] = 1;
+            }
+            int n = 0, img = 4 * FBR_TILE;
+            for (int c : cnt) n += (c + FBR_SEGW - 1) / FBR_SEGW;
+            for (int ti = 0; ti < NT; ti++)
+                if (need[ti]) img += (tiles[ti].depth + 3) / 4 * 4 * FBR_TILE;
+            if (img > IMG_BUDGET) {
+                if (e - b <= 1) throw std::runtime_error("a single tile pair exceeds the LDS image budget (too many rows per sample)");
+                return SEGCAP + 1;
+            }
+            return n;
+        };
+        int64_t total_w = 0;
+        for (auto &p : pairs) total_w += p.nk4();
+        std::vector<int> part_begin;
+        for (T = std::max(1, (np + PPB - 1) / PPB);; T++) {
+            part_begin.assign(T + 1, 0);
             int idx = 0;
             int64_t done = 0;
-            for (int t = 0; t < T; t++) {
+            bool ok = true;
+            for (int t = 0; t < T && ok; t++) {
                 part_begin[t] = idx;
-                int64_t target = (total - done) / (T - t);
+                const int64_t target = (total_w - done + (T - t) - 1) / (T - t);
                 int64_t acc = 0;
-                int cnt = 0;
                 while (idx < np) {
-                    int remaining_after = np - (idx + 1);
-                    if (cnt >= PPB) break;
-                    if (cnt > 0 && acc >= target && remaining_after + 1 <= (int64_t)(T - t - 1) * PPB) break;
+                    if (acc >= target && t + 1 < T) break;
+                    if (seg_count(part_begin[t], idx + 1) > SEGCAP) break;
                     acc += pairs[idx].nk4();
-                    cnt++;
-                    idx++;
-                    // must leave no more than what the remaining parts can hold
-                    (void)remaining_after;
-                }
-                // if the remaining pairs do not fit in the remaining parts, keep taking
-                while (idx < np && (np - idx) > (int64_t)(T - t - 1) * PPB && cnt < PPB) {
-                    acc += pairs[idx].nk4();
-                    cnt++;
                     idx++;
                 }
                 done += acc;
             }
             part_begin[T] = np;
-            if (idx != np) throw std::runtime_error("internal: pair partition failed");
+            if (idx == np) break;
+            if (T > np + 1) throw std::runtime_error("internal: pair partition failed");
+            (void)ok;
         }
-        // ---- slots: LPT assignment of each part's pairs to its waves
+        // ---- segments and slots: LPT assignment of each part's segments to its waves; part-local images, DMA pieces
         slots.assign((size_t)T * PPB, FbrSlot{-1});
-        items.assign(T, {});
+        part_tiles.assign(T, {});
+        part_tile_off.assign(T, std::vector<int>(NT, -1));
+        pieces.assign(T, {});
+        part_image.assign(T, 0);
+        part_image_max = 0;
         for (int t = 0; t < T; t++) {
-            std::vector<int> idx;
-            for (int i = part_begin[t]; i < part_begin[t + 1]; i++) idx.push_back(i);
-            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return pairs[x].nk4() > pairs[y].nk4(); });
+            struct Seg { int I; std::vector<int> pr; int w; };
+            std::vector<Seg> segs;
+            {
+                std::vector<std::vector<int>> byI(NT);
+                for (int i = part_begin[t]; i < part_begin[t + 1]; i++) byI[pairs[i].I].push_back(i);
+                for (int I = 0; I < NT; I++) {
+                    auto &v = byI[I];
+                    std::stable_sort(v.begin(), v.end(), [&](int x, int y) {
+                        if (pairs[x].common != pairs[y].common) return pairs[x].common > pairs[y].common;
+                        return pairs[x].mode < pairs[y].mode;
+                    });
+                    for (size_t o = 0; o < v.size(); o += FBR_SEGW) {
+                        Seg sgm{I, {}, 0};
+                        for (size_t j = o; j < std::min(v.size(), o + FBR_SEGW); j++) {
+                            sgm.pr.push_back(v[j]);
+                            sgm.w += pairs[v[j]].nk4();
+                        }
+                        segs.push_back(sgm);
+                    }
+                }
+            }
+            if ((int)segs.size() > SEGCAP) throw std::runtime_error("internal: too many row segments in a part");
+            std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.w > b.w; });
             int load[FBR_WPB] = {0}, cnt[FBR_WPB] = {0};
-            for (int i : idx) {
+            for (auto &sgm : segs) {
                 int best = -1;
                 for (int w = 0; w < FBR_WPB; w++)
-                    if (cnt[w] < FBR_NPW && (best < 0 || load[w] < load[best])) best = w;
-                slots[((size_t)t * FBR_WPB + best) * FBR_NPW + cnt[best]].pair = i;
+                    if (cnt[w] < FBR_NSEG && (best < 0 || load[w] < load[best])) best = w;
+                for (size_t j = 0; j < sgm.pr.size(); j++)
+                    slots[((size_t)t * FBR_WPB + best) * FBR_NPW + cnt[best] * FBR_SEGW + j].pair = sgm.pr[j];
+                {
+                    bool uni = true;
+                    for (int pi : sgm.pr)
+                        uni = uni && pairs[pi].common == pairs[sgm.pr[0]].common && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
+                    if (uni) mfma_uniform += sgm.w;
+                }
                 cnt[best]++;
-                load[best] += pairs[i].nk4();
+                load[best] += sgm.w;
             }
-            // producer items: every real column of every tile this part touches
             std::vector<char> need(NT, 0);
             for (int i = part_begin[t]; i < part_begin[t + 1]; i++) need[pairs[i].I] = need[pairs[i].J] = 1;
+            int loff = 0;
             for (int ti = 0; ti < NT; ti++) {
                 if (!need[ti]) continue;
-                for (int s = 0; s < FBR_TILE; s++) {
-                    int c = tiles[ti].col[s];
-                    if (c < 0) continue;
-                    FbrItem it;
-                    it.off = tiles[ti].off + s;
-                    if (c >= hm.cols) {
-                        it.kind = 2; it.a = c - hm.cols; it.b = 0;
-                    } else if (hm.coldesc[c].kind == 0) {
-                        it.kind = 0; it.a = hm.coldesc[c].link; it.b = hm.coldesc[c].pidx;
-                    } else {
-                        it.kind = 1; it.a = hm.coldesc[c].joint; it.b = hm.coldesc[c].pidx;
-                    }
-                    items[t].push_back(it);
+                part_tiles[t].push_back(ti);
+                part_tile_off[t][ti] = loff;
+                loff += (tiles[ti].depth + 3) / 4 * 4 * FBR_TILE;
+            }
+            part_image[t] = loff;
+            part_image_max = std::max(part_image_max, loff + 4 * FBR_TILE);
+            // DMA pieces over maximal runs of tiles that are adjacent both in the global and the local image
+            size_t i = 0;
+            const std::vector<int> &pt = part_tiles[t];
+            while (i < pt.size()) {
+                size_t j = i;
+                int run = 0;
+                while (j < pt.size() && (j == i || pt[j] == pt[j - 1] + 1)) {
+                    run += (tiles[pt[j]].depth + 3) / 4 * 4 * FBR_TILE;
+                    j++;
                 }
+                int g0 = tiles[pt[i]].off, l0 = part_tile_off[t][pt[i]];
+                int o = 0;
+                while (run - o >= 128) {
+                    pieces[t].push_back({g0 + o, l0 + o, 0});
+                    o += 128;
+                }
+                if (run - o == 64) pieces[t].push_back({g0 + o, l0 + o, 1});
+                else if (run - o != 0) throw std::runtime_error("internal: tile size not a multiple of 64 doubles");
+                i = j;
             }
         }
     }

@@ -154,22 +154,24 @@ int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const 
 }
 
 int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma, int *T, int *image_doubles,
-                      int *items_total)
+                      int *items_total, long *mfma_uniform)
 {
     FbrHostModel hm;
     make(t, hm);
     FbrGramProgram gp;
     gp.build(hm, k);
     *NT = gp.NT; *npairs = (int)gp.pairs.size(); *mfma = gp.mfma_per_sample; *T = gp.T;
-    *image_doubles = gp.image_doubles;
-    int it = 0;
-    for (auto &v : gp.items) it += (int)v.size();
-    *items_total = it;
+    *image_doubles = gp.part_image_max;
+    long dma = 0;
+    for (int p = 0; p < gp.T; p++) dma += gp.part_image[p];
+    *items_total = (int)dma;  // doubles copied per sample summed over the parts
+    *mfma_uniform = gp.mfma_uniform;
     return 0;
 }
 
-// mirrors fbr_gram_kernel + fbr_gram_reduce_kernel: per part, per sample: producer fills the packed image,
-// each (wave, slot) runs its k-steps with the 16x16x4 MFMA lane mapping, results scattered into G.
+// mirrors fbr_pack_kernel + fbr_gram_kernel + fbr_gram_reduce_kernel: the packed image of each sample is
+// produced once; every part copies its DMA pieces into a part-local image, each (wave, slot) runs its k-steps
+// with the 16x16x4 MFMA lane mapping on part-local offsets, results are scattered into G.
 int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv,
               const double *ba, const double *rpy, const double *sign, const double *rhs, int k, const double *wts,
               double *G)
@@ -180,53 +182,58 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
     gp.build(hm, k);
     const int REC = hm.rec_size();
     const int Pa = gp.Pa;
-    std::vector<double> rec(REC), img(gp.image_doubles);
+    std::vector<double> rec(REC), img(gp.image_doubles, 0.0), loc(gp.part_image_max, 0.0);
     std::vector<double> acc((size_t)gp.T * FBR_WPB * FBR_NPW * 256, 0.0);
-    for (int part = 0; part < gp.T; part++) {
-        for (long s = 0; s < S; s++) {
-            kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
-                       hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
-            if (s == 0) std::fill(img.begin(), img.end(), 0.0);  // image zeroed once per block
-            const double *ws = wts ? wts + (size_t)s * hm.rows : nullptr;
-            for (const FbrItem &it : gp.items[part]) {
-                if (it.kind == 0) {
-                    double w6[6];
-                    fbr_unit_wrench(&rec[21 * it.a], it.b, w6);
-                    for (int r = 0; r < hm.fb; r++) img[it.off + r * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
-                    int j = 0;
-                    for (int d : hm.path[it.a]) {
-                        img[it.off + (hm.fb + j) * FBR_TILE] =
-                            fbr_dot6(&rec[21 * hm.L + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
-                        j++;
-                    }
-                } else if (it.kind == 1) {
-                    int r = hm.fb + it.a;
-                    img[it.off + r * FBR_TILE] =
-                        fbr_friction_value(it.b, dq[s * hm.n + it.a], sign ? sign[s * hm.n + it.a] : 0.0, hm.stribeck) *
-                        (ws ? ws[r] : 1.0);
-                } else {
-                    for (int r = 0; r < hm.rows; r++)
-                        img[it.off + r * FBR_TILE] = rhs[((size_t)s * hm.rows + r) * k + it.a] * (ws ? ws[r] : 1.0);
+    for (long s = 0; s < S; s++) {
+        kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
+                   hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
+        const double *ws = wts ? wts + (size_t)s * hm.rows : nullptr;
+        // pack kernel: image zeroed once, only real entries rewritten
+        for (const FbrItem &it : gp.items) {
+            if (it.kind == 0) {
+                double w6[6];
+                fbr_unit_wrench(&rec[21 * it.a], it.b, w6);
+                for (int r = 0; r < hm.fb; r++) img[it.off + r * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
+                int j = 0;
+                for (int d : hm.path[it.a]) {
+                    img[it.off + hm.ppos[it.a][j] * FBR_TILE] = fbr_dot6(&rec[21 * hm.L + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
+                    j++;
                 }
+            } else if (it.kind == 1) {
+                int r = hm.fb + it.a;
+                img[it.off + r * FBR_TILE] =
+                    fbr_friction_value(it.b, dq[s * hm.n + it.a], sign ? sign[s * hm.n + it.a] : 0.0, hm.stribeck) *
+                    (ws ? ws[r] : 1.0);
+            } else {
+                for (int r = 0; r < hm.rows; r++)
+                    img[it.off + r * FBR_TILE] = rhs[((size_t)s * hm.rows + r) * k + it.a] * (ws ? ws[r] : 1.0);
             }
+        }
+        for (int part = 0; part < gp.T; part++) {
+            std::fill(loc.begin(), loc.end(), 0.0);
+            for (const FbrPiece &pc : gp.pieces[part]) {
+                const int nd = pc.half ? 64 : 128;
+                for (int i = 0; i < nd; i++) loc[pc.loff + i] = img[pc.goff + i];
+            }
+            // part-image row -> regressor row
+            std::vector<int> ridl(gp.part_image_max / FBR_TILE, 0);
+            for (int ti : gp.part_tiles[part])
+                for (size_t j = 0; j < gp.tiles[ti].rowid.size(); j++) ridl[gp.part_tile_off[part][ti] / FBR_TILE + j] = gp.tiles[ti].rowid[j];
             for (int w = 0; w < FBR_WPB; w++)
                 for (int sl = 0; sl < FBR_NPW; sl++) {
                     int pi = gp.slots[((size_t)part * FBR_WPB + w) * FBR_NPW + sl].pair;
                     if (pi < 0) continue;
                     const FbrPair &p = gp.pairs[pi];
-                    const FbrTile &ta = gp.tiles[p.I], &tb = gp.tiles[p.J];
+                    const int oA = gp.part_tile_off[part][p.I], oB = gp.part_tile_off[part][p.J];
+                    if (oA < 0 || oB < 0 || (oA % 64) || (oB % 64)) return -7;
                     double *a4 = &acc[(((size_t)part * FBR_WPB + w) * FBR_NPW + sl) * 256];
                     for (int ks = 0; ks < p.nk4(); ks++) {
-                        // D[i][j] += sum_kk A[i][kk] B[kk][j]; lane = kk*16 + i supplies A[i][kk], B[kk][j=lane&15]
                         double A[16][4], B[4][16];
                         for (int lane = 0; lane < 64; lane++) {
                             int i = lane & 15, kk = lane >> 4;
                             int pos = 4 * ks + kk;
-                            double a = img[ta.off + pos * FBR_TILE + i];
-                            if (pos >= p.common) a = 0.0;
-                            int posb = pos;
-                            if (p.mode == 1) posb = (pos < (int)ta.rowid.size()) ? ta.rowid[pos] : 0;
-                            double b = img[tb.off + posb * FBR_TILE + i];
+                            double a = loc[oA + 64 * ks + lane];  // no masking: see FbrHostModel::ppos
+                            double b = (p.mode == 1) ? loc[oB + ridl[(oA >> 4) + pos] * FBR_TILE + i] : loc[oB + 64 * ks + lane];
                             A[i][kk] = a;
                             B[kk][i] = b;
                         }

@@ -85,11 +85,11 @@ class Emul:
 
     def program_info(self, k):
         NT, npairs, T, img, items = (ctypes.c_int() for _ in range(5))
-        mfma = ctypes.c_long()
+        mfma, uni = ctypes.c_long(), ctypes.c_long()
         lib().emul_program_info(ctypes.byref(self.t), int(k), ctypes.byref(NT), ctypes.byref(npairs), ctypes.byref(mfma),
-                                ctypes.byref(T), ctypes.byref(img), ctypes.byref(items))
-        return dict(NT=NT.value, npairs=npairs.value, mfma=mfma.value, T=T.value, image_doubles=img.value,
-                    items=items.value)
+                                ctypes.byref(T), ctypes.byref(img), ctypes.byref(items), ctypes.byref(uni))
+        return dict(NT=NT.value, npairs=npairs.value, mfma=mfma.value, T=T.value, part_image_max=img.value,
+                    dma_doubles=items.value, mfma_uniform=uni.value)
 
     def gram(self, st, rhs=None, sign=None, w=None):
         S, q, dq, ddq, bv, ba, rpy = self._st(st)
@@ -100,6 +100,7 @@ class Emul:
             k = rhs.shape[1]
         w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
         G = np.zeros((self.cols + k, self.cols + k))
-        lib().emul_gram(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
-                        _d(rhs), int(k), _d(w), _d(G))
+        rc = lib().emul_gram(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
+                             _d(rhs), int(k), _d(w), _d(G))
+        assert rc == 0, rc
         return G
