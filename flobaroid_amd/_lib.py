@@ -89,6 +89,11 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
          ctypes.c_void_p, ctypes.c_int32],
     ),
+    "fbr_tsqr_cols": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), _ip, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32],
+    ),
     "fbr_tsqr_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "fbr_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "fbr_profile_get": (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.POINTER(ctypes.c_int64)]),
@@ -364,16 +369,22 @@ class Engine:
         )
         return ret
 
-    def tsqr(self, st: dict, rhs=None, w=None, R_in=None, out=None):
-        """Upper-triangular R with R^T R = [Y|rhs]^T [Y|rhs] (blocked Householder TSQR)."""
+    def tsqr(self, st: dict, rhs=None, w=None, R_in=None, out=None, cols=None):
+        """Upper-triangular R with R^T R = [Y[:, cols]|rhs]^T [Y[:, cols]|rhs] (blocked Householder TSQR);
+        ``cols=None`` takes every identified column."""
         s, keep, S, mem = self._states(st)
         rr, wr, k = self._rhs(rhs, w, S, mem)
-        Pa = self.cols + k
+        ca = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+        Pa = (self.cols if ca is None else int(ca.size)) + k
         r, ret = self._out(out, (Pa, Pa), mem)
         rin = _Ref(R_in, (Pa, Pa), "R_in") if R_in is not None else _Ref(None)
         if rin.mem is not None and rin.mem != r.mem:
             raise ValueError("R_in must live in the same memory space as the output")
-        _check(self._lib.fbr_tsqr(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, rin.ptr, r.ptr, r.mem), "fbr_tsqr")
+        if ca is None:
+            _check(self._lib.fbr_tsqr(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, rin.ptr, r.ptr, r.mem), "fbr_tsqr")
+        else:
+            _check(self._lib.fbr_tsqr_cols(self._h, ctypes.byref(s), ca.ctypes.data_as(_ip), int(ca.size), rr.ptr, k, wr.ptr,
+                                           rin.ptr, r.ptr, r.mem), "fbr_tsqr_cols")
         return ret
 
     def tsqr_merge(self, R_a, R_b, out=None):

@@ -774,8 +774,8 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
 // ------------------------------------------------------------------------------------------------
 // TSQR (fbr_tsqr.h)
 // ------------------------------------------------------------------------------------------------
-extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
-                        const double *R_in, double *R_out, int32_t out_mem)
+static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
+                     const double *w, const double *R_in, double *R_out, int32_t out_mem)
 {
     DevStates d;
     int rc = stage_states(m, st, &d);
@@ -785,7 +785,27 @@ extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, i
         return FBR_E_INVALID;
     }
     const FbrHostModel &hm = m->hm;
-    const int Pa = hm.cols + k;
+    const int *dcols = nullptr;
+    int Psel = hm.cols;
+    if (cols) {
+        if (ncols <= 0 || ncols > hm.cols) {
+            set_err("bad column subset size");
+            return FBR_E_INVALID;
+        }
+        std::vector<char> seen(hm.cols, 0);
+        for (int i = 0; i < ncols; i++) {
+            if (cols[i] < 0 || cols[i] >= hm.cols || seen[cols[i]]) {
+                set_err("column subset entries must be distinct and in range");
+                return FBR_E_INVALID;
+            }
+            seen[cols[i]] = 1;
+        }
+        if ((rc = m->st_x.ensure((size_t)ncols * sizeof(int)))) return rc;
+        HIPCHK(hipMemcpyAsync(m->st_x.p, cols, (size_t)ncols * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        dcols = m->st_x.as<int>();
+        Psel = ncols;
+    }
+    const int Pa = Psel + k;
     const size_t rcount = (size_t)Pa * Pa;
     const long S = d.S;
     const double *drhs = nullptr, *dw = nullptr;
@@ -829,8 +849,9 @@ extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, i
             }
             HIPCHK(hipGetLastError());
             ProfScope ps(m, FBR_PROF_TSQR);
-            rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, cs * hm.rows, hm.cols, m->out_tmp.as<double>(), k,
-                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr);
+            rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, cs * hm.rows, Psel, m->out_tmp.as<double>(), k,
+                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
+                                    hm.cols, dcols);
             if (rc) return tsqr_fail(rc, "tsqr fold");
         }
     }
@@ -839,6 +860,22 @@ extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, i
         if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
     }
     return finish_output(m, R, R_out, rcount, out_mem);
+}
+
+extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
+                        const double *R_in, double *R_out, int32_t out_mem)
+{
+    return tsqr_impl(m, st, nullptr, 0, rhs, k, w, R_in, R_out, out_mem);
+}
+
+extern "C" int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs,
+                             int32_t k, const double *w, const double *R_in, double *R_out, int32_t out_mem)
+{
+    if (!cols) {
+        set_err("cols is NULL");
+        return FBR_E_INVALID;
+    }
+    return tsqr_impl(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem);
 }
 
 extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem)

@@ -145,6 +145,15 @@ int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, i
 int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
              const double *R_in, double *R_out, int32_t out_mem);
 
+/*
+ * Same as fbr_tsqr for a COLUMN SUBSET of the regressor: R_out [(ncols+k)][(ncols+k)] with
+ * R^T R = [Y[:, cols] | rhs]^T [Y[:, cols] | rhs].  cols (host, int32, ncols entries, any order, no repeats) are
+ * typically Model.independent_cols, which makes this la.qr(YBase) of sdp.py:470 / the lstsq of identifier.py:712
+ * at (nb+k)^2 instead of (P+k)^2 cost.  R_in, if given, is a factor of the same subset.
+ */
+int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
+                  const double *w, const double *R_in, double *R_out, int32_t out_mem);
+
 /* R_out = R factor of [R_a; R_b] (both n x n upper triangular, row-major) -- one node of the TSQR tree. */
 int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem);
 

@@ -187,3 +187,24 @@ def test_tsqr_keeps_small_singular_directions():
     Rs = np.linalg.qr(R[:, sel], mode="r")
     Rn = np.linalg.qr(A[:, sel], mode="r")
     assert abs(abs(Rs[1, 1]) - abs(Rn[1, 1])) <= 1e-4 * abs(Rn[1, 1])
+
+
+def test_tsqr_column_subset_is_qr_of_ybase():
+    """fbr_tsqr_cols on Model.independent_cols == numpy.linalg.qr(YBase | tau) (sdp.py:470) up to row signs."""
+    from oracle.oracle import lin_deps_qr
+
+    cfg = CONFIGS[6]
+    t, eng, om = _engine_oracle(cfg)
+    S = 800
+    st, rng = _states(t, cfg, S, 21)
+    rhs = rng.standard_normal((S * om.rows, 1))
+    Yo = om.regressor(st, st["sign"])
+    d = lin_deps_qr(Yo.T @ Yo, 1e-6 * np.abs(Yo.T @ Yo).max())
+    ic = d["independent_cols"]
+    R = eng.tsqr(st, rhs=rhs, cols=ic)
+    assert R.shape == (len(ic) + 1, len(ic) + 1)
+    Rn = np.linalg.qr(np.hstack([Yo[:, ic], rhs]), mode="r")
+    sg = lambda M: M * np.where(np.diag(M) < 0, -1.0, 1.0)[:, None]
+    assert np.linalg.norm(sg(R) - sg(Rn)) <= 1e-10 * np.linalg.norm(Rn)
+    with pytest.raises(Exception):
+        eng.tsqr(st, cols=[0, 0, 1])

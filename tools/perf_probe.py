@@ -29,7 +29,7 @@ def main():
     which = sys.argv[1:] or ["regressor", "gram", "tsqr", "id"]
     dev = torch.device("cuda", 0)
     out = {}
-    for robot, floating, S_reg, S_gram, S_tsqr in [("walkman_apriori", True, 100_000, 500_000, 30_000),
+    for robot, floating, S_reg, S_gram, S_tsqr in [("walkman_apriori", True, 100_000, 500_000, 150_000),
                                                    ("walkman_left_arm", True, 500_000, 500_000, 200_000),
                                                    ("kuka_lwr4", False, 500_000, 500_000, 200_000)]:
         topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", robot + ".topology.json"))
