@@ -185,6 +185,45 @@ def main():
         },
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
     }
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2
+    # correction of FETCH_SIZE) are committed under profiles/; scaled here to this run's samples per launch
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_gram_pmc_traffic.json")))
+        per_sample = (pm["gram_kernel_fetch_KB_per_sample_corrected_x2"] + pm["gram_kernel_write_KB_per_sample"]) * 1024.0
+        out["roofline"]["traffic"] = per_sample * samples_per_launch
+        out["roofline"]["traffic_source"] = "profiles/r01_gram_pmc_traffic.json (bytes per sample x samples per launch)"
+    except Exception:
+        pass
+    if world == 1:
+        # secondary figures of the path (not part of the timed steps): Householder TSQR GF/s and the
+        # materialising regressor kernel against the HBM roofline
+        S2 = min(S, 150_000)
+        sub = {k2: v[:S2].contiguous() for k2, v in st.items()}
+        rhs2 = rhs[: S2 * rows].contiguous()
+        eng.tsqr(sub, rhs=rhs2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.tsqr(sub, rhs=rhs2)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        tflop = 2.0 * S2 * rows * (P + 1) ** 2 / dt2 / 1e12
+        out["tsqr"] = {"samples": S2, "columns": P + 1, "seconds": dt2, "samples_per_s": S2 / dt2, "TFLOP_per_s": tflop,
+                       "frac_of_fp64_mfma_peak": tflop / PEAK_FP64_MFMA_TFLOPS,
+                       "flop_model": "2*rows*(P+k)^2 per sample (SURVEY 8d)"}
+        S3 = min(S, 60_000)
+        sub3 = {k2: v[:S3].contiguous() for k2, v in st.items()}
+        Y = torch.empty((S3 * rows, P), dtype=torch.float64, device=dev)
+        eng.regressor(sub3, out=Y)
+        eng.profile_enable(True)
+        eng.profile_get()
+        eng.regressor(sub3, out=Y)
+        pr3 = eng.profile_get()
+        eng.profile_enable(False)
+        kms = pr3["regressor"][0]
+        gbs = 8.0 * rows * P * S3 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out["assembly"] = {"samples": S3, "kernel": "fbr_regressor_kernel", "kernel_ms": kms, "GB_per_s": gbs,
+                           "frac_of_hbm_peak": gbs / PEAK_HBM_GBS, "bytes_per_sample": 8 * rows * P}
+        del Y
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(topo)
     elif world == 1:

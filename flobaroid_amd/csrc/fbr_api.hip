@@ -68,7 +68,7 @@ struct GramHolder {
     FbrGramProgram prog;
     DevGram dev;
     std::vector<DevBuf> pool;
-    DevBuf pimg;              // packed tile images of one chunk of samples (zeroed when (re)allocated)
+    DevBuf pimg[2];           // packed tile images of one chunk of samples, double buffered (zeroed when (re)allocated)
     size_t lds_bytes = 0;     // streaming Gram kernel
     size_t pack_lds_bytes = 0;
 };
@@ -79,6 +79,9 @@ struct fbr_model {
     int device = 0;
     int num_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side = nullptr;                 // producer stream: kinematics + tile-image packing of the next chunk
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_gram[2] = {nullptr, nullptr}, ev_fork = nullptr;
+    DevBuf rec2;
     std::vector<DevBuf> tables;
     std::map<int, std::unique_ptr<GramHolder>> gram;
     // workspace
@@ -97,7 +100,8 @@ struct fbr_model {
 struct ProfScope {
     fbr_model *m;
     int idx = -1;
-    ProfScope(fbr_model *m_, int cls) : m(m_)
+    hipStream_t st;
+    ProfScope(fbr_model *m_, int cls, hipStream_t st_ = nullptr) : m(m_), st(st_ ? st_ : m_->stream)
     {
         if (!m->prof) return;
         size_t i = m->ev_used.size();
@@ -108,11 +112,11 @@ struct ProfScope {
         }
         idx = (int)i;
         m->ev_used.emplace_back(cls, idx);
-        (void)hipEventRecord(m->ev_pool[idx].first, m->stream);
+        (void)hipEventRecord(m->ev_pool[idx].first, st);
     }
     ~ProfScope()
     {
-        if (idx >= 0) (void)hipEventRecord(m->ev_pool[idx].second, m->stream);
+        if (idx >= 0) (void)hipEventRecord(m->ev_pool[idx].second, st);
     }
 };
 static void prof_collect(fbr_model *m)
@@ -170,6 +174,12 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
     m->num_cus = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
     m->stream = m->own_stream;
+    HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&m->ev_pack[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_gram[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
 
     const FbrHostModel &hm = m->hm;
     DevModel &dm = m->dm;
@@ -230,7 +240,8 @@ extern "C" void fbr_model_destroy(fbr_model *m)
     for (auto &b : m->tables) b.release();
     for (auto &kv : m->gram) {
         for (auto &b : kv.second->pool) b.release();
-        kv.second->pimg.release();
+        kv.second->pimg[0].release();
+        kv.second->pimg[1].release();
     }
     DevBuf *bufs[] = {&m->st_q, &m->st_dq, &m->st_ddq, &m->st_bv, &m->st_ba, &m->st_rpy, &m->st_sign, &m->st_aux,
                       &m->st_aux2, &m->st_x, &m->rec, &m->partial, &m->out_tmp, &m->g_tmp};
@@ -240,6 +251,13 @@ extern "C" void fbr_model_destroy(fbr_model *m)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (m->side) (void)hipStreamDestroy(m->side);
+    for (int i = 0; i < 2; i++) {
+        if (m->ev_pack[i]) (void)hipEventDestroy(m->ev_pack[i]);
+        if (m->ev_gram[i]) (void)hipEventDestroy(m->ev_gram[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    m->rec2.release();
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
@@ -364,18 +382,19 @@ static long chunk_size(const fbr_model *m, long S)
     return std::min(S, ch);
 }
 
-static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, bool zero_twist = false)
+static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, hipStream_t st = nullptr, DevBuf *recbuf = nullptr)
 {
     const FbrHostModel &hm = m->hm;
-    int rc = m->rec.ensure((size_t)cs * hm.rec_size() * sizeof(double));
+    if (!st) st = m->stream;
+    if (!recbuf) recbuf = &m->rec;
+    int rc = recbuf->ensure((size_t)cs * hm.rec_size() * sizeof(double));
     if (rc) return rc;
-    (void)zero_twist;
     const int threads = 256;
     const int blocks = (int)((cs + threads - 1) / threads);
-    ProfScope ps(m, FBR_PROF_KIN);
-    hipLaunchKernelGGL(fbr_kin_kernel, dim3(blocks), dim3(threads), 0, m->stream, m->dm, cs, d.q + s0 * hm.n,
+    ProfScope ps(m, FBR_PROF_KIN, st);
+    hipLaunchKernelGGL(fbr_kin_kernel, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n,
                        d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
-                       d.rpy ? d.rpy + s0 * 3 : nullptr, m->rec.as<double>());
+                       d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
     HIPCHK(hipGetLastError());
     return FBR_OK;
 }
@@ -705,25 +724,44 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
                                    (int)h->pack_lds_bytes));
         const size_t img_bytes = (size_t)h->prog.image_doubles * sizeof(double);
         long ch = chunk_size(m, S);
-        ch = std::max(1L, std::min(ch, (long)((size_t)6 * 1024 * 1024 * 1024 / img_bytes)));
-        if ((size_t)ch * img_bytes > h->pimg.bytes) {
-            if ((rc = h->pimg.ensure((size_t)ch * img_bytes))) return rc;
-            HIPCHK(hipMemsetAsync(h->pimg.p, 0, h->pimg.bytes, m->stream));  // structural zeros / padding are never rewritten
-        }
-        for (long s0 = 0; s0 < S; s0 += ch) {
-            const long cs = std::min(ch, S - s0);
-            if ((rc = run_kin(m, d, s0, cs))) return rc;
+        ch = std::max(1L, std::min(ch, (long)((size_t)4 * 1024 * 1024 * 1024 / img_bytes)));
+        const long nchunks = (S + ch - 1) / ch;
+        for (int b = 0; b < (nchunks > 1 ? 2 : 1); b++)
+            if ((size_t)ch * img_bytes > h->pimg[b].bytes) {
+                if ((rc = h->pimg[b].ensure((size_t)ch * img_bytes))) return rc;
+                HIPCHK(hipMemsetAsync(h->pimg[b].p, 0, h->pimg[b].bytes, m->stream));  // structural zeros are never rewritten
+            }
+        // producer (kinematics + tile-image packing of chunk i+1) runs on a second stream and shares the CUs with the
+        // MFMA-bound Gram kernel of chunk i; the images are double buffered
+        HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        auto produce = [&](long ci) -> int {
+            const long s0 = ci * ch, cs = std::min(ch, S - s0);
+            const int b = (int)(ci & 1);
+            if (ci >= 2) HIPCHK(hipStreamWaitEvent(m->side, m->ev_gram[b], 0));  // Gram of chunk ci-2 is done with this buffer
+            int rc2 = run_kin(m, d, s0, cs, m->side, &m->rec2);
+            if (rc2) return rc2;
             {
-                ProfScope ps(m, FBR_PROF_REGRESSOR);
+                ProfScope ps(m, FBR_PROF_REGRESSOR, m->side);
                 const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
-                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, m->stream, h->dev, m->dm, cs,
-                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, m->side, h->dev, m->dm, cs,
+                                   m->rec2.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
-                                   h->pimg.as<double>());
+                                   h->pimg[b].as<double>());
             }
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(m->ev_pack[b], m->side));
+            return FBR_OK;
+        };
+        if ((rc = produce(0))) return rc;
+        for (long ci = 0; ci < nchunks; ci++) {
+            const long s0 = ci * ch, cs = std::min(ch, S - s0);
+            const int b = (int)(ci & 1);
+            if (ci + 1 < nchunks && (rc = produce(ci + 1))) return rc;
+            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_pack[b], 0));
+            // one workgroup per CU; the slice count is not rounded to the XCD count: measured (profiles/r01_gram_pmc_traffic)
+            // the parts of a slice drift apart and do not share L2 lines, so filling every CU is worth more
             int NS = std::max(1, (m->num_cus * blocks_per_cu) / T);
-            if (NS >= 8) NS &= ~7;  // multiple of 8: the parts of a slice share an XCD
             if ((long)NS > cs) NS = (int)cs;
             const size_t pcount = (size_t)NS * T * FBR_WPB * FBR_NPW * 256;
             if ((rc = m->partial.ensure(pcount * sizeof(double)))) return rc;
@@ -736,12 +774,13 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
                 ProfScope ps(m, FBR_PROF_GRAM);
                 if (timing)
                     hipLaunchKernelGGL(fbr_gram_kernel<true>, dim3(T * NS), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, h->dev, cs, NS,
-                                       h->pimg.as<double>(), m->partial.as<double>(), dbg);
+                                       h->pimg[b].as<double>(), m->partial.as<double>(), dbg);
                 else
                     hipLaunchKernelGGL(fbr_gram_kernel<false>, dim3(T * NS), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, h->dev, cs, NS,
-                                       h->pimg.as<double>(), m->partial.as<double>(), dbg);
+                                       h->pimg[b].as<double>(), m->partial.as<double>(), dbg);
             }
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(m->ev_gram[b], m->stream));
             if (timing) {
                 std::vector<unsigned long long> hb((size_t)T * NS * FBR_WPB * 8);
                 HIPCHK(hipMemcpyAsync(hb.data(), dbg, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
@@ -767,6 +806,7 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
             }
             HIPCHK(hipGetLastError());
         }
+        HIPCHK(hipStreamSynchronize(m->side));
     }
     return finish_output(m, G, G_out, gcount, out_mem);
 }

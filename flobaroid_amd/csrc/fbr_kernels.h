@@ -360,10 +360,32 @@ __global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, lo
     const int li = lane & 15, kk = lane >> 4;
     unsigned long long tacc[3] = {0, 0, 0}, t0 = 0;
 
-    // LDS-DMA of sample s into buf: wave w issues pieces w, w+WPB, ...
+    // LDS-DMA of sample s into buf: wave w issues pieces w, w+WPB, ...; the first FBR_NQ descriptors of the wave are kept
+    // in SGPRs for the whole kernel so that the issue is a straight run of s_mov m0 / global_load_lds pairs
+    constexpr int FBR_NQ = 10;
+    int pgx[FBR_NQ], ply[FBR_NQ];
+    __syncthreads();  // tables visible
+#pragma unroll
+    for (int q = 0; q < FBR_NQ; q++) {
+        const int i = wave + FBR_WPB * q;
+        pgx[q] = (i < npc) ? __builtin_amdgcn_readfirstlane(pcs[2 * i]) : 0;
+        ply[q] = (i < npc) ? __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]) : -1;
+    }
     auto dma = [&](long s, double *buf) {
         const double *src = pimg + s * (long)g.image_doubles + 2 * lane;
-        for (int i = wave; i < npc; i += FBR_WPB) {
+#pragma unroll
+        for (int q = 0; q < FBR_NQ; q++) {
+            const int ly = ply[q];
+            if (ly < 0) continue;
+            const int loff = ly & 0x3fffffff;
+            if (ly >> 30) {
+                if (lane < 32)
+                    __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + pgx[q]), (fbr_lds_ptr)(buf + loff), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + pgx[q]), (fbr_lds_ptr)(buf + loff), 16, 0, 0);
+            }
+        }
+        for (int i = wave + FBR_WPB * FBR_NQ; i < npc; i += FBR_WPB) {
             const int gx = __builtin_amdgcn_readfirstlane(pcs[2 * i]);
             const int ly = __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]);
             const int loff = ly & 0x3fffffff;

@@ -302,6 +302,7 @@ struct FbrGramProgram {
         const int PPB = FBR_WPB * FBR_NPW;
         int BE = 1;
         while ((BE + 1) * (BE + 1) <= PPB) BE++;
+        BE = std::max(FBR_SEGW, BE / FBR_SEGW * FBR_SEGW);  // block rows split into whole row segments
         mfma_per_sample = 0;
         mfma_uniform = 0;
         const int NB = (NT + BE - 1) / BE;
