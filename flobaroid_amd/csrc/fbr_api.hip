@@ -2,6 +2,7 @@
 // gfx950 only; there is deliberately no CPU path in this library.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -431,6 +432,9 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
     }
     const size_t lds = (size_t)hm.rec_size() * sizeof(double);
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int spb = std::max(1, std::min(16, 256 / std::max(1, hm.cols / 2)));  // samples side by side in one workgroup
+    const size_t lds2 = lds * spb;
+    HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     for (long s0 = 0; s0 < S; s0 += ch) {
         const long cs = std::min(ch, S - s0);
         if ((rc = run_kin(m, d, s0, cs))) return rc;
@@ -438,8 +442,13 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
         const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
         {
             ProfScope ps(m, FBR_PROF_REGRESSOR);
-            hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                               d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst);
+            // even column count (and a 16-byte aligned output): paired columns, 16-byte stores
+            if ((hm.cols & 1) == 0 && (((uintptr_t)dst) & 15) == 0)
+                hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2, m->stream, m->dm, cs, spb,
+                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst);
+            else
+                hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
+                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst);
         }
         HIPCHK(hipGetLastError());
         if (out_mem == FBR_HOST) {

@@ -124,6 +124,65 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
     }
 }
 
+// K2b: same result as K2 for an EVEN number of columns: one thread per PAIR of adjacent columns, 16-byte stores
+// (1 KiB per wave-instruction), ancestor masks hoisted into registers.  Adjacent inertial columns always belong to
+// the same link (10 or 4 columns per link).
+typedef double fbr_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
+                                                              const double *__restrict__ dq,
+                                                              const double *__restrict__ sign, double *__restrict__ Y)
+{
+    // spb samples per workgroup pass (small robots: 256 / (cols/2) samples side by side)
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int npairs = m.cols >> 1;
+    const int ls = tid / npairs, pr = tid - ls * npairs;  // local sample, column pair
+    const long ngroups = (S + spb - 1) / spb;
+    for (long gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
+        const long sb = gi * spb;
+        const int ns = (int)min((long)spb, S - sb);
+        __syncthreads();
+        for (int i = tid; i < ns * m.rec; i += blockDim.x) smem[i] = rec[sb * (long)m.rec + i];
+        __syncthreads();
+        if (ls >= ns) continue;
+        const long s = sb + ls;
+        const double *rs = smem + (long)ls * m.rec;
+        double *Ys = Y + s * (long)m.rows * m.cols;
+        for (int prr = pr; prr < npairs; prr += (spb > 1 ? npairs : (int)blockDim.x)) {
+            const int c = 2 * prr;
+            const int4 ca = m.coldesc[c], cb = m.coldesc[c + 1];
+            fbr_d2 *dst = (fbr_d2 *)(Ys + c);
+            const long rstride = m.cols >> 1;  // in double2 units
+            if (ca.x == 0) {
+                double wa[6], wb[6];
+                fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, ca.z, wa);
+                fbr_unit_wrench(rs + FBR_LINK_REC * cb.y, cb.z, wb);
+                for (int r = 0; r < m.fb; r++) dst[r * rstride] = (fbr_d2){wa[r], wb[r]};
+                // same link for both columns: one ancestor mask
+                for (int wd = 0; wd < m.nw; wd++) {
+                    const unsigned mask = m.ancmask[ca.y * m.nw + wd];
+                    const int dmax = min(32, m.n - 32 * wd);
+                    for (int b = 0; b < dmax; b++) {
+                        const int d = 32 * wd + b;
+                        fbr_d2 v = {0.0, 0.0};
+                        if ((mask >> b) & 1u) {
+                            const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d;
+                            v[0] = fbr_dot6(Sd, wa);
+                            v[1] = fbr_dot6(Sd, wb);
+                        }
+                        dst[(m.fb + d) * rstride] = v;
+                    }
+                }
+            } else {
+                const double va = fbr_friction_value(ca.z, dq[s * m.n + ca.w], sign ? sign[s * m.n + ca.w] : 0.0, m.stribeck);
+                const double vb = fbr_friction_value(cb.z, dq[s * m.n + cb.w], sign ? sign[s * m.n + cb.w] : 0.0, m.stribeck);
+                for (int r = 0; r < m.rows; r++)
+                    dst[r * rstride] = (fbr_d2){(r == m.fb + ca.w) ? va : 0.0, (r == m.fb + cb.w) ? vb : 0.0};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: inverse dynamics / prediction, one wavefront per sample.
 //   mode 0: x = full standard vector (10 per link + friction slots), friction model of model.py:299-326
