@@ -112,6 +112,18 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
             }
     }
 
+    // R_pp of the first panel (its owner only); later panels are prefetched one panel ahead
+    fbr_td4 rpp = {0.0, 0.0, 0.0, 0.0};
+    {
+        const int p0 = first_col / 16;
+        if (p0 < NP && wave == p0 % FBR_TSQR_WAVES) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = 4 * reg + kk;
+                rpp[reg] = (li >= i) ? R[(long)(16 * p0 + i) * n + 16 * p0 + li] : 0.0;
+            }
+        }
+    }
     for (int p = first_col / 16; p < NP; p++) {  // panels left of first_col: block columns are zero, identity reflectors
         {
             const int ow = p % FBR_TSQR_WAVES, tp = p / FBR_TSQR_WAVES;
@@ -130,18 +142,20 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
                         for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
                     }
                 {
-                    // R_pp (upper triangle) from global: lane (kk, c) fetches rows kk, kk+4, kk+8, kk+12 of column c
+                    // R_pp (upper triangle): prefetched by this wave during the previous panel's update phase
+                    // (lane (kk, c) holds rows kk, kk+4, kk+8, kk+12 of column c)
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
                         const int i = 4 * reg + kk;
-                        const double rv = (li >= i) ? R[(long)(j0 + i) * n + j0 + li] : 0.0;
-                        Rp[i * 16 + li] = rv;
-                        Rq[i * 16 + li] = rv;
+                        Rp[i * 16 + li] = rpp[reg];
+                        Rq[i * 16 + li] = rpp[reg];
                         Tm[i * 16 + li] = 0.0;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
+                unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
+                if (tacc) { tacc[4] += tq - tk; }
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     // (loads first: they do not depend on the chain below)
@@ -198,6 +212,7 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
                         }
                     }
                 }
+                if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[5] += t1 - tq; tq = t1; }
                 // ---- publish V; Z = V^T V straight from the registers; T by the triangular recurrence
                 fbr_td4 z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -235,6 +250,7 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
+                if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[6] += t1 - tq; tq = t1; }
                 // R_pp back to global (upper triangle)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
@@ -245,6 +261,14 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
             FBR_TT(1)
             __syncthreads();  // panel published
             FBR_TT(2)
+            // the owner of the next panel fetches its R_pp now (panel p only touches its own 16 rows of R)
+            if (p + 1 < NP && wave == (p + 1) % FBR_TSQR_WAVES) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int i = 4 * reg + kk;
+                    rpp[reg] = (li >= i) ? R[(long)(j0 + 16 + i) * n + j0 + 16 + li] : 0.0;
+                }
+            }
             // ---- trailing update of this wave's tiles right of the panel
 #pragma unroll
             for (int t = 0; t < TPW; t++) {
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_level0_kernel(co
                                                                                double *__restrict__ Rw, long nblocks,
                                                                                unsigned long long *dbg)
 {
-    unsigned long long tacc[4] = {0, 0, 0, 0};
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
     double *R = Rw + (long)blockIdx.x * n * n;
@@ -310,8 +334,8 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_level0_kernel(co
         fbr_tsqr_fold_regs<TPW, SUB>(R, n, A + r0 * n, n, m, 0, smem, dbg ? tacc : nullptr);
     }
     if (dbg && (threadIdx.x & 63) == 0) {
-        unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 4;
-        for (int i = 0; i < 4; i++) d[i] = tacc[i];
+        unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 8; i++) d[i] = tacc[i];
     }
 }
 
@@ -451,21 +475,23 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
     const int grid = (int)std::min<long>(wk.NW, nblocks);
     unsigned long long *dbg = nullptr;
     if (getenv("FBR_TSQR_TIMING")) {
-        TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 4 * 8));
-        TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 4 * 8, st));
+        TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 8 * 8));
+        TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 8 * 8, st));
     }
     FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB>), dim3(grid), dim3(FBR_TSQR_THREADS),
                                                  fbr_tsqr_lds_doubles<SUB>() * sizeof(double), st, wk.A, Mpad, n, wk.Rw, nblocks, dbg));
     TSQR_HIP(hipGetLastError());
     if (dbg) {
-        std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 4);
+        std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 8);
         TSQR_HIP(hipMemcpyAsync(hb.data(), dbg, hb.size() * 8, hipMemcpyDeviceToHost, st));
         TSQR_HIP(hipStreamSynchronize(st));
-        double sum[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < hb.size(); i++) sum[i & 3] += (double)hb[i];
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < hb.size(); i++) sum[i & 7] += (double)hb[i];
         const double folds = (double)nblocks * FBR_TSQR_WAVES;
         fprintf(stderr, "[fbr tsqr timing] cycles per fold per wave: barrier_in=%.0f panel(or idle)=%.0f barrier_pub=%.0f update=%.0f  (mb=%d n=%d)\n",
                 sum[0] / folds, sum[1] / folds, sum[2] / folds, sum[3] / folds, wk.mb, n);
+        fprintf(stderr, "[fbr tsqr timing]   panel owner split per fold per wave: load_Rpp=%.0f steps=%.0f ZT=%.0f store=%.0f\n", sum[4] / folds,
+                sum[5] / folds, sum[6] / folds, sum[7] / folds);
         (void)hipFree(dbg);
     }
     return 0;
