@@ -18,7 +18,7 @@
 #include <vector>
 
 #define FBR_TILE 16
-#define FBR_WPB 8         // waves per workgroup of the Gram kernel (2 per SIMD, one workgroup per CU)
+#define FBR_WPB 8         // waves per workgroup of the Gram kernel (2 per SIMD, one workgroup per CU; 2 x 4 waves measured 3% slower)
 #define FBR_SEGW 6        // tile pairs per row segment (same tile I, up to SEGW different tiles J)
 #define FBR_NSEG 3        // row segments per wave
 #define FBR_NPW (FBR_SEGW * FBR_NSEG)  // tile pairs (MFMA accumulators) per wave
@@ -404,10 +404,13 @@ struct FbrGramProgram {
                     });
                     for (size_t o = 0; o < v.size(); o += FBR_SEGW) {
                         Seg sgm{I, {}, 0};
+                        int nkmax = 0;
                         for (size_t j = o; j < std::min(v.size(), o + FBR_SEGW); j++) {
                             sgm.pr.push_back(v[j]);
-                            sgm.w += pairs[v[j]].nk4();
+                            sgm.w += 2 * pairs[v[j]].nk4();  // one MFMA = 2 cost units
+                            nkmax = std::max(nkmax, pairs[v[j]].nk4());
                         }
+                        sgm.w += 3 + 3 * nkmax;  // measured fixed cost: segment preamble + per-k-step A / row-map fetch
                         segs.push_back(sgm);
                     }
                 }
@@ -425,7 +428,7 @@ struct FbrGramProgram {
                     bool uni = true;
                     for (int pi : sgm.pr)
                         uni = uni && pairs[pi].common == pairs[sgm.pr[0]].common && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
-                    if (uni) mfma_uniform += sgm.w;
+                    if (uni) for (int pi : sgm.pr) mfma_uniform += pairs[pi].nk4();
                 }
                 cnt[best]++;
                 load[best] += sgm.w;

@@ -119,3 +119,50 @@ def sdp_inputs(R_aug: np.ndarray, independent_cols, K: np.ndarray, P: int, xBase
 def find_std_from_base(K: np.ndarray, xBase: np.ndarray) -> np.ndarray:
     """``findStdFromBaseParameters`` (identifier.py:328-341): xStd = pinv(K) xBase."""
     return la.pinv(K).dot(xBase)
+
+
+def identify_standard_direct(R_aug: np.ndarray, P: int, num_base_params: int, rhs_col: int = 0):
+    """``Identification.identifyStandardParametersDirect`` (identifier.py:792-814) without the tall SVD:
+    with [YStd | tau] = Q R_aug, the thin SVD YStd = U S V^T has U = Q[:, :P] U_r, (U_r, S, V) = svd(R_aug[:P, :P]),
+    and U_1^T tau = U_r[:, :nb]^T R_aug[:P, P+rhs_col].  Returns x_est = V_1 S_1^-1 U_1^T tau and the singular values."""
+    Rpp = R_aug[:P, :P]
+    z = R_aug[:P, P + rhs_col]
+    U, s, Vt = la.svd(Rpp)
+    nb = int(num_base_params)
+    x = Vt[:nb].T @ ((U[:, :nb].T @ z) / s[:nb])
+    return x, s
+
+
+def d_optimality(G_aug: np.ndarray, independent_cols, delta: float = 0.0) -> float:
+    """Excitation criterion of the trajectory optimiser (excitation/trajectoryOptimizer.py:263-272):
+    -sum(log(eig(YBase^T YBase) + delta)) from the fused Gram, YBase^T YBase = G[ic, ic]."""
+    ic = np.asarray(independent_cols, dtype=np.int64)
+    ev = la.eigvalsh(G_aug[np.ix_(ic, ic)])
+    return float(-np.sum(np.log(np.maximum(ev, 0.0) + delta)))
+
+
+def base_wrench_row_mask(num_samples: int, rows: int) -> np.ndarray:
+    """0/1 row weights selecting the 6 base-wrench rows of every sample (``_extractBaseWrenchRows``,
+    identifier.py:629-636) -- pass as ``w`` to ``Engine.gram`` / ``Engine.tsqr``."""
+    w = np.zeros((num_samples, rows))
+    w[:, :6] = 1.0
+    return w.reshape(-1)
+
+
+def trajectory_row_weights(residual_bw: np.ndarray, file_boundaries, num_used_samples: int, skip: int = 0) -> np.ndarray:
+    """Per-(file, wrench component) inverse-noise row weights of ``_extractBaseWrenchRows`` (identifier.py:654-679).
+
+    ``residual_bw`` (S, 6): base-wrench residual tau_bw - YBase_bw x_pre of a cheap OLS pre-pass (obtainable with
+    ``Engine.predict``).  Returns the (S, 6) weights (mean ~ 1); files with <= 6 samples keep weight 1."""
+    fb = 6
+    S = num_used_samples
+    loaded_idx = np.arange(S) * (skip + 1)
+    file_idx = np.searchsorted(file_boundaries, loaded_idx, side="right") - 1
+    n_files = len(file_boundaries) - 1
+    sigma = np.ones((n_files, fb))
+    for k in range(n_files):
+        mask = file_idx == k
+        if np.count_nonzero(mask) > fb:
+            sigma[k] = np.sqrt(np.mean(residual_bw[mask] ** 2, axis=0))
+    weights = np.mean(sigma) / np.maximum(sigma, 1e-12)
+    return weights[file_idx]

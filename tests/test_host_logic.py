@@ -172,3 +172,37 @@ def test_random_state_generator_follows_reference_call_order():
         bv = np.pi * np.random.rand(6); ba = np.pi * np.random.rand(6); rpy = np.random.ranf(3) * 0.1
         assert np.array_equal(st["q"][i], q) and np.array_equal(st["dq"][i], dq) and np.array_equal(st["ddq"][i], ddq)
         assert np.array_equal(st["base_vel"][i], bv) and np.array_equal(st["base_acc"][i], ba) and np.array_equal(st["rpy"][i], rpy)
+
+
+def test_direct_std_identification_dopt_and_row_weights():
+    t = load_topo("kuka_lwr4")
+    rng = np.random.default_rng(8)
+    st = random_states(t, 400, rng, 0, use_limits=True)
+    om = OracleModel(t)
+    Y = om.regressor(st)
+    tau = om.inverse_dynamics(st, t.x_std()).reshape(-1) + 0.01 * rng.standard_normal(Y.shape[0])
+    d = lin_deps_qr(Y.T @ Y, 1e-4)
+    nb = d["r"]
+    # identifyStandardParametersDirect (identifier.py:796-809) on the tall matrix
+    U, s, VH = la.svd(Y, full_matrices=False)
+    x_ref = VH.T[:, :nb] @ la.inv(np.diag(s[:nb])) @ U[:, :nb].T @ tau
+    R_aug = la.qr(np.column_stack([Y, tau]), mode="r")
+    x, sv = est.identify_standard_direct(R_aug, 80, nb)
+    assert la.norm(x - x_ref) <= 1e-8 * la.norm(x_ref)
+    assert np.allclose(sv[:nb], s[:nb], rtol=1e-10)
+    # D-optimality from the Gram (trajectoryOptimizer.py:263-272)
+    ic = d["independent_cols"]
+    YB = Y[:, ic]
+    ref = -np.sum(np.log(la.eigvalsh(YB.T @ YB) + 1e-6))
+    G = np.column_stack([Y, tau]).T @ np.column_stack([Y, tau])
+    assert abs(est.d_optimality(G, ic, 1e-6) - ref) <= 1e-8 * abs(ref)
+    # per-trajectory row weights (identifier.py:654-679)
+    S = 300
+    res = rng.standard_normal((S, 6)) * np.array([1, 2, 3, 1, 1, 1.0])
+    res[150:] *= 4.0
+    w = est.trajectory_row_weights(res, [0, 150, 300], S)
+    sigma = np.stack([np.sqrt(np.mean(res[:150] ** 2, axis=0)), np.sqrt(np.mean(res[150:] ** 2, axis=0))])
+    wref = np.mean(sigma) / sigma
+    assert np.allclose(w[:150], wref[0]) and np.allclose(w[150:], wref[1])
+    m = est.base_wrench_row_mask(5, 13).reshape(5, 13)
+    assert np.all(m[:, :6] == 1) and np.all(m[:, 6:] == 0)
