@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #define FBR_TSQR_THREADS 256
@@ -65,17 +66,187 @@ __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, i
 //   * only R (the panel's 16 rows) is streamed from global memory: read once, written once per fold.
 #define FBR_TSQR_LDV 17  // LDS row stride of the published V panel (conflict-free for both operand walks)
 
-// LDS carve (doubles): Vl[MB*17] | Rp[256] | Rq[256] | Tm[256] | Tau[16] | Wt[WAVES*256]
-template <int SUB> static inline size_t fbr_tsqr_lds_doubles() { return (size_t)16 * SUB * FBR_TSQR_LDV + 3 * 256 + 16 + (size_t)FBR_TSQR_WAVES * 256; }
-
-// broadcast, inside every group of 16 lanes, the value of lane j of that group
-__device__ __forceinline__ double fbr_row_bcast(double v, int j, int lane)
+// LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vl[MB*17] | Tm[256] | Rp[256]
+template <int TPW, int SUB> static inline size_t fbr_tsqr_lds_doubles()
 {
-    return __shfl(v, (lane & 48) | j, 64);
+    return (size_t)FBR_TSQR_WAVES * TPW * 256 + (size_t)16 * SUB * FBR_TSQR_LDV + 512;
+}
+typedef __attribute__((address_space(3))) void *fbr_tsqr_lds_ptr;
+typedef const __attribute__((address_space(1))) void *fbr_tsqr_glb_ptr;
+
+// Cross-lane primitives of the panel chain: all VALU (no LDS crossbar round trips).
+//   fbr_dpp_bcast<J>  every lane gets the value of lane J of its own row of 16 lanes (DPP row_newbcast)
+//   fbr_xor16_sum     v + (value of lane ^ 16);  fbr_xor32_sum  v + (value of lane ^ 32)   (gfx950 permlane swaps;
+//                     both orders add the same two numbers, so every lane ends with bit-identical sums)
+template <int J> __device__ __forceinline__ double fbr_dpp_bcast(double v)
+{
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0x150 + J, 0xf, 0xf, true);
+    b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0x150 + J, 0xf, 0xf, true);
+    return b.d;
+}
+__device__ __forceinline__ double fbr_xor16_sum(double v)
+{
+    union { double d; unsigned i[2]; } a, lo, hi;
+    a.d = v;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a.i[0], a.i[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a.i[1], a.i[1], false, false);
+    lo.i[0] = r0[0]; lo.i[1] = r1[0];
+    hi.i[0] = r0[1]; hi.i[1] = r1[1];
+    return lo.d + hi.d;
+}
+__device__ __forceinline__ double fbr_xor32_sum(double v)
+{
+    union { double d; unsigned i[2]; } a, lo, hi;
+    a.d = v;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a.i[0], a.i[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a.i[1], a.i[1], false, false);
+    lo.i[0] = r0[0]; lo.i[1] = r1[0];
+    hi.i[0] = r0[1]; hi.i[1] = r1[1];
+    return lo.d + hi.d;
 }
 
+// acc += trow[l] * (z of lane l), l = 0..J-1   (column J of the T recurrence; lane i holds row i of T)
+template <int J, int L = 0> struct FbrTAcc {
+    static __device__ __forceinline__ void run(const double (&trow)[16], double z, double &a0, double &a1)
+    {
+        if constexpr (L < J) {
+            if constexpr (L & 1)
+                a1 += trow[L] * fbr_dpp_bcast<L>(z);
+            else
+                a0 += trow[L] * fbr_dpp_bcast<L>(z);
+            FbrTAcc<J, L + 1>::run(trow, z, a0, a1);
+        }
+    }
+};
+
+// One Householder step (column J) of the panel [R_pp ; B_p] held by one wave:
+//   v[sb][reg]  lane (kk, c): B_p[16 sb + 4 reg + kk][c]   (MFMA C/D layout of the block tile)
+//   Rp          LDS copy of the original R_pp (row-major 16 x 16, 0 below the diagonal)
+//   rq[reg]     lane (kk, c): new R_pp[4 reg + kk][c];   trow[j]: lane (., i): T[i][j];   myscale: 1/(alpha - beta) of column c
+// The vectors stay unscaled in v (scaled by myscale when published), so one fused multiply-add per element per step.
+template <int SUB, int J>
+__device__ __forceinline__ void fbr_tsqr_panel_step(fbr_td4 (&v)[SUB], const double *Rp, fbr_td4 &rq, double (&trow)[16],
+                                                    double &myscale, int li, int kk)
+{
+    const double rjc = Rp[J * 16 + li];
+    const double alpha = fbr_dpp_bcast<J>(rjc);
+    // s_c = x . B[:, c] with x = B[:, J] (lane J's registers); lane J's own s is |x|^2
+    fbr_td4 x[SUB];
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg += 2) {
+            x[sb][reg] = fbr_dpp_bcast<J>(v[sb][reg]);
+            x[sb][reg + 1] = fbr_dpp_bcast<J>(v[sb][reg + 1]);
+            s0 += x[sb][reg] * v[sb][reg];
+            s1 += x[sb][reg + 1] * v[sb][reg + 1];
+        }
+    double s = fbr_xor32_sum(fbr_xor16_sum(s0 + s1));
+    const double normsq = fbr_dpp_bcast<J>(s);
+    // branch-free (a zero column gives tau = scale = 0, beta = alpha); two independent reciprocals (hardware seed +
+    // 2 Newton steps) instead of two divisions
+    const bool nz = normsq > 0.0;
+    const double bet = -copysign(sqrt(alpha * alpha + normsq), alpha);
+    const double d1 = alpha - bet;
+    double r1 = __builtin_amdgcn_rcp(d1), r2 = __builtin_amdgcn_rcp(bet);
+    r1 = r1 * (2.0 - d1 * r1);
+    r2 = r2 * (2.0 - bet * r2);
+    r1 = r1 * (2.0 - d1 * r1);
+    r2 = r2 * (2.0 - bet * r2);
+    const double scale = nz ? r1 : 0.0;
+    const double tau = nz ? -d1 * r2 : 0.0;
+    const double beta = nz ? bet : alpha;
+    // column J of T: Z[l][J] = v_l . v_J = myscale_l * scale * s_l sits on lane l (l < J)
+    {
+        double a0 = 0.0, a1 = 0.0;
+        FbrTAcc<J>::run(trow, scale * s * myscale, a0, a1);
+        trow[J] = (li == J) ? tau : ((li < J) ? -tau * (a0 + a1) : 0.0);
+    }
+    const double wc = rjc + scale * s;
+    const double g = (li > J) ? tau * wc * scale : 0.0;
+#pragma unroll
+    for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) v[sb][reg] -= g * x[sb][reg];
+    if (li == J) myscale = scale;
+    const double newr = (li > J) ? rjc - tau * wc : beta;
+    if (kk == (J & 3)) rq[J >> 2] = newr;
+    // pin the step's results here: otherwise their computation is sunk to the stores after the chain and every step's
+    // inputs stay live (spills)
+    asm volatile("" : "+v"(rq[J >> 2]));
+    asm volatile("" : "+v"(trow[J]));
+    asm volatile("" : "+v"(myscale));
+    __builtin_amdgcn_sched_barrier(0);  // keep each step's side work (T column, R row) inside the step: bounded live ranges
+}
+
+template <int SUB, int... Js>
+__device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const double *Rp, fbr_td4 &rq, double (&trow)[16],
+                                                     double &myscale, int li, int kk, std::integer_sequence<int, Js...>)
+{
+    (fbr_tsqr_panel_step<SUB, Js>(v, Rp, rq, trow, myscale, li, kk), ...);
+}
+
+// Trailing update of a wave's column tiles t >= t0 with the published panel (V in Vl, T in Tm), two tiles at a time:
+//   acc = R_rows + V^T C;  W = T^T acc;  R_rows -= W;  C -= V W        (Rl = LDS copy of the R_rows tiles, [tile][16][16])
+// The MFMA C/D layout (reg r, lane (kk, j) = row 4r + kk, column j) is also the B-operand layout of k-step r, so acc
+// and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
+// Tiles are indexed statically (one code path, pairs skipped by a uniform branch): a pair that straddles t0 also runs
+// its dead left tile (already consumed as a panel) through the MFMAs, only its R store is suppressed.
+template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdate {
+    static __device__ __forceinline__ void run(int t0, fbr_td4 (&C)[TPW][SUB], const double *Rl, double *__restrict__ R, unsigned ld, unsigned j0,
+                                               int wave, int li, int kk, const double *Vl, const double *Tm)
+    {
+        if constexpr (T < TPW) {
+            constexpr int NB = (T + 1 < TPW) ? 2 : 1;
+            if (T + NB - 1 >= t0) {
+                fbr_td4 acc[NB], w2[NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) acc[b][reg] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li];
+                    w2[b] = fbr_td4{0.0, 0.0, 0.0, 0.0};
+                }
+#pragma unroll
+                for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const double a = Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li];
+#pragma unroll
+                        for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, C[T + b][sb][reg], acc[b], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const double a = Tm[(4 * ks + kk) * 16 + li];
+#pragma unroll
+                    for (int b = 0; b < NB; b++) w2[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[b][ks], w2[b], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+                    if (T + b >= t0) {
+                        const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * (T + b));
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++)
+                            R[(j0 + 4 * reg + kk) * ld + c0 + li] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li] - w2[b][reg];
+                    }
+#pragma unroll
+                for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const double a = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk];
+#pragma unroll
+                        for (int b = 0; b < NB; b++) C[T + b][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -w2[b][ks], C[T + b][sb], 0, 0, 0);
+                    }
+            }
+            FbrTsqrUpdate<TPW, SUB, T + NB>::run(t0, C, Rl, R, ld, j0, wave, li, kk, Vl, Tm);
+        }
+    }
+};
+
 template <int TPW, int SUB>
-__device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n, const double *__restrict__ B, long ldb, int mrows, int first_col,
+__device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n, int ldr, const double *__restrict__ B, int ldb, int mrows, int first_col,
                                    double *smem, unsigned long long *tacc = nullptr)
 {
     unsigned long long tk = tacc ? __builtin_readcyclecounter() : 0;
@@ -86,17 +257,15 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
         tk = t1;                                                          \
     }
     constexpr int MB = 16 * SUB;
-    double *Vl = smem;
-    double *Rp = Vl + MB * FBR_TSQR_LDV;
-    double *Rq = Rp + 256;
-    double *Tm = Rq + 256;
-    double *Tau = Tm + 256;
-    double *Wt = Tau + 16;
+    double *Rl = smem;  // 16-byte aligned tiles for the LDS-DMA
+    double *Vl = Rl + FBR_TSQR_WAVES * TPW * 256;
+    double *Tm = Vl + MB * FBR_TSQR_LDV;
+    double *Rp = Tm + 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kk = lane >> 4;
     const int NP = n / 16;
-    double *Wm = Wt + wave * 256;
+    const unsigned ld = (unsigned)ldr;
 
     // ---- load this wave's tiles of the block (rows >= mrows are zero)
     fbr_td4 C[TPW][SUB];
@@ -108,11 +277,12 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int r = 16 * sb + 4 * reg + kk;
-                C[t][sb][reg] = (ct < NP && r < mrows) ? B[(long)r * ldb + 16 * ct + li] : 0.0;
+                C[t][sb][reg] = (ct < NP && r < mrows) ? B[(unsigned)r * (unsigned)ldb + 16 * ct + li] : 0.0;
             }
     }
 
     // R_pp of the first panel (its owner only); later panels are prefetched one panel ahead
+    // (lane (kk, c) holds rows kk, kk+4, kk+8, kk+12 of column c, 0 below the diagonal)
     fbr_td4 rpp = {0.0, 0.0, 0.0, 0.0};
     {
         const int p0 = first_col / 16;
@@ -120,198 +290,85 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int i = 4 * reg + kk;
-                rpp[reg] = (li >= i) ? R[(long)(16 * p0 + i) * n + 16 * p0 + li] : 0.0;
+                rpp[reg] = (li >= i) ? R[(unsigned)(16 * p0 + i) * ld + 16 * p0 + li] : 0.0;
             }
         }
     }
     for (int p = first_col / 16; p < NP; p++) {  // panels left of first_col: block columns are zero, identity reflectors
-        {
-            const int ow = p % FBR_TSQR_WAVES, tp = p / FBR_TSQR_WAVES;
-            const int j0 = 16 * p;
-            FBR_TT(3)
-            __syncthreads();  // every wave is done with the previous panel's V / T / R rows
-            FBR_TT(0)
-            if (wave == ow) {
-                // ---- panel: Householder factorisation of [R_pp ; V]; the tile is copied out of the block registers
-                //      with a static switch (it is dead afterwards), so the block array is only indexed statically
-                fbr_td4 v[SUB];
+        const int ow = p % FBR_TSQR_WAVES, tp = p / FBR_TSQR_WAVES;
+        const int j0 = 16 * p;
+        const int t0 = (p >= wave) ? (p - wave) / FBR_TSQR_WAVES + 1 : 0;  // this wave's first tile right of the panel
+        // the R rows of the panel under this wave's tiles (final since the previous fold) are copied to the LDS by
+        // LDS-DMA (no VGPRs) while the panel is being factorised; every wave fetches and consumes its own tiles only
+        auto fetch_rows = [&]() {
 #pragma unroll
-                for (int t = 0; t < TPW; t++)
-                    if (t == tp) {
+            for (int t = 0; t < TPW; t++)
+                if (t >= t0) {
+                    const int ct = wave + FBR_TSQR_WAVES * t;
 #pragma unroll
-                        for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
-                    }
-                {
-                    // R_pp (upper triangle): prefetched by this wave during the previous panel's update phase
-                    // (lane (kk, c) holds rows kk, kk+4, kk+8, kk+12 of column c)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int i = 4 * reg + kk;
-                        Rp[i * 16 + li] = rpp[reg];
-                        Rq[i * 16 + li] = rpp[reg];
-                        Tm[i * 16 + li] = 0.0;
-                    }
+                    for (int h = 0; h < 2; h++)  // lane l -> row 8 h + l / 8, columns 2 (l % 8), +1  (16 bytes)
+                        __builtin_amdgcn_global_load_lds((fbr_tsqr_glb_ptr)(R + (unsigned)(j0 + 8 * h + (lane >> 3)) * ld + 16 * ct + 2 * (lane & 7)),
+                                                         (fbr_tsqr_lds_ptr)(Rl + ct * 256 + h * 128), 16, 0, 0);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
-                if (tacc) { tacc[4] += tq - tk; }
+        };
+        FBR_TT(3)
+        __syncthreads();  // every wave is done with the previous panel's V / T
+        FBR_TT(0)
+        if (wave == ow) {
+            // ---- panel: Householder factorisation of [R_pp ; V] in this wave's registers; the tile is copied out of
+            //      the block registers with a static switch (it is dead afterwards)
+            fbr_td4 v[SUB];
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    // (loads first: they do not depend on the chain below)
-                    const double alpha = Rp[j * 16 + j];
-                    const double rjc = Rp[j * 16 + li];
-                    // x = column j of the panel at this lane's rows; s = x . B[:, c], q = |x|^2 (every lane, no broadcast)
-                    fbr_td4 x[SUB];
-                    double sa = 0.0, sb2 = 0.0, qa = 0.0, qb = 0.0;
+            for (int t = 0; t < TPW; t++)
+                if (t == tp) {
 #pragma unroll
-                    for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                        for (int reg = 0; reg < 4; reg += 2) {
-                            x[sb][reg] = fbr_row_bcast(v[sb][reg], j, lane);
-                            x[sb][reg + 1] = fbr_row_bcast(v[sb][reg + 1], j, lane);
-                            sa += x[sb][reg] * v[sb][reg];
-                            sb2 += x[sb][reg + 1] * v[sb][reg + 1];
-                            qa += x[sb][reg] * x[sb][reg];
-                            qb += x[sb][reg + 1] * x[sb][reg + 1];
-                        }
-                    double s = sa + sb2, normsq = qa + qb;
-                    s += __shfl_xor(s, 16, 64);
-                    normsq += __shfl_xor(normsq, 16, 64);
-                    s += __shfl_xor(s, 32, 64);
-                    normsq += __shfl_xor(normsq, 32, 64);
-                    double tau = 0.0, scale = 0.0, beta = alpha;
-                    if (normsq > 0.0) {
-                        beta = -copysign(sqrt(alpha * alpha + normsq), alpha);
-                        // two independent reciprocals (hardware seed + 2 Newton steps) instead of two divisions
-                        const double d1 = alpha - beta;
-                        double r1 = __builtin_amdgcn_rcp(d1), r2 = __builtin_amdgcn_rcp(beta);
-                        r1 = r1 * (2.0 - d1 * r1);
-                        r2 = r2 * (2.0 - beta * r2);
-                        r1 = r1 * (2.0 - d1 * r1);
-                        r2 = r2 * (2.0 - beta * r2);
-                        scale = r1;
-                        tau = -d1 * r2;
-                    }
-                    if (li > j) {
-                        const double wc = rjc + scale * s;
-                        const double f = tau * wc * scale;
-#pragma unroll
-                        for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                            for (int reg = 0; reg < 4; reg++) v[sb][reg] -= f * x[sb][reg];
-                        if (kk == 0) Rq[j * 16 + li] = rjc - tau * wc;
-                    } else if (li == j) {
-#pragma unroll
-                        for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                            for (int reg = 0; reg < 4; reg++) v[sb][reg] *= scale;
-                        if (kk == 0) {
-                            Rq[j * 16 + j] = beta;
-                            Tau[j] = tau;
-                        }
-                    }
+                    for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
                 }
-                if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[5] += t1 - tq; tq = t1; }
-                // ---- publish V; Z = V^T V straight from the registers; T by the triangular recurrence
-                fbr_td4 z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int sb = 0; sb < SUB; sb++)
+            for (int reg = 0; reg < 4; reg++) Rp[(4 * reg + kk) * 16 + li] = rpp[reg];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            fetch_rows();
+            unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
+            if (tacc) { tacc[4] += tq - tk; }
+            fbr_td4 rq = {0.0, 0.0, 0.0, 0.0};
+            double trow[16];
+            double myscale = 0.0;
+            fbr_tsqr_panel_steps<SUB>(v, Rp, rq, trow, myscale, li, kk, std::make_integer_sequence<int, 16>{});
+            if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[5] += t1 - tq; tq = t1; }
+            // ---- publish the scaled vectors V and T
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li] = v[sb][reg];
-                        z = __builtin_amdgcn_mfma_f64_16x16x4f64(v[sb][reg], v[sb][reg], z, 0, 0, 0);
-                    }
+            for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) Wm[(4 * reg + kk) * 16 + li] = z[reg];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                {
-                    // T[i][j] = tau_j (i == j), -tau_j * sum_{l<j} T[i][l] Z[l][j] (i < j); lane i keeps row i in registers
-                    // (T[i][l] = 0 for l < i, so the sum may start at 0); Z is read with static LDS offsets
-                    const int i = li;
-                    double trow[16];
+                for (int reg = 0; reg < 4; reg++) Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li] = v[sb][reg] * myscale;
+            if (kk == 0) {
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-                        for (int l = 0; l + 1 < j; l += 2) {
-                            acc0 += trow[l] * Wm[l * 16 + j];
-                            acc1 += trow[l + 1] * Wm[(l + 1) * 16 + j];
-                        }
-                        if (j & 1) acc0 += trow[j - 1] * Wm[(j - 1) * 16 + j];
-                        const double tj = Tau[j];
-                        trow[j] = (i == j) ? tj : ((i < j) ? -tj * (acc0 + acc1) : 0.0);
-                    }
-                    if (kk == 0) {
-#pragma unroll
-                        for (int j = 0; j < 16; j++) Tm[i * 16 + j] = trow[j];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[6] += t1 - tq; tq = t1; }
-                // R_pp back to global (upper triangle)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int i = 4 * reg + kk;
-                    if (li >= i) R[(long)(j0 + i) * n + j0 + li] = Rq[i * 16 + li];
-                }
+                for (int j = 0; j < 16; j++) Tm[li * 16 + j] = trow[j];
             }
-            FBR_TT(1)
-            __syncthreads();  // panel published
-            FBR_TT(2)
-            // the owner of the next panel fetches its R_pp now (panel p only touches its own 16 rows of R)
-            if (p + 1 < NP && wave == (p + 1) % FBR_TSQR_WAVES) {
+            if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[6] += t1 - tq; tq = t1; }
+            // R_pp back to global (upper triangle)
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int i = 4 * reg + kk;
-                    rpp[reg] = (li >= i) ? R[(long)(j0 + 16 + i) * n + j0 + 16 + li] : 0.0;
-                }
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = 4 * reg + kk;
+                if (li >= i) R[(unsigned)(j0 + i) * ld + j0 + li] = rq[reg];
             }
-            // ---- trailing update of this wave's tiles right of the panel
+        } else {
+            fetch_rows();
+        }
+        FBR_TT(1)
+        __syncthreads();  // panel published, R rows landed (the barrier waits for vmcnt(0))
+        FBR_TT(2)
+        // the owner of the next panel fetches its R_pp now (panel p only touches its own 16 rows of R)
+        if (p + 1 < NP && wave == (p + 1) % FBR_TSQR_WAVES) {
 #pragma unroll
-            for (int t = 0; t < TPW; t++) {
-                const int ct = wave + FBR_TSQR_WAVES * t;
-                if (ct <= p || ct >= NP) continue;
-                const int c0 = 16 * ct;
-                fbr_td4 r0;
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) r0[reg] = R[(long)(j0 + 4 * reg + kk) * n + c0 + li];
-                fbr_td4 acc = r0;
-#pragma unroll
-                for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li], C[t][sb][reg], acc, 0, 0, 0);
-                // W2 = T^T acc (through LDS: C/D layout -> B operand)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) Wm[(4 * reg + kk) * 16 + li] = acc[reg];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                fbr_td4 w2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++)
-                    w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * 16 + li], Wm[(4 * ks + kk) * 16 + li], w2, 0, 0, 0);
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) R[(long)(j0 + 4 * reg + kk) * n + c0 + li] = r0[reg] - w2[reg];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) Wm[(4 * reg + kk) * 16 + li] = -w2[reg];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                double wb[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) wb[ks] = Wm[(4 * ks + kk) * 16 + li];
-                // C += V (-W2), accumulated straight into the register tile
-#pragma unroll
-                for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++)
-                        C[t][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk], wb[ks], C[t][sb], 0, 0, 0);
-                __builtin_amdgcn_wave_barrier();
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = 4 * reg + kk;
+                rpp[reg] = (li >= i) ? R[(unsigned)(j0 + 16 + i) * ld + j0 + 16 + li] : 0.0;
             }
         }
+        // ---- trailing update of this wave's tiles right of the panel (tiles past the last column tile are zero columns
+        //      of the padded factor: ld = 16 * WAVES * TPW)
+        FbrTsqrUpdate<TPW, SUB>::run(t0, C, Rl, R, ld, (unsigned)j0, wave, li, kk, Vl, Tm);
     }
     FBR_TT(3)
     __syncthreads();
@@ -327,11 +384,12 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_level0_kernel(co
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
-    double *R = Rw + (long)blockIdx.x * n * n;
+    constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;  // leading dimension of the working factors (>= n)
+    double *R = Rw + (long)blockIdx.x * n * LD;
     for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const long r0 = b * MB;
         const int m = (int)std::min<long>(MB, Mpad - r0);
-        fbr_tsqr_fold_regs<TPW, SUB>(R, n, A + r0 * n, n, m, 0, smem, dbg ? tacc : nullptr);
+        fbr_tsqr_fold_regs<TPW, SUB>(R, n, LD, A + r0 * n, n, m, 0, smem, dbg ? tacc : nullptr);
     }
     if (dbg && (threadIdx.x & 63) == 0) {
         unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 8;
@@ -345,11 +403,12 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_tree_kernel(doub
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
+    constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;
     const long a = (long)2 * blockIdx.x * stride, b = a + stride;
     if (b >= count) return;
     for (int i0 = 0; i0 < n; i0 += MB) {
         const int m = std::min(MB, n - i0);
-        fbr_tsqr_fold_regs<TPW, SUB>(Rw + a * n * n, n, Rw + b * n * n + (long)i0 * n, n, m, i0, smem);
+        fbr_tsqr_fold_regs<TPW, SUB>(Rw + a * n * LD, n, LD, Rw + b * n * LD + (long)i0 * LD, LD, m, i0, smem);
     }
 }
 
@@ -370,7 +429,7 @@ struct FbrTsqrWork {
     double *Rw = nullptr;   // [NW][n][n]
     double *A = nullptr;    // packed chunk [Mpad][n]
     size_t rw_bytes = 0, a_bytes = 0;
-    int n = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0;
+    int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0;
     bool active = false;
     void release()
     {
@@ -430,8 +489,11 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
     const int sub = fbr_tsqr_sub_for(tpw);
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
-    const int NW = (int)std::max(1L, std::min<long>(2L * num_cus, want));
-    const size_t need = (size_t)NW * n * n * sizeof(double);
+    const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
+    const long per_cu = envw ? std::max(1, atoi(envw)) : 2;
+    const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
+    const int ld = 16 * FBR_TSQR_WAVES * tpw;
+    const size_t need = (size_t)NW * n * ld * sizeof(double);
     if (need > wk.rw_bytes) {
         if (wk.Rw) (void)hipFree(wk.Rw);
         wk.Rw = nullptr;
@@ -439,10 +501,10 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         TSQR_HIP(hipMalloc((void **)&wk.Rw, need));
         wk.rw_bytes = need;
     }
-    wk.n = n; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub;
+    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub;
     TSQR_HIP(hipMemsetAsync(wk.Rw, 0, need, st));
     if (R_in) {
-        hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, Pa, R_in, Pa, wk.Rw, n, n, n);
+        hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, Pa, R_in, Pa, wk.Rw, ld, n, ld);
         TSQR_HIP(hipGetLastError());
     }
     wk.active = true;
@@ -478,8 +540,10 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
         TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 8 * 8));
         TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 8 * 8, st));
     }
+    FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
     FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                 fbr_tsqr_lds_doubles<SUB>() * sizeof(double), st, wk.A, Mpad, n, wk.Rw, nblocks, dbg));
+                                                 (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, dbg));
     TSQR_HIP(hipGetLastError());
     if (dbg) {
         std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 8);
@@ -505,13 +569,15 @@ static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out
         return -1;
     }
     const int n = wk.n;
+    FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
     for (int stride = 1; stride < wk.NW; stride *= 2) {
         const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB>), dim3(pairs), dim3(FBR_TSQR_THREADS),
-                                                     fbr_tsqr_lds_doubles<SUB>() * sizeof(double), st, wk.Rw, n, stride, wk.NW));
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW));
         TSQR_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, wk.Pa, wk.Rw, n, R_out, wk.Pa, wk.Pa, wk.Pa);
+    hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, wk.Pa, wk.Rw, wk.ld, R_out, wk.Pa, wk.Pa, wk.Pa);
     TSQR_HIP(hipGetLastError());
     wk.active = false;
     return 0;
