@@ -3,17 +3,19 @@
 // R^T R = A^T A for a tall row stream A (rows = samples x N_OUT, columns = [Y | rhs], padded to a
 // multiple of 16), WITHOUT forming A^T A (no squaring of the condition number):
 //
-//   level 0  every workgroup w owns a private upper-triangular R_w (global memory, L2/MALL resident) and folds
-//            its share of the 64-row blocks into it with a triangular-pentagonal Householder QR ("TPQRT": QR of
+//   level 0  every workgroup w owns a private upper-triangular R_w (global memory) and folds its share of the
+//            MB-row blocks (MB = 16 SUB <= 64) into it with a triangular-pentagonal Householder QR ("TPQRT": QR of
 //            [R_w ; B], only R_w's panel rows and the dense block take part).  The block lives in the VGPRs of the
-//            workgroup's 8 waves for the whole fold (see fbr_tsqr_fold_regs) -- only R_w is streamed:
-//              panel (16 columns): owner wave, in registers; T from V^T V by MFMA + 16x16 triangular recurrence
+//            workgroup's 8 waves for the whole fold (see fbr_tsqr_stream) -- only R_w is streamed:
+//              panel (16 columns): owner wave, all in registers (DPP / permlane cross-lane ops), T built in-chain
 //              trailing update:    W = T^T (R_rows + V^T C),  R_rows -= W,  C -= V W on v_mfma_f64_16x16x4_f64
-//   level 1+ binary tree over the R_w (one launch per level; the partner's R is folded in 64-row chunks, panels
+//            Panels are software-pipelined ACROSS the waves: the owner of panel q+1 updates its tile first and
+//            factorises it while the other waves are still applying panel q (LDS flags, no workgroup barrier).
+//   level 1+ binary tree over the R_w (one launch per level; the partner's R is folded in MB-row chunks, panels
 //            left of a chunk's first non-zero column are skipped).  Across ranks the same merge runs on R factors
 //            exchanged over xGMI (flobaroid_amd/dist.py).
 //
-// Everything is deterministic (fixed block -> workgroup assignment, fixed tree).
+// Everything is deterministic (fixed block -> workgroup assignment, fixed tree, fixed evaluation order per wave).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,9 +26,11 @@
 #include <utility>
 #include <vector>
 
-#define FBR_TSQR_THREADS 256
+#define FBR_TSQR_THREADS 512
 #define FBR_TSQR_WAVES (FBR_TSQR_THREADS / 64)
+#define FBR_TSQR_RING 6            // published panels (V, T) kept in the LDS: how far the waves may drift apart
 #define FBR_TSQR_MAXN 768          // widest supported factor (columns incl. rhs, padded to 16)
+#define FBR_TSQR_SPIN_LIMIT (1 << 18)
 
 typedef double fbr_td4 __attribute__((ext_vector_type(4)));
 
@@ -56,20 +60,24 @@ __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, i
     }
 }
 
-// Register-resident TPQRT.  A workgroup of 8 waves folds a block of MB = 16*SUB rows into its private R:
+// Register-resident, wave-pipelined TPQRT.  A workgroup of 8 waves folds a block of MB = 16*SUB rows into its R:
 //   * wave w owns the column tiles ct = w, w+8, ... (TPW per wave); the whole block lives in VGPRs in the MFMA
 //     C/D layout (lane (kk, j) of tile/sub-tile holds row 16*sub + 4*reg + kk, column j), so
 //       - V^T C consumes the block straight from the registers as the B operand (k-step = (sub, reg)),
 //       - C -= V W accumulates straight into them;
-//   * the panel (tile p) is factorised by its owner wave in registers (cross-lane broadcasts, no barrier per
-//     column), the scaled Householder vectors V (MB x 16) and T (16 x 16) are published through LDS;
-//   * only R (the panel's 16 rows) is streamed from global memory: read once, written once per fold.
+//   * panel q (tile q) is factorised by its owner wave q % 8 in registers, the scaled Householder vectors V (MB x 16)
+//     and T (16 x 16) are published in slot q % RING of an LDS ring, then `pub` (LDS) is advanced;
+//   * every wave applies the panels in order to its own tiles as soon as they are published; the owner of panel q+1
+//     updates tile q+1 first, factorises it, and only then finishes panel q on its other tiles -- the serial
+//     dependency chain is  chain(q) -> one tile update -> chain(q+1), everything else runs beside it;
+//   * only R (the panel's 16 rows) is streamed from global memory: each wave copies the R rows under its own tiles
+//     to the LDS with LDS-DMA one panel ahead, and writes them back after the update.
 #define FBR_TSQR_LDV 17  // LDS row stride of the published V panel (conflict-free for both operand walks)
 
-// LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vl[MB*17] | Tm[256] | Rp[256]
+// LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vr[RING][MB*17] | Tr[RING][256] | Rp[WAVES][256] | flags[16]
 template <int TPW, int SUB> static inline size_t fbr_tsqr_lds_doubles()
 {
-    return (size_t)FBR_TSQR_WAVES * TPW * 256 + (size_t)16 * SUB * FBR_TSQR_LDV + 512;
+    return (size_t)FBR_TSQR_WAVES * TPW * 256 + (size_t)FBR_TSQR_RING * (16 * SUB * FBR_TSQR_LDV + 256) + (size_t)FBR_TSQR_WAVES * 256 + 16;
 }
 typedef __attribute__((address_space(3))) void *fbr_tsqr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_tsqr_glb_ptr;
@@ -107,15 +115,27 @@ __device__ __forceinline__ double fbr_xor32_sum(double v)
     return lo.d + hi.d;
 }
 
+// acc += (value of lane J of the row of `bsrc`) * mul  in ONE instruction: gfx90a+ lets the DP-ALU VOP2 ops take a DPP
+// row_newbcast source operand, which the compiler does not select from the intrinsics (it emits 2 v_mov_b32_dpp + FMA).
+// The leading s_nop covers the VALU-write -> DPP-read hazard, which the hazard recogniser cannot see inside inline asm.
+// NOP = false only where the DPP source register was written at least two VALU instructions earlier.
+template <int J, bool NOP = true> __device__ __forceinline__ void fbr_fmac_bcast(double &acc, double bsrc, double mul)
+{
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(J));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(J));
+}
+
 // acc += trow[l] * (z of lane l), l = 0..J-1   (column J of the T recurrence; lane i holds row i of T)
 template <int J, int L = 0> struct FbrTAcc {
     static __device__ __forceinline__ void run(const double (&trow)[16], double z, double &a0, double &a1)
     {
         if constexpr (L < J) {
             if constexpr (L & 1)
-                a1 += trow[L] * fbr_dpp_bcast<L>(z);
+                fbr_fmac_bcast<L, false>(a1, z, trow[L]);
             else
-                a0 += trow[L] * fbr_dpp_bcast<L>(z);
+                fbr_fmac_bcast<L, (L == 0)>(a0, z, trow[L]);
             FbrTAcc<J, L + 1>::run(trow, z, a0, a1);
         }
     }
@@ -132,33 +152,40 @@ __device__ __forceinline__ void fbr_tsqr_panel_step(fbr_td4 (&v)[SUB], const dou
 {
     const double rjc = Rp[J * 16 + li];
     const double alpha = fbr_dpp_bcast<J>(rjc);
-    // s_c = x . B[:, c] with x = B[:, J] (lane J's registers); lane J's own s is |x|^2
-    fbr_td4 x[SUB];
+    // s_c = x . B[:, c] with x = B[:, J] (lane J's registers, read through the DPP operand); lane J's own s is |x|^2
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg += 2) {
-            x[sb][reg] = fbr_dpp_bcast<J>(v[sb][reg]);
-            x[sb][reg + 1] = fbr_dpp_bcast<J>(v[sb][reg + 1]);
-            s0 += x[sb][reg] * v[sb][reg];
-            s1 += x[sb][reg + 1] * v[sb][reg + 1];
+            if (sb == 0 && reg == 0)
+                fbr_fmac_bcast<J, true>(s0, v[sb][reg], v[sb][reg]);
+            else
+                fbr_fmac_bcast<J, false>(s0, v[sb][reg], v[sb][reg]);  // written by the previous step's update, >= 3 instructions ago
+            fbr_fmac_bcast<J, false>(s1, v[sb][reg + 1], v[sb][reg + 1]);
         }
     double s = fbr_xor32_sum(fbr_xor16_sum(s0 + s1));
     const double normsq = fbr_dpp_bcast<J>(s);
-    // branch-free (a zero column gives tau = scale = 0, beta = alpha); two independent reciprocals (hardware seed +
-    // 2 Newton steps) instead of two divisions
+    // branch-free (a zero column gives tau = scale = 0, beta = alpha).  beta = -sign(alpha) g with g = sqrt(alpha^2 + |x|^2)
+    // from the hardware rsq seed, one coupled Newton step on (g, h = 1/(2g)) and one residual correction of g;
+    // tau = (beta - alpha) / beta = 1 + |alpha| / g = 1 + 2 |alpha| h;  scale = 1 / (alpha - beta) = sign(alpha) / (|alpha| + g)
+    // by two Newton steps from a reciprocal seed taken on the unrefined g (off the dependency chain).
     const bool nz = normsq > 0.0;
-    const double bet = -copysign(sqrt(alpha * alpha + normsq), alpha);
-    const double d1 = alpha - bet;
-    double r1 = __builtin_amdgcn_rcp(d1), r2 = __builtin_amdgcn_rcp(bet);
-    r1 = r1 * (2.0 - d1 * r1);
-    r2 = r2 * (2.0 - bet * r2);
-    r1 = r1 * (2.0 - d1 * r1);
-    r2 = r2 * (2.0 - bet * r2);
-    const double scale = nz ? r1 : 0.0;
-    const double tau = nz ? -d1 * r2 : 0.0;
-    const double beta = nz ? bet : alpha;
+    const double aa = fabs(alpha);
+    const double tt = fma(alpha, alpha, normsq);
+    const double y0 = __builtin_amdgcn_rsq(tt);
+    double g = tt * y0, h = 0.5 * y0;
+    double r1 = __builtin_amdgcn_rcp(aa + g);
+    const double rr = fma(-h, g, 0.5);
+    g = fma(g, rr, g);
+    h = fma(h, rr, h);
+    g = fma(fma(-g, g, tt), h, g);
+    const double d1m = aa + g;
+    r1 = fma(r1, fma(-d1m, r1, 1.0), r1);
+    r1 = fma(r1, fma(-d1m, r1, 1.0), r1);
+    const double scale = nz ? copysign(r1, alpha) : 0.0;
+    const double tau = nz ? fma(aa, h + h, 1.0) : 0.0;
+    const double beta = nz ? -copysign(g, alpha) : alpha;
     // column J of T: Z[l][J] = v_l . v_J = myscale_l * scale * s_l sits on lane l (l < J)
     {
         double a0 = 0.0, a1 = 0.0;
@@ -166,11 +193,19 @@ __device__ __forceinline__ void fbr_tsqr_panel_step(fbr_td4 (&v)[SUB], const dou
         trow[J] = (li == J) ? tau : ((li < J) ? -tau * (a0 + a1) : 0.0);
     }
     const double wc = rjc + scale * s;
-    const double g = (li > J) ? tau * wc * scale : 0.0;
+    const double ng = (li > J) ? -(tau * wc * scale) : 0.0;
+    // B[:, c] -= g_c x: lane J itself has g = 0, so the broadcast source stays intact while the registers are rewritten
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) v[sb][reg] -= g * x[sb][reg];
+        for (int reg = 0; reg < 4; reg++) {
+            double e = v[sb][reg];
+            if (sb == 0 && reg == 0)
+                fbr_fmac_bcast<J, true>(e, e, ng);
+            else
+                fbr_fmac_bcast<J, false>(e, e, ng);
+            v[sb][reg] = e;
+        }
     if (li == J) myscale = scale;
     const double newr = (li > J) ? rjc - tau * wc : beta;
     if (kk == (J & 3)) rq[J >> 2] = newr;
@@ -189,65 +224,145 @@ __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const do
     (fbr_tsqr_panel_step<SUB, Js>(v, Rp, rq, trow, myscale, li, kk), ...);
 }
 
-// Trailing update of a wave's column tiles t >= t0 with the published panel (V in Vl, T in Tm), two tiles at a time:
+// Trailing update of NB (1 or 2) column tiles T, T+1 of a wave with a published panel (V in Vl, T in Tm):
 //   acc = R_rows + V^T C;  W = T^T acc;  R_rows -= W;  C -= V W        (Rl = LDS copy of the R_rows tiles, [tile][16][16])
 // The MFMA C/D layout (reg r, lane (kk, j) = row 4r + kk, column j) is also the B-operand layout of k-step r, so acc
 // and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
-// Tiles are indexed statically (one code path, pairs skipped by a uniform branch): a pair that straddles t0 also runs
-// its dead left tile (already consumed as a panel) through the MFMAs, only its R store is suppressed.
-template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdate {
-    static __device__ __forceinline__ void run(int t0, fbr_td4 (&C)[TPW][SUB], const double *Rl, double *__restrict__ R, unsigned ld, unsigned j0,
-                                               int wave, int li, int kk, const double *Vl, const double *Tm)
+// live[b] == false: the tile is dead (already consumed as a panel); it still runs through the MFMAs (static register
+// indexing, one code path) but its R rows are neither stored nor prefetched.
+template <int TPW, int SUB, int T, int NB>
+__device__ __forceinline__ void fbr_tsqr_update_tiles(fbr_td4 (&C)[TPW][SUB], const bool (&live)[NB], double *Rl, double *__restrict__ R, unsigned ld,
+                                                      int q, int NP, int wave, int lane, const double *Vl, const double *Tm)
+{
+    const int li = lane & 15, kk = lane >> 4;
+    const unsigned j0 = 16u * (unsigned)q;
+    fbr_td4 acc[NB], w2[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) acc[b][reg] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li];
+        w2[b] = fbr_td4{0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const double a = Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li];
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, C[T + b][sb][reg], acc[b], 0, 0, 0);
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const double a = Tm[(4 * ks + kk) * 16 + li];
+#pragma unroll
+        for (int b = 0; b < NB; b++) w2[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[b][ks], w2[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        if (live[b]) {
+            // uniform (scalar) base + one per-lane offset shared by every store of the kernel
+            const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * (T + b));
+            const unsigned voff = (unsigned)kk * ld + (unsigned)li;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                double *Rs = R + ((j0 + 4 * reg) * ld + c0);
+                Rs[voff] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li] - w2[b][reg];
+            }
+        }
+#pragma unroll
+    for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const double a = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk];
+#pragma unroll
+            for (int b = 0; b < NB; b++) C[T + b][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -w2[b][ks], C[T + b][sb], 0, 0, 0);
+        }
+}
+
+// LDS-DMA of the R rows of panel q under the wave's tiles t >= t0 into their LDS slots (lane l -> row 8 h + l / 8,
+// columns 2 (l % 8), +1: 16 bytes per lane).  Issued once per panel AFTER the wave's whole update: the compiler orders
+// every later LDS read behind an outstanding LDS-DMA (vmcnt(0)), so a copy issued between two tile updates would stall
+// the second one for a full memory latency.
+template <int TPW>
+__device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, double *Rl, const double *__restrict__ R, unsigned ld, int q, int wave, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+        if (t >= t0) {
+            const int ct = wave + FBR_TSQR_WAVES * t;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const double *Rs = R + ((unsigned)(16 * q + 8 * h) * ld + 16u * (unsigned)ct);  // uniform
+                __builtin_amdgcn_global_load_lds((fbr_tsqr_glb_ptr)(Rs + ((unsigned)(lane >> 3) * ld + 2u * (unsigned)(lane & 7))),
+                                                 (fbr_tsqr_lds_ptr)(Rl + ct * 256 + h * 128), 16, 0, 0);
+            }
+        }
+}
+
+// all tiles t >= t0 of the wave, in static pairs (a pair that straddles t0 runs its dead left tile too)
+template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateFrom {
+    static __device__ __forceinline__ void run(int t0, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
+                                               int wave, int lane, const double *Vl, const double *Tm)
     {
         if constexpr (T < TPW) {
             constexpr int NB = (T + 1 < TPW) ? 2 : 1;
             if (T + NB - 1 >= t0) {
-                fbr_td4 acc[NB], w2[NB];
+                bool live[NB];
 #pragma unroll
-                for (int b = 0; b < NB; b++) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) acc[b][reg] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li];
-                    w2[b] = fbr_td4{0.0, 0.0, 0.0, 0.0};
-                }
-#pragma unroll
-                for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const double a = Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li];
-#pragma unroll
-                        for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, C[T + b][sb][reg], acc[b], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const double a = Tm[(4 * ks + kk) * 16 + li];
-#pragma unroll
-                    for (int b = 0; b < NB; b++) w2[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[b][ks], w2[b], 0, 0, 0);
-                }
-#pragma unroll
-                for (int b = 0; b < NB; b++)
-                    if (T + b >= t0) {
-                        const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * (T + b));
-#pragma unroll
-                        for (int reg = 0; reg < 4; reg++)
-                            R[(j0 + 4 * reg + kk) * ld + c0 + li] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li] - w2[b][reg];
-                    }
-#pragma unroll
-                for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) {
-                        const double a = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk];
-#pragma unroll
-                        for (int b = 0; b < NB; b++) C[T + b][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -w2[b][ks], C[T + b][sb], 0, 0, 0);
-                    }
+                for (int b = 0; b < NB; b++) live[b] = T + b >= t0;
+                fbr_tsqr_update_tiles<TPW, SUB, T, NB>(C, live, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
             }
-            FbrTsqrUpdate<TPW, SUB, T + NB>::run(t0, C, Rl, R, ld, j0, wave, li, kk, Vl, Tm);
+            FbrTsqrUpdateFrom<TPW, SUB, T + NB>::run(t0, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
         }
     }
 };
 
-template <int TPW, int SUB>
-__device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n, int ldr, const double *__restrict__ B, int ldb, int mrows, int first_col,
-                                   double *smem, unsigned long long *tacc = nullptr)
+// the single tile tp (uniform, selected by a static switch)
+template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateOne {
+    static __device__ __forceinline__ void run(int tp, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
+                                               int wave, int lane, const double *Vl, const double *Tm)
+    {
+        if constexpr (T < TPW) {
+            if (tp == T) {
+                const bool live[1] = {true};
+                fbr_tsqr_update_tiles<TPW, SUB, T, 1>(C, live, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            }
+            FbrTsqrUpdateOne<TPW, SUB, T + 1>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+        }
+    }
+};
+
+// Ordering of the pipeline's LDS traffic.  All flags and payloads (V, T) live in the LDS, which executes a CU's
+// operations in issue order, so publishing needs only "my LDS operations have been issued and returned" -- a workgroup
+// fence would also drain the wave's global stores and LDS-DMA loads (vmcnt(0)), a full memory latency per panel.
+__device__ __forceinline__ void fbr_lds_release() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void fbr_lds_acquire() { asm volatile("" ::: "memory"); }
+
+// spin on an LDS word until it reaches `want` (bounded: a protocol error must not hang the device)
+__device__ __forceinline__ bool fbr_tsqr_wait_ge(const int *flag, int want)
+{
+    for (int it = 0; it < FBR_TSQR_SPIN_LIMIT; it++) {
+        if (__atomic_load_n(flag, __ATOMIC_RELAXED) >= want) {
+            fbr_lds_acquire();
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+// One fold = one MB-row block B folded into R.  The folds of a workgroup form ONE continuous pipeline: panels are
+// numbered globally (G = panels of all earlier folds + q - q0), the flags only ever grow, and there is no barrier
+// between folds -- a wave that has consumed all its tiles of fold f loads its tiles of fold f + 1 and goes on while
+// the last, narrow panels of fold f are still being factorised by the other waves (up to RING panels of drift).
+struct FbrTsqrFoldDesc {
+    const double *B;  // block rows (row-major, leading dimension ldb), rows >= mrows are zero
+    int ldb, mrows, first_col;
+};
+
+template <int TPW, int SUB, class FoldFn>
+__device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, int ldr, int nfolds, FoldFn fold_of, double *smem, unsigned *errflag,
+                                                unsigned long long *tacc = nullptr)
 {
     unsigned long long tk = tacc ? __builtin_readcyclecounter() : 0;
 #define FBR_TT(i)                                                         \
@@ -257,66 +372,71 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
         tk = t1;                                                          \
     }
     constexpr int MB = 16 * SUB;
+    constexpr int W = FBR_TSQR_WAVES;
     double *Rl = smem;  // 16-byte aligned tiles for the LDS-DMA
-    double *Vl = Rl + FBR_TSQR_WAVES * TPW * 256;
-    double *Tm = Vl + MB * FBR_TSQR_LDV;
-    double *Rp = Tm + 256;
+    double *Vr = Rl + W * TPW * 256;
+    double *Tr = Vr + FBR_TSQR_RING * MB * FBR_TSQR_LDV;
+    double *Rps = Tr + FBR_TSQR_RING * 256;
+    int *pub = (int *)(Rps + W * 256);  // panels (global index) < *pub are published
+    int *done = pub + 1;                // done[w]: wave w needs no panel < done[w] any more
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kk = lane >> 4;
     const int NP = n / 16;
     const unsigned ld = (unsigned)ldr;
+    double *Rp = Rps + wave * 256;  // R_pp staging of this wave's panel factorisations
 
-    // ---- load this wave's tiles of the block (rows >= mrows are zero)
-    fbr_td4 C[TPW][SUB];
-#pragma unroll
-    for (int t = 0; t < TPW; t++) {
-        const int ct = wave + FBR_TSQR_WAVES * t;
-#pragma unroll
-        for (int sb = 0; sb < SUB; sb++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int r = 16 * sb + 4 * reg + kk;
-                C[t][sb][reg] = (ct < NP && r < mrows) ? B[(unsigned)r * (unsigned)ldb + 16 * ct + li] : 0.0;
-            }
-    }
+    if (tid == 0) *pub = 0;
+    if (tid < W) done[tid] = 0;
+    __syncthreads();  // the only workgroup barrier
 
-    // R_pp of the first panel (its owner only); later panels are prefetched one panel ahead
-    // (lane (kk, c) holds rows kk, kk+4, kk+8, kk+12 of column c, 0 below the diagonal)
-    fbr_td4 rpp = {0.0, 0.0, 0.0, 0.0};
-    {
-        const int p0 = first_col / 16;
-        if (p0 < NP && wave == p0 % FBR_TSQR_WAVES) {
+    bool ok = true;
+    int gbase = 0;  // global index of panel q0 of the current fold
+    for (int f = 0; f < nfolds; f++) {
+        const FbrTsqrFoldDesc fd = fold_of(f);
+        const int q0 = fd.first_col / 16;  // panels left of first_col: block columns are zero, identity reflectors
+        if (q0 >= NP) continue;
+        // ---- load this wave's tiles of the block
+        fbr_td4 C[TPW][SUB];
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int i = 4 * reg + kk;
-                rpp[reg] = (li >= i) ? R[(unsigned)(16 * p0 + i) * ld + 16 * p0 + li] : 0.0;
-            }
-        }
-    }
-    for (int p = first_col / 16; p < NP; p++) {  // panels left of first_col: block columns are zero, identity reflectors
-        const int ow = p % FBR_TSQR_WAVES, tp = p / FBR_TSQR_WAVES;
-        const int j0 = 16 * p;
-        const int t0 = (p >= wave) ? (p - wave) / FBR_TSQR_WAVES + 1 : 0;  // this wave's first tile right of the panel
-        // the R rows of the panel under this wave's tiles (final since the previous fold) are copied to the LDS by
-        // LDS-DMA (no VGPRs) while the panel is being factorised; every wave fetches and consumes its own tiles only
-        auto fetch_rows = [&]() {
+        for (int t = 0; t < TPW; t++) {
+            const int ct = wave + W * t;
 #pragma unroll
-            for (int t = 0; t < TPW; t++)
-                if (t >= t0) {
-                    const int ct = wave + FBR_TSQR_WAVES * t;
+            for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-                    for (int h = 0; h < 2; h++)  // lane l -> row 8 h + l / 8, columns 2 (l % 8), +1  (16 bytes)
-                        __builtin_amdgcn_global_load_lds((fbr_tsqr_glb_ptr)(R + (unsigned)(j0 + 8 * h + (lane >> 3)) * ld + 16 * ct + 2 * (lane & 7)),
-                                                         (fbr_tsqr_lds_ptr)(Rl + ct * 256 + h * 128), 16, 0, 0);
+                for (int reg = 0; reg < 4; reg++) {
+                    // unconditional loads from a clamped address + select: a conditional load would have to complete
+                    // before the other lanes may write the zero into the same register (one latency per element)
+                    // (row group and tile clamped uniformly: scalar base + per-lane offset kk * ldb + li)
+                    const int rg = 16 * sb + 4 * reg;
+                    const bool gvalid = ct < NP && rg < fd.mrows;
+                    const double *Bs = fd.B + ((unsigned)(gvalid ? rg : 0) * (unsigned)fd.ldb + (gvalid ? 16u * (unsigned)ct : 0u));
+                    const bool valid = gvalid && rg + kk < fd.mrows;
+                    const double x = Bs[(valid ? (unsigned)kk * (unsigned)fd.ldb : 0u) + (unsigned)li];
+                    C[t][sb][reg] = valid ? x : 0.0;
                 }
+        }
+        // R_pp of the next panel this wave owns (lane (kk, c): rows kk, kk+4, kk+8, kk+12 of column c, 0 below the diagonal)
+        fbr_td4 rpp = {0.0, 0.0, 0.0, 0.0};
+        auto fetch_rpp = [&](int p) {
+            if (p < NP) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const double *Rs = R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)p);  // uniform
+                    rpp[reg] = Rs[(unsigned)kk * ld + (unsigned)li];  // (entries below the diagonal are masked at use)
+                }
+            }
         };
-        FBR_TT(3)
-        __syncthreads();  // every wave is done with the previous panel's V / T
+        fetch_rpp(q0 + ((wave - q0) % W + W) % W);
+        // R rows of the first panel under this wave's tiles right of it (the wave is done with its tiles of the
+        // previous fold, so their LDS slots are free)
+        fbr_tsqr_fetch_rows<TPW>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, Rl, R, ld, q0, wave, lane);
         FBR_TT(0)
-        if (wave == ow) {
-            // ---- panel: Householder factorisation of [R_pp ; V] in this wave's registers; the tile is copied out of
-            //      the block registers with a static switch (it is dead afterwards)
+
+        // factorise panel p = tile p of this wave (global index G): Householder QR of [R_pp ; tile] in registers,
+        // publish V, T in ring slot G % RING
+        auto chain = [&](int p, int G) {
+            const int tp = p / W;
             fbr_td4 v[SUB];
 #pragma unroll
             for (int t = 0; t < TPW; t++)
@@ -325,18 +445,31 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
                     for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
                 }
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) Rp[(4 * reg + kk) * 16 + li] = rpp[reg];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            for (int reg = 0; reg < 4; reg++) Rp[(4 * reg + kk) * 16 + li] = (li >= 4 * reg + kk) ? rpp[reg] : 0.0;
+            fbr_lds_release();
             __builtin_amdgcn_wave_barrier();
-            fetch_rows();
-            unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
-            if (tacc) { tacc[4] += tq - tk; }
             fbr_td4 rq = {0.0, 0.0, 0.0, 0.0};
             double trow[16];
             double myscale = 0.0;
+            unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
             fbr_tsqr_panel_steps<SUB>(v, Rp, rq, trow, myscale, li, kk, std::make_integer_sequence<int, 16>{});
-            if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[5] += t1 - tq; tq = t1; }
-            // ---- publish the scaled vectors V and T
+            if (tacc) tacc[4] += __builtin_readcyclecounter() - tq;
+            // the ring slot is free once no wave needs panel G - RING any more
+            {
+                const int need = G - FBR_TSQR_RING + 1;
+                tq = tacc ? __builtin_readcyclecounter() : 0;
+                bool free_ = !ok;
+                for (int it = 0; it < FBR_TSQR_SPIN_LIMIT && !free_; it++) {
+                    const int d = __atomic_load_n(done + (lane & (W - 1)), __ATOMIC_RELAXED);
+                    free_ = __builtin_amdgcn_ballot_w64(d < need) == 0;
+                    if (!free_) __builtin_amdgcn_s_sleep(1);
+                }
+                fbr_lds_acquire();
+                ok = ok && free_;
+                if (tacc) tacc[5] += __builtin_readcyclecounter() - tq;
+            }
+            double *Vl = Vr + (G % FBR_TSQR_RING) * (MB * FBR_TSQR_LDV);
+            double *Tm = Tr + (G % FBR_TSQR_RING) * 256;
 #pragma unroll
             for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
@@ -345,40 +478,65 @@ __device__ __forceinline__ void fbr_tsqr_fold_regs(double *__restrict__ R, int n
 #pragma unroll
                 for (int j = 0; j < 16; j++) Tm[li * 16 + j] = trow[j];
             }
-            if (tacc) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[6] += t1 - tq; tq = t1; }
-            // R_pp back to global (upper triangle)
+            // panels are published in order (the previous one may belong to the previous fold and still be in flight)
+            tq = tacc ? __builtin_readcyclecounter() : 0;
+            ok = ok && fbr_tsqr_wait_ge(pub, G);
+            if (tacc) tacc[6] += __builtin_readcyclecounter() - tq;
+            fbr_lds_release();
+            if (lane == 0) __atomic_store_n(pub, G + 1, __ATOMIC_RELAXED);
+            // R_pp back to global (upper triangle), then the R_pp of the next panel this wave owns
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int i = 4 * reg + kk;
-                if (li >= i) R[(unsigned)(j0 + i) * ld + j0 + li] = rq[reg];
+                double *Rs = R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)p);  // uniform
+                if (li >= i) Rs[(unsigned)kk * ld + (unsigned)li] = rq[reg];
             }
-        } else {
-            fetch_rows();
-        }
-        FBR_TT(1)
-        __syncthreads();  // panel published, R rows landed (the barrier waits for vmcnt(0))
-        FBR_TT(2)
-        // the owner of the next panel fetches its R_pp now (panel p only touches its own 16 rows of R)
-        if (p + 1 < NP && wave == (p + 1) % FBR_TSQR_WAVES) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int i = 4 * reg + kk;
-                rpp[reg] = (li >= i) ? R[(unsigned)(j0 + 16 + i) * ld + j0 + 16 + li] : 0.0;
+            fetch_rpp(p + W);
+        };
+
+        // iteration q applies panel q; the owner of panel q + 1 factorises it inside iteration q (q = q0 - 1: only that)
+        for (int q = q0 - 1; q < NP; q++) {
+            const bool apply = q >= q0;
+            const int G = gbase + (q - q0);
+            const bool next_owner = q + 1 < NP && wave == (q + 1) % W;
+            int t0 = (q >= wave) ? (q - wave) / W + 1 : 0;  // this wave's first tile right of panel q
+            const bool need_panel = apply && (next_owner || t0 < TPW);
+            if (need_panel) ok = ok && fbr_tsqr_wait_ge(pub, G + 1);
+            if (need_panel || next_owner) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's R rows / R_pp have landed
+            FBR_TT(2)
+            const int slot = (G + FBR_TSQR_RING) % FBR_TSQR_RING;
+            const double *Vl = Vr + slot * (MB * FBR_TSQR_LDV);
+            const double *Tm = Tr + slot * 256;
+            if (next_owner) {
+                // next panel's owner: its tile first, then its factorisation, then the rest of panel q.  This is the
+                // serial dependency chain of the fold: raise the wave's issue priority over the waves that only update
+                __builtin_amdgcn_s_setprio(3);
+                if (apply) FbrTsqrUpdateOne<TPW, SUB>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                FBR_TT(3)
+                chain(q + 1, G + 1);
+                __builtin_amdgcn_s_setprio(0);
+                FBR_TT(1)
+                t0 = (q + 1) / W + 1;
             }
+            if (apply) {
+                FbrTsqrUpdateFrom<TPW, SUB>::run(t0, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                fbr_lds_release();
+                if (lane == 0) __atomic_store_n(done + wave, G + 1, __ATOMIC_RELAXED);
+                // R rows of the next panel under the tiles right of it
+                if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, Rl, R, ld, q + 1, wave, lane);
+            }
+            FBR_TT(3)
         }
-        // ---- trailing update of this wave's tiles right of the panel (tiles past the last column tile are zero columns
-        //      of the padded factor: ld = 16 * WAVES * TPW)
-        FbrTsqrUpdate<TPW, SUB>::run(t0, C, Rl, R, ld, (unsigned)j0, wave, li, kk, Vl, Tm);
+        gbase += NP - q0;
     }
-    FBR_TT(3)
-    __syncthreads();
+    if (!ok && lane == 0) atomicOr(errflag, 1u);
 #undef FBR_TT
 }
 
 // level 0: workgroup w folds blocks w, w+NW, ... of A into Rw[w]
 template <int TPW, int SUB>
-__global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
-                                                                               double *__restrict__ Rw, long nblocks,
+__global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
+                                                                               double *__restrict__ Rw, long nblocks, unsigned *errflag,
                                                                                unsigned long long *dbg)
 {
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -386,11 +544,12 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_level0_kernel(co
     constexpr int MB = 16 * SUB;
     constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;  // leading dimension of the working factors (>= n)
     double *R = Rw + (long)blockIdx.x * n * LD;
-    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        const long r0 = b * MB;
-        const int m = (int)std::min<long>(MB, Mpad - r0);
-        fbr_tsqr_fold_regs<TPW, SUB>(R, n, LD, A + r0 * n, n, m, 0, smem, dbg ? tacc : nullptr);
-    }
+    const int nfolds = (int)((nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    auto fold_of = [&](int f) {
+        const long r0 = ((long)blockIdx.x + (long)f * gridDim.x) * MB;
+        return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), 0};
+    };
+    fbr_tsqr_stream<TPW, SUB>(R, n, LD, nfolds, fold_of, smem, errflag, dbg ? tacc : nullptr);
     if (dbg && (threadIdx.x & 63) == 0) {
         unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 8;
         for (int i = 0; i < 8; i++) d[i] = tacc[i];
@@ -399,17 +558,19 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_level0_kernel(co
 
 // tree level: workgroup i folds Rw[(2i+1)*stride] (upper triangular, MB rows at a time) into Rw[2i*stride]
 template <int TPW, int SUB>
-__global__ __launch_bounds__(FBR_TSQR_THREADS, 2) void fbr_tsqr_tree_kernel(double *__restrict__ Rw, int n, int stride, int count)
+__global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_tree_kernel(double *__restrict__ Rw, int n, int stride, int count, unsigned *errflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
     constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;
     const long a = (long)2 * blockIdx.x * stride, b = a + stride;
     if (b >= count) return;
-    for (int i0 = 0; i0 < n; i0 += MB) {
-        const int m = std::min(MB, n - i0);
-        fbr_tsqr_fold_regs<TPW, SUB>(Rw + a * n * LD, n, LD, Rw + b * n * LD + (long)i0 * LD, LD, m, i0, smem);
-    }
+    const double *Rb = Rw + b * n * LD;
+    auto fold_of = [&](int f) {
+        const int i0 = f * MB;
+        return FbrTsqrFoldDesc{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), i0};
+    };
+    fbr_tsqr_stream<TPW, SUB>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
 }
 
 // copy between the caller's Pa x Pa factor and the padded n x n working factor (upper triangle only)
@@ -426,8 +587,9 @@ __global__ void fbr_tsqr_copy_kernel(int Pa, const double *__restrict__ src, int
 }
 
 struct FbrTsqrWork {
-    double *Rw = nullptr;   // [NW][n][n]
+    double *Rw = nullptr;   // [NW][n][ld]
     double *A = nullptr;    // packed chunk [Mpad][n]
+    unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
     size_t rw_bytes = 0, a_bytes = 0;
     int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0;
     bool active = false;
@@ -435,6 +597,8 @@ struct FbrTsqrWork {
     {
         if (Rw) (void)hipFree(Rw);
         if (A) (void)hipFree(A);
+        if (err) (void)hipFree(err);
+        err = nullptr;
         Rw = A = nullptr;
         rw_bytes = a_bytes = 0;
         active = false;
@@ -458,24 +622,18 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
     return std::max(1L, (long)(4.0 * 1024 * 1024 * 1024 / per));
 }
 
-// kernel instantiations: 4 waves per workgroup, two workgroups per CU (one's serial panel factorisation overlaps the
-// other's trailing update); tiles per wave 1..12; block rows 64 / 32 / 16 so that the block fits the VGPRs
+// kernel instantiations: 8 waves per workgroup, one workgroup per CU; tiles per wave 1..6 (n <= 768); block rows
+// 64 / 48 / 32 so that the block (TPW * SUB * 8 VGPRs) and the panel chain fit the 256 VGPRs of a wave
 #define FBR_TSQR_DISPATCH(TPWV, CALL)                  \
     switch (TPWV) {                                    \
     case 1: { constexpr int TPW = 1, SUB = 4; CALL; } break; \
     case 2: { constexpr int TPW = 2, SUB = 4; CALL; } break; \
     case 3: { constexpr int TPW = 3, SUB = 4; CALL; } break; \
-    case 4: { constexpr int TPW = 4, SUB = 3; CALL; } break; \
-    case 5: { constexpr int TPW = 5, SUB = 2; CALL; } break; \
-    case 6: { constexpr int TPW = 6, SUB = 2; CALL; } break; \
-    case 7: { constexpr int TPW = 7, SUB = 2; CALL; } break; \
-    case 8: { constexpr int TPW = 8, SUB = 2; CALL; } break; \
-    case 9: { constexpr int TPW = 9, SUB = 1; CALL; } break; \
-    case 10: { constexpr int TPW = 10, SUB = 1; CALL; } break; \
-    case 11: { constexpr int TPW = 11, SUB = 1; CALL; } break; \
-    default: { constexpr int TPW = 12, SUB = 1; CALL; } break; \
+    case 4: { constexpr int TPW = 4, SUB = 4; CALL; } break; \
+    case 5: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
+    default: { constexpr int TPW = 6, SUB = 2; CALL; } break; \
     }
-static inline int fbr_tsqr_sub_for(int tpw) { return tpw <= 3 ? 4 : (tpw == 4 ? 3 : (tpw <= 8 ? 2 : 1)); }
+static inline int fbr_tsqr_sub_for(int tpw) { return tpw <= 4 ? 4 : (tpw == 5 ? 3 : 2); }
 
 // Start a factorisation of width Pa: working factors zeroed, R_in (device, Pa x Pa, may be null) seeded into slot 0.
 static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint)
@@ -490,7 +648,7 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
     const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
-    const long per_cu = envw ? std::max(1, atoi(envw)) : 2;
+    const long per_cu = envw ? std::max(1, atoi(envw)) : 1;
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
     const int ld = 16 * FBR_TSQR_WAVES * tpw;
     const size_t need = (size_t)NW * n * ld * sizeof(double);
@@ -502,6 +660,8 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         wk.rw_bytes = need;
     }
     wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub;
+    if (!wk.err) TSQR_HIP(hipMalloc((void **)&wk.err, sizeof(unsigned)));
+    TSQR_HIP(hipMemsetAsync(wk.err, 0, sizeof(unsigned), st));
     TSQR_HIP(hipMemsetAsync(wk.Rw, 0, need, st));
     if (R_in) {
         hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, Pa, R_in, Pa, wk.Rw, ld, n, ld);
@@ -543,7 +703,7 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
     FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
     FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                 (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, dbg));
+                                                 (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg));
     TSQR_HIP(hipGetLastError());
     if (dbg) {
         std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 8);
@@ -552,10 +712,8 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
         double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t i = 0; i < hb.size(); i++) sum[i & 7] += (double)hb[i];
         const double folds = (double)nblocks * FBR_TSQR_WAVES;
-        fprintf(stderr, "[fbr tsqr timing] cycles per fold per wave: barrier_in=%.0f panel(or idle)=%.0f barrier_pub=%.0f update=%.0f  (mb=%d n=%d)\n",
-                sum[0] / folds, sum[1] / folds, sum[2] / folds, sum[3] / folds, wk.mb, n);
-        fprintf(stderr, "[fbr tsqr timing]   panel owner split per fold per wave: load_Rpp=%.0f steps=%.0f ZT=%.0f store=%.0f\n", sum[4] / folds,
-                sum[5] / folds, sum[6] / folds, sum[7] / folds);
+        fprintf(stderr, "[fbr tsqr timing] cycles per fold per wave: load+init=%.0f chain=%.0f (16 steps %.0f, ring wait %.0f, order wait %.0f) wait_panel=%.0f update=%.0f  (mb=%d n=%d, %ld folds)\n",
+                sum[0] / folds, sum[1] / folds, sum[4] / folds, sum[5] / folds, sum[6] / folds, sum[2] / folds, sum[3] / folds, wk.mb, n, nblocks);
         (void)hipFree(dbg);
     }
     return 0;
@@ -574,11 +732,18 @@ static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out
     for (int stride = 1; stride < wk.NW; stride *= 2) {
         const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB>), dim3(pairs), dim3(FBR_TSQR_THREADS),
-                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW));
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, wk.err));
         TSQR_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, wk.Pa, wk.Rw, wk.ld, R_out, wk.Pa, wk.Pa, wk.Pa);
     TSQR_HIP(hipGetLastError());
     wk.active = false;
+    unsigned herr = 0;
+    TSQR_HIP(hipMemcpyAsync(&herr, wk.err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    TSQR_HIP(hipStreamSynchronize(st));
+    if (herr) {
+        g_tsqr_err = "TSQR pipeline flag wait timed out (internal error)";
+        return -5;
+    }
     return 0;
 }
