@@ -279,23 +279,30 @@ __device__ __forceinline__ void fbr_tsqr_update_tiles(fbr_td4 (&C)[TPW][SUB], co
         }
 }
 
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into the LDS, no VGPR data) written as inline assembly:
+//   * scalar base + 32-bit per-lane byte offset (the builtin takes a 64-bit per-lane address: VGPR pairs and 64-bit adds);
+//   * the compiler does not see an LDS write tracked by vmcnt, so it does not put s_waitcnt vmcnt(0) in front of every
+//     later LDS read (the flag polls!) -- the consumer waits explicitly with fbr_dma_wait() before it reads the tiles.
+__device__ __forceinline__ void fbr_dma16(const double *sbase, unsigned voff_bytes, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void fbr_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // LDS-DMA of the R rows of panel q under the wave's tiles t >= t0 into their LDS slots (lane l -> row 8 h + l / 8,
-// columns 2 (l % 8), +1: 16 bytes per lane).  Issued once per panel AFTER the wave's whole update: the compiler orders
-// every later LDS read behind an outstanding LDS-DMA (vmcnt(0)), so a copy issued between two tile updates would stall
-// the second one for a full memory latency.
+// columns 2 (l % 8), +1: 16 bytes per lane).  Issued once per panel after the wave's whole update.
 template <int TPW>
 __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, double *Rl, const double *__restrict__ R, unsigned ld, int q, int wave, int lane)
 {
+    const unsigned voff = ((unsigned)(lane >> 3) * ld + 2u * (unsigned)(lane & 7)) * 8u;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(fbr_tsqr_lds_ptr)Rl;
 #pragma unroll
     for (int t = 0; t < TPW; t++)
         if (t >= t0) {
             const int ct = wave + FBR_TSQR_WAVES * t;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const double *Rs = R + ((unsigned)(16 * q + 8 * h) * ld + 16u * (unsigned)ct);  // uniform
-                __builtin_amdgcn_global_load_lds((fbr_tsqr_glb_ptr)(Rs + ((unsigned)(lane >> 3) * ld + 2u * (unsigned)(lane & 7))),
-                                                 (fbr_tsqr_lds_ptr)(Rl + ct * 256 + h * 128), 16, 0, 0);
-            }
+            for (int h = 0; h < 2; h++)
+                fbr_dma16(R + ((unsigned)(16 * q + 8 * h) * ld + 16u * (unsigned)ct), voff, lds0 + (unsigned)(ct * 256 + h * 128) * 8u);
         }
 }
 
@@ -502,7 +509,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             int t0 = (q >= wave) ? (q - wave) / W + 1 : 0;  // this wave's first tile right of panel q
             const bool need_panel = apply && (next_owner || t0 < TPW);
             if (need_panel) ok = ok && fbr_tsqr_wait_ge(pub, G + 1);
-            if (need_panel || next_owner) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's R rows / R_pp have landed
+            if (need_panel || next_owner) fbr_dma_wait();  // vmcnt(0): this wave's R rows (LDS-DMA) / R_pp have landed
             FBR_TT(2)
             const int slot = (G + FBR_TSQR_RING) % FBR_TSQR_RING;
             const double *Vl = Vr + slot * (MB * FBR_TSQR_LDV);
