@@ -188,10 +188,12 @@ def main():
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2
     # correction of FETCH_SIZE) are committed under profiles/; scaled here to this run's samples per launch
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_gram_pmc_traffic.json")))
-        per_sample = (pm["gram_kernel_fetch_KB_per_sample_corrected_x2"] + pm["gram_kernel_write_KB_per_sample"]) * 1024.0
-        out["roofline"]["traffic"] = per_sample * samples_per_launch
-        out["roofline"]["traffic_source"] = "profiles/r01_gram_pmc_traffic.json (bytes per sample x samples per launch)"
+        import glob
+
+        src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gram_pmc_traffic.json")))[-1]  # latest committed PMC summary
+        pm = json.load(open(src))
+        out["roofline"]["traffic"] = pm["hbm_bytes_per_sample"] * samples_per_launch
+        out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(src)} (HBM bytes per sample x samples per launch)"
     except Exception:
         pass
     if world == 1:

@@ -228,8 +228,8 @@ __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const do
 //   acc = R_rows + V^T C;  W = T^T acc;  R_rows -= W;  C -= V W        (Rl = LDS copy of the R_rows tiles, [tile][16][16])
 // The MFMA C/D layout (reg r, lane (kk, j) = row 4r + kk, column j) is also the B-operand layout of k-step r, so acc
 // and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
-// live[b] == false: the tile is dead (already consumed as a panel); it still runs through the MFMAs (static register
-// indexing, one code path) but its R rows are neither stored nor prefetched.
+// live[b] == false: the R rows of tile b are not stored (unused since the tiles are updated one at a time: the paired
+// form ran dead / padding tiles through the MFMAs, +34 % MFMA work, and was slower).
 template <int TPW, int SUB, int T, int NB>
 __device__ __forceinline__ void fbr_tsqr_update_tiles(fbr_td4 (&C)[TPW][SUB], const bool (&live)[NB], double *Rl, double *__restrict__ R, unsigned ld,
                                                       int q, int NP, int wave, int lane, const double *Vl, const double *Tm)
@@ -292,13 +292,13 @@ __device__ __forceinline__ void fbr_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 // LDS-DMA of the R rows of panel q under the wave's tiles t >= t0 into their LDS slots (lane l -> row 8 h + l / 8,
 // columns 2 (l % 8), +1: 16 bytes per lane).  Issued once per panel after the wave's whole update.
 template <int TPW>
-__device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, double *Rl, const double *__restrict__ R, unsigned ld, int q, int wave, int lane)
+__device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, int t1, double *Rl, const double *__restrict__ R, unsigned ld, int q, int wave, int lane)
 {
     const unsigned voff = ((unsigned)(lane >> 3) * ld + 2u * (unsigned)(lane & 7)) * 8u;
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(fbr_tsqr_lds_ptr)Rl;
 #pragma unroll
     for (int t = 0; t < TPW; t++)
-        if (t >= t0) {
+        if (t >= t0 && t < t1) {
             const int ct = wave + FBR_TSQR_WAVES * t;
 #pragma unroll
             for (int h = 0; h < 2; h++)
@@ -306,20 +306,18 @@ __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, double *Rl, const do
         }
 }
 
-// all tiles t >= t0 of the wave, in static pairs (a pair that straddles t0 runs its dead left tile too)
+// the wave's tiles t0 <= t < t1, one at a time (static register indexing, a uniform branch per tile; dead and padding
+// tiles cost nothing)
 template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateFrom {
-    static __device__ __forceinline__ void run(int t0, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
+    static __device__ __forceinline__ void run(int t0, int t1, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
                                                int wave, int lane, const double *Vl, const double *Tm)
     {
         if constexpr (T < TPW) {
-            constexpr int NB = (T + 1 < TPW) ? 2 : 1;
-            if (T + NB - 1 >= t0) {
-                bool live[NB];
-#pragma unroll
-                for (int b = 0; b < NB; b++) live[b] = T + b >= t0;
-                fbr_tsqr_update_tiles<TPW, SUB, T, NB>(C, live, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            if (T >= t0 && T < t1) {
+                const bool live[1] = {true};
+                fbr_tsqr_update_tiles<TPW, SUB, T, 1>(C, live, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
             }
-            FbrTsqrUpdateFrom<TPW, SUB, T + NB>::run(t0, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            FbrTsqrUpdateFrom<TPW, SUB, T + 1>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
         }
     }
 };
@@ -392,6 +390,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
     const int NP = n / 16;
     const unsigned ld = (unsigned)ldr;
     double *Rp = Rps + wave * 256;  // R_pp staging of this wave's panel factorisations
+    const int t1 = (NP - wave + W - 1) / W;  // this wave's tiles t < t1 are real column tiles (the rest is padding)
 
     if (tid == 0) *pub = 0;
     if (tid < W) done[tid] = 0;
@@ -437,7 +436,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         fetch_rpp(q0 + ((wave - q0) % W + W) % W);
         // R rows of the first panel under this wave's tiles right of it (the wave is done with its tiles of the
         // previous fold, so their LDS slots are free)
-        fbr_tsqr_fetch_rows<TPW>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, Rl, R, ld, q0, wave, lane);
+        fbr_tsqr_fetch_rows<TPW>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, t1, Rl, R, ld, q0, wave, lane);
         FBR_TT(0)
 
         // factorise panel p = tile p of this wave (global index G): Householder QR of [R_pp ; tile] in registers,
@@ -507,7 +506,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             const int G = gbase + (q - q0);
             const bool next_owner = q + 1 < NP && wave == (q + 1) % W;
             int t0 = (q >= wave) ? (q - wave) / W + 1 : 0;  // this wave's first tile right of panel q
-            const bool need_panel = apply && (next_owner || t0 < TPW);
+            const bool need_panel = apply && (next_owner || t0 < t1);
             if (need_panel) ok = ok && fbr_tsqr_wait_ge(pub, G + 1);
             if (need_panel || next_owner) fbr_dma_wait();  // vmcnt(0): this wave's R rows (LDS-DMA) / R_pp have landed
             FBR_TT(2)
@@ -526,11 +525,11 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 t0 = (q + 1) / W + 1;
             }
             if (apply) {
-                FbrTsqrUpdateFrom<TPW, SUB>::run(t0, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                FbrTsqrUpdateFrom<TPW, SUB>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
                 fbr_lds_release();
                 if (lane == 0) __atomic_store_n(done + wave, G + 1, __ATOMIC_RELAXED);
                 // R rows of the next panel under the tiles right of it
-                if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, Rl, R, ld, q + 1, wave, lane);
+                if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, t1, Rl, R, ld, q + 1, wave, lane);
             }
             FBR_TT(3)
         }
