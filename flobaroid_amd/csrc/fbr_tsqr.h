@@ -121,7 +121,12 @@ __device__ __forceinline__ double fbr_xor32_sum(double v)
 // NOP = false only where the DPP source register was written at least two VALU instructions earlier.
 template <int J, bool NOP = true> __device__ __forceinline__ void fbr_fmac_bcast(double &acc, double bsrc, double mul)
 {
-    if constexpr (NOP)
+#ifdef FBR_TSQR_SAFE_DPP
+    constexpr bool nop = true;
+#else
+    constexpr bool nop = NOP;
+#endif
+    if constexpr (nop)
         asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(J));
     else
         asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(mul), "n"(J));
@@ -221,6 +226,11 @@ template <int SUB, int... Js>
 __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const double *Rp, fbr_td4 &rq, double (&trow)[16],
                                                      double &myscale, int li, int kk, std::integer_sequence<int, Js...>)
 {
+    // The inline-asm DPP reads below are invisible to the hazard recogniser: make sure every earlier VALU write of the
+    // tile registers (e.g. the 32-bit selects that copy the tile, which could sit right in front of the first step and
+    // leave half of a double stale -- observed as 1e-8 relative errors) has retired before the first DPP operand read.
+    asm volatile("s_nop 4" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     (fbr_tsqr_panel_step<SUB, Js>(v, Rp, rq, trow, myscale, li, kk), ...);
 }
 
@@ -579,6 +589,145 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_tree_kernel(doub
     fbr_tsqr_stream<TPW, SUB>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow factors (n <= 128 columns: left arm, KUKA): wave-private TSQR.  With 6-8 column tiles there is not enough
+// trailing work to feed 8 waves and the fold is pure panel-chain latency, so here EVERY WAVE is an independent worker:
+// it owns a private R (global memory, L2 / Infinity-Cache resident), holds a 32-row block of all NPT tiles in its
+// VGPRs, factorises the panels itself and applies them to its own tiles.  No synchronisation at all between waves;
+// 8 waves per CU (2 per SIMD) keep 8 dependency chains in flight per CU instead of one.
+//   per-wave LDS (doubles): Vl[MB*17] | Tm[256] | Rp[256]   (A-operand staging of V and T, R_pp staging)
+template <int SUB> __host__ __device__ constexpr size_t fbr_tsqr_narrow_lds_doubles() { return (size_t)16 * SUB * FBR_TSQR_LDV + 512; }
+#define FBR_TSQR_NARROW_WAVES 4  // waves per workgroup of the narrow kernels (two workgroups per CU)
+
+template <int NPT, int SUB>
+__device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const double *__restrict__ B, unsigned ldb, int mrows, int first_col,
+                                                   double *lds, int lane)
+{
+    constexpr int MB = 16 * SUB;
+    constexpr unsigned ld = 16 * NPT;
+    double *Vl = lds;
+    double *Tm = Vl + MB * FBR_TSQR_LDV;
+    double *Rp = Tm + 256;
+    const int li = lane & 15, kk = lane >> 4;
+    const unsigned voff = (unsigned)kk * ld + (unsigned)li;
+    const int q0 = first_col / 16;
+    if (q0 >= NPT) return;
+
+    fbr_td4 C[NPT][SUB];
+#pragma unroll
+    for (int t = 0; t < NPT; t++)
+#pragma unroll
+        for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int rg = 16 * sb + 4 * reg;
+                const bool gvalid = rg < mrows;
+                const double *Bs = B + ((unsigned)(gvalid ? rg : 0) * ldb + 16u * (unsigned)t);
+                const bool valid = gvalid && rg + kk < mrows;
+                const double x = Bs[(valid ? (unsigned)kk * ldb : 0u) + (unsigned)li];
+                C[t][sb][reg] = valid ? x : 0.0;
+            }
+    // rows 4 reg + kk of the 16 x 16 tile (row panel p, column tile t) of R
+    auto load_tile = [&](int p, int t) {
+        fbr_td4 r;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) r[reg] = (R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)t))[voff];
+        return r;
+    };
+    fbr_td4 rpp = load_tile(q0, q0);
+    for (int p = q0; p < NPT; p++) {
+        fbr_td4 rn = {0.0, 0.0, 0.0, 0.0};
+        if (p + 1 < NPT) rn = load_tile(p, p + 1);  // R rows of the first tile to update: in flight during the chain
+        fbr_td4 v[SUB];
+#pragma unroll
+        for (int t = 0; t < NPT; t++)
+            if (t == p) {
+#pragma unroll
+                for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
+            }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) Rp[(4 * reg + kk) * 16 + li] = (li >= 4 * reg + kk) ? rpp[reg] : 0.0;
+        fbr_lds_release();
+        __builtin_amdgcn_wave_barrier();
+        fbr_td4 rq = {0.0, 0.0, 0.0, 0.0};
+        double trow[16];
+        double myscale = 0.0;
+        fbr_tsqr_panel_steps<SUB>(v, Rp, rq, trow, myscale, li, kk, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+        for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li] = v[sb][reg] * myscale;
+        if (kk == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) Tm[li * 16 + j] = trow[j];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            double *Rs = R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)p);
+            if (li >= 4 * reg + kk) Rs[voff] = rq[reg];
+        }
+        if (p + 1 < NPT) rpp = load_tile(p + 1, p + 1);  // row panel p + 1 is not touched by panel p's update
+        fbr_lds_release();
+        __builtin_amdgcn_wave_barrier();
+        // ---- trailing update of the tiles right of the panel (static register indexing, uniform branch per tile)
+#pragma unroll
+        for (int t = 0; t < NPT; t++)
+            if (t > p) {
+                const fbr_td4 r0 = rn;
+                if (t + 1 < NPT) rn = load_tile(p, t + 1);
+                fbr_td4 acc = r0, w2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li], C[t][sb][reg], acc, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * 16 + li], acc[ks], w2, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) (R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)t))[voff] = r0[reg] - w2[reg];
+#pragma unroll
+                for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++)
+                        C[t][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk], -w2[ks], C[t][sb], 0, 0, 0);
+            }
+        __builtin_amdgcn_wave_barrier();  // (the wave's own LDS reads are in order with the next panel's writes)
+    }
+}
+
+// level 0: wave g folds blocks g, g + NWV, ... of A into its private Rw[g]
+template <int NPT, int SUB>
+__global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow_level0_kernel(const double *__restrict__ A, long Mpad,
+                                                                                                 double *__restrict__ Rw, long nblocks, int nwaves)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int MB = 16 * SUB, n = 16 * NPT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * FBR_TSQR_NARROW_WAVES + wave;
+    if (g >= nwaves) return;
+    double *lds = smem + wave * fbr_tsqr_narrow_lds_doubles<SUB>();
+    double *R = Rw + (long)g * n * n;
+    for (long b = g; b < nblocks; b += nwaves) {
+        const long r0 = b * MB;
+        fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), 0, lds, lane);
+    }
+}
+
+// tree level: wave i folds Rw[(2i+1)*stride] (upper triangular, MB rows at a time) into Rw[2i*stride]
+template <int NPT, int SUB>
+__global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow_tree_kernel(double *__restrict__ Rw, int stride, int count)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int MB = 16 * SUB, n = 16 * NPT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long i = (long)blockIdx.x * FBR_TSQR_NARROW_WAVES + wave;
+    const long a = 2 * i * stride, b = a + stride;
+    if (b >= count) return;
+    double *lds = smem + wave * fbr_tsqr_narrow_lds_doubles<SUB>();
+    const double *Rb = Rw + b * n * n;
+    for (int i0 = 0; i0 < n; i0 += MB) fbr_tsqr_wave_fold<NPT, SUB>(Rw + a * n * n, Rb + (long)i0 * n, n, std::min(MB, n - i0), i0, lds, lane);
+}
+
 // copy between the caller's Pa x Pa factor and the padded n x n working factor (upper triangle only)
 __global__ void fbr_tsqr_copy_kernel(int Pa, const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd,
                                      int rows_dst, int cols_dst)
@@ -598,7 +747,7 @@ struct FbrTsqrWork {
     unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
     size_t rw_bytes = 0, a_bytes = 0;
     int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0;
-    bool active = false;
+    bool active = false, narrow = false;
     void release()
     {
         if (Rw) (void)hipFree(Rw);
@@ -641,6 +790,20 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
     }
 static inline int fbr_tsqr_sub_for(int tpw) { return tpw <= 4 ? 4 : (tpw == 5 ? 3 : 2); }
 
+// narrow (wave-private) kernels: column tiles 1..8, 32-row blocks
+#define FBR_TSQR_NARROW_MAX_TILES 8
+#define FBR_TSQR_NARROW_DISPATCH(NPTV, CALL)           \
+    switch (NPTV) {                                    \
+    case 1: { constexpr int NPT = 1, SUB = 2; CALL; } break; \
+    case 2: { constexpr int NPT = 2, SUB = 2; CALL; } break; \
+    case 3: { constexpr int NPT = 3, SUB = 2; CALL; } break; \
+    case 4: { constexpr int NPT = 4, SUB = 2; CALL; } break; \
+    case 5: { constexpr int NPT = 5, SUB = 2; CALL; } break; \
+    case 6: { constexpr int NPT = 6, SUB = 2; CALL; } break; \
+    case 7: { constexpr int NPT = 7, SUB = 2; CALL; } break; \
+    default: { constexpr int NPT = 8, SUB = 2; CALL; } break; \
+    }
+
 // Start a factorisation of width Pa: working factors zeroed, R_in (device, Pa x Pa, may be null) seeded into slot 0.
 static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint)
 {
@@ -649,14 +812,15 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         g_tsqr_err = "TSQR supports at most " + std::to_string(FBR_TSQR_MAXN) + " columns";
         return -4;
     }
-    const int tpw = (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
-    const int sub = fbr_tsqr_sub_for(tpw);
+    const bool narrow = n / 16 <= FBR_TSQR_NARROW_MAX_TILES && !getenv("FBR_TSQR_NO_NARROW");
+    const int tpw = narrow ? n / 16 : (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
+    const int sub = narrow ? 2 : fbr_tsqr_sub_for(tpw);
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
     const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
-    const long per_cu = envw ? std::max(1, atoi(envw)) : 1;
+    const long per_cu = envw ? std::max(1, atoi(envw)) : (narrow ? 2 * FBR_TSQR_NARROW_WAVES : 1);  // narrow: private R per WAVE
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
-    const int ld = 16 * FBR_TSQR_WAVES * tpw;
+    const int ld = narrow ? n : 16 * FBR_TSQR_WAVES * tpw;
     const size_t need = (size_t)NW * n * ld * sizeof(double);
     if (need > wk.rw_bytes) {
         if (wk.Rw) (void)hipFree(wk.Rw);
@@ -665,7 +829,7 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         TSQR_HIP(hipMalloc((void **)&wk.Rw, need));
         wk.rw_bytes = need;
     }
-    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub;
+    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub; wk.narrow = narrow;
     if (!wk.err) TSQR_HIP(hipMalloc((void **)&wk.err, sizeof(unsigned)));
     TSQR_HIP(hipMemsetAsync(wk.err, 0, sizeof(unsigned), st));
     TSQR_HIP(hipMemsetAsync(wk.Rw, 0, need, st));
@@ -700,6 +864,15 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
     hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(2048), dim3(256), 0, st, M, Mpad, P, k, n, Y, ldy, cols, rhs, w, wk.A);
     TSQR_HIP(hipGetLastError());
     const long nblocks = (Mpad + wk.mb - 1) / wk.mb;
+    if (wk.narrow) {
+        const int nwaves = (int)std::min<long>(wk.NW, nblocks);
+        const int grid = (nwaves + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
+        FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
+                                                            (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, wk.A, Mpad,
+                                                            wk.Rw, nblocks, nwaves));
+        TSQR_HIP(hipGetLastError());
+        return 0;
+    }
     const int grid = (int)std::min<long>(wk.NW, nblocks);
     unsigned long long *dbg = nullptr;
     if (getenv("FBR_TSQR_TIMING")) {
@@ -733,6 +906,16 @@ static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out
         return -1;
     }
     const int n = wk.n;
+    if (wk.narrow) {
+        for (int stride = 1; stride < wk.NW; stride *= 2) {
+            const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
+            const int grid = (pairs + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
+            FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_tree_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
+                                                                (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, wk.Rw,
+                                                                stride, wk.NW));
+            TSQR_HIP(hipGetLastError());
+        }
+    } else {
     FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
     for (int stride = 1; stride < wk.NW; stride *= 2) {
@@ -740,6 +923,7 @@ static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB>), dim3(pairs), dim3(FBR_TSQR_THREADS),
                                                      (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, wk.err));
         TSQR_HIP(hipGetLastError());
+    }
     }
     hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, wk.Pa, wk.Rw, wk.ld, R_out, wk.Pa, wk.Pa, wk.Pa);
     TSQR_HIP(hipGetLastError());
