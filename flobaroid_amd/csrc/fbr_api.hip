@@ -445,10 +445,10 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
             // even column count (and a 16-byte aligned output): paired columns, 16-byte stores
             if ((hm.cols & 1) == 0 && (((uintptr_t)dst) & 15) == 0)
                 hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2, m->stream, m->dm, cs, spb,
-                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst);
+                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols);
             else
                 hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst);
+                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols);
         }
         HIPCHK(hipGetLastError());
         if (out_mem == FBR_HOST) {
@@ -880,27 +880,45 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
     };
     if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
     if (S > 0) {
-        // materialise Y chunk by chunk (K1 + K2) and fold each chunk into the per-workgroup factors
+        // materialise Y chunk by chunk (K1 + K2) and fold each chunk into the per-workgroup factors.  Without row
+        // weights / column subset the regressor kernel writes straight into the padded chunk [Y | rhs | 0] of the
+        // factorisation (leading dimension n): no second pass over Y.
         const size_t per = (size_t)hm.rows * hm.cols;
         long ch = fbr_tsqr_chunk_samples(hm.rows, Pa);
         ch = std::min(ch, chunk_size(m, S));
         const size_t lds = (size_t)hm.rec_size() * sizeof(double);
         HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if ((rc = m->out_tmp.ensure((size_t)ch * per * sizeof(double)))) return rc;
+        const int spb = std::max(1, std::min(16, 256 / std::max(1, hm.cols / 2)));
+        const size_t lds2 = lds * spb;
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const bool direct = !dcols && !dw;
+        if (!direct && (rc = m->out_tmp.ensure((size_t)ch * per * sizeof(double)))) return rc;
         for (long s0 = 0; s0 < S; s0 += ch) {
             const long cs = std::min(ch, S - s0);
             if ((rc = run_kin(m, d, s0, cs))) return rc;
             const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
+            double *dst = m->out_tmp.as<double>();
+            int ldy = hm.cols;
+            if (direct) {
+                if ((rc = fbr_tsqr_chunk_buffer(m->tsqr, cs * hm.rows, &dst))) return tsqr_fail(rc, "tsqr chunk");
+                ldy = m->tsqr.n;
+            }
             {
                 ProfScope ps(m, FBR_PROF_REGRESSOR);
-                hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, m->out_tmp.as<double>());
+                if ((hm.cols & 1) == 0)
+                    hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2,
+                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy);
+                else
+                    hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
+                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy);
             }
             HIPCHK(hipGetLastError());
             ProfScope ps(m, FBR_PROF_TSQR);
-            rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, cs * hm.rows, Psel, m->out_tmp.as<double>(), k,
-                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
-                                    hm.cols, dcols);
+            if (direct)
+                rc = fbr_tsqr_fold_chunk(m->tsqr, m->stream, cs * hm.rows, Psel, k, drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr);
+            else
+                rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, cs * hm.rows, Psel, m->out_tmp.as<double>(), k,
+                                        drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr, hm.cols, dcols);
             if (rc) return tsqr_fail(rc, "tsqr fold");
         }
     }

@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void fbr_kin_kernel(DevModel m, long S, const 
 // thread per column, every row of a sample written as one contiguous, coalesced run of `cols` doubles.
 // Bound: HBM write (8*rows*cols bytes per sample).
 // ------------------------------------------------------------------------------------------------
+// ldy = leading dimension of Y in doubles (>= cols; the TSQR path writes straight into its padded chunk)
 __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, const double *__restrict__ rec,
                                                              const double *__restrict__ dq,
-                                                             const double *__restrict__ sign, double *__restrict__ Y)
+                                                             const double *__restrict__ sign, double *__restrict__ Y, int ldy)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *rs = smem;  // [rec]
@@ -102,23 +103,23 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
         __syncthreads();
         for (int i = tid; i < m.rec; i += blockDim.x) rs[i] = rec[s * (long)m.rec + i];
         __syncthreads();
-        double *Ys = Y + s * (long)m.rows * m.cols;
+        double *Ys = Y + s * (long)m.rows * ldy;
         for (int c = tid; c < m.cols; c += blockDim.x) {
             const int4 cd = m.coldesc[c];
             if (cd.x == 0) {
                 double w6[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
-                for (int r = 0; r < m.fb; r++) Ys[(long)r * m.cols + c] = w6[r];
+                for (int r = 0; r < m.fb; r++) Ys[(long)r * ldy + c] = w6[r];
                 for (int d = 0; d < m.n; d++) {
                     const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
                     double v = 0.0;
                     if (bit) v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
-                    Ys[(long)(m.fb + d) * m.cols + c] = v;
+                    Ys[(long)(m.fb + d) * ldy + c] = v;
                 }
             } else {
                 const int j = cd.w;
                 const double v = fbr_friction_value(cd.z, dq[s * m.n + j], sign ? sign[s * m.n + j] : 0.0, m.stribeck);
-                for (int r = 0; r < m.rows; r++) Ys[(long)r * m.cols + c] = (r == m.fb + j) ? v : 0.0;
+                for (int r = 0; r < m.rows; r++) Ys[(long)r * ldy + c] = (r == m.fb + j) ? v : 0.0;
             }
         }
     }
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
 typedef double fbr_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
                                                               const double *__restrict__ dq,
-                                                              const double *__restrict__ sign, double *__restrict__ Y)
+                                                              const double *__restrict__ sign, double *__restrict__ Y, int ldy)
 {
     // spb samples per workgroup pass (small robots: 256 / (cols/2) samples side by side)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -147,12 +148,12 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
         if (ls >= ns) continue;
         const long s = sb + ls;
         const double *rs = smem + (long)ls * m.rec;
-        double *Ys = Y + s * (long)m.rows * m.cols;
+        double *Ys = Y + s * (long)m.rows * ldy;
         for (int prr = pr; prr < npairs; prr += (spb > 1 ? npairs : (int)blockDim.x)) {
             const int c = 2 * prr;
             const int4 ca = m.coldesc[c], cb = m.coldesc[c + 1];
             fbr_d2 *dst = (fbr_d2 *)(Ys + c);
-            const long rstride = m.cols >> 1;  // in double2 units
+            const long rstride = ldy >> 1;  // in double2 units (ldy even)
             if (ca.x == 0) {
                 double wa[6], wb[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, ca.z, wa);

@@ -60,6 +60,23 @@ __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, i
     }
 }
 
+// columns [P, ld) of rows < M: rhs then zeros; rows M..Mpad: all zeros  (completes a chunk whose first P columns were
+// written in place by the regressor kernel)
+__global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, int P, int k, int ld, const double *__restrict__ rhs, double *__restrict__ A)
+{
+    const int tw = ld - P;
+    const long t1 = M * tw, total = t1 + (Mpad - M) * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < t1) {
+            const long r = i / tw;
+            const int c = (int)(i - r * tw);
+            A[r * ld + P + c] = (c < k) ? rhs[r * k + c] : 0.0;
+        } else {
+            A[M * ld + (i - t1)] = 0.0;
+        }
+    }
+}
+
 // Register-resident, wave-pipelined TPQRT.  A workgroup of 8 waves folds a block of MB = 16*SUB rows into its R:
 //   * wave w owns the column tiles ct = w, w+8, ... (TPW per wave); the whole block lives in VGPRs in the MFMA
 //     C/D layout (lane (kk, j) of tile/sub-tile holds row 16*sub + 4*reg + kk, column j), so
@@ -841,19 +858,15 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
     return 0;
 }
 
-// Fold M rows of [Y (M x P) | rhs (M x k)] (row weights w optional) into the working factors.
-static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, int P, const double *Y, int k, const double *rhs,
-                                     const double *w, int ldy = 0, const int *cols = nullptr)
+// Packed chunk of the factorisation for M rows ([Mpad][n] doubles, Mpad = M rounded up to 16): (re)allocated on demand.
+static inline int fbr_tsqr_chunk_buffer(FbrTsqrWork &wk, long M, double **A)
 {
-    if (ldy <= 0) ldy = P;
-    if (!wk.active || P + k != wk.Pa) {
-        g_tsqr_err = "tsqr fold without matching begin";
+    if (!wk.active) {
+        g_tsqr_err = "tsqr chunk without begin";
         return -1;
     }
-    if (M <= 0) return 0;
-    const int n = wk.n;
     const long Mpad = (M + 15) & ~15L;
-    const size_t need = (size_t)Mpad * n * sizeof(double);
+    const size_t need = (size_t)std::max(Mpad, 16L) * wk.n * sizeof(double);
     if (need > wk.a_bytes) {
         if (wk.A) (void)hipFree(wk.A);
         wk.A = nullptr;
@@ -861,8 +874,15 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
         TSQR_HIP(hipMalloc((void **)&wk.A, need));
         wk.a_bytes = need;
     }
-    hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(2048), dim3(256), 0, st, M, Mpad, P, k, n, Y, ldy, cols, rhs, w, wk.A);
-    TSQR_HIP(hipGetLastError());
+    *A = wk.A;
+    return 0;
+}
+
+// level 0 over the packed chunk wk.A (M rows)
+static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M)
+{
+    const int n = wk.n;
+    const long Mpad = (M + 15) & ~15L;
     const long nblocks = (Mpad + wk.mb - 1) / wk.mb;
     if (wk.narrow) {
         const int nwaves = (int)std::min<long>(wk.NW, nblocks);
@@ -896,6 +916,40 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
         (void)hipFree(dbg);
     }
     return 0;
+}
+
+// Fold M rows of [Y (M x P) | rhs (M x k)] (row weights w optional, column gather optional) into the working factors.
+static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, int P, const double *Y, int k, const double *rhs,
+                                     const double *w, int ldy = 0, const int *cols = nullptr)
+{
+    if (ldy <= 0) ldy = P;
+    if (!wk.active || P + k != wk.Pa) {
+        g_tsqr_err = "tsqr fold without matching begin";
+        return -1;
+    }
+    if (M <= 0) return 0;
+    double *A = nullptr;
+    int rc = fbr_tsqr_chunk_buffer(wk, M, &A);
+    if (rc) return rc;
+    const long Mpad = (M + 15) & ~15L;
+    hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(2048), dim3(256), 0, st, M, Mpad, P, k, wk.n, Y, ldy, cols, rhs, w, A);
+    TSQR_HIP(hipGetLastError());
+    return fbr_tsqr_fold_packed(wk, st, M);
+}
+
+// Fold the chunk whose first P columns were already written into fbr_tsqr_chunk_buffer() (leading dimension wk.n):
+// append the rhs columns and the zero padding, then level 0.
+static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, int P, int k, const double *rhs)
+{
+    if (!wk.active || P + k != wk.Pa) {
+        g_tsqr_err = "tsqr fold without matching begin";
+        return -1;
+    }
+    if (M <= 0) return 0;
+    const long Mpad = (M + 15) & ~15L;
+    hipLaunchKernelGGL(fbr_tsqr_tail_kernel, dim3(1024), dim3(256), 0, st, M, Mpad, P, k, wk.n, rhs, wk.A);
+    TSQR_HIP(hipGetLastError());
+    return fbr_tsqr_fold_packed(wk, st, M);
 }
 
 // Binary tree over the working factors, result (Pa x Pa, upper triangular) to R_out (device).
