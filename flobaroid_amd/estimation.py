@@ -133,6 +133,29 @@ def identify_standard_direct(R_aug: np.ndarray, P: int, num_base_params: int, rh
     return x, s
 
 
+def identify_standard_essential(R_aug: np.ndarray, P: int, x_std_essential: np.ndarray, num_essential: int, rhs_col: int = 0):
+    """``Identification.identifyStandardEssentialParameters`` (identifier.py:816-838) from the small factor:
+    W_e = YStd diag(x_e) = Q (R_pp diag(x_e)), thin SVD (U_r, s, V) of R_pp diag(x_e), and
+    x = diag(x_e) V_1e S_1e^-1 U_1e^T tau with U_1e^T tau = U_r[:, :ne]^T R_aug[:P, P+rhs_col]."""
+    xe = np.asarray(x_std_essential, dtype=float)
+    Re = R_aug[:P, :P] * xe[None, :]
+    z = R_aug[:P, P + rhs_col]
+    U, s, Vt = la.svd(Re)
+    ne = int(num_essential)
+    return xe * (Vt[:ne].T @ ((U[:, :ne].T @ z) / s[:ne]))
+
+
+def wls_row_weights(p_sigma_x: np.ndarray, num_used_samples: int, rows_total: int) -> np.ndarray:
+    """Row weights of the reference's IDIM-WLS pass (identifier.py:739-790): the diagonal of
+    ``spdiags(np.repeat([1 / p_sigma_x], num_used_samples), 0, r, r)``, verbatim -- i.e. entry i is
+    1 / p_sigma_x[i // num_used_samples] (the reference repeats the per-parameter deviations, not per-joint ones;
+    off in every shipped config, SURVEY 8(a) flags it unpinned).  Pass as ``w`` to ``Engine.gram`` / ``Engine.tsqr``."""
+    d = np.repeat(1.0 / np.asarray(p_sigma_x, dtype=float), int(num_used_samples))
+    if d.shape[0] < rows_total:
+        raise ValueError("WLS: fewer weights than rows (num_base_params < rows per sample); the reference's expression is undefined here")
+    return d[:rows_total].copy()
+
+
 def d_optimality(G_aug: np.ndarray, independent_cols, delta: float = 0.0) -> float:
     """Excitation criterion of the trajectory optimiser (excitation/trajectoryOptimizer.py:263-272):
     -sum(log(eig(YBase^T YBase) + delta)) from the fused Gram, YBase^T YBase = G[ic, ic]."""

@@ -208,3 +208,26 @@ def test_tsqr_column_subset_is_qr_of_ybase():
     assert np.linalg.norm(sg(R) - sg(Rn)) <= 1e-10 * np.linalg.norm(Rn)
     with pytest.raises(Exception):
         eng.tsqr(st, cols=[0, 0, 1])
+
+
+@pytest.mark.parametrize("name,fl,S", [("kuka_lwr4", 0, 120_000), ("walkman_left_arm", 1, 60_000), ("walkman_apriori", 1, 40_000)])
+def test_tsqr_long_streams_agree_with_fused_gram(name, fl, S):
+    """Many folds per worker (continuous wave pipeline / wave-private narrow kernels) and a deep merge tree:
+    R^T R must equal the fused Gram of the same inputs (itself pinned on the oracle above) -- size-independent property
+    at sizes the CPU oracle cannot reach in a test."""
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo(name)
+    eng = Engine(t, floating=bool(fl))
+    rng = np.random.default_rng(77)
+    st = random_states(t, S, rng, fl)
+    rhs = rng.standard_normal((S * eng.rows, 1))
+    R = eng.tsqr(st, rhs=rhs)
+    G = eng.gram(st, rhs=rhs)
+    assert np.all(np.tril(R, -1) == 0.0) and np.all(np.isfinite(R))
+    assert np.linalg.norm(R.T @ R - G) <= 1e-11 * np.linalg.norm(G)
+    # streaming in two halves through R_in gives the same Gram
+    h = S // 2
+    R1 = eng.tsqr({k: v[:h] for k, v in st.items()}, rhs=rhs[: h * eng.rows])
+    R2 = eng.tsqr({k: v[h:] for k, v in st.items()}, rhs=rhs[h * eng.rows:], R_in=R1)
+    assert np.linalg.norm(R2.T @ R2 - G) <= 1e-11 * np.linalg.norm(G)

@@ -206,3 +206,42 @@ def test_direct_std_identification_dopt_and_row_weights():
     assert np.allclose(w[:150], wref[0]) and np.allclose(w[150:], wref[1])
     m = est.base_wrench_row_mask(5, 13).reshape(5, 13)
     assert np.all(m[:, :6] == 1) and np.all(m[:, 6:] == 0)
+
+
+def test_essential_direct_and_wls_weights_match_reference_expressions():
+    import scipy.sparse
+
+    t = load_topo("kuka_lwr4")
+    rng = np.random.default_rng(9)
+    S = 300
+    st = random_states(t, S, rng, 0, use_limits=True)
+    om = OracleModel(t)
+    Y = om.regressor(st)
+    tau = om.inverse_dynamics(st, t.x_std()).reshape(-1) + 0.01 * rng.standard_normal(Y.shape[0])
+    R_aug = la.qr(np.column_stack([Y, tau]), mode="r")
+    # identifyStandardEssentialParameters (identifier.py:821-832) on the tall matrix
+    xe = np.zeros(80)
+    ess = np.flatnonzero(np.abs(Y).sum(axis=0) > 0)[::3]
+    xe[ess] = t.x_std()[ess] + 0.3
+    ne = 12
+    Ue, se, VHe = la.svd(Y @ np.diag(xe), full_matrices=False)
+    x_ref = np.diag(xe) @ VHe.T[:, :ne] @ la.inv(np.diag(se[:ne])) @ Ue[:, :ne].T @ tau
+    x = est.identify_standard_essential(R_aug, 80, xe, ne)
+    assert la.norm(x - x_ref) <= 1e-8 * la.norm(x_ref)
+    # IDIM-WLS weighting (identifier.py:767-784): G = spdiags(repeat([1/p_sigma_x], S), 0, r, r); WLS solution
+    # of the weighted base regressor equals the solution from the weighted small factor
+    d = lin_deps_qr(Y.T @ Y, 1e-4)
+    ic = d["independent_cols"]
+    nb = d["r"]
+    p_sigma_x = 0.5 + rng.random(nb)
+    r = Y.shape[0]
+    G = scipy.sparse.spdiags(np.repeat(np.array([1 / p_sigma_x]), S), 0, r, r)
+    w = est.wls_row_weights(p_sigma_x, S, r)
+    assert np.array_equal(w, G.diagonal())
+    YB = Y[:, ic]
+    x_wls_ref = la.lstsq(G.dot(YB), G.dot(tau), rcond=None)[0]
+    Rw = la.qr(np.column_stack([YB, tau]) * w[:, None], mode="r")
+    x_wls = la.solve(Rw[:nb, :nb], Rw[:nb, nb])
+    assert la.norm(x_wls - x_wls_ref) <= 1e-9 * la.norm(x_wls_ref)
+    with pytest.raises(ValueError):
+        est.wls_row_weights(p_sigma_x[:3], S, r)
