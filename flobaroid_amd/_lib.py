@@ -84,6 +84,11 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
          ctypes.c_int32, ctypes.c_int32],
     ),
+    "fbr_gram_grouped": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_int32],
+    ),
     "fbr_tsqr": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -367,6 +372,17 @@ class Engine:
             self._lib.fbr_gram_accumulate(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, r.ptr, r.mem, int(bool(accumulate))),
             "fbr_gram_accumulate",
         )
+        return ret
+
+    def gram_grouped(self, st: dict, ngroups: int, rhs=None, w=None, out=None):
+        """One raw Gram per group of S / ngroups consecutive samples, shape (ngroups, cols+k, cols+k), in one pass."""
+        s, keep, S, mem = self._states(st)
+        if ngroups < 1 or S % ngroups:
+            raise ValueError("the number of samples must be a multiple of ngroups")
+        rr, wr, k = self._rhs(rhs, w, S, mem)
+        Pa = self.cols + k
+        r, ret = self._out(out, (int(ngroups), Pa, Pa), mem)
+        _check(self._lib.fbr_gram_grouped(self._h, ctypes.byref(s), int(ngroups), rr.ptr, k, wr.ptr, r.ptr, r.mem), "fbr_gram_grouped")
         return ret
 
     def tsqr(self, st: dict, rhs=None, w=None, R_in=None, out=None, cols=None):

@@ -380,6 +380,7 @@ static long chunk_size(const fbr_model *m, long S)
     const size_t per = (size_t)m->hm.rec_size() * sizeof(double);
     long ch = (long)((size_t)(768u << 20) / per);
     if (ch < 1024) ch = 1024;
+    if (const char *e = getenv("FBR_CHUNK_SAMPLES")) ch = std::max(1L, atol(e));  // tests: force the multi-chunk paths at small sizes
     return std::min(S, ch);
 }
 
@@ -695,8 +696,9 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
     return FBR_OK;
 }
 
-extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
-                                   double *G_out, int32_t out_mem, int32_t accumulate)
+// ngroups > 1: the samples form ngroups consecutive groups of equal size, one Gram per group (G_out [ngroups][Pa][Pa])
+static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
+                     int32_t out_mem, int32_t accumulate, int32_t ngroups)
 {
     DevStates d;
     int rc = stage_states(m, st, &d);
@@ -705,11 +707,15 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
         set_err("bad rhs / G_out arguments");
         return FBR_E_INVALID;
     }
+    if (ngroups < 1 || d.S % ngroups != 0) {
+        set_err("the number of samples must be a multiple of the number of groups");
+        return FBR_E_INVALID;
+    }
     const FbrHostModel &hm = m->hm;
     GramHolder *h = nullptr;
     if ((rc = get_gram(m, k, &h))) return rc;
     const int Pa = h->prog.Pa;
-    const size_t gcount = (size_t)Pa * Pa;
+    const size_t gcount = (size_t)Pa * Pa * ngroups;
     const long S = d.S;
     const double *drhs = nullptr, *dw = nullptr;
     if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
@@ -734,7 +740,22 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
         const size_t img_bytes = (size_t)h->prog.image_doubles * sizeof(double);
         long ch = chunk_size(m, S);
         ch = std::max(1L, std::min(ch, (long)((size_t)4 * 1024 * 1024 * 1024 / img_bytes)));
-        const long nchunks = (S + ch - 1) / ch;
+        // work items: several whole groups per launch, or (groups larger than a chunk) pieces of one group
+        struct Item { long s0, cs; int g0, ng; };
+        std::vector<Item> items;
+        const long Sg = S / ngroups;
+        if (Sg <= ch) {
+            const int gpc = (int)std::min<long>(ngroups, std::max(1L, ch / Sg));
+            for (int g0 = 0; g0 < ngroups; g0 += gpc) {
+                const int ng = std::min(gpc, ngroups - g0);
+                items.push_back({g0 * Sg, ng * Sg, g0, ng});
+            }
+            ch = gpc * Sg;
+        } else {
+            for (int g = 0; g < ngroups; g++)
+                for (long c0 = 0; c0 < Sg; c0 += ch) items.push_back({g * Sg + c0, std::min(ch, Sg - c0), g, 1});
+        }
+        const long nchunks = (long)items.size();
         for (int b = 0; b < (nchunks > 1 ? 2 : 1); b++)
             if ((size_t)ch * img_bytes > h->pimg[b].bytes) {
                 if ((rc = h->pimg[b].ensure((size_t)ch * img_bytes))) return rc;
@@ -745,7 +766,7 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
         HIPCHK(hipEventRecord(m->ev_fork, m->stream));
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
         auto produce = [&](long ci) -> int {
-            const long s0 = ci * ch, cs = std::min(ch, S - s0);
+            const long s0 = items[ci].s0, cs = items[ci].cs;
             const int b = (int)(ci & 1);
             if (ci >= 2) HIPCHK(hipStreamWaitEvent(m->side, m->ev_gram[b], 0));  // Gram of chunk ci-2 is done with this buffer
             int rc2 = run_kin(m, d, s0, cs, m->side, &m->rec2);
@@ -764,14 +785,17 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
         };
         if ((rc = produce(0))) return rc;
         for (long ci = 0; ci < nchunks; ci++) {
-            const long s0 = ci * ch, cs = std::min(ch, S - s0);
+            const long cs = items[ci].cs;
+            const int ng = items[ci].ng;
             const int b = (int)(ci & 1);
             if (ci + 1 < nchunks && (rc = produce(ci + 1))) return rc;
             HIPCHK(hipStreamWaitEvent(m->stream, m->ev_pack[b], 0));
             // one workgroup per CU; the slice count is not rounded to the XCD count: measured (profiles/r01_gram_pmc_traffic)
-            // the parts of a slice drift apart and do not share L2 lines, so filling every CU is worth more
-            int NS = std::max(1, (m->num_cus * blocks_per_cu) / T);
-            if ((long)NS > cs) NS = (int)cs;
+            // the parts of a slice drift apart and do not share L2 lines, so filling every CU is worth more.
+            // Groups: spg slices per group, slice boundaries coincide with the group boundaries (equal group sizes).
+            int spg = std::max(1, (m->num_cus * blocks_per_cu) / T / ng);
+            if ((long)spg > cs / ng) spg = (int)(cs / ng);
+            const int NS = spg * ng;
             const size_t pcount = (size_t)NS * T * FBR_WPB * FBR_NPW * 256;
             if ((rc = m->partial.ensure(pcount * sizeof(double)))) return rc;
             unsigned long long *dbg = nullptr;
@@ -810,14 +834,26 @@ extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const dou
             }
             {
                 ProfScope ps(m, FBR_PROF_REDUCE);
-                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW), dim3(256), 0, m->stream, h->dev, NS,
-                                   m->partial.as<double>(), G);
+                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW, ng), dim3(256), 0, m->stream, h->dev, spg,
+                                   m->partial.as<double>(), G + (size_t)items[ci].g0 * Pa * Pa);
             }
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(m->side));
     }
     return finish_output(m, G, G_out, gcount, out_mem);
+}
+
+extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
+                                   double *G_out, int32_t out_mem, int32_t accumulate)
+{
+    return gram_impl(m, st, rhs, k, w, G_out, out_mem, accumulate, 1);
+}
+
+extern "C" int fbr_gram_grouped(fbr_model *m, const fbr_states *st, int32_t ngroups, const double *rhs, int32_t k, const double *w,
+                                double *G_out, int32_t out_mem)
+{
+    return gram_impl(m, st, rhs, k, w, G_out, out_mem, 0, ngroups);
 }
 
 // ------------------------------------------------------------------------------------------------

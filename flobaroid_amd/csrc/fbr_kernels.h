@@ -521,19 +521,22 @@ __global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, lo
 // Deterministic reduction over the sample slices + scatter into the symmetric G (augmented column order).
 // One workgroup (256 threads = 4 regs x 64 lanes) per accumulator slot.  G must be pre-zeroed or hold the
 // running sum: every G entry is touched by exactly one thread.
-__global__ __launch_bounds__(256) void fbr_gram_reduce_kernel(DevGram g, int NS, const double *__restrict__ partial,
+__global__ __launch_bounds__(256) void fbr_gram_reduce_kernel(DevGram g, int spg, const double *__restrict__ partial,
                                                                double *__restrict__ G)
 {
+    // blockIdx.y = sample group: its spg consecutive slices are summed into G + group * Pa^2 (one group: spg = NS)
     const int slot = blockIdx.x;  // (part*WPB + wave)*NPW + p
     const int I = g.slot_tiles[2 * slot], J = g.slot_tiles[2 * slot + 1];
     if (I < 0) return;
     const int t = threadIdx.x, reg = t >> 6, lane = t & 63;
     const long per_slice = (long)g.T * FBR_WPB * FBR_NPW * 256;
+    const long sl0 = (long)blockIdx.y * spg;
     double v = 0.0;
-    for (int sl = 0; sl < NS; sl++) v += partial[sl * per_slice + (long)slot * 256 + t];
+    for (int sl = 0; sl < spg; sl++) v += partial[(sl0 + sl) * per_slice + (long)slot * 256 + t];
     const int row = (lane >> 4) + 4 * reg, col = lane & 15;
     const int ci = g.tilecol[I * FBR_TILE + row], cj = g.tilecol[J * FBR_TILE + col];
     if (ci < 0 || cj < 0) return;
-    G[(long)ci * g.Pa + cj] += v;
-    if (I != J) G[(long)cj * g.Pa + ci] += v;
+    double *Gg = G + (long)blockIdx.y * g.Pa * g.Pa;
+    Gg[(long)ci * g.Pa + cj] += v;
+    if (I != J) Gg[(long)cj * g.Pa + ci] += v;
 }

@@ -164,6 +164,14 @@ def d_optimality(G_aug: np.ndarray, independent_cols, delta: float = 0.0) -> flo
     return float(-np.sum(np.log(np.maximum(ev, 0.0) + delta)))
 
 
+def d_optimality_batch(G_groups: np.ndarray, independent_cols, delta: float = 0.0) -> np.ndarray:
+    """``d_optimality`` of every candidate trajectory of a batch: ``G_groups`` (ngroups, Pa, Pa) from
+    ``Engine.gram_grouped`` (one pass over all candidates; the optimiser's inner loop, trajectoryOptimizer.py:248-272)."""
+    ic = np.asarray(independent_cols, dtype=np.int64)
+    ev = la.eigvalsh(G_groups[:, ic[:, None], ic[None, :]])
+    return -np.sum(np.log(np.maximum(ev, 0.0) + delta), axis=1)
+
+
 def base_wrench_row_mask(num_samples: int, rows: int) -> np.ndarray:
     """0/1 row weights selecting the 6 base-wrench rows of every sample (``_extractBaseWrenchRows``,
     identifier.py:629-636) -- pass as ``w`` to ``Engine.gram`` / ``Engine.tsqr``."""

@@ -136,6 +136,15 @@ int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, i
                         double *G_out, int32_t out_mem, int32_t accumulate);
 
 /*
+ * The same reduction for ngroups consecutive, equally sized groups of samples in ONE pass: G_out [ngroups][(cols+k)][(cols+k)],
+ * group g = samples [g*S/ngroups, (g+1)*S/ngroups) (num_samples must be a multiple of ngroups).  Serves the
+ * trajectory optimiser's inner loop (excitation/trajectoryOptimizer.py:248-272: YBase^T YBase of every candidate
+ * trajectory) and finite-difference sweeps, where one Gram per small trajectory would be launch-bound.
+ */
+int fbr_gram_grouped(fbr_model *m, const fbr_states *st, int32_t ngroups, const double *rhs, int32_t k, const double *w,
+                     double *G_out, int32_t out_mem);
+
+/*
  * R_out [(cols+k)][(cols+k)] upper triangular with R^T R = [Y|rhs]^T [Y|rhs], by blocked Householder
  * TSQR over sample blocks (no Gram squaring of the condition number).  If R_in != NULL it is an
  * existing triangular factor (same shape, out_mem space) that is folded in first (streaming / tree

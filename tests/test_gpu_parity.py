@@ -231,3 +231,61 @@ def test_tsqr_long_streams_agree_with_fused_gram(name, fl, S):
     R1 = eng.tsqr({k: v[:h] for k, v in st.items()}, rhs=rhs[: h * eng.rows])
     R2 = eng.tsqr({k: v[h:] for k, v in st.items()}, rhs=rhs[h * eng.rows:], R_in=R1)
     assert np.linalg.norm(R2.T @ R2 - G) <= 1e-11 * np.linalg.norm(G)
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[3], CONFIGS[7]], ids=cfg_id)
+def test_grouped_gram_equals_one_gram_per_group(cfg):
+    """fbr_gram_grouped: one pass over ngroups candidate trajectories == ngroups separate fbr_gram_accumulate calls
+    (bitwise up to the fixed slice order: compared to 1e-13), and the batch D-optimality of trajectoryOptimizer.py:263-272."""
+    from flobaroid_amd import estimation as est
+
+    t, eng, om = _engine_oracle(cfg)
+    ng, Sg = 7, 90
+    st, rng = _states(t, cfg, ng * Sg, 31)
+    rhs = rng.standard_normal((ng * Sg * om.rows, 1))
+    w = rng.random(ng * Sg * om.rows) + 0.5
+    Gg = eng.gram_grouped(st, ng, rhs=rhs, w=w)
+    assert Gg.shape == (ng, om.P + 1, om.P + 1)
+    for g in range(ng):
+        sl = slice(g * Sg, (g + 1) * Sg)
+        rs = slice(g * Sg * om.rows, (g + 1) * Sg * om.rows)
+        G1 = eng.gram({k: v[sl] for k, v in st.items()}, rhs=rhs[rs], w=w[rs])
+        assert np.linalg.norm(Gg[g] - G1) <= 1e-13 * np.linalg.norm(G1)
+    A = _aug(om, {k: v[:Sg] for k, v in st.items()}, rhs[: Sg * om.rows], w[: Sg * om.rows])
+    assert np.linalg.norm(Gg[0] - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
+    ic = np.flatnonzero(np.diag(Gg.sum(axis=0))[: om.P] > 0)[:20]
+    dopt = est.d_optimality_batch(Gg, ic, 1e-6)
+    for g in range(ng):
+        assert abs(dopt[g] - est.d_optimality(Gg[g], ic, 1e-6)) <= 1e-9 * abs(dopt[g])
+    with pytest.raises(Exception):
+        eng.gram_grouped(st, 4)  # 630 samples are not a multiple of 4
+
+
+def test_multi_chunk_paths_at_small_sizes(monkeypatch):
+    """FBR_CHUNK_SAMPLES forces the chunked code paths (double-buffered producer stream of the Gram, groups larger /
+    smaller than a chunk, several TSQR chunks, chunked regressor / inverse dynamics) at sizes the oracle can check."""
+    cfg = CONFIGS[7]
+    t, eng, om = _engine_oracle(cfg)
+    S = 330
+    st, rng = _states(t, cfg, S, 41)
+    rhs = rng.standard_normal((S * om.rows, 2))
+    A = _aug(om, st, rhs)
+    Go = A.T @ A
+    x = rng.standard_normal(om.P)
+    monkeypatch.setenv("FBR_CHUNK_SAMPLES", "70")
+    G = eng.gram(st, rhs=rhs)
+    assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go)
+    R = eng.tsqr(st, rhs=rhs)
+    assert np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
+    Rw = eng.tsqr(st, rhs=rhs, w=np.full(S * om.rows, 2.0))
+    assert np.linalg.norm(Rw.T @ Rw - 4.0 * Go) <= 1e-11 * np.linalg.norm(4.0 * Go)
+    Y = eng.regressor(st)
+    assert np.abs(Y - A[:, : om.P]).max() <= 1e-11 * np.abs(A).max()
+    assert np.abs(eng.predict(st, x) - (A[:, : om.P] @ x).reshape(S, om.rows)).max() <= 1e-10 * np.abs(A @ np.r_[x, 0, 0]).max()
+    # groups of 110 samples > chunk of 70 (pieces of one group), and groups of 30 < chunk (two groups per launch)
+    for ng in (3, 11):
+        Gg = eng.gram_grouped(st, ng, rhs=rhs)
+        Sg = S // ng
+        for g in range(ng):
+            Ag = A[g * Sg * om.rows:(g + 1) * Sg * om.rows]
+            assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * np.linalg.norm(Ag.T @ Ag)
