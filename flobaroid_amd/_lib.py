@@ -89,6 +89,10 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
          ctypes.c_int32],
     ),
+    "fbr_fd_scores": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32],
+    ),
     "fbr_tsqr": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -383,6 +387,17 @@ class Engine:
         Pa = self.cols + k
         r, ret = self._out(out, (int(ngroups), Pa, Pa), mem)
         _check(self._lib.fbr_gram_grouped(self._h, ctypes.byref(s), int(ngroups), rr.ptr, k, wr.ptr, r.ptr, r.mem), "fbr_gram_grouped")
+        return ret
+
+    def fd_scores(self, st: dict, W, eps: float, out=None):
+        """Weighted regressor scores sum(W_s * Y) of every sample's baseline state and its 3n states perturbed by +eps
+        in q_d, dq_d, ddq_d: shape (S, 1 + 3n) (analyticalGradient.py:92-185 without the per-sample Python loop)."""
+        s, keep, S, mem = self._states(st)
+        Wr = _Ref(W if _is_torch(W) else np.asarray(W, dtype=np.float64).reshape(S * self.rows, self.cols), (S * self.rows, self.cols), "W")
+        if Wr.mem != mem:
+            raise ValueError("W must live in the same memory space as the states")
+        r, ret = self._out(out, (S, 1 + 3 * self.topo.num_dofs), mem)
+        _check(self._lib.fbr_fd_scores(self._h, ctypes.byref(s), Wr.ptr, float(eps), r.ptr, r.mem), "fbr_fd_scores")
         return ret
 
     def tsqr(self, st: dict, rhs=None, w=None, R_in=None, out=None, cols=None):

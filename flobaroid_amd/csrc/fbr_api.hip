@@ -88,6 +88,7 @@ struct fbr_model {
     // workspace
     DevBuf st_q, st_dq, st_ddq, st_bv, st_ba, st_rpy, st_sign, st_aux, st_aux2, st_x;
     DevBuf rec, partial, out_tmp, g_tmp;
+    DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     FbrTsqrWork tsqr;
     // profiling
     bool prof = false;
@@ -247,6 +248,7 @@ extern "C" void fbr_model_destroy(fbr_model *m)
     DevBuf *bufs[] = {&m->st_q, &m->st_dq, &m->st_ddq, &m->st_bv, &m->st_ba, &m->st_rpy, &m->st_sign, &m->st_aux,
                       &m->st_aux2, &m->st_x, &m->rec, &m->partial, &m->out_tmp, &m->g_tmp};
     for (DevBuf *b : bufs) b->release();
+    for (DevBuf &b : m->fd) b.release();
     m->tsqr.release();
     for (auto &e : m->ev_pool) {
         (void)hipEventDestroy(e.first);
@@ -854,6 +856,64 @@ extern "C" int fbr_gram_grouped(fbr_model *m, const fbr_states *st, int32_t ngro
                                 double *G_out, int32_t out_mem)
 {
     return gram_impl(m, st, rhs, k, w, G_out, out_mem, 0, ngroups);
+}
+
+extern "C" int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W, double eps, double *out, int32_t out_mem)
+{
+    DevStates d;
+    int rc = stage_states(m, st, &d);
+    if (rc) return rc;
+    if (!W || !out) {
+        set_err("W / out is NULL");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    const long S = d.S;
+    const int n = hm.n, nper = 1 + 3 * n;
+    const double *dW = nullptr;
+    if ((rc = stage_one(m, m->st_aux, W, (size_t)S * hm.rows * hm.cols, st->mem, &dW))) return rc;
+    double *dout = out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure((size_t)S * nper * sizeof(double)))) return rc;
+        dout = m->g_tmp.as<double>();
+    }
+    if (S > 0) {
+        // chunks of original samples such that the expanded kinematic records stay within the usual chunk
+        long ch = std::max(1L, chunk_size(m, S * nper) / nper);
+        const size_t lds = ((size_t)hm.rec_size() + 4) * sizeof(double);
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t cnt[7] = {(size_t)n, (size_t)n, (size_t)n, 6, 6, 3, (size_t)n};
+        for (long s0 = 0; s0 < S; s0 += ch) {
+            const long cs = std::min(ch, S - s0), ce = cs * nper;
+            for (int i = 0; i < 7; i++)
+                if ((rc = m->fd[i].ensure((size_t)ce * cnt[i] * sizeof(double)))) return rc;
+            hipLaunchKernelGGL(fbr_fd_expand_kernel, dim3((unsigned)std::min<long>((ce + 255) / 256, 4096)), dim3(256), 0, m->stream, cs, n,
+                               d.bv ? 1 : 0, d.sign ? 1 : 0, eps, d.q + s0 * n, d.dq + s0 * n, d.ddq + s0 * n, d.bv ? d.bv + s0 * 6 : nullptr,
+                               d.ba ? d.ba + s0 * 6 : nullptr, d.rpy ? d.rpy + s0 * 3 : nullptr, d.sign ? d.sign + s0 * n : nullptr,
+                               m->fd[0].as<double>(), m->fd[1].as<double>(), m->fd[2].as<double>(), m->fd[3].as<double>(),
+                               m->fd[4].as<double>(), m->fd[5].as<double>(), m->fd[6].as<double>());
+            HIPCHK(hipGetLastError());
+            DevStates de;
+            de.S = ce;
+            de.q = m->fd[0].as<double>();
+            de.dq = m->fd[1].as<double>();
+            de.ddq = m->fd[2].as<double>();
+            if (d.bv) {
+                de.bv = m->fd[3].as<double>();
+                de.ba = m->fd[4].as<double>();
+                de.rpy = m->fd[5].as<double>();
+            }
+            if (d.sign) de.sign = m->fd[6].as<double>();
+            if ((rc = run_kin(m, de, 0, ce))) return rc;
+            {
+                ProfScope ps(m, FBR_PROF_REGRESSOR);
+                hipLaunchKernelGGL(fbr_score_kernel, dim3((unsigned)std::min<long>(ce, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, ce,
+                                   nper, m->rec.as<double>(), de.dq, de.sign, dW + (size_t)s0 * hm.rows * hm.cols, dout + (size_t)s0 * nper);
+            }
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return finish_output(m, dout, out, (size_t)S * nper, out_mem);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -128,6 +128,79 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
 // K2b: same result as K2 for an EVEN number of columns: one thread per PAIR of adjacent columns, 16-byte stores
 // (1 KiB per wave-instruction), ancestor masks hoisted into registers.  Adjacent inertial columns always belong to
 // the same link (10 or 4 columns per link).
+// ------------------------------------------------------------------------------------------------
+// Finite-difference sweep (excitation/analyticalGradient.py:92-185): per sample the baseline state and
+// 3n states perturbed by +eps in q_d, dq_d, ddq_d.  fbr_fd_expand_kernel writes the 1 + 3n states of every sample,
+// fbr_score_kernel evaluates score = sum_{r,c} W_s[r][c] * Y[r][c] of each (the regressor block is never stored).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fbr_fd_expand_kernel(long S, int n, int has_base, int has_sign, double eps, const double *__restrict__ q,
+                                                             const double *__restrict__ dq, const double *__restrict__ ddq,
+                                                             const double *__restrict__ bv, const double *__restrict__ ba,
+                                                             const double *__restrict__ rpy, const double *__restrict__ sign,
+                                                             double *__restrict__ eq, double *__restrict__ edq, double *__restrict__ eddq,
+                                                             double *__restrict__ ebv, double *__restrict__ eba, double *__restrict__ erpy,
+                                                             double *__restrict__ esign)
+{
+    const int nper = 1 + 3 * n;
+    const long total = S * nper;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long s = e / nper;
+        const int j = (int)(e - s * nper);          // 0 = baseline, 1 + d = q_d, 1 + n + d = dq_d, 1 + 2n + d = ddq_d
+        const int kind = (j == 0) ? -1 : (j - 1) / n, d = (j == 0) ? -1 : (j - 1) % n;
+        for (int i = 0; i < n; i++) {
+            eq[e * n + i] = q[s * n + i] + ((kind == 0 && i == d) ? eps : 0.0);
+            edq[e * n + i] = dq[s * n + i] + ((kind == 1 && i == d) ? eps : 0.0);
+            eddq[e * n + i] = ddq[s * n + i] + ((kind == 2 && i == d) ? eps : 0.0);
+            if (has_sign) esign[e * n + i] = sign[s * n + i];
+        }
+        if (has_base) {
+            for (int i = 0; i < 6; i++) {
+                ebv[e * 6 + i] = bv[s * 6 + i];
+                eba[e * 6 + i] = ba[s * 6 + i];
+            }
+            for (int i = 0; i < 3; i++) erpy[e * 3 + i] = rpy[s * 3 + i];
+        }
+    }
+}
+
+// out[e] = <W_{e / nper}, Y_e>: one workgroup per (expanded) sample, one thread per column, block reduction
+__global__ __launch_bounds__(256) void fbr_score_kernel(DevModel m, long SE, int nper, const double *__restrict__ rec,
+                                                         const double *__restrict__ dq, const double *__restrict__ sign,
+                                                         const double *__restrict__ W, double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *rs = smem;  // [rec] + [4] reduction
+    double *red = smem + m.rec;
+    const int tid = threadIdx.x;
+    for (long e = blockIdx.x; e < SE; e += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < m.rec; i += blockDim.x) rs[i] = rec[e * (long)m.rec + i];
+        __syncthreads();
+        const double *Ws = W + (e / nper) * (long)m.rows * m.cols;
+        double acc = 0.0;
+        for (int c = tid; c < m.cols; c += blockDim.x) {
+            const int4 cd = m.coldesc[c];
+            if (cd.x == 0) {
+                double w6[6];
+                fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
+                for (int r = 0; r < m.fb; r++) acc += Ws[(long)r * m.cols + c] * w6[r];
+                for (int d = 0; d < m.n; d++) {
+                    const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
+                    if (bit) acc += Ws[(long)(m.fb + d) * m.cols + c] * fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
+                }
+            } else {
+                const int j = cd.w;
+                acc += Ws[(long)(m.fb + j) * m.cols + c] * fbr_friction_value(cd.z, dq[e * m.n + j], sign ? sign[e * m.n + j] : 0.0, m.stribeck);
+            }
+        }
+        // deterministic block reduction: wave sums by xor butterflies, then 4 partials in fixed order
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 typedef double fbr_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
                                                               const double *__restrict__ dq,

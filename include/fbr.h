@@ -145,6 +145,18 @@ int fbr_gram_grouped(fbr_model *m, const fbr_states *st, int32_t ngroups, const 
                      double *G_out, int32_t out_mem);
 
 /*
+ * Finite-difference sweep of a weighted regressor score (the per-sample worker of the analytical trajectory gradient,
+ * excitation/analyticalGradient.py:92-185): out [num_samples][1 + 3 n] with
+ *   out[s][0]        = sum_{r,c} W_s[r][c] * Y_s[r][c]                     (baseline state of sample s)
+ *   out[s][1 + d]    = the same sum for the state with q_d   + eps,
+ *   out[s][1+n + d]  =                                    dq_d  + eps,
+ *   out[s][1+2n + d] =                                    ddq_d + eps      (d = 0..n-1),
+ * W [num_samples*rows][cols] the weight blocks (st->mem).  (out[s][1+j] - out[s][0]) / eps are the reference's
+ * sens_q / sens_dq / sens_ddq; the 1 + 3 n regressor blocks per sample are evaluated on the fly, never stored.
+ */
+int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W, double eps, double *out, int32_t out_mem);
+
+/*
  * R_out [(cols+k)][(cols+k)] upper triangular with R^T R = [Y|rhs]^T [Y|rhs], by blocked Householder
  * TSQR over sample blocks (no Gram squaring of the condition number).  If R_in != NULL it is an
  * existing triangular factor (same shape, out_mem space) that is folded in first (streaming / tree

@@ -289,3 +289,34 @@ def test_multi_chunk_paths_at_small_sizes(monkeypatch):
         for g in range(ng):
             Ag = A[g * Sg * om.rows:(g + 1) * Sg * om.rows]
             assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * np.linalg.norm(Ag.T @ Ag)
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[7]], ids=cfg_id)
+def test_fd_sweep_scores_match_oracle_regressors(cfg):
+    """fbr_fd_scores == sum(W_t * Y(state_t + eps e_d)) with the oracle's regressor on every perturbed state
+    (the per-sample worker of analyticalGradient.py:92-185)."""
+    from flobaroid_amd import excitation as exc
+
+    t, eng, om = _engine_oracle(cfg)
+    S, eps = 9, 1e-6
+    st, rng = _states(t, cfg, S, 51)
+    n = t.num_dofs
+    W = rng.standard_normal((S * om.rows, om.P))
+    sc = eng.fd_scores(st, W, eps)
+    assert sc.shape == (S, 1 + 3 * n)
+    Wb = W.reshape(S, om.rows, om.P)
+    ref = np.empty_like(sc)
+    ref[:, 0] = np.einsum("src,src->s", Wb, om.regressor(st, st["sign"]).reshape(S, om.rows, om.P))
+    for kind, key in enumerate(("q", "dq", "ddq")):
+        for d in range(n):
+            sp = {k: v.copy() for k, v in st.items()}
+            sp[key][:, d] += eps
+            ref[:, 1 + kind * n + d] = np.einsum("src,src->s", Wb, om.regressor(sp, st["sign"]).reshape(S, om.rows, om.P))
+    assert np.abs(sc - ref).max() <= 1e-11 * np.abs(ref).max()
+    sq, sdq, sddq = exc.dopt_sensitivities(eng, st, W, eps)
+    assert sq.shape == sdq.shape == sddq.shape == (S, n)
+    # (differences of nearly equal scores: compare through the scores' own scale)
+    assert np.abs(sq - (ref[:, 1:1 + n] - ref[:, :1]) / eps).max() <= 1e-10 * np.abs(ref).max() / eps
+    # regressor is linear in ddq: the acceleration sensitivity is exact, independent of eps
+    sc2 = eng.fd_scores(st, W, 1e-3)
+    assert np.abs((sc2[:, 1 + 2 * n:] - sc2[:, :1]) / 1e-3 - sddq).max() <= 1e-6 * np.abs(sddq).max()
