@@ -68,6 +68,67 @@ def cpu_baseline(topo, budget_s=15.0):
             "sample": f"{done} WALK-MAN floating-base samples: oracle regressor + RNEA (C, 1 thread) + NumPy A^T A (1 BLAS thread), {dt:.1f} s"}
 
 
+def other_configs(dev):
+    """BASELINE.json configs[1] and configs[2] on this GPU (secondary figures, outside the timed steps):
+    KUKA LWR4 fixed base, 50 k samples: regressor assembly + fused Gram + base-parameter QR (host, 80 x 80);
+    WALK-MAN left arm (floating base, 13 x 90 block), 500 k samples: Householder TSQR."""
+    import torch
+
+    from flobaroid_amd._lib import Engine
+    from flobaroid_amd.topology import Topology
+    from flobaroid_amd import estimation as est
+
+    res = {}
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # configs[1]
+    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "kuka_lwr4.topology.json"))
+    eng = Engine(topo, floating=False, device=dev.index or 0)
+    S = 50_000
+    st_np, rng = synth_states(topo, S, 7, False)
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
+    tau = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
+    Y = torch.empty((S * eng.rows, eng.cols), dtype=torch.float64, device=dev)
+    t_reg = timed(lambda: eng.regressor(st, out=Y))
+    t_gram = timed(lambda: eng.gram(st, rhs=tau))
+    G = eng.gram(st, rhs=tau).cpu().numpy()
+    t0 = time.perf_counter()
+    import scipy.linalg as sla
+
+    Gs = G[: eng.cols, : eng.cols]
+    Rq = sla.qr(Gs, pivoting=True, mode="economic")[1]
+    nb = int(np.count_nonzero(np.abs(np.diag(Rq)) > 1e-4 * np.abs(Rq[0, 0])))
+    t_qr = time.perf_counter() - t0
+    res["kuka_lwr4_fixed_50k"] = {"samples": S, "block": [eng.rows, eng.cols], "regressor_ms": t_reg * 1e3,
+                                  "regressor_GB_per_s": 8.0 * S * eng.rows * eng.cols / t_reg / 1e9, "fused_gram_ms": t_gram * 1e3,
+                                  "fused_gram_samples_per_s": S / t_gram, "base_param_qr_host_ms": t_qr * 1e3, "base_rank": nb}
+    eng.close()
+    del Y, st
+    # configs[2]
+    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "walkman_left_arm.topology.json"))
+    eng = Engine(topo, floating=True, device=dev.index or 0)
+    S = 500_000
+    st_np, rng = synth_states(topo, S, 8, True)
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
+    tau = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
+    t_q = timed(lambda: eng.tsqr(st, rhs=tau), reps=2)
+    t_g = timed(lambda: eng.gram(st, rhs=tau), reps=2)
+    fl = 2.0 * S * eng.rows * (eng.cols + 1) ** 2
+    res["walkman_left_arm_floating_500k"] = {"samples": S, "block": [eng.rows, eng.cols], "tsqr_ms": t_q * 1e3, "tsqr_TFLOP_per_s": fl / t_q / 1e12,
+                                             "tsqr_samples_per_s": S / t_q, "fused_gram_ms": t_g * 1e3, "fused_gram_samples_per_s": S / t_g}
+    eng.close()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +287,7 @@ def main():
         out["assembly"] = {"samples": S3, "kernel": "fbr_regressor_kernel", "kernel_ms": kms, "GB_per_s": gbs,
                            "frac_of_hbm_peak": gbs / PEAK_HBM_GBS, "bytes_per_sample": 8 * rows * P}
         del Y
+        out["other_configs"] = other_configs(dev)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(topo)
     elif world == 1:

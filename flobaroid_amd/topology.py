@@ -372,3 +372,80 @@ def parse_urdf(path: str, joint_names: list[str] | None = None) -> Topology:
         friction=friction,
         frames=frames,
     )
+
+
+# ---------------------------------------------------------------------------------------------------------
+# On-disk side after the path: identified standard parameters back into a URDF
+# ---------------------------------------------------------------------------------------------------------
+def params_link_to_bary(params: np.ndarray, num_links: int) -> np.ndarray:
+    """``ParamHelpers.paramsLink2Bary`` (identification/helpers.py:374-407): per link [m, m c, I about the link origin]
+    -> [m, c, I about the COM] (what a URDF ``<inertial>`` holds); trailing friction entries are left alone."""
+    out = np.array(params, dtype=float, copy=True)
+    for l in range(num_links):
+        p = out[10 * l:10 * l + 10]
+        m = p[0]
+        c = p[1:4] / m if m != 0 else np.zeros(3)
+        I_o = np.array([[p[4], p[5], p[6]], [p[5], p[7], p[8]], [p[6], p[8], p[9]]])
+        I_c = I_o - m * (float(c @ c) * np.eye(3) - np.outer(c, c))
+        p[1:4] = c
+        p[4:10] = [I_c[0, 0], I_c[0, 1], I_c[0, 2], I_c[1, 1], I_c[1, 2], I_c[2, 2]]
+    return out
+
+
+def params_bary_to_link(params: np.ndarray, num_links: int) -> np.ndarray:
+    """``ParamHelpers.paramsBary2Link`` (identification/helpers.py:409-435), the inverse of ``params_link_to_bary``."""
+    out = np.array(params, dtype=float, copy=True)
+    for l in range(num_links):
+        p = out[10 * l:10 * l + 10]
+        I_c = np.array([[p[4], p[5], p[6]], [p[5], p[7], p[8]], [p[6], p[8], p[9]]])
+        out[10 * l:10 * l + 10] = inertial_to_params(p[0], p[1:4].copy(), I_c)
+    return out
+
+
+def replace_params_in_urdf(input_urdf: str, output_urdf: str, topo: "Topology", new_params: np.ndarray,
+                           friction_layout: dict[str, Any] | None = None) -> None:
+    """``URDFHelpers.replaceParamsInURDF`` (identification/helpers.py:511-577): write the standard parameters
+    ``new_params`` (link-frame convention, 10 per kept link, then friction slots) into a copy of ``input_urdf``:
+    mass, COM (``origin xyz``), inertia about the COM, and per joint ``dynamics friction`` (Coulomb) / ``damping``
+    (symmetric viscous).  ``friction_layout`` = {"coulomb_offset": index of F_c of joint 0, "viscous_offset": index of
+    F_v of joint 0 or None}; without it the joint dynamics are written as 0 like the reference does when friction was
+    not identified.  Like the reference, the ``<inertial><origin rpy>`` of the input is kept: inputs whose inertial frame
+    is rotated get ``rpy`` reset to zero here (the written tensor is in link axes), which the reference silently skips."""
+    import xml.etree.ElementTree as ET
+
+    x = params_link_to_bary(np.asarray(new_params, dtype=float), topo.num_links)
+    tree = ET.parse(input_urdf)
+    root = tree.getroot()
+    for le in root.findall("link"):
+        name = le.attrib.get("name")
+        if name not in topo.link_names:
+            continue
+        i = topo.link_names.index(name)
+        b = x[10 * i:10 * i + 10]
+        me = le.find("inertial/mass")
+        if me is not None:
+            me.attrib["value"] = repr(float(b[0]))
+        oe = le.find("inertial/origin")
+        if oe is not None:
+            oe.attrib["xyz"] = f"{float(b[1])!r} {float(b[2])!r} {float(b[3])!r}"
+            if "rpy" in oe.attrib:
+                oe.attrib["rpy"] = "0 0 0"
+        ie = le.find("inertial/inertia")
+        if ie is not None:
+            for key, v in zip(("ixx", "ixy", "ixz", "iyy", "iyz", "izz"), b[4:10]):
+                ie.attrib[key] = repr(float(v))
+    for je in root.findall("joint"):
+        name = je.attrib.get("name")
+        if name not in topo.dof_names:
+            continue
+        j = topo.dof_names.index(name)
+        fc = fv = 0.0
+        if friction_layout is not None:
+            fc = float(x[friction_layout["coulomb_offset"] + j])
+            if friction_layout.get("viscous_offset") is not None:
+                fv = float(x[friction_layout["viscous_offset"] + j])
+        de = je.find("dynamics")
+        if de is not None:
+            de.attrib["friction"] = repr(fc)
+            de.attrib["damping"] = repr(fv)
+    tree.write(output_urdf, xml_declaration=True)

@@ -5,7 +5,11 @@ import os
 import numpy as np
 
 from common import GOLDEN, load_topo
+import pytest
+
 from flobaroid_amd.topology import Topology, parse_urdf
+
+REF_MODEL = "/root/reference/model"
 
 _URDF = """<robot name="t">
   <link name="world_box"/>
@@ -75,3 +79,38 @@ def test_structure_counts():
     assert abs(w.params[:, 0].sum() - s["walkman_apriori"]["mass"]) < 0.01
     anc = w.ancestors_dofs()
     assert sum(len(a) for a in anc) == 228 and max(len(a) for a in anc) == 10
+
+
+def test_urdf_write_back_round_trip(tmp_path):
+    """replaceParamsInURDF (helpers.py:511-577): parameters written into a URDF copy and parsed again come back
+    (link <-> barycentric conversions of helpers.py:374-435 are inverses; fake links / frames untouched)."""
+    import os
+
+    from flobaroid_amd import topology as T
+
+    src = os.path.join(REF_MODEL, "kuka_lwr4.urdf") if os.path.isdir(REF_MODEL) else None
+    if src is None or not os.path.exists(src):
+        pytest.skip("reference URDFs not present (GPU box)")
+    topo = T.parse_urdf(src)
+    L = topo.num_links
+    rng = np.random.default_rng(3)
+    x = topo.x_std().copy()
+    # perturb to a physically plausible set: scale masses, move COMs, add SPD inertia about the COM
+    bary = T.params_link_to_bary(x, L)
+    assert np.allclose(T.params_bary_to_link(bary, L), x, rtol=1e-12, atol=1e-14)
+    for l in range(L):
+        b = bary[10 * l:10 * l + 10]
+        b[0] = b[0] * (1.0 + 0.2 * rng.random()) + 0.1
+        b[1:4] += 0.01 * rng.standard_normal(3)
+        A = rng.standard_normal((3, 3)) * 0.05
+        Ic = A @ A.T + 0.01 * np.eye(3)
+        b[4:10] = [Ic[0, 0], Ic[0, 1], Ic[0, 2], Ic[1, 1], Ic[1, 2], Ic[2, 2]]
+    xnew = np.concatenate([T.params_bary_to_link(bary, L), 0.3 + rng.random(2 * topo.num_dofs)])
+    out = str(tmp_path / "kuka_new.urdf")
+    T.replace_params_in_urdf(src, out, topo, xnew, {"coulomb_offset": 10 * L, "viscous_offset": 10 * L + topo.num_dofs})
+    t2 = T.parse_urdf(out)
+    assert t2.link_names == topo.link_names and t2.dof_names == topo.dof_names
+    assert np.allclose(t2.x_std(), xnew[: 10 * L], rtol=1e-12, atol=1e-13)
+    for j, name in enumerate(topo.dof_names):
+        assert abs(t2.friction[name]["f_constant"] - xnew[10 * L + j]) < 1e-14
+        assert abs(t2.friction[name]["f_velocity"] - xnew[10 * L + topo.num_dofs + j]) < 1e-14
