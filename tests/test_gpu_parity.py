@@ -320,3 +320,51 @@ def test_fd_sweep_scores_match_oracle_regressors(cfg):
     # regressor is linear in ddq: the acceleration sensitivity is exact, independent of eps
     sc2 = eng.fd_scores(st, W, 1e-3)
     assert np.abs((sc2[:, 1 + 2 * n:] - sc2[:, :1]) / 1e-3 - sddq).max() <= 1e-6 * np.abs(sddq).max()
+
+
+@pytest.mark.parametrize("n", [5, 16, 33, 100, 128, 129, 200, 256, 300, 384, 400, 512, 520, 640, 700, 768])
+def test_tsqr_merge_every_kernel_instantiation(n):
+    """fbr_tsqr_merge for every factor width: wave-private kernels (1..8 column tiles) and the wave-pipelined kernels
+    (1..6 tiles per wave, 64 / 48 / 32-row blocks): Rm^T Rm = R1^T R1 + R2^T R2, Rm upper triangular.
+    One of the inputs is rank deficient (zero diagonal entries and dependent columns)."""
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo("threeLinks")
+    eng = Engine(t, floating=True)
+    rng = np.random.default_rng(1000 + n)
+    R1 = np.triu(rng.standard_normal((n, n)))
+    R2 = np.triu(rng.standard_normal((n, n)))
+    if n > 4:
+        R2[:, n // 2] = R2[:, n // 3]          # dependent column
+        R2[n // 2:, n // 2] = 0.0
+        R1[:, 1] = 0.0                          # zero column / zero pivot
+    Rm = eng.tsqr_merge(R1, R2)
+    assert np.all(np.tril(Rm, -1) == 0.0) and np.all(np.isfinite(Rm))
+    G = R1.T @ R1 + R2.T @ R2
+    assert np.linalg.norm(Rm.T @ Rm - G) <= 1e-12 * np.linalg.norm(G)
+
+
+@pytest.mark.parametrize("ncols,friction", [(100, 0), (140, 0), (300, 0), (0, 1)])
+def test_tsqr_widths_on_many_workers(ncols, friction):
+    """Level 0 on many workgroups + tree for the factor widths the robots do not reach by themselves (column subsets of
+    WALK-MAN: 7 / 9 / 19 tiles; all columns with friction: 36 tiles): R^T R == the fused Gram restricted to the columns."""
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo("walkman_apriori")
+    eng = Engine(t, floating=True, friction=bool(friction))
+    rng = np.random.default_rng(500 + ncols)
+    S = 6000
+    st = random_states(t, S, rng, 1)
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    rhs = rng.standard_normal((S * eng.rows, 1))
+    G = eng.gram(st, rhs=rhs)
+    if ncols:
+        cols = np.sort(rng.choice(eng.cols, size=ncols, replace=False)).astype(np.int32)
+        R = eng.tsqr(st, rhs=rhs, cols=cols)
+        idx = np.r_[cols, eng.cols]
+        Gs = G[np.ix_(idx, idx)]
+    else:
+        R = eng.tsqr(st, rhs=rhs)
+        Gs = G
+    assert np.all(np.tril(R, -1) == 0.0)
+    assert np.linalg.norm(R.T @ R - Gs) <= 1e-11 * np.linalg.norm(Gs)
