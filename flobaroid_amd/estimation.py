@@ -197,3 +197,48 @@ def trajectory_row_weights(residual_bw: np.ndarray, file_boundaries, num_used_sa
             sigma[k] = np.sqrt(np.mean(residual_bw[mask] ** 2, axis=0))
     weights = np.mean(sigma) / np.maximum(sigma, 1e-12)
     return weights[file_idx]
+
+
+def post_identify_friction(tau_residual_2d: np.ndarray, velocities: np.ndarray, velocities_for_sign: np.ndarray,
+                           sign_series: np.ndarray, fb: int, deadzone: float = 0.0, lambda_fv: float = 0.0,
+                           alpha_fv: float = 0.0, fv_apriori: np.ndarray | None = None) -> dict:
+    """Per-joint friction refit on the torque residual after the inertial identification
+    (``Identification._postIdentifyFriction``, identifier.py:979-1099).
+
+    ``tau_residual_2d`` (S, fb + n) = tau_measured - YStd[:, :10L] x_inertial (the streaming prediction pass:
+    ``Engine.predict`` with the friction slots of x zeroed); ``velocities`` (S, n) the filtered joint velocities,
+    ``velocities_for_sign`` / ``sign_series`` (S, n) from ``helpers.getFrictionSignVelocities / getFrictionSignSeries``.
+    Fits [Fc, Fv, off] of tau_res = Fc * sign + Fv * v + off by OLS per joint with the reference's Swevers dead zone
+    (samples with |v_sign| < deadzone dropped unless < 30 remain or one direction is missing), the Tikhonov pull of Fv
+    towards ``fv_apriori`` (weight ``lambda_fv``, or ``alpha_fv`` x median kept velocity energy) and the clamp Fv >= 0.
+    Returns {"Fc", "Fv", "off", "deadzone_kept", "lambda_fv", "fv_energy"}."""
+    S, n = velocities.shape
+    keep_masks = []
+    fv_energy = np.zeros(n)
+    kept = np.zeros(n)
+    for j in range(n):
+        vs = velocities_for_sign[:, j]
+        if deadzone > 0:
+            keep = np.abs(vs) >= deadzone
+            if np.count_nonzero(keep) < 10 * 3 or not (vs[keep] > 0).any() or not (vs[keep] < 0).any():
+                keep = np.ones(S, dtype=bool)
+        else:
+            keep = np.ones(S, dtype=bool)
+        keep_masks.append(keep)
+        kept[j] = np.count_nonzero(keep) / S
+        fv_energy[j] = float(np.sum(velocities[keep, j] ** 2))
+    lam = alpha_fv * float(np.median(fv_energy)) if alpha_fv > 0 else float(lambda_fv)
+    if lam > 0 and fv_apriori is None:
+        raise ValueError("Fv regularisation needs the a-priori viscous friction of every joint")
+    Fc, Fv, off = np.zeros(n), np.zeros(n), np.zeros(n)
+    for j in range(n):
+        keep = keep_masks[j]
+        A = np.column_stack([sign_series[keep, j], velocities[keep, j], np.ones(np.count_nonzero(keep))])
+        b = tau_residual_2d[keep, fb + j]
+        if lam > 0:
+            wq = np.sqrt(lam)
+            A = np.vstack((A, [0.0, wq, 0.0]))
+            b = np.append(b, wq * fv_apriori[j])
+        p = la.lstsq(A, b, rcond=None)[0]
+        Fc[j], Fv[j], off[j] = p[0], max(p[1], 0.0), p[2]
+    return {"Fc": Fc, "Fv": Fv, "off": off, "deadzone_kept": kept, "lambda_fv": lam, "fv_energy": fv_energy}

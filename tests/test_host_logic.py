@@ -245,3 +245,32 @@ def test_essential_direct_and_wls_weights_match_reference_expressions():
     assert la.norm(x_wls - x_wls_ref) <= 1e-9 * la.norm(x_wls_ref)
     with pytest.raises(ValueError):
         est.wls_row_weights(p_sigma_x[:3], S, r)
+
+
+def test_post_identification_friction_refit():
+    """_postIdentifyFriction (identifier.py:979-1099): recovery of [Fc, Fv, off] from a synthetic residual, the dead-zone
+    rule with its fallback, the Fv prior and the Fv >= 0 clamp."""
+    rng = np.random.default_rng(5)
+    S, n, fb = 4000, 4, 6
+    tt = np.linspace(0, 20, S)[:, None]
+    vel = np.sin(tt * (1.0 + np.arange(n))) * (0.5 + np.arange(n))
+    vel[:, 3] = np.abs(vel[:, 3]) + 0.2          # joint 3 moves in one direction only
+    sign = np.tanh(vel / 0.02)
+    Fc, Fv, off = np.array([1.0, 2.0, 0.5, 1.5]), np.array([0.3, 0.0, 1.2, 0.4]), np.array([0.1, -0.2, 0.0, 0.3])
+    res = np.zeros((S, fb + n))
+    res[:, fb:] = Fc * sign + Fv * vel + off + 1e-3 * rng.standard_normal((S, n))
+    r = est.post_identify_friction(res, vel, vel, sign, fb)
+    assert np.allclose(r["Fc"][:3], Fc[:3], atol=2e-3) and np.allclose(r["Fv"][:3], Fv[:3], atol=2e-3) and np.allclose(r["off"][:3], off[:3], atol=2e-3)
+    assert np.all(r["Fv"] >= 0.0) and np.all(r["deadzone_kept"] == 1.0)
+    # dead zone: samples near zero velocity dropped, except where one direction would vanish (joint 3: fallback to all)
+    r2 = est.post_identify_friction(res, vel, vel, sign, fb, deadzone=0.3)
+    assert np.all(r2["deadzone_kept"][:3] < 1.0) and r2["deadzone_kept"][3] == 1.0
+    assert np.allclose(r2["Fc"][:3], Fc[:3], atol=5e-3)
+    # a huge Fv prior pins Fv to the a-priori value; relative weight = alpha x median energy
+    prior = np.array([0.9, 0.9, 0.9, 0.9])
+    r3 = est.post_identify_friction(res, vel, vel, sign, fb, lambda_fv=1e12, fv_apriori=prior)
+    assert np.allclose(r3["Fv"], prior, atol=1e-6)
+    r4 = est.post_identify_friction(res, vel, vel, sign, fb, alpha_fv=2.0, fv_apriori=prior)
+    assert abs(r4["lambda_fv"] - 2.0 * np.median(r4["fv_energy"])) < 1e-9
+    with pytest.raises(ValueError):
+        est.post_identify_friction(res, vel, vel, sign, fb, lambda_fv=1.0)
