@@ -1,8 +1,9 @@
 """``Data`` container work-alike (reference: identification/data.py:12-161).
 
-Only the container part that feeds the hot path is provided (loading, startOffset, concatenation,
-file_boundaries, skipSamples accounting).  Pre-processing and block selection (data.py:148-345,
-369-619) are upstream of the path and out of scope."""
+The container part that feeds the hot path (loading, startOffset, concatenation, file_boundaries, skipSamples
+accounting) and the step before the path, ``preprocess`` (data.py:369-619): zero-phase
+Butterworth low-passes, median filters and 4th-order central differences that turn raw logs into q, dq, ddq, tau.
+Block selection (data.py:148-345) is out of scope."""
 from __future__ import annotations
 
 from typing import Any
@@ -111,3 +112,111 @@ class Data:
     def updateNumSamples(self) -> None:
         self.num_selected_samples = self.samples["positions"].shape[0]
         self.num_used_samples = self.num_selected_samples // (self.opt["skipSamples"] + 1)
+
+    # ------------------------------------------------------------------ step before the path (N2)
+    @staticmethod
+    def _central_diff(a: np.ndarray, times: np.ndarray) -> np.ndarray:
+        """4th-order central difference of data.py:396-418 (n = 2), vectorised.  The divisor of sample i is
+        times[i] - times[i-1]; the two leading samples use times[1] - times[0] and the two trailing ones the step of the
+        last interior sample (the reference's loop variable is still set to it) -- reproduced, not 'corrected'."""
+        size = a.shape[0]
+        d = np.zeros_like(a)
+        div0 = times[1] - times[0]
+        d[0] = (a[1] - a[0]) / div0
+        d[1] = (a[2] - a[0]) / (2 * div0)
+        if size > 4:
+            dv = (times[2:size - 2] - times[1:size - 3]).reshape((-1,) + (1,) * (a.ndim - 1))
+            d[2:size - 2] = (-a[4:] + 8 * a[3:size - 1] - 8 * a[1:size - 3] + a[:size - 4]) / (12 * dv)
+            div_last = times[size - 3] - times[size - 4]
+        else:
+            div_last = div0
+        d[size - 2] = (a[size - 1] - a[size - 3]) / (2 * div_last)
+        d[size - 1] = (a[size - 1] - a[size - 2]) / div_last
+        return d
+
+    def preprocess(self, Q, V, Vdot, Tau, T, Fs, Q_raw=None, V_raw=None, Tau_raw=None, IMUlinVel=None, IMUrotVel=None,
+                   IMUlinAcc=None, IMUrotAcc=None, IMUrpy=None, FT=None) -> None:
+        """Derivation and filtering of measurements, arrays changed in place like the reference (data.py:369-619):
+        Q, Tau filtered; V, Vdot, *_raw overwritten; IMUrotVel, IMUlinAcc, IMUrpy filtered; IMUlinVel, IMUrotAcc
+        overwritten; every FT array median + low-pass filtered (first three columns).  All columns of an array are
+        filtered in one SciPy call (identical per-column arithmetic)."""
+        import scipy.integrate
+        import scipy.signal as sig
+
+        from .topology import rpy_to_matrix
+
+        k = self.opt["filterMedianSize"]
+        n = self.opt["num_dofs"]
+        med = lambda X: sig.medfilt(X, (k, 1))
+        if self.opt["useDeg"]:
+            np.copyto(Q, np.deg2rad(Q))
+            np.copyto(V, np.deg2rad(V))
+        lp = {}
+        for key in ("filterLowPass1", "filterLowPass2", "filterLowPass3"):
+            fc, order = self.opt[key][0], self.opt[key][1]
+            lp[key] = sig.butter(order, fc / (Fs / 2), btype="low", analog=False)
+        b8, a8 = lp["filterLowPass1"]
+        b6, a6 = lp["filterLowPass2"]
+        b3, a3 = lp["filterLowPass3"]
+        # joint positions: low-pass
+        Q_orig = Q.copy()
+        Q[:, :n] = sig.filtfilt(b8, a8, Q_orig[:, :n], axis=0)
+        if Q_raw is not None:
+            np.copyto(Q_raw, Q_orig)
+        # joint velocities: derivative of the filtered positions, median, low-pass
+        Vs = self._central_diff(Q, T)
+        if V_raw is not None:
+            np.copyto(V_raw, Vs)
+        Vs[:, :n] = med(Vs[:, :n].copy())
+        Vs[:, :n] = sig.filtfilt(b6, a6, Vs[:, :n].copy(), axis=0)
+        np.copyto(V, Vs)
+        # joint accelerations: derivative of the velocities, median
+        np.copyto(Vdot, self._central_diff(Vs, T))
+        Vdot[:, :n] = med(Vdot[:, :n].copy())
+        # joint torques: median, low-pass
+        if Tau_raw is not None:
+            np.copyto(Tau_raw, Tau)
+        Tau[:, :n] = med(Tau[:, :n].copy())
+        Tau[:, :n] = sig.filtfilt(b8, a8, Tau[:, :n].copy(), axis=0)
+        # IMU
+        if IMUlinAcc is not None and IMUrotVel is not None:
+            IMUlinAcc[:, :3] = med(IMUlinAcc[:, :3].copy())
+            IMUrotVel[:, :3] = med(IMUrotVel[:, :3].copy())
+            IMUlinAcc[:, :3] = sig.filtfilt(b8, a8, IMUlinAcc[:, :3].copy(), axis=0)
+            IMUrotVel[:, :3] = sig.filtfilt(b8, a8, IMUrotVel[:, :3].copy(), axis=0)
+            IMUrpy[:, :3] = sig.filtfilt(b3, a3, IMUrpy[:, :3].copy(), axis=0)
+            if IMUlinVel is not None:
+                # rotate to the (estimated) world frame
+                R = np.stack([rpy_to_matrix(r) for r in IMUrpy])
+                accW = np.einsum("sij,sj->si", R, IMUlinAcc)
+                np.copyto(IMUrotVel, np.einsum("sij,sj->si", R, IMUrotVel))
+                grav_norm = np.mean(np.linalg.norm(accW, axis=1))
+                if grav_norm < 9.81 or grav_norm > 9.82:
+                    print(f"Warning: mean base acceleration is different than gravity ({grav_norm})!")
+                accW -= np.array([0, 0, -9.81])
+                if self.opt["waitForZeroAcc"]:
+                    means = np.mean(accW, axis=0)
+                    accW -= means
+                    start = 0
+                    for j in range(3):
+                        for s_ in range(accW.shape[0]):
+                            if np.linalg.norm(accW[s_:s_ + 10, j]) < self.opt["zeroAccThresh"]:
+                                start = max(s_, start)
+                                break
+                    accW[:start, :] = 0
+                    accW += means
+                elif np.linalg.norm(accW[:, 0]) > 0.1:
+                    print("Warning: proper base acceleration not zero at time 0 (assuming start at zero, integrated velocity will be wrong)!")
+                accW -= np.mean(accW, axis=0)
+                np.copyto(IMUlinAcc, accW)
+                for j in range(3):
+                    IMUlinVel[:, j] = scipy.integrate.cumulative_trapezoid(IMUlinAcc[:, j], T, initial=0)
+                    IMUlinVel[:, j] -= np.mean(IMUlinVel[:, j])
+            if IMUrotAcc is not None:
+                for j in range(3):
+                    IMUrotAcc[:, j] = np.gradient(IMUrotVel[:, j])
+        # contact wrenches
+        if FT is not None:
+            for ft in FT:
+                ft[:, :3] = med(ft[:, :3].copy())
+                ft[:, :3] = sig.filtfilt(b3, a3, ft[:, :3].copy(), axis=0)

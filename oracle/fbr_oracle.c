@@ -13,6 +13,10 @@
  * link order, the 10-parameter convention and the a-priori vector (documentation/TUTORIAL.md:60-160),
  * the structurally-zero column set non_id={0..18,20,22}, the base-parameter counts
  * 24/43(+21=64)/59/213, and regressor == inverse dynamics (the reference's own property).
+ * The reference's PYTHON code around the iDynTree calls (stacking, friction blocks, random-state order, lin-deps QR,
+ * estimators, pre-processing) is pinned separately on outputs of the reference's own functions run in the build
+ * container (tools/make_fixtures.py -> tests/golden/ref_*.npz); in ref_compute_regressors.npz this
+ * oracle answers the iDynTree calls of the reference's loop, so that fixture pins the loop's logic, not these numerics.
  *
  * The functions below follow the published algorithms the reference calls:
  *   orc_kinematics            KinDynComputations::setRobotState + ForwardVelAccKinematics

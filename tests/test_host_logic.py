@@ -274,3 +274,139 @@ def test_post_identification_friction_refit():
     assert abs(r4["lambda_fv"] - 2.0 * np.median(r4["fv_energy"])) < 1e-9
     with pytest.raises(ValueError):
         est.post_identify_friction(res, vel, vel, sign, fb, lambda_fv=1.0)
+
+
+# ---- golden vectors produced by the reference's OWN host functions (tools/make_fixtures.py: reference_host_functions)
+def _ref_golden():
+    return np.load(os.path.join(GOLDEN, "ref_host_functions.npz"), allow_pickle=True)
+
+
+def test_preprocess_matches_reference_outputs():
+    """Data.preprocess == the reference's Data.preprocess (identification/data.py:369-619) on seeded inputs:
+    filtered positions / torques, derived velocities / accelerations, raw copies, contact wrenches; radians and degrees."""
+    z = _ref_golden()
+    opt = json.loads(str(z["pre_opt"]))
+    Q, V, Tau, T = z["pre_Q"].copy(), z["pre_V"].copy(), z["pre_Tau"].copy(), z["pre_T"].copy()
+    FT = [z["pre_FT0"].copy(), z["pre_FT1"].copy()]
+    Vdot = np.zeros_like(Q)
+    Qr, Vr, Tr = np.zeros_like(Q), np.zeros_like(Q), np.zeros_like(Q)
+    Data(opt).preprocess(Q, V, Vdot, Tau, T, float(z["pre_Fs"]), Q_raw=Qr, V_raw=Vr, Tau_raw=Tr, FT=FT)
+    for name, got in [("Q", Q), ("V", V), ("Vdot", Vdot), ("Tau", Tau), ("Q_raw", Qr), ("V_raw", Vr), ("Tau_raw", Tr), ("FT0", FT[0]), ("FT1", FT[1])]:
+        want = z["pre_out_" + name]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), name
+    optd = dict(opt, useDeg=1)
+    Qd, Vd, Td = np.rad2deg(z["pre_Q"][:200]).copy(), z["pre_V"][:200].copy(), z["pre_Tau"][:200].copy()
+    Vdd = np.zeros_like(Qd)
+    Data(optd).preprocess(Qd, Vd, Vdd, Td, z["pre_T"][:200].copy(), float(z["pre_Fs"]))
+    for name, got in [("Q", Qd), ("V", Vd), ("Vdot", Vdd)]:
+        want = z["pre_deg_out_" + name]
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), name
+
+
+def test_friction_sign_helpers_match_reference_outputs():
+    """helpers.getFrictionSignVelocities / getFrictionSignSeries == the reference's (helpers.py:89-156): filtered raw
+    velocities below Nyquist, fallbacks above Nyquist / without raw data, tanh threshold."""
+    z = _ref_golden()
+    vel, raw, Fs = z["fs_vel"], z["fs_raw"], float(z["fs_freq"])
+    cases = {"a": ({"velocities": vel.copy(), "velocities_raw": raw.copy(), "frequency": Fs}, {"frictionVelocityCutoff": 25.0, "frictionSignThreshold": 0.02}),
+             "b": ({"velocities": vel.copy(), "velocities_raw": raw.copy(), "frequency": Fs}, {"frictionVelocityCutoff": 150.0}),
+             "c": ({"velocities": vel.copy()}, {"frictionSignThreshold": 0.05})}
+    for tag, (samples, o) in cases.items():
+        v = helpers.getFrictionSignVelocities(samples, o)
+        s = helpers.getFrictionSignSeries(samples, o)
+        assert np.abs(v - z["fs_%s_velocities" % tag]).max() <= 1e-13
+        assert np.abs(s - z["fs_%s_series" % tag]).max() <= 1e-12
+
+
+def test_init_from_files_matches_reference_outputs(tmp_path):
+    """Data.init_from_files == the reference's (data.py:55-146) on three small files in two groups: startOffset,
+    time re-basing, scalars, file_boundaries, skipSamples accounting."""
+    z = _ref_golden()
+    files = []
+    for i in range(3):
+        fn = str(tmp_path / ("m%d.npz" % i))
+        np.savez(fn, **{k[len("iff_in%d_" % i):]: z[k] for k in z.files if k.startswith("iff_in%d_" % i)})
+        files.append(fn)
+    d = Data(json.loads(str(z["iff_opt"])))
+    d.init_from_files([[files[0], files[1]], [files[2]]])
+    assert d.num_loaded_samples == int(z["iff_num_loaded"]) and d.num_used_samples == int(z["iff_num_used"])
+    assert list(d.file_boundaries) == list(z["iff_file_boundaries"])
+    keys = [k[len("iff_out_"):] for k in z.files if k.startswith("iff_out_")]
+    assert sorted(keys) == sorted(d.measurements.keys())
+    for k in keys:
+        assert np.allclose(np.asarray(d.measurements[k]), z["iff_out_" + k], rtol=0, atol=1e-13), k
+
+
+def _ref_est():
+    return np.load(os.path.join(GOLDEN, "ref_estimators.npz"), allow_pickle=True)
+
+
+def _golden_regressor(z, tag):
+    meta = json.loads(str(z[tag + "_meta"]))
+    t = load_topo(meta["robot"])
+    st = {k: z["%s_st_%s" % (tag, k)] for k in ("q", "dq", "ddq", "base_vel", "base_acc", "rpy") if "%s_st_%s" % (tag, k) in z.files}
+    om = OracleModel(t, floating=bool(meta["floating"]), fric=bool(meta["friction"]), fric_sym=True)
+    Y = om.regressor(st, np.tanh(st["dq"] / 0.02) if meta["friction"] else None)
+    return meta, t, st, Y
+
+
+@pytest.mark.parametrize("tag", ["ldA", "ldB", "ldC"])
+def test_lin_deps_qr_matches_the_reference_code_outputs(tag):
+    """Model.computeRegressorLinDepsQR(regressor) against the outputs of the REFERENCE'S OWN method (model.py:832-1052,
+    run by tools/make_fixtures.py on the same regressor): pivots, rank, independent columns, K, linear_deps and the
+    SymPy-derived non_id / identifiable lists -- bit-exact index sets, matrices to 1e-12."""
+    z = _ref_est()
+    meta, t, st, Y = _golden_regressor(z, tag)
+    path = os.path.join(ROBOTS, meta["robot"] + ".topology.json")
+    m = Model(_opt(identifyFrictionSimultaneously=meta["friction"], floatingBase=meta["floating"], minTol=meta["minTol"]), path, regressor_init=False)
+    m.computeRegressorLinDepsQR(Y)
+    assert m.num_base_params == int(z[tag + "_num_base_params"])
+    assert np.array_equal(np.asarray(m.P), z[tag + "_P"])
+    assert np.array_equal(np.asarray(m.independent_cols), z[tag + "_independent_cols"])
+    assert np.array_equal(np.asarray(m.identified_params), z[tag + "_identified_params"])
+    assert list(m.non_id) == list(z[tag + "_non_id"]) and list(m.identifiable) == list(z[tag + "_identifiable"])
+    assert np.array_equal(m.Pb, z[tag + "_Pb"])
+    assert np.abs(np.diag(m.R) - z[tag + "_Rdiag"]).max() <= 1e-12 * np.abs(z[tag + "_Rdiag"]).max()
+    assert np.abs(m.linear_deps - z[tag + "_linear_deps"]).max() <= 1e-10
+    assert np.abs(m.K - z[tag + "_K"]).max() <= 1e-10
+
+
+def test_estimators_match_the_reference_code_outputs():
+    """estimation.* (fed by the small factor R_aug) against the outputs of the REFERENCE'S OWN Identification methods
+    on the tall problem (identifier.py:328-370,617-855; generated by tools/make_fixtures.py)."""
+    z = _ref_est()
+    meta, t, st, Y = _golden_regressor(z, "ldC")
+    S = meta["S"]
+    rows = Y.shape[0] // S
+    P = Y.shape[1]
+    ic, K = z["ldC_independent_cols"], z["ldC_K"]
+    nb = len(ic)
+    xStdModel = t.x_std()
+    torques, cf = z["id_torques"], z["id_cf"]
+    tau = torques - Y @ xStdModel
+    assert np.allclose(K @ xStdModel, z["id_xBaseModel"], rtol=0, atol=1e-12)
+    R_aug = la.qr(np.column_stack([Y, tau, cf]), mode="r")
+    # identifyBaseParameters: lstsq(YBase, tau) - pinv(YBase) cf
+    xB, Rb, s = est.identify_base_parameters(R_aug, ic, P, Y.shape[0])
+    assert la.norm(xB - z["id_xBase"]) <= 1e-9 * la.norm(z["id_xBase"])
+    # getStdDevForParams with the residual tauMeasured - tauEstimated = tau - cf - YBase xBase
+    rho = est.residual_sq_from_R(Rb, nb, xB, rhs_cols=(0, 1), signs=(1.0, -1.0))
+    p = est.std_dev_for_params(Rb, nb, xB, rho, Y.shape[0])
+    assert np.allclose(p, z["id_p_sigma_x"], rtol=1e-6)
+    # findStdFromBaseParameters (useAPriori: + xStdModel)
+    xStd = est.find_std_from_base(K, xB) + xStdModel
+    assert la.norm(xStd - z["id_xStd_from_base"]) <= 1e-9 * la.norm(z["id_xStd_from_base"])
+    # identifyStandardParametersDirect / Essential (useAPriori: + xStdModel)
+    xd, _ = est.identify_standard_direct(R_aug, P, nb)
+    assert la.norm(xd + xStdModel - z["id_xStd_direct"]) <= 1e-8 * la.norm(z["id_xStd_direct"])
+    xe = est.identify_standard_essential(R_aug, P, z["id_xStdEssential"], int(z["id_num_essential"]))
+    assert la.norm(xe + xStdModel - z["id_xStd_essential"]) <= 1e-8 * la.norm(z["id_xStd_essential"])
+    # _extractBaseWrenchRows with per-trajectory weighting: the row weights reproduce the weighted base-wrench problem
+    YB = Y[:, ic]
+    bw = est.base_wrench_row_mask(S, rows).astype(bool)
+    x_pre = la.lstsq(YB[bw], tau[bw], rcond=None)[0]
+    w6 = est.trajectory_row_weights((tau[bw] - YB[bw] @ x_pre).reshape(S, 6), list(z["id_file_boundaries"]), S)
+    assert np.allclose(YB[bw] * w6.reshape(-1)[:, None], z["id_bw_YBase"], rtol=0, atol=1e-10)
+    assert np.allclose(tau[bw] * w6.reshape(-1), z["id_bw_tau"], rtol=0, atol=1e-10)
+    assert np.allclose(cf[bw] * w6.reshape(-1), z["id_bw_cf"], rtol=0, atol=1e-10)

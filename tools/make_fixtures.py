@@ -12,6 +12,30 @@ npz) and writes small derived fixtures; no reference source code is copied.
                                               model/kuka_lwr4.urdf.trajectory_opt_1.npz and its recorded
                                               n_observable_base_params (= 64)            (known answer F5)
   tests/golden/structure.json                 documented structure counts (links/DOF/base ranks)
+  tests/golden/ref_host_functions.npz         seeded inputs and the OUTPUTS OF THE REFERENCE'S OWN pure NumPy/SciPy host
+                                              functions run here: Data.preprocess (identification/data.py:369-619),
+                                              helpers.getFrictionSignVelocities / getFrictionSignSeries
+                                              (identification/helpers.py:89-156), Data.init_from_files (data.py:55-146).
+                                              Importing identification.* pulls in idyntree / colorama, which the image
+                                              lacks: they are replaced by empty placeholder modules for the import only --
+                                              none of the executed code paths touches them (joint channels, FT and plain
+                                              npz concatenation).
+  tests/golden/ref_estimators.npz             outputs of the reference's own estimator code on a seeded KUKA / threeLinks
+                                              problem: Model.computeRegressorLinDepsQR (identification/model.py:832-1052),
+                                              Identification.identifyBaseParameters / getStdDevForParams /
+                                              findStdFromBaseParameters / identifyStandardParametersDirect /
+                                              identifyStandardEssentialParameters / _extractBaseWrenchRows
+                                              (identifier.py:328-370,617-855), called as unbound methods on plain attribute
+                                              holders (the real constructors need iDynTree).  The regressor matrices come
+                                              from this repository's CPU oracle; the fixture stores the states, not Y.
+  tests/golden/ref_compute_regressors.npz     the reference's own Model.computeRegressors + simulateDynamicsIDynTree
+                                              (identification/model.py:239-632) executed on small sample sets with the
+                                              iDynTree calls answered by this repository's CPU oracle (a minimal object shim:
+                                              state setters, regressor / inverse dynamics / frame Jacobian getters).  What
+                                              this pins is the reference's PYTHON logic around those calls -- stacking order,
+                                              friction column blocks, gravity-only column deletion, skipSamples, a-priori
+                                              torques, simulated base wrench, contact-force bookkeeping -- not iDynTree's
+                                              numerics (those stay unpinned).
 """
 import json
 import os
@@ -91,5 +115,377 @@ def main():
         )
 
 
+def reference_host_functions(golden):
+    """Golden vectors from the reference's own host functions (see the module docstring)."""
+    import tempfile
+    import types
+
+    class _Blank:
+        def __getattr__(self, k):
+            return ""
+
+    for name in ["idyntree", "idyntree.bindings", "colorama", "trimesh", "cvxpy"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["colorama"].Fore = sys.modules["colorama"].Back = sys.modules["colorama"].Style = _Blank()
+    sys.modules["idyntree"].bindings = sys.modules["idyntree.bindings"]
+    sys.path.insert(0, REF)
+    import identification.data as rdata
+    import identification.helpers as rhelpers
+
+    out = {}
+    rng = np.random.default_rng(2024)
+    # ---- Data.preprocess, joint channels + FT
+    S, n, Fs = 600, 3, 200.0
+    T = np.arange(S) / Fs
+    T[300:] += 0.0004  # one irregular step
+    Q = np.cumsum(rng.standard_normal((S, n)) * 0.01, axis=0) + np.sin(T[:, None] * (1 + np.arange(n)))
+    V = rng.standard_normal((S, n))
+    Tau = 5 * np.sin(T[:, None] * 3) + 0.3 * rng.standard_normal((S, n))
+    Tau[rng.integers(0, S, 12), rng.integers(0, n, 12)] += 8.0  # outliers for the median filter
+    FT = [rng.standard_normal((S, 6)), rng.standard_normal((S, 6))]
+    opt = {"filterMedianSize": 5, "useDeg": 0, "num_dofs": n, "filterLowPass1": [8.0, 5], "filterLowPass2": [6.0, 5],
+           "filterLowPass3": [3.0, 4], "waitForZeroAcc": 0, "zeroAccThresh": 0.1}
+    out.update(pre_Q=Q.copy(), pre_V=V.copy(), pre_Tau=Tau.copy(), pre_T=T.copy(), pre_Fs=Fs, pre_FT0=FT[0].copy(), pre_FT1=FT[1].copy(),
+               pre_opt=json.dumps(opt))
+    d = rdata.Data(opt)
+    Vdot = np.zeros_like(Q)
+    Qr, Vr, Tr = np.zeros_like(Q), np.zeros_like(Q), np.zeros_like(Q)
+    d.preprocess(Q, V, Vdot, Tau, T, Fs, Q_raw=Qr, V_raw=Vr, Tau_raw=Tr, FT=FT)
+    out.update(pre_out_Q=Q, pre_out_V=V, pre_out_Vdot=Vdot, pre_out_Tau=Tau, pre_out_Q_raw=Qr, pre_out_V_raw=Vr, pre_out_Tau_raw=Tr,
+               pre_out_FT0=FT[0], pre_out_FT1=FT[1])
+    # degrees variant (short)
+    optd = dict(opt, useDeg=1)
+    Qd, Vd, Td = np.rad2deg(out["pre_Q"][:200]).copy(), out["pre_V"][:200].copy(), out["pre_Tau"][:200].copy()
+    Vdd = np.zeros_like(Qd)
+    rdata.Data(optd).preprocess(Qd, Vd, Vdd, Td, T[:200].copy(), Fs)
+    out.update(pre_deg_out_Q=Qd, pre_deg_out_V=Vd, pre_deg_out_Vdot=Vdd)
+    # ---- friction sign helpers
+    vel = np.sin(T[:, None] * (2 + np.arange(n))) * 0.5
+    raw = vel + 0.05 * rng.standard_normal(vel.shape)
+    out.update(fs_vel=vel, fs_raw=raw, fs_freq=Fs)
+    for tag, samples, o in [("a", {"velocities": vel.copy(), "velocities_raw": raw.copy(), "frequency": Fs}, {"frictionVelocityCutoff": 25.0, "frictionSignThreshold": 0.02}),
+                            ("b", {"velocities": vel.copy(), "velocities_raw": raw.copy(), "frequency": Fs}, {"frictionVelocityCutoff": 150.0}),
+                            ("c", {"velocities": vel.copy()}, {"frictionSignThreshold": 0.05})]:
+        out["fs_%s_velocities" % tag] = rhelpers.getFrictionSignVelocities(samples, o).copy()
+        out["fs_%s_series" % tag] = rhelpers.getFrictionSignSeries(samples, o).copy()
+    # ---- Data.init_from_files on three small files
+    tmp = tempfile.mkdtemp()
+    files = []
+    for i, S_i in enumerate((40, 25, 33)):
+        fn = os.path.join(tmp, "m%d.npz" % i)
+        tt = 0.01 * np.arange(S_i) + 3.0 * i
+        np.savez(fn, positions=rng.standard_normal((S_i, n)), velocities=rng.standard_normal((S_i, n)), accelerations=rng.standard_normal((S_i, n)),
+                 torques=rng.standard_normal((S_i, n)), times=tt, frequency=100.0, target_positions=rng.standard_normal((S_i, n)))
+        files.append(fn)
+        z = np.load(fn)
+        for k in z.files:
+            out["iff_in%d_%s" % (i, k)] = z[k]
+    optf = {"startOffset": 4, "skipSamples": 1, "verbose": 0, "showTiming": 0, "selectBlocksFromMeasurements": 0}
+    d = rdata.Data(optf)
+    d.init_from_files([[files[0], files[1]], [files[2]]])
+    for k, v in d.measurements.items():
+        out["iff_out_" + k] = np.asarray(v)
+    out.update(iff_opt=json.dumps(optf), iff_num_loaded=d.num_loaded_samples, iff_num_used=d.num_used_samples,
+               iff_file_boundaries=np.array(d.file_boundaries))
+    np.savez_compressed(os.path.join(golden, "ref_host_functions.npz"), **out)
+    print("ref_host_functions.npz:", len(out), "arrays")
+
+
+def _import_reference(mod):
+    """import a reference module, replacing any third-party module the image lacks by a permissive placeholder"""
+    import importlib
+    import types
+
+    class _Blank:
+        def __getattr__(self, k):
+            return ""
+
+        def __call__(self, *a, **k):
+            return _Blank()
+
+    class _Mod(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Blank()
+
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # the console/plot output module of the reference builds colour tables at import time: not on any executed path here
+    sys.modules.setdefault("identification.output", _Mod("identification.output"))
+    for _ in range(40):
+        try:
+            return importlib.import_module(mod)
+        except ModuleNotFoundError as e:
+            missing = e.name
+            if missing is None or missing.startswith("identification"):
+                raise
+            parts = missing.split(".")
+            for i in range(1, len(parts) + 1):
+                nm = ".".join(parts[:i])
+                if nm not in sys.modules:
+                    sys.modules[nm] = _Mod(nm)
+            print("  (placeholder for missing module %s)" % missing)
+    raise RuntimeError("could not import " + mod)
+
+
+def reference_estimators(golden):
+    """Golden vectors of the reference's estimator code (see the module docstring)."""
+    from types import SimpleNamespace as NS
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from common import load_topo, random_states
+    from oracle.oracle import OracleModel
+
+    rmodel = _import_reference("identification.model")
+    rident = _import_reference("identifier")
+    out = {}
+
+    def lin_deps(tag, topo_name, floating, fric, S, seed, minTol):
+        t = load_topo(topo_name)
+        rng = np.random.default_rng(seed)
+        st = random_states(t, S, rng, floating, use_limits=True)
+        om = OracleModel(t, floating=bool(floating), fric=bool(fric), fric_sym=True)
+        sign = np.tanh(st["dq"] / 0.02)
+        Y = om.regressor(st, sign if fric else None)
+        L, n = t.num_links, t.num_dofs
+        nall = 10 * L + (3 * n if fric else 0)
+        fm = NS(opt={"minTol": minTol, "useBasisProjection": 0, "orthogonalizeBasis": 1, "identifyGravityParamsOnly": 0,
+                     "identifyFrictionSimultaneously": int(fric), "identifySymmetricVelFriction": 1, "stribeckVelocity": 0, "randomSamples": 0},
+                num_dofs=n, num_links=L, num_model_params=10 * L, num_all_params=nall, num_identified_params=nall)
+        rmodel.Model.computeRegressorLinDepsQR(fm, regressor=Y)
+        for k in ("q", "dq", "ddq", "base_vel", "base_acc", "rpy"):
+            if k in st:
+                out["%s_st_%s" % (tag, k)] = st[k]
+        out.update({tag + "_meta": json.dumps({"robot": topo_name, "floating": int(floating), "friction": int(fric), "S": S, "minTol": minTol}),
+                    tag + "_P": np.asarray(fm.P), tag + "_num_base_params": fm.num_base_params, tag + "_independent_cols": np.asarray(fm.independent_cols),
+                    tag + "_linear_deps": fm.linear_deps, tag + "_K": fm.K, tag + "_Pb": fm.Pb, tag + "_Rdiag": np.diag(fm.R),
+                    tag + "_identified_params": np.asarray(fm.identified_params), tag + "_non_id": np.asarray(fm.non_id, dtype=np.int64),
+                    tag + "_identifiable": np.asarray(fm.identifiable, dtype=np.int64)})
+        return t, st, Y, fm, rng
+
+    lin_deps("ldA", "kuka_lwr4", 0, 0, 60, 11, 1e-8)
+    lin_deps("ldB", "kuka_lwr4", 0, 1, 60, 12, 1e-8)
+    t, st, Y, fm, rng = lin_deps("ldC", "threeLinks", 1, 0, 50, 13, 1e-8)
+
+    # ---- Identification methods on the threeLinks floating problem (two "files", contact forces, a-priori vector)
+    S = 50
+    rows = Y.shape[0] // S
+    x_true = t.x_std() * (1.0 + 0.1 * rng.standard_normal(30))
+    xStdModel = t.x_std()
+    cf = 0.05 * rng.standard_normal(Y.shape[0])
+    torques = Y @ x_true + cf + 0.01 * rng.standard_normal(Y.shape[0])
+    torquesAP = Y @ xStdModel
+    fm.YStd = Y
+    fm.YBase = Y @ fm.Pb
+    fm.xStdModel = xStdModel
+    fm.torques_stack = torques
+    fm.torquesAP_stack = torquesAP
+    fm.tau = torques - torquesAP
+    fm.tauMeasured = torques.reshape(S, rows)
+    fm.contactForcesSum = cf
+    opt = {"useBasisProjection": 0, "addContacts": 1, "showBaseParams": 0, "verbose": 0, "useRegressorRegularization": 0, "useWLS": 0,
+           "useAPriori": 1, "floatingBase": 1, "useTrajectoryWeighting": 1, "skipSamples": 0, "showTiming": 0}
+    idf = NS(opt=opt, model=fm, data=NS(num_used_samples=S, file_boundaries=[0, 20, 50]), urdf_file_real=None)
+    rident.Identification.identifyBaseParameters(idf)
+    out.update(id_x_true=x_true, id_cf=cf, id_torques=torques, id_xBaseModel=fm.xBaseModel, id_xBase=fm.xBase.copy())
+    idf.tauEstimated = (fm.YBase @ fm.xBase + torquesAP + cf).reshape(S, rows)
+    out["id_p_sigma_x"] = rident.Identification.getStdDevForParams(idf)
+    rident.Identification.findStdFromBaseParameters(idf)
+    out["id_xStd_from_base"] = fm.xStd.copy()
+    rident.Identification.identifyStandardParametersDirect(idf)
+    out["id_xStd_direct"] = fm.xStd.copy()
+    xe = np.zeros(30)
+    ess = np.array([0, 1, 4, 10, 11, 13, 20, 22, 25])
+    xe[ess] = x_true[ess]
+    idf.xStdEssential = xe
+    idf.num_essential_params = 6
+    idf.stdEssentialIdx = ess
+    rident.Identification.identifyStandardEssentialParameters(idf)
+    out.update(id_xStdEssential=xe, id_num_essential=6, id_xStd_essential=fm.xStd.copy())
+    YB_bw, tau_bw = rident.Identification._extractBaseWrenchRows(idf)
+    out.update(id_bw_YBase=YB_bw, id_bw_tau=tau_bw, id_bw_cf=idf._bw_contactForcesSum, id_file_boundaries=np.array([0, 20, 50]))
+    np.savez_compressed(os.path.join(golden, "ref_estimators.npz"), **out)
+    print("ref_estimators.npz:", len(out), "arrays")
+
+
+def reference_compute_regressors(golden):
+    """Golden vectors of the reference's computeRegressors logic (see the module docstring)."""
+    from types import SimpleNamespace as NS
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from common import load_topo, random_states
+    from oracle.oracle import OracleModel
+
+    rmodel = _import_reference("identification.model")
+
+    class Arr:
+        def __init__(self, n=6):
+            self.a = np.zeros(int(n))
+
+        def setVal(self, i, v):
+            self.a[i] = v
+
+        def getVal(self, i):
+            return self.a[i]
+
+        def toNumPy(self):
+            return self.a
+
+    class Mat:
+        def __init__(self, *shape):
+            self.m = np.zeros(shape) if shape else None
+
+        def toNumPy(self):
+            return self.m
+
+    class Gen:
+        def __init__(self, model=None):
+            self.v = None
+
+        def jointTorques(self):
+            return NS(toNumPy=lambda: self.v[-self.n:].copy())
+
+        def baseWrench(self):
+            return NS(toNumPy=lambda: self.v[:6].copy())
+
+    class KinDyn:
+        """answers the iDynTree KinDynComputations calls of model.py with the CPU oracle"""
+
+        def __init__(self, topo, floating):
+            self.t, self.fl = topo, bool(floating)
+            self.om = OracleModel(topo, floating=self.fl)
+            self.n = topo.num_dofs
+
+        def setRobotState(self, *a):
+            if len(a) == 3:
+                self.st = {"q": a[0].a.copy()[None], "dq": a[1].a.copy()[None]}
+            else:
+                self.st = {"q": a[1].a.copy()[None], "dq": a[3].a.copy()[None], "base_vel": np.asarray(a[2].v, float)[None], "rpy": np.asarray(a[0].rpy, float)[None]}
+            return True
+
+        def _full(self, bacc, ddq):
+            st = dict(self.st, ddq=ddq.a.copy()[None])
+            if self.fl:
+                st["base_acc"] = bacc.a.copy()[None]
+            return st
+
+        def inverseDynamicsInertialParametersRegressor(self, bacc, ddq, out):
+            Y = self.om.regressor(self._full(bacc, ddq))
+            out.m = Y if self.fl else np.vstack([np.zeros((6, Y.shape[1])), Y])
+            return True
+
+        def inverseDynamics(self, bacc, ddq, ext, gen):
+            tau = self.om.inverse_dynamics(self._full(bacc, ddq), self.xstd)[0]
+            gen.v = tau if self.fl else np.concatenate([np.zeros(6), tau])
+            gen.n = self.n
+            return True
+
+        def getFrameFreeFloatingJacobian(self, frame, out):
+            st = dict(self.st, ddq=np.zeros((1, self.n)))
+            if self.fl:
+                st["base_acc"] = np.zeros((1, 6))
+            JT = np.column_stack([self.om.contact_torques(st, frame, np.eye(6)[i][None])[0] for i in range(6)])
+            out.m = (JT if self.fl else np.vstack([np.zeros((6, 6)), JT])).T
+            return True
+
+    shim = NS(JointPosDoubleArray=Arr, JointDOFsDoubleArray=Arr, Vector6=Arr, VectorDynSize=Arr, MatrixDynSize=Mat,
+              Rotation=NS(RPY=lambda r, p, y: NS(rpy=(r, p, y))), Position=NS(Zero=lambda: NS()),
+              Transform=lambda rot, pos: NS(inverse=lambda: NS(rpy=rot.rpy)), Twist=NS(FromPython=lambda v: NS(v=np.asarray(v, float))),
+              LinkWrenches=lambda model: NS(), FreeFloatingGeneralizedTorques=Gen)
+    rmodel.iDynTree = shim
+    out = {}
+
+    def run(tag, robot, floating, S, seed, opt_over, contacts=None, torques_with_base=False):
+        t = load_topo(robot)
+        n, L = t.num_dofs, t.num_links
+        rng = np.random.default_rng(seed)
+        st = random_states(t, S, rng, floating, use_limits=True)
+        opt = {"floatingBase": int(floating), "skipSamples": 0, "identifyGravityParamsOnly": 0, "simulateTorques": 0, "useAPriori": 0,
+               "useRegressorForSimulation": 0, "identifyFrictionSimultaneously": 0, "identifySymmetricVelFriction": 1, "stribeckVelocity": 0,
+               "addContacts": 1, "useStructuralRegressor": 1, "useBasisProjection": 0, "filterRegressor": 0, "showTiming": 0, "verbose": 0,
+               "frictionVelocityCutoff": 25.0, "frictionSignThreshold": 0.02}
+        opt.update(opt_over)
+        fric = opt["identifyFrictionSimultaneously"]
+        grav = opt["identifyGravityParamsOnly"]
+        nfr = 0
+        if fric:
+            nfr = n if grav else (3 * n if opt["identifySymmetricVelFriction"] else 4 * n) + (n if opt["stribeckVelocity"] > 0 else 0)
+        nall = 10 * L + nfr
+        identified = []
+        for i in range(L):
+            identified += [10 * i + j for j in (range(4) if grav else range(10))]
+        identified += list(range(10 * L, 10 * L + nfr))
+        inertia_params = [10 * i + j for i in range(L) for j in range(4, 10)]
+        xStdModel = np.concatenate([t.x_std(), 0.2 + rng.random(nfr)])
+        rows = n + (6 if floating else 0)
+        samples = {"positions": st["q"].copy(), "velocities": st["dq"].copy(), "accelerations": st["ddq"].copy(),
+                   "torques": rng.standard_normal((S, rows if torques_with_base else n)), "times": 0.01 * np.arange(S), "frequency": np.array(100.0),
+                   "velocities_raw": st["dq"] + 0.01 * rng.standard_normal((S, n))}
+        if floating:
+            samples.update(base_velocity=st["base_vel"].copy(), base_acceleration=st["base_acc"].copy(), base_rpy=st["rpy"].copy())
+        if contacts:
+            samples["contacts"] = np.array({f: rng.standard_normal((S, 6)) for f in contacts})
+        for k, v in samples.items():
+            if k == "contacts":
+                for f, a in v.item(0).items():
+                    out["%s_in_contacts_%s" % (tag, f)] = a.copy()
+            else:
+                out["%s_in_%s" % (tag, k)] = np.array(v).copy()
+        kd = KinDyn(t, floating)
+        kd.xstd = xStdModel[: 10 * L]
+        used = S // (opt["skipSamples"] + 1)
+        nb = 5
+        fm = NS(opt=opt, num_dofs=n, num_links=L, num_model_params=10 * L, num_all_params=nall, num_identified_params=len(identified),
+                identified_params=identified, inertia_params=inertia_params, xStdModel=xStdModel, friction_params_start=10 * L, kinDyn=kd,
+                gravity_vec=None, idyn_model=None, progress=lambda it: it, Pb=np.eye(len(identified))[:, :nb])
+        fm.simulateDynamicsIDynTree = lambda samples_, idx, kinDyn=None, xStdModel=None: rmodel.Model.simulateDynamicsIDynTree(fm, samples_, idx, kinDyn, xStdModel)
+        data = NS(samples=samples, num_used_samples=used)
+        rmodel.Model.computeRegressors(fm, data)
+        out[tag + "_meta"] = json.dumps({"robot": robot, "floating": int(floating), "S": S, "opt": opt, "contacts": contacts or [], "nb": nb})
+        out[tag + "_xStdModel"] = xStdModel
+        for k in ("YStd", "YBase", "torques_stack", "torquesAP_stack", "tau", "contacts_stack", "contactForcesSum", "tauMeasured", "T", "sim_torq_stack"):
+            out["%s_out_%s" % (tag, k)] = np.asarray(getattr(fm, k))
+        out[tag + "_out_samples_torques"] = np.asarray(fm.data.samples["torques"])
+
+    run("crA", "kuka_lwr4", 0, 20, 21, {"identifyFrictionSimultaneously": 1, "stribeckVelocity": 0.05, "skipSamples": 1, "useAPriori": 1})
+    run("crB", "threeLinks", 1, 10, 22, {}, contacts=["link3"])
+    run("crC", "kuka_lwr4", 0, 16, 23, {"identifyGravityParamsOnly": 1, "identifyFrictionSimultaneously": 1})
+    run("crD", "threeLinks", 1, 16, 24, {"simulateTorques": 1, "useAPriori": 1, "identifyFrictionSimultaneously": 1, "identifySymmetricVelFriction": 0},
+        contacts=["link2", "link3"], torques_with_base=True)
+    # ---- getRandomRegressor (model.py:634-830): global-RNG call order, raw Gram, pivoted QR, cache file keys
+    import tempfile
+
+    def run_random(tag, robot, floating, n_samples, seed, opt_over):
+        t = load_topo(robot)
+        n, L = t.num_dofs, t.num_links
+        opt = {"floatingBase": int(floating), "identifyGravityParamsOnly": 0, "identifyFrictionSimultaneously": 0, "identifySymmetricVelFriction": 1,
+               "stribeckVelocity": 0, "verbose": 0, "frictionSignThreshold": 0.02}
+        opt.update(opt_over)
+        nfr = 0
+        if opt["identifyFrictionSimultaneously"]:
+            nfr = 3 * n if opt["identifySymmetricVelFriction"] else 4 * n
+        kd = KinDyn(t, floating)
+        tmpd = tempfile.mkdtemp()
+        fm = NS(opt=opt, num_dofs=n, num_links=L, num_model_params=10 * L, num_identified_params=10 * L + nfr, N_OUT=n + (6 if floating else 0),
+                inertia_params=[], limits={k: dict(v) for k, v in t.limits.items()}, jointNames=list(t.dof_names), kinDyn=kd, gravity_vec=None,
+                progress=lambda it: it, urdf_file=os.path.join(tmpd, robot + ".urdf"))
+        np.random.seed(seed)
+        R, Q, RQ, PQ = rmodel.Model.getRandomRegressor(fm, n_samples=n_samples)
+        cache = np.load(fm.urdf_file + ".regressor.npz")
+        out.update({tag + "_meta": json.dumps({"robot": robot, "floating": int(floating), "n_samples": n_samples, "seed": seed, "opt": opt}),
+                    tag + "_R": R, tag + "_PQ": PQ, tag + "_RQdiag": np.diag(RQ), tag + "_cache_keys": np.array(sorted(cache.files)),
+                    tag + "_cache_n": cache["n"], tag + "_cache_fb": cache["fb"], tag + "_cache_fric": cache["fric"]})
+
+    run_random("rrA", "kuka_lwr4", 0, 40, 7, {"identifyFrictionSimultaneously": 1})
+    run_random("rrB", "threeLinks", 1, 30, 8, {})
+    np.savez_compressed(os.path.join(golden, "ref_compute_regressors.npz"), **out)
+    print("ref_compute_regressors.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     main()
+    reference_host_functions(os.path.join(REPO, "tests", "golden"))
+    reference_estimators(os.path.join(REPO, "tests", "golden"))
+    reference_compute_regressors(os.path.join(REPO, "tests", "golden"))
