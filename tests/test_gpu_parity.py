@@ -4,6 +4,8 @@ Tolerances (fp64 path, stated by north_star as 1e-6 on identified parameters; th
 much tighter bars): regressor / torques entries <= 1e-11 * max|.| of the array, Gram <= 1e-11 relative
 Frobenius.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -368,3 +370,36 @@ def test_tsqr_widths_on_many_workers(ncols, friction):
         Gs = G
     assert np.all(np.tril(R, -1) == 0.0)
     assert np.linalg.norm(R.T @ R - Gs) <= 1e-11 * np.linalg.norm(Gs)
+
+
+@pytest.mark.parametrize("tag", ["gwA", "gwB"])
+def test_dopt_sensitivities_match_the_reference_worker(tag):
+    """excitation.dopt_sensitivities (fbr_fd_scores) against the sens_q / sens_dq / sens_ddq that the reference's own
+    _dopt_gradient_worker_func (excitation/analyticalGradient.py:46-185) returned on the same samples and weights
+    (tools/make_fixtures.py; its iDynTree calls answered by the oracle).  The worker evaluates a floating base at the
+    identity pose with zero twist and zero base acceleration; finite differences with eps = 1e-6 amplify rounding by
+    1/eps, hence the tolerance relative to |score| / eps."""
+    import json
+
+    from common import GOLDEN
+    from flobaroid_amd import excitation as exc
+    from flobaroid_amd._lib import Engine
+
+    z = np.load(os.path.join(GOLDEN, "ref_compute_regressors.npz"), allow_pickle=True)
+    meta = json.loads(str(z[tag + "_meta"]))
+    t = load_topo(meta["robot"])
+    eng = Engine(t, floating=bool(meta["floating"]))
+    S = meta["S"]
+    st = {"q": z[tag + "_q"], "dq": z[tag + "_dq"], "ddq": z[tag + "_ddq"]}
+    if meta["floating"]:
+        st.update(base_vel=np.zeros((S, 6)), base_acc=np.zeros((S, 6)), rpy=np.zeros((S, 3)))
+    W = z[tag + "_W"]
+    sq, sdq, sddq = exc.dopt_sensitivities(eng, st, W, meta["eps"], W_visc=z[tag + "_W_visc"], reference_state_carryover=True)
+    scale = np.abs(eng.fd_scores(st, W, meta["eps"])).max() / meta["eps"]
+    for got, name in ((sq, "sens_q"), (sdq, "sens_dq"), (sddq, "sens_ddq")):
+        want = z["%s_%s" % (tag, name)]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-10 * scale, name
+    # without the reference's state carry-over the acceleration sensitivities differ by exactly sens_dq_inertial[:, n-1]
+    _, sdq0, sddq0 = exc.dopt_sensitivities(eng, st, W, meta["eps"])
+    assert np.abs((sddq - sddq0) - sdq0[:, -1:]).max() <= 1e-9 * scale

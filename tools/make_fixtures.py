@@ -35,7 +35,9 @@ npz) and writes small derived fixtures; no reference source code is copied.
                                               this pins is the reference's PYTHON logic around those calls -- stacking order,
                                               friction column blocks, gravity-only column deletion, skipSamples, a-priori
                                               torques, simulated base wrench, contact-force bookkeeping -- not iDynTree's
-                                              numerics (those stay unpinned).
+                                              numerics (those stay unpinned).  Same for
+                                              Model.getRandomRegressor (model.py:634-830) and the D-optimality gradient worker
+                                              _dopt_gradient_worker_func (excitation/analyticalGradient.py:46-185).
 """
 import json
 import os
@@ -478,6 +480,29 @@ def reference_compute_regressors(golden):
                     tag + "_R": R, tag + "_PQ": PQ, tag + "_RQdiag": np.diag(RQ), tag + "_cache_keys": np.array(sorted(cache.files)),
                     tag + "_cache_n": cache["n"], tag + "_cache_fb": cache["fb"], tag + "_cache_fric": cache["fric"]})
 
+    # ---- the D-optimality gradient worker (excitation/analyticalGradient.py:46-185), same shim
+    rgrad = _import_reference("excitation.analyticalGradient")
+    rgrad.iDynTree = NS(JointPosDoubleArray=Arr, JointDOFsDoubleArray=Arr, Vector6=Arr, MatrixDynSize=Mat,
+                        Transform=NS(Identity=lambda: NS(rpy=(0.0, 0.0, 0.0))), Twist=NS(Zero=lambda: NS(v=np.zeros(6))))
+
+    def run_gradient(tag, robot, floating, S, seed, eps):
+        t = load_topo(robot)
+        n, L = t.num_dofs, t.num_links
+        rng = np.random.default_rng(seed)
+        st = random_states(t, S, rng, 0, use_limits=True)
+        kd = KinDyn(t, floating)
+        rgrad._worker_state["model"] = NS(num_dofs=n, kinDyn=kd, gravity_vec=None)
+        nout = n + (6 if floating else 0)
+        W = rng.standard_normal((S * nout, 10 * L))
+        W_visc = rng.standard_normal(S * nout)
+        args = (np.arange(S), st["q"], st["dq"], st["ddq"], W, np.zeros(10 * L), nout, eps, bool(floating), 0 if floating else 6, True, W_visc,
+                np.zeros(n), 6 if floating else 0, -np.ones(n, dtype=int))
+        sq, sdq, sddq, _ = rgrad._dopt_gradient_worker_func(args)
+        out.update({tag + "_meta": json.dumps({"robot": robot, "floating": int(floating), "S": S, "eps": eps}), tag + "_q": st["q"], tag + "_dq": st["dq"],
+                    tag + "_ddq": st["ddq"], tag + "_W": W, tag + "_W_visc": W_visc, tag + "_sens_q": sq, tag + "_sens_dq": sdq, tag + "_sens_ddq": sddq})
+
+    run_gradient("gwA", "kuka_lwr4", 0, 6, 31, 1e-6)
+    run_gradient("gwB", "threeLinks", 1, 7, 32, 1e-6)
     run_random("rrA", "kuka_lwr4", 0, 40, 7, {"identifyFrictionSimultaneously": 1})
     run_random("rrB", "threeLinks", 1, 30, 8, {})
     np.savez_compressed(os.path.join(golden, "ref_compute_regressors.npz"), **out)
