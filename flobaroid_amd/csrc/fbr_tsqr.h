@@ -30,7 +30,7 @@
 #define FBR_TSQR_WAVES (FBR_TSQR_THREADS / 64)
 #define FBR_TSQR_RING 6            // published panels (V, T) kept in the LDS: how far the waves may drift apart
 #define FBR_TSQR_MAXN 768          // widest supported factor (columns incl. rhs, padded to 16)
-#define FBR_TSQR_SPIN_LIMIT (1 << 18)
+#define FBR_TSQR_SPIN_LIMIT (1 << 20)  // ~50 ms of polling: far beyond any legitimate wait (a fold tail is ~0.1 ms)
 
 typedef double fbr_td4 __attribute__((ext_vector_type(4)));
 
