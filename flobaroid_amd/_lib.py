@@ -350,10 +350,10 @@ class Engine:
         k = 0
         rr = _Ref(None)
         if rhs is not None:
-            if _is_torch(rhs):
-                rhs2 = rhs.reshape(S * self.rows, -1)
-            else:
-                rhs2 = np.asarray(rhs, dtype=np.float64).reshape(S * self.rows, -1)
+            if not _is_torch(rhs):
+                rhs = np.asarray(rhs, dtype=np.float64)
+            ncol = int(rhs.shape[-1]) if rhs.ndim >= 2 else 1  # (an empty batch cannot infer the column count by reshape)
+            rhs2 = rhs.reshape(S * self.rows, ncol)
             k = int(rhs2.shape[1])
             rr = _Ref(rhs2, (S * self.rows, k), "rhs")
             if rr.mem != mem:

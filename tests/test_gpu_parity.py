@@ -403,3 +403,27 @@ def test_dopt_sensitivities_match_the_reference_worker(tag):
     # without the reference's state carry-over the acceleration sensitivities differ by exactly sens_dq_inertial[:, n-1]
     _, sdq0, sddq0 = exc.dopt_sensitivities(eng, st, W, meta["eps"])
     assert np.abs((sddq - sddq0) - sdq0[:, -1:]).max() <= 1e-9 * scale
+
+
+@pytest.mark.parametrize("S", [0, 1, 2, 5])
+def test_tiny_batches(S):
+    """Edge sizes: empty, one sample, fewer samples than workers -- every reduction entry point."""
+    cfg = CONFIGS[7]
+    t, eng, om = _engine_oracle(cfg)
+    st, rng = _states(t, cfg, S, 61)
+    rhs = rng.standard_normal((S * om.rows, 1))
+    Pa = om.P + 1
+    if S == 0:
+        assert np.all(eng.gram(st, rhs=rhs) == 0.0) and np.all(eng.tsqr(st, rhs=rhs) == 0.0)
+        assert eng.regressor(st).shape == (0, om.P) and eng.fd_scores(st, np.zeros((0, om.P)), 1e-6).shape == (0, 1 + 3 * t.num_dofs)
+        return
+    A = _aug(om, st, rhs)
+    Go = A.T @ A
+    G = eng.gram(st, rhs=rhs)
+    assert G.shape == (Pa, Pa) and np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go)
+    R = eng.tsqr(st, rhs=rhs)
+    assert np.all(np.tril(R, -1) == 0.0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
+    Gg = eng.gram_grouped(st, S, rhs=rhs)
+    for g in range(S):
+        Ag = A[g * om.rows:(g + 1) * om.rows]
+        assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * np.linalg.norm(Ag.T @ Ag)
