@@ -14,6 +14,8 @@ B="python $REPO/bench.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT" -o bench -- $B --no-cpu-baseline > "$REPO/$OUT/bench_rocprof_stdout.txt" 2>&1
 # 2. the same command without the profiler (the bench line the summary quotes)
 $B > "$REPO/$OUT/bench_default.json" 2> "$REPO/$OUT/bench_default.err"
+# 2b. secondary figures of the other BASELINE configs (KUKA 50 k, left arm 500 k)
+$B --other-configs --no-cpu-baseline > "$REPO/$OUT/bench_other_configs.json" 2>/dev/null
 # 3. HBM traffic counters, one pass each, on a shorter run of the same workload
 S="--samples 200000 --steps 1 --warmup 0 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/$OUT" -o pmc_fetch -- $B $S > /dev/null 2>&1

@@ -41,6 +41,12 @@ line = [l for l in open(os.path.join(src, "bench_default.json")) if l.startswith
 bench = json.loads(line)
 json.dump(bench, open(os.path.join(dst, tag + "_bench_default.json"), "w"), indent=1)
 
+oc = os.path.join(src, "bench_other_configs.json")
+if os.path.exists(oc):
+    lines = [l for l in open(oc) if l.startswith("{")]
+    if lines:
+        json.dump(json.loads(lines[-1]).get("other_configs", {}), open(os.path.join(dst, tag + "_other_configs.json"), "w"), indent=1)
+
 pmc = {}
 for prefix in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_sq"):
     pmc.update(counters(prefix))
