@@ -251,59 +251,42 @@ __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const do
     (fbr_tsqr_panel_step<SUB, Js>(v, Rp, rq, trow, myscale, li, kk), ...);
 }
 
-// Trailing update of NB (1 or 2) column tiles T, T+1 of a wave with a published panel (V in Vl, T in Tm):
+// Trailing update of column tile T of a wave with a published panel (V in Vl, T in Tm):
 //   acc = R_rows + V^T C;  W = T^T acc;  R_rows -= W;  C -= V W        (Rl = LDS copy of the R_rows tiles, [tile][16][16])
 // The MFMA C/D layout (reg r, lane (kk, j) = row 4r + kk, column j) is also the B-operand layout of k-step r, so acc
 // and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
-// live[b] == false: the R rows of tile b are not stored (unused since the tiles are updated one at a time: the paired
-// form ran dead / padding tiles through the MFMAs, +34 % MFMA work, and was slower).
-template <int TPW, int SUB, int T, int NB>
-__device__ __forceinline__ void fbr_tsqr_update_tiles(fbr_td4 (&C)[TPW][SUB], const bool (&live)[NB], double *Rl, double *__restrict__ R, unsigned ld,
-                                                      int q, int NP, int wave, int lane, const double *Vl, const double *Tm)
+// Tiles are updated one at a time (a paired form ran dead / padding tiles through the MFMAs: +34 % MFMA work, slower;
+// splitting V^T C over two accumulators to shorten the dependent chain was 3 % slower as well).
+template <int TPW, int SUB, int T>
+__device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], const double *Rl, double *__restrict__ R, unsigned ld, int q, int wave,
+                                                     int lane, const double *Vl, const double *Tm)
 {
     const int li = lane & 15, kk = lane >> 4;
     const unsigned j0 = 16u * (unsigned)q;
-    fbr_td4 acc[NB], w2[NB];
+    const double *Rt = Rl + (wave + FBR_TSQR_WAVES * T) * 256;
+    fbr_td4 acc, w2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) acc[b][reg] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li];
-        w2[b] = fbr_td4{0.0, 0.0, 0.0, 0.0};
-    }
+    for (int reg = 0; reg < 4; reg++) acc[reg] = Rt[(4 * reg + kk) * 16 + li];
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const double a = Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li];
-#pragma unroll
-            for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, C[T + b][sb][reg], acc[b], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li], C[T][sb][reg], acc, 0, 0, 0);
         }
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-        const double a = Tm[(4 * ks + kk) * 16 + li];
+    for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * 16 + li], acc[ks], w2, 0, 0, 0);
+    {
+        // uniform (scalar) base + one per-lane offset shared by every store of the kernel
+        const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * T);
+        const unsigned voff = (unsigned)kk * ld + (unsigned)li;
 #pragma unroll
-        for (int b = 0; b < NB; b++) w2[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[b][ks], w2[b], 0, 0, 0);
+        for (int reg = 0; reg < 4; reg++) (R + ((j0 + 4 * reg) * ld + c0))[voff] = Rt[(4 * reg + kk) * 16 + li] - w2[reg];
     }
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-        if (live[b]) {
-            // uniform (scalar) base + one per-lane offset shared by every store of the kernel
-            const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * (T + b));
-            const unsigned voff = (unsigned)kk * ld + (unsigned)li;
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                double *Rs = R + ((j0 + 4 * reg) * ld + c0);
-                Rs[voff] = Rl[(wave + FBR_TSQR_WAVES * (T + b)) * 256 + (4 * reg + kk) * 16 + li] - w2[b][reg];
-            }
-        }
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const double a = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk];
-#pragma unroll
-            for (int b = 0; b < NB; b++) C[T + b][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -w2[b][ks], C[T + b][sb], 0, 0, 0);
-        }
+        for (int ks = 0; ks < 4; ks++)
+            C[T][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk], -w2[ks], C[T][sb], 0, 0, 0);
 }
 
 // LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into the LDS, no VGPR data) written as inline assembly:
@@ -340,10 +323,7 @@ template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateFrom {
                                                int wave, int lane, const double *Vl, const double *Tm)
     {
         if constexpr (T < TPW) {
-            if (T >= t0 && T < t1) {
-                const bool live[1] = {true};
-                fbr_tsqr_update_tiles<TPW, SUB, T, 1>(C, live, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
-            }
+            if (T >= t0 && T < t1) fbr_tsqr_update_tile<TPW, SUB, T>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
             FbrTsqrUpdateFrom<TPW, SUB, T + 1>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
         }
     }
@@ -355,10 +335,7 @@ template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateOne {
                                                int wave, int lane, const double *Vl, const double *Tm)
     {
         if constexpr (T < TPW) {
-            if (tp == T) {
-                const bool live[1] = {true};
-                fbr_tsqr_update_tiles<TPW, SUB, T, 1>(C, live, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
-            }
+            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
             FbrTsqrUpdateOne<TPW, SUB, T + 1>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
         }
     }
