@@ -68,6 +68,49 @@ def cpu_baseline(topo, budget_s=15.0):
             "sample": f"{done} WALK-MAN floating-base samples: oracle regressor + RNEA (C, 1 thread) + NumPy A^T A (1 BLAS thread), {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(topo, budget_s=8.0):
+    """The same port on every host core: one Python thread per core, each running the C oracle (ctypes releases the GIL)
+    and its own 1-thread NumPy A^T A on private sample blocks, Grams summed at the end ("1 thread, then all
+    host cores").  The reference itself is single-threaded on this path."""
+    import concurrent.futures as cf
+
+    from oracle.oracle import OracleModel
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    cores = os.cpu_count() or 1
+    x = topo.x_std()
+    block = 256
+    st, _ = synth_states(topo, block, 4321)
+    oms = [OracleModel(topo, floating=True) for _ in range(cores)]
+    t_end = time.perf_counter() + budget_s
+
+    def work(i):
+        om = oms[i]
+        G = np.zeros((om.P + 1, om.P + 1))
+        done = 0
+        while time.perf_counter() < t_end:
+            Y = om.regressor(st)
+            tau = om.inverse_dynamics(st, x).reshape(-1, 1)
+            Ya = np.hstack([Y, tau])
+            G += Ya.T @ Ya
+            done += block
+        return done, G
+
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    if ctx is not None and hasattr(ctx, "unregister"):
+        ctx.unregister()
+    done = sum(r[0] for r in res)
+    return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{done} WALK-MAN floating-base samples over {cores} threads (C oracle + 1-thread NumPy A^T A each), {dt:.1f} s"}
+
+
 def other_configs(dev):
     """BASELINE.json configs[1] and configs[2] on this GPU (secondary figures, outside the timed steps):
     KUKA LWR4 fixed base, 50 k samples: regressor assembly + fused Gram + base-parameter QR (host, 80 x 80);
@@ -294,6 +337,10 @@ def main():
             out["other_configs"] = other_configs(dev)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(topo)
+        try:
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(topo)
+        except Exception as e:  # secondary figure: never lose the bench line over it
+            out["cpu_baseline_all_cores"] = {"error": repr(e)}
     elif world == 1:
         out["cpu_baseline"] = None
     print(json.dumps(out))
