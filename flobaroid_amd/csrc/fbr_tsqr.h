@@ -663,7 +663,18 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
         if (p + 1 < NPT) rpp = load_tile(p + 1, p + 1);  // row panel p + 1 is not touched by panel p's update
         fbr_lds_release();
         __builtin_amdgcn_wave_barrier();
-        // ---- trailing update of the tiles right of the panel (static register indexing, uniform branch per tile)
+        // ---- trailing update of the tiles right of the panel (static register indexing, uniform branch per tile).
+        //      The A operands (V for V^T C, V for V W, T) are the same for every tile: read from the LDS once per panel.
+        double va[SUB][4], vb[SUB][4], ta[4];
+#pragma unroll
+        for (int sb = 0; sb < SUB; sb++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                va[sb][r4] = Vl[(16 * sb + 4 * r4 + kk) * FBR_TSQR_LDV + li];
+                vb[sb][r4] = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * r4 + kk];
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) ta[ks] = Tm[(4 * ks + kk) * 16 + li];
 #pragma unroll
         for (int t = 0; t < NPT; t++)
             if (t > p) {
@@ -673,17 +684,15 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
 #pragma unroll
                 for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li], C[t][sb][reg], acc, 0, 0, 0);
+                    for (int reg = 0; reg < 4; reg++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[sb][reg], C[t][sb][reg], acc, 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * 16 + li], acc[ks], w2, 0, 0, 0);
+                for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks], acc[ks], w2, 0, 0, 0);
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) (R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)t))[voff] = r0[reg] - w2[reg];
 #pragma unroll
                 for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ks++)
-                        C[t][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk], -w2[ks], C[t][sb], 0, 0, 0);
+                    for (int ks = 0; ks < 4; ks++) C[t][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[sb][ks], -w2[ks], C[t][sb], 0, 0, 0);
             }
         __builtin_amdgcn_wave_barrier();  // (the wave's own LDS reads are in order with the next panel's writes)
     }
