@@ -192,7 +192,7 @@ __device__ __forceinline__ void fbr_tsqr_panel_step(fbr_td4 (&v)[SUB], const dou
     // from the hardware rsq seed, one coupled Newton step on (g, h = 1/(2g)) and one residual correction of g;
     // tau = (beta - alpha) / beta = 1 + |alpha| / g = 1 + 2 |alpha| h;  scale = 1 / (alpha - beta) = sign(alpha) / (|alpha| + g)
     // by two Newton steps from a reciprocal seed taken on the unrefined g (off the dependency chain).
-    const bool nz = normsq > 0.0;
+    const bool nz = normsq > 1e-290;  // (denormal-range column norms count as zero: the unscaled rsq below would overflow)
     const double aa = fabs(alpha);
     const double tt = fma(alpha, alpha, normsq);
     const double y0 = __builtin_amdgcn_rsq(tt);

@@ -427,3 +427,23 @@ def test_tiny_batches(S):
     for g in range(S):
         Ag = A[g * om.rows:(g + 1) * om.rows]
         assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * np.linalg.norm(Ag.T @ Ag)
+
+
+def test_tsqr_badly_scaled_and_tiny_columns():
+    """Columns 12 orders of magnitude apart and a column in the denormal range: no NaN / Inf, R^T R == G column-wise."""
+    from flobaroid_amd._lib import Engine
+
+    eng = Engine(load_topo("threeLinks"), floating=True)
+    rng = np.random.default_rng(71)
+    n = 40
+    sc = 10.0 ** rng.uniform(-6, 6, n)
+    sc[7] = 1e-170          # squares to the denormal range
+    R1 = np.triu(rng.standard_normal((n, n))) * sc[None, :]
+    R2 = np.triu(rng.standard_normal((n, n))) * sc[None, :]
+    Rm = eng.tsqr_merge(R1, R2)
+    assert np.all(np.isfinite(Rm))
+    G = R1.T @ R1 + R2.T @ R2
+    D = 1.0 / np.sqrt(np.maximum(np.diag(G), 1e-300))
+    keep = np.arange(n) != 7
+    E = (Rm.T @ Rm - G) * D[:, None] * D[None, :]
+    assert np.abs(E[np.ix_(keep, keep)]).max() <= 1e-12
