@@ -731,7 +731,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
     if (S > 0) {
         const int T = h->prog.T;
-        const int blocks_per_cu = 1;  // 8 waves = 2 per SIMD; the register budget admits one workgroup per CU
+        const int blocks_per_cu = (h->lds_bytes <= 79 * 1024) ? 2 : 1;
         const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
         HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes));

@@ -19,8 +19,15 @@
 
 #define FBR_TILE 16
 #define FBR_WPB 8         // waves per workgroup of the Gram kernel (2 per SIMD, one workgroup per CU; 2 x 4 waves measured 3% slower)
-#define FBR_SEGW 6        // tile pairs per row segment (same tile I, up to SEGW different tiles J)
-#define FBR_NSEG 3        // row segments per wave
+#ifndef FBR_SEGW
+#define FBR_SEGW 5        // tile pairs per row segment (same tile I, up to SEGW different tiles J)
+#endif
+#ifndef FBR_NSEG
+#define FBR_NSEG 2        // row segments per wave
+#endif
+#ifndef FBR_IMG_BUDGET
+#define FBR_IMG_BUDGET 4608  // doubles per LDS image buffer of a part
+#endif
 #define FBR_NPW (FBR_SEGW * FBR_NSEG)  // tile pairs (MFMA accumulators) per wave
 #define FBR_MAX_RHS 16
 
@@ -340,7 +347,7 @@ struct FbrGramProgram {
         const int np = (int)pairs.size();
         const int SEGCAP = FBR_WPB * FBR_NSEG;
         // a part must fit its row segments in WPB*NSEG slots and two copies of its tile image in the LDS
-        const int IMG_BUDGET = 9472;  // doubles per image buffer (2 x 74 KiB + tables < 160 KiB)
+        const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer (2 x 74 KiB + tables < 160 KiB)
         auto seg_count = [&](int b, int e) {
             std::vector<int> cnt(NT, 0);
             std::vector<char> need(NT, 0);
