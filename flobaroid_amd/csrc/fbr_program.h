@@ -19,6 +19,7 @@
 
 #define FBR_TILE 16
 #define FBR_WPB 8         // waves per workgroup of the Gram kernel (2 per SIMD, one workgroup per CU; 2 x 4 waves measured 3% slower)
+// (overridable with -D for tuning sweeps; the values below are the measured optimum for two workgroups per CU)
 #ifndef FBR_SEGW
 #define FBR_SEGW 5        // tile pairs per row segment (same tile I, up to SEGW different tiles J)
 #endif
@@ -347,7 +348,7 @@ struct FbrGramProgram {
         const int np = (int)pairs.size();
         const int SEGCAP = FBR_WPB * FBR_NSEG;
         // a part must fit its row segments in WPB*NSEG slots and two copies of its tile image in the LDS
-        const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer (2 x 74 KiB + tables < 160 KiB)
+        const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer: two workgroups per CU x (2 x 36 KiB + tables) < 160 KiB
         auto seg_count = [&](int b, int e) {
             std::vector<int> cnt(NT, 0);
             std::vector<char> need(NT, 0);
