@@ -47,61 +47,52 @@ class Data:
         self.inited = True
 
     def init_from_files(self, measurements_files) -> None:
-        """Load and concatenate measurement npz files (list of lists of paths), dropping the first
-        ``startOffset`` samples of each, re-basing ``times`` and recording ``file_boundaries``."""
-        with Timer() as t:
+        """Load and concatenate measurement npz files (list of groups of paths; reference: data.py:55-146).
+
+        Every file drops its first ``startOffset`` samples.  Per key: 2-D arrays are stacked along the sample axis, 1-D
+        arrays appended, scalars (e.g. ``frequency``) keep the last file's value; ``times`` of a later file continue the
+        running clock: t - t[so] + (t[so+1] - t[so]) + last time so far.  ``file_boundaries`` records the sample index
+        at which every file starts.  Contact dictionaries are concatenated per frame (the reference keeps the last file's)."""
+        with Timer() as timer:
             so = self.opt["startOffset"]
-            self.file_boundaries = [0]
-            for group in measurements_files:
-                for fn in group:
-                    m = np.load(fn, encoding="latin1", allow_pickle=True)
-                    self.file_boundaries.append(self.file_boundaries[-1] + m["positions"].shape[0] - so)
-                    for k in m.keys():
-                        v = m[k]
-                        first = k not in self.measurements
-                        if v.ndim == 0:
-                            if isinstance(v.item(0), dict):
-                                cd = {c: a[so:, :] for c, a in v.item(0).items() if c != "dummy_sim"}
-                                if not first and isinstance(self.measurements[k].item(0), dict):
-                                    prev = self.measurements[k].item(0)
-                                    cd = {c: np.concatenate((prev[c], a), axis=0) if c in prev else a for c, a in cd.items()}
-                                self.measurements[k] = np.array(cd)
-                            else:
-                                self.measurements[k] = v
-                        elif v.ndim == 1:
-                            if first:
-                                self.measurements[k] = v[so:]
-                            else:
-                                vv = v
-                                if k == "times":
-                                    vv = v - v[so] + (v[so + 1] - v[so]) + self.measurements[k][-1]
-                                self.measurements[k] = np.concatenate((self.measurements[k], vv[so:]), axis=0)
+            bounds = [0]
+            merged: dict[str, Any] = self.measurements
+
+            def append(key: str, arr: np.ndarray) -> None:
+                merged[key] = arr if key not in merged else np.concatenate((merged[key], arr), axis=0)
+
+            for path in (p for group in measurements_files for p in group):
+                with np.load(path, encoding="latin1", allow_pickle=True) as f:
+                    bounds.append(bounds[-1] + f["positions"].shape[0] - so)
+                    for key in f.keys():
+                        v = f[key]
+                        if v.ndim >= 1:
+                            if key == "times" and key in merged:
+                                v = v - v[so] + (v[so + 1] - v[so]) + merged[key][-1]
+                            append(key, v[so:])
+                        elif isinstance(v.item(0), dict):  # contact wrenches: {frame: (S, 6)}
+                            frames = {c: w[so:, :] for c, w in v.item(0).items() if c != "dummy_sim"}
+                            if key in merged and isinstance(merged[key].item(0), dict):
+                                old = merged[key].item(0)
+                                frames = {c: np.concatenate((old[c], w), axis=0) if c in old else w for c, w in frames.items()}
+                            merged[key] = np.array(frames)
                         else:
-                            if first:
-                                self.measurements[k] = v[so:, :]
-                            else:
-                                self.measurements[k] = np.concatenate((self.measurements[k], v[so:, :]), axis=0)
-                    m.close()
-            self._validate_required_keys(self.measurements)
-            self.num_loaded_samples = self.measurements["positions"].shape[0]
+                            merged[key] = v
+            self.file_boundaries = bounds
+            self._validate_required_keys(merged)
+            self.num_loaded_samples = merged["positions"].shape[0]
             self.num_used_samples = self.num_loaded_samples // (self.opt["skipSamples"] + 1)
             if self.opt.get("verbose"):
                 print(f"loaded {self.num_loaded_samples} measurement samples (using {self.num_used_samples})")
-            self.samples = {}
             self.block_pos = 0
             if self.opt.get("selectBlocksFromMeasurements"):
                 bs = self.opt["blockSize"]
-                for k, v in self.measurements.items():
-                    if v.ndim == 0:
-                        self.samples[k] = v
-                    else:
-                        self.samples[k] = v[self.block_pos : self.block_pos + bs]
-                self.num_selected_samples = self.samples["positions"].shape[0]
-                self.num_used_samples = self.num_selected_samples // (self.opt["skipSamples"] + 1)
+                self.samples = {k: (v if v.ndim == 0 else v[self.block_pos:self.block_pos + bs]) for k, v in merged.items()}
+                self.updateNumSamples()
             else:
-                self.samples = self.measurements
+                self.samples = merged
         if self.opt.get("showTiming"):
-            print(f"(loading samples from file took {t.interval:.3f} sec.)")
+            print(f"(loading samples from file took {timer.interval:.3f} sec.)")
         self.inited = True
 
     def hasMoreSamples(self) -> bool:

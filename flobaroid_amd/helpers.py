@@ -11,38 +11,40 @@ from typing import Any
 import numpy as np
 
 
+def _memo(samples: dict[str, np.ndarray], key: str, make) -> np.ndarray:
+    """value cached in the samples dict under ``key`` (the reference keeps both series there so that the regressor
+    columns, the friction fit and every torque prediction use the same arrays)"""
+    if key not in samples:
+        samples[key] = make()
+    return samples[key]
+
+
 def getFrictionSignVelocities(samples: dict[str, np.ndarray], opt: dict[str, Any]) -> np.ndarray:
     """Velocities used for the Coulomb sign term (reference: helpers.py:89-132).
 
-    Zero-phase 3rd-order Butterworth low-pass of ``velocities_raw`` at ``frictionVelocityCutoff`` when raw
-    velocities and the sampling frequency exist and the cutoff is below Nyquist, else the pipeline
-    velocities.  Cached in the samples dict under ``velocities_for_sign``."""
-    if "velocities_for_sign" in samples:
-        return samples["velocities_for_sign"]
-    cutoff = float(opt.get("frictionVelocityCutoff", 25.0))
-    has_raw = "velocities_raw" in samples and "frequency" in samples
-    freq = float(samples["frequency"]) if has_raw else 0.0
-    if has_raw and cutoff < freq / 2:
-        import scipy.signal
+    Zero-phase 3rd-order Butterworth low-pass (second-order sections) of ``velocities_raw`` at
+    ``frictionVelocityCutoff`` [Hz, default 25] when raw velocities and the sampling frequency are present and the
+    cutoff lies below Nyquist; the pipeline velocities otherwise.  Cached as ``velocities_for_sign``."""
 
-        sos = scipy.signal.butter(3, cutoff, btype="low", fs=freq, output="sos")
-        raw = samples["velocities_raw"]
-        vfs = np.column_stack([scipy.signal.sosfiltfilt(sos, raw[:, j]) for j in range(raw.shape[1])])
-    else:
-        vfs = samples["velocities"]
-    samples["velocities_for_sign"] = vfs
-    return vfs
+    def make():
+        fc = float(opt.get("frictionVelocityCutoff", 25.0))
+        raw_ok = "velocities_raw" in samples and "frequency" in samples
+        fs = float(samples["frequency"]) if raw_ok else 0.0
+        if not (raw_ok and fc < fs / 2):
+            return samples["velocities"]
+        import scipy.signal as sig
+
+        # all joints in one call along the time axis (same per-column arithmetic as filtering joint by joint)
+        return sig.sosfiltfilt(sig.butter(3, fc, btype="low", fs=fs, output="sos"), samples["velocities_raw"], axis=0)
+
+    return _memo(samples, "velocities_for_sign", make)
 
 
 def getFrictionSignSeries(samples: dict[str, np.ndarray], opt: dict[str, Any]) -> np.ndarray:
-    """tanh(v_sign / frictionSignThreshold), cached under ``friction_sign_series`` (helpers.py:135-156)."""
-    if "friction_sign_series" in samples:
-        return samples["friction_sign_series"]
-    v = getFrictionSignVelocities(samples, opt)
-    thr = float(opt.get("frictionSignThreshold", 0.02))
-    s = np.tanh(v / thr)
-    samples["friction_sign_series"] = s
-    return s
+    """Smoothed Coulomb sign tanh(v_sign / frictionSignThreshold) [default 0.02], cached as ``friction_sign_series``
+    (helpers.py:135-156)."""
+    return _memo(samples, "friction_sign_series",
+                 lambda: np.tanh(getFrictionSignVelocities(samples, opt) / float(opt.get("frictionSignThreshold", 0.02))))
 
 
 class Timer:
