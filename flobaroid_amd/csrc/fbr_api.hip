@@ -72,7 +72,35 @@ struct GramHolder {
     DevBuf pimg[2];           // packed tile images of one chunk of samples, double buffered (zeroed when (re)allocated)
     size_t lds_bytes = 0;     // streaming Gram kernel
     size_t pack_lds_bytes = 0;
+    struct Deal { const int2 *tab; const int *begin; };
+    std::map<int, Deal> deals;  // workgroups per sample group -> device tables of fbr_gram_deal (at most one per count)
 };
+
+// Device tables of the deal of `wpg` workgroups to the parts (cached per holder).
+static int get_deal(GramHolder *h, int wpg, GramHolder::Deal *out)
+{
+    auto it = h->deals.find(wpg);
+    if (it != h->deals.end()) {
+        *out = it->second;
+        return FBR_OK;
+    }
+    const std::vector<int> n = fbr_gram_deal(h->prog, wpg);
+    // dispatch order: round robin over the parts.  The SIMD arbiter favours the older waves, so the workgroups dispatched first
+    // run ~20 % faster than the ones that arrive second on a CU; every part gets the same mix of both.
+    std::vector<int2> tab;
+    std::vector<int> begin(h->prog.T + 1, 0), given(h->prog.T, 0);
+    for (int p = 0; p < h->prog.T; p++) begin[p + 1] = begin[p] + n[p];
+    while ((int)tab.size() < begin[h->prog.T])
+        for (int p = 0; p < h->prog.T; p++)
+            if (given[p] < n[p]) tab.push_back(make_int2(p, given[p]++ | (n[p] << 16)));
+    GramHolder::Deal d;
+    int rc;
+    if ((rc = upload(h->pool, tab, &d.tab))) return rc;
+    if ((rc = upload(h->pool, begin, &d.begin))) return rc;
+    h->deals[wpg] = d;
+    *out = d;
+    return FBR_OK;
+}
 
 struct fbr_model {
     FbrHostModel hm;
@@ -594,7 +622,7 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     }
     std::unique_ptr<GramHolder> h(new GramHolder());
     try {
-        h->prog.build(m->hm, k);
+        fbr_gram_build_best(h->prog, m->hm, k, getenv("FBR_GRAM_SHAPE"));  // "one" / "two": force a kernel shape
     } catch (const std::exception &e) {
         set_err(std::string("gram program: ") + e.what());
         return FBR_E_INVALID;
@@ -625,6 +653,8 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     }
     piece_begin[gp.T] = (int)pieces.size();
     rid_begin[gp.T] = (int)ridl.size();
+    const int FBR_SEGW = gp.cfg.segw, FBR_NSEG = gp.cfg.nseg, FBR_NPW = gp.cfg.npw();
+    dg.npw = FBR_NPW;
     const size_t nslots = gp.slots.size();
     std::vector<int> meta((size_t)gp.T * FBR_WPB * FBR_NSEG * 8, 0);
     std::vector<int> slot_tiles(2 * nslots, -1);
@@ -731,12 +761,14 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
     if (S > 0) {
         const int T = h->prog.T;
-        const int blocks_per_cu = (h->lds_bytes <= 79 * 1024) ? 2 : 1;
+        const bool two_per_cu = h->prog.cfg == FBR_CFG_TWO_PER_CU;
+        const int blocks_per_cu = (two_per_cu && h->lds_bytes <= 79 * 1024) ? 2 : 1;
+        const int FBR_NPW = h->prog.cfg.npw();
         const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
-        HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)h->lds_bytes));
-        HIPCHK(hipFuncSetAttribute((const void *)fbr_gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)h->lds_bytes));
+        typedef void (*gram_fn)(DevGram, long, int, const double *, double *, unsigned long long *);
+        const gram_fn gram_kernel = two_per_cu ? (timing ? fbr_gram_kernel<true, 5, 2> : fbr_gram_kernel<false, 5, 2>)
+                                               : (timing ? fbr_gram_kernel<true, 6, 3> : fbr_gram_kernel<false, 6, 3>);
+        HIPCHK(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)fbr_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->pack_lds_bytes));
         const size_t img_bytes = (size_t)h->prog.image_doubles * sizeof(double);
@@ -792,51 +824,56 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             const int b = (int)(ci & 1);
             if (ci + 1 < nchunks && (rc = produce(ci + 1))) return rc;
             HIPCHK(hipStreamWaitEvent(m->stream, m->ev_pack[b], 0));
-            // one workgroup per CU; the slice count is not rounded to the XCD count: measured (profiles/r01_gram_pmc_traffic)
-            // the parts of a slice drift apart and do not share L2 lines, so filling every CU is worth more.
-            // Groups: spg slices per group, slice boundaries coincide with the group boundaries (equal group sizes).
-            int spg = std::max(1, (m->num_cus * blocks_per_cu) / T / ng);
-            if ((long)spg > cs / ng) spg = (int)(cs / ng);
-            const int NS = spg * ng;
-            const size_t pcount = (size_t)NS * T * FBR_WPB * FBR_NPW * 256;
+            // every resident workgroup slot is used: the slots of a sample group are dealt to the parts by cost (fbr_gram_deal),
+            // a part's workgroups split the group's samples evenly.  Tiny batches: no more workgroups than samples per part.
+            const long spg_max = std::max(1L, cs / ng);
+            int wpg = std::max(T, (m->num_cus * blocks_per_cu) / ng);
+            if ((long)wpg > (long)T * spg_max) wpg = (int)((long)T * spg_max);
+            if (wpg > 0xffff) wpg = 0xffff;
+            GramHolder::Deal deal;
+            if ((rc = get_deal(h, wpg, &deal))) return rc;
+            DevGram dg = h->dev;
+            dg.wpg = wpg;
+            dg.wg_tab = deal.tab;
+            dg.wg_begin = deal.begin;
+            const int NW = wpg * ng;  // workgroups of this launch
+            const size_t pcount = (size_t)NW * FBR_WPB * FBR_NPW * 256;
             if ((rc = m->partial.ensure(pcount * sizeof(double)))) return rc;
             unsigned long long *dbg = nullptr;
             if (timing) {
-                if ((rc = m->st_x.ensure((size_t)T * NS * FBR_WPB * 8 * sizeof(unsigned long long)))) return rc;
+                if ((rc = m->st_x.ensure((size_t)NW * FBR_WPB * 8 * sizeof(unsigned long long)))) return rc;
                 dbg = m->st_x.as<unsigned long long>();
             }
             {
                 ProfScope ps(m, FBR_PROF_GRAM);
-                if (timing)
-                    hipLaunchKernelGGL(fbr_gram_kernel<true>, dim3(T * NS), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, h->dev, cs, NS,
-                                       h->pimg[b].as<double>(), m->partial.as<double>(), dbg);
-                else
-                    hipLaunchKernelGGL(fbr_gram_kernel<false>, dim3(T * NS), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, h->dev, cs, NS,
-                                       h->pimg[b].as<double>(), m->partial.as<double>(), dbg);
+                hipLaunchKernelGGL(gram_kernel, dim3(NW), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, dg, cs, ng,
+                                   h->pimg[b].as<double>(), m->partial.as<double>(), dbg);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(m->ev_gram[b], m->stream));
             if (timing) {
-                std::vector<unsigned long long> hb((size_t)T * NS * FBR_WPB * 8);
+                std::vector<unsigned long long> hb((size_t)NW * FBR_WPB * 8);
                 HIPCHK(hipMemcpyAsync(hb.data(), dbg, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
                 HIPCHK(hipStreamSynchronize(m->stream));
                 static const char *names[3] = {"wait_dma+barrier", "dma_issue", "mfma"};
-                std::vector<double> sum((size_t)T * 3, 0.0), ns(T, 0.0);
+                std::vector<double> sum((size_t)T * 3, 0.0), ns(T, 0.0), nw(T, 0.0);
                 for (size_t e = 0; e + 8 <= hb.size(); e += 8) {
                     const int part = (int)hb[e + 6];
                     if (part < 0 || part >= T) continue;
                     for (int i = 0; i < 3; i++) sum[(size_t)part * 3 + i] += (double)hb[e + i];
                     ns[part] += (double)hb[e + 7];
+                    nw[part] += 1.0;
                 }
                 for (int part = 0; part < T; part++) {
                     fprintf(stderr, "[fbr gram timing] part %d (cycles per sample per wave):", part);
                     for (int i = 0; i < 3; i++) fprintf(stderr, " %s=%.0f", names[i], sum[(size_t)part * 3 + i] / std::max(ns[part], 1.0));
-                    fprintf(stderr, "\n");
+                    fprintf(stderr, " | workgroups=%.0f cycles per workgroup=%.0f\n", nw[part] / FBR_WPB,
+                            (sum[(size_t)part * 3] + sum[(size_t)part * 3 + 1] + sum[(size_t)part * 3 + 2]) / std::max(nw[part], 1.0));
                 }
             }
             {
                 ProfScope ps(m, FBR_PROF_REDUCE);
-                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW, ng), dim3(256), 0, m->stream, h->dev, spg,
+                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW, ng), dim3(256), 0, m->stream, dg,
                                    m->partial.as<double>(), G + (size_t)items[ci].g0 * Pa * Pa);
             }
             HIPCHK(hipGetLastError());

@@ -25,6 +25,7 @@ struct DevModel {
 
 struct DevGram {
     int T, NT, k, Pa, image_doubles, part_image_max, nitems;
+    int npw;                  // accumulators per wave of the kernel shape the program was built for (segw * nseg)
     const int4 *items;        // every real column: image offset, kind, a, b
     const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | nkmax<<14 ;
                               //   [1+j] = offB_j/64 | common_j<<10 | lookup_j<<18   (part-local offsets)
@@ -33,6 +34,10 @@ struct DevGram {
     const int *rid_begin;     // [T+1]
     const int *ridl;          // per part: part-image row -> regressor row (chain tiles)
     const int *slot_tiles;    // [T*WPB*NPW*2] tile I, tile J (or -1)
+    // workgroups of one sample group (the deal of fbr_gram_deal), set per launch:
+    int wpg;                  // workgroups per sample group
+    const int2 *wg_tab;       // [wpg] in dispatch order: x = part, y = index among the part's workgroups | their count << 16
+    const int *wg_begin;      // [T+1] first partial-sum block of each part (partial sums are stored sorted by part)
     const int *tilecol;       // [NT*16] augmented column of each slot, -1 = padding
 };
 
@@ -442,20 +447,22 @@ __global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, lo
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5b: streaming Gram.  Workgroup = (part of the tile-pair list, slice of the samples).  Per sample the part's
+// K5b: streaming Gram.  Workgroup = (part of the tile-pair list, share of the samples).  Per sample the part's
 // tiles are copied global -> LDS by LDS-DMA (global_load_lds, no VGPRs) into one of two buffers while every
 // wave runs its <= FBR_NPW accumulators over the other buffer with v_mfma_f64_16x16x4_f64; operands of the
 // next k-step (and of the next accumulator's first k-step) are fetched before the current MFMA issues.
-// The parts of one slice share an XCD so that a sample's image is read from HBM once.  Bound: fp64 MFMA.
+// Workgroups are dealt to the parts in proportion to the parts' cost, so that all of them finish together.  Bound: fp64 MFMA.
 // TIMING: diagnostic instantiation (s_memtime cycles per phase and wave into dbg[block][wave][8]).
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void *fbr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_glb_ptr;
 
-template <bool TIMING>
-__global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, long S, int NS, const double *__restrict__ pimg,
+// FBR_SEGW x FBR_NSEG: the wave's accumulator shape (FbrGramConfig, fbr_program.h); (5,2) must fit 128 VGPRs (two workgroups per CU).
+template <bool TIMING, int FBR_SEGW, int FBR_NSEG>
+__global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) void fbr_gram_kernel(DevGram g, long S, int NG, const double *__restrict__ pimg,
                                                            double *__restrict__ partial, unsigned long long *__restrict__ dbg)
 {
+    constexpr int FBR_NPW = FBR_SEGW * FBR_NSEG;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *buf0 = smem, *buf1 = smem + g.part_image_max;
     int *ridl = (int *)(smem + 2 * g.part_image_max);   // [part image rows]
@@ -463,17 +470,13 @@ __global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, lo
     int *pcs = mslot + FBR_WPB * FBR_NSEG * 8;          // [2*pieces] DMA pieces of this part
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware mapping: workgroup b runs on XCD b % 8; the T parts of a slice are consecutive workgroups of one XCD
-    int part, slice;
-    if ((NS & 7) == 0) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        part = j % g.T;
-        slice = (j / g.T) * 8 + x;
-    } else {
-        part = blockIdx.x % g.T;
-        slice = blockIdx.x / g.T;
-    }
-    const long s0 = (S * slice) / NS, s1 = (S * (slice + 1)) / NS;
+    // workgroup -> (sample group, part, share of the group's samples): a part's workgroups split the group's samples evenly,
+    // the more expensive parts have more workgroups (fbr_gram_deal)
+    const int group = blockIdx.x / g.wpg;
+    const int2 wt = g.wg_tab[blockIdx.x - group * g.wpg];
+    const int part = wt.x, widx = wt.y & 0xffff, wcnt = (int)((unsigned)wt.y >> 16);
+    const long gs0 = (S * group) / NG, gs1 = (S * (group + 1)) / NG;
+    const long s0 = gs0 + ((gs1 - gs0) * widx) / wcnt, s1 = gs0 + ((gs1 - gs0) * (widx + 1)) / wcnt;
     const int pc0 = g.piece_begin[part], npc = g.piece_begin[part + 1] - pc0;
     const int rb0 = g.rid_begin[part], nrid = g.rid_begin[part + 1] - rb0;
 
@@ -580,8 +583,8 @@ __global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, lo
         d[6] = (unsigned long long)part;
         d[7] = (unsigned long long)(s1 - s0);
     }
-    // ---- write this workgroup's accumulators: partial[slice][part][wave][slot][reg][lane]
-    double *pp = partial + ((((long)slice * g.T + part) * FBR_WPB + wave) * FBR_NPW) * 256;
+    // ---- write this workgroup's accumulators: partial[workgroup][wave][slot][reg][lane]
+    double *pp = partial + ((((long)group * g.wpg + g.wg_begin[part] + widx) * FBR_WPB + wave) * FBR_NPW) * 256;
 #pragma unroll
     for (int p = 0; p < FBR_NPW; p++) {
         pp[p * 256 + 0 * 64 + lane] = acc[p][0];
@@ -591,21 +594,21 @@ __global__ __launch_bounds__(FBR_WPB * 64, 2) void fbr_gram_kernel(DevGram g, lo
     }
 }
 
-// Deterministic reduction over the sample slices + scatter into the symmetric G (augmented column order).
+// Deterministic reduction over the workgroups of a part + scatter into the symmetric G (augmented column order).
 // One workgroup (256 threads = 4 regs x 64 lanes) per accumulator slot.  G must be pre-zeroed or hold the
 // running sum: every G entry is touched by exactly one thread.
-__global__ __launch_bounds__(256) void fbr_gram_reduce_kernel(DevGram g, int spg, const double *__restrict__ partial,
-                                                               double *__restrict__ G)
+__global__ __launch_bounds__(256) void fbr_gram_reduce_kernel(DevGram g, const double *__restrict__ partial, double *__restrict__ G)
 {
-    // blockIdx.y = sample group: its spg consecutive slices are summed into G + group * Pa^2 (one group: spg = NS)
+    // blockIdx.y = sample group: the partial sums of its workgroups go to G + group * Pa^2
     const int slot = blockIdx.x;  // (part*WPB + wave)*NPW + p
     const int I = g.slot_tiles[2 * slot], J = g.slot_tiles[2 * slot + 1];
     if (I < 0) return;
     const int t = threadIdx.x, reg = t >> 6, lane = t & 63;
-    const long per_slice = (long)g.T * FBR_WPB * FBR_NPW * 256;
-    const long sl0 = (long)blockIdx.y * spg;
+    const int per_wg = FBR_WPB * g.npw;
+    const int part = slot / per_wg, rem = slot - part * per_wg;
+    const long w0 = (long)blockIdx.y * g.wpg + g.wg_begin[part], w1 = (long)blockIdx.y * g.wpg + g.wg_begin[part + 1];
     double v = 0.0;
-    for (int sl = 0; sl < spg; sl++) v += partial[(sl0 + sl) * per_slice + (long)slot * 256 + t];
+    for (long w = w0; w < w1; w++) v += partial[((w * per_wg + rem) << 8) + t];
     const int row = (lane >> 4) + 4 * reg, col = lane & 15;
     const int ci = g.tilecol[I * FBR_TILE + row], cj = g.tilecol[J * FBR_TILE + col];
     if (ci < 0 || cj < 0) return;

@@ -18,18 +18,30 @@
 #include <vector>
 
 #define FBR_TILE 16
-#define FBR_WPB 8         // waves per workgroup of the Gram kernel (2 per SIMD, one workgroup per CU; 2 x 4 waves measured 3% slower)
-// (overridable with -D for tuning sweeps; the values below are the measured optimum for two workgroups per CU)
-#ifndef FBR_SEGW
-#define FBR_SEGW 5        // tile pairs per row segment (same tile I, up to SEGW different tiles J)
-#endif
-#ifndef FBR_NSEG
-#define FBR_NSEG 2        // row segments per wave
-#endif
-#ifndef FBR_IMG_BUDGET
-#define FBR_IMG_BUDGET 4608  // doubles per LDS image buffer of a part
-#endif
-#define FBR_NPW (FBR_SEGW * FBR_NSEG)  // tile pairs (MFMA accumulators) per wave
+#define FBR_WPB 8         // waves per workgroup of the Gram kernel
+
+// Shape of the streaming Gram kernel.  Two shapes are compiled (fbr_kernels.h) and chosen per model:
+//   two workgroups per CU:  2 row segments x 5 pairs per wave (10 accumulators, ~106 VGPRs, 4 waves / SIMD), LDS images of
+//                           <= 36 KiB -- one workgroup's barrier / DMA phase hides behind the other's MFMAs; best when the
+//                           tile images are small enough that the model still splits into few parts (WALK-MAN: 14);
+//   one workgroup per CU:   3 row segments x 6 pairs per wave (18 accumulators, ~176 VGPRs), LDS images of <= 74 KiB --
+//                           fewer parts and far less image re-reading when the dense (friction) tiles inflate the images
+//                           (WALK-MAN with friction: 7 parts instead of 25; 5.5 vs 3.2 M samples/s).
+struct FbrGramConfig {
+    int segw;        // tile pairs per row segment (same tile I, up to segw different tiles J)
+    int nseg;        // row segments per wave
+    int img_budget;  // doubles per LDS image buffer of a part
+    // cycles per sample of a part's workgroup ~ c0 + cload * (cost units of its most loaded wave) + cmfma * (MFMAs of the part)
+    // + cimg * (image doubles): least squares over the per-part s_memtime phases of WALK-MAN with and without friction
+    // (FBR_GRAM_TIMING=1, tools/gram_shape_probe.py; 7 % / 3 % rms).  Only ratios matter: workgroups are dealt to the parts in
+    // proportion to these costs (fbr_gram_deal).
+    double c0, cload, cmfma, cimg;
+    int npw() const { return segw * nseg; }  // tile pairs (MFMA accumulators) per wave
+    bool operator==(const FbrGramConfig &o) const { return segw == o.segw && nseg == o.nseg && img_budget == o.img_budget; }
+};
+static const FbrGramConfig FBR_CFG_TWO_PER_CU = {5, 2, 4608, 1171.0, 29.0, 30.6, 0.27};
+static const FbrGramConfig FBR_CFG_ONE_PER_CU = {6, 3, 9472, 1873.0, 79.1, 0.0, 0.10};
+#define FBR_MAX_PARTS_TWO_PER_CU 16  // beyond this many parts the small-image shape loses to the large-image one
 #define FBR_MAX_RHS 16
 
 struct FbrCol {
@@ -203,6 +215,9 @@ struct FbrGramProgram {
     std::vector<std::vector<int>> part_tile_off;  // per part: local LDS offset (doubles) of each tile, -1 if absent
     std::vector<std::vector<FbrPiece>> pieces;    // per part: DMA pieces
     std::vector<int> part_image;                  // per part: local image size (doubles)
+    std::vector<int> part_load;                   // per part: cost units of its most loaded wave (2 per MFMA + fixed costs)
+    std::vector<int> part_mfma;                   // per part: MFMAs per sample (all waves)
+    std::vector<double> part_cost;                // per part: modelled cycles per sample of one workgroup (FbrGramConfig)
     int64_t mfma_per_sample = 0;
     int64_t mfma_uniform = 0;  // k-steps that run in row segments whose pairs all share `common` and the operand mode
 
@@ -220,8 +235,12 @@ struct FbrGramProgram {
         return (int)i;
     }
 
-    void build(const FbrHostModel &hm, int k_)
+    FbrGramConfig cfg = FBR_CFG_TWO_PER_CU;
+
+    void build(const FbrHostModel &hm, int k_, const FbrGramConfig &cfg_)
     {
+        cfg = cfg_;
+        const int FBR_SEGW = cfg.segw, FBR_NSEG = cfg.nseg, FBR_NPW = cfg.npw(), FBR_IMG_BUDGET = cfg.img_budget;
         k = k_;
         if (k < 0 || k > FBR_MAX_RHS) throw std::runtime_error("rhs column count must be 0..16");
         Pa = hm.cols + k;
@@ -348,7 +367,7 @@ struct FbrGramProgram {
         const int np = (int)pairs.size();
         const int SEGCAP = FBR_WPB * FBR_NSEG;
         // a part must fit its row segments in WPB*NSEG slots and two copies of its tile image in the LDS
-        const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer: two workgroups per CU x (2 x 36 KiB + tables) < 160 KiB
+        const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer (see FbrGramConfig)
         auto seg_count = [&](int b, int e) {
             std::vector<int> cnt(NT, 0);
             std::vector<char> need(NT, 0);
@@ -397,6 +416,9 @@ struct FbrGramProgram {
         part_tile_off.assign(T, std::vector<int>(NT, -1));
         pieces.assign(T, {});
         part_image.assign(T, 0);
+        part_load.assign(T, 0);
+        part_mfma.assign(T, 0);
+        part_cost.assign(T, 0.0);
         part_image_max = 0;
         for (int t = 0; t < T; t++) {
             struct Seg { int I; std::vector<int> pr; int w; };
@@ -440,6 +462,8 @@ struct FbrGramProgram {
                 }
                 cnt[best]++;
                 load[best] += sgm.w;
+                part_load[t] = std::max(part_load[t], load[best]);
+                for (int pi : sgm.pr) part_mfma[t] += pairs[pi].nk4();
             }
             std::vector<char> need(NT, 0);
             for (int i = part_begin[t]; i < part_begin[t + 1]; i++) need[pairs[i].I] = need[pairs[i].J] = 1;
@@ -451,6 +475,7 @@ struct FbrGramProgram {
                 loff += (tiles[ti].depth + 3) / 4 * 4 * FBR_TILE;
             }
             part_image[t] = loff;
+            part_cost[t] = cfg.c0 + cfg.cload * part_load[t] + cfg.cmfma * part_mfma[t] + cfg.cimg * loff;
             part_image_max = std::max(part_image_max, loff + 4 * FBR_TILE);
             // DMA pieces over maximal runs of tiles that are adjacent both in the global and the local image
             size_t i = 0;
@@ -475,3 +500,29 @@ struct FbrGramProgram {
         }
     }
 };
+
+
+// Deal `slots` workgroups (>= T) to the parts so that the slowest workgroup is as fast as possible: every part gets one, each
+// further one goes to the part with the largest cost per workgroup.  Returns n[part]; deterministic.
+static inline std::vector<int> fbr_gram_deal(const FbrGramProgram &gp, int slots)
+{
+    std::vector<int> n(gp.T, 1);
+    for (int left = slots - gp.T; left > 0; left--) {
+        int best = 0;
+        for (int p = 1; p < gp.T; p++)
+            if (gp.part_cost[p] * n[best] > gp.part_cost[best] * n[p]) best = p;
+        n[best]++;
+    }
+    return n;
+}
+
+// Program for the shape that suits the model: small images / two workgroups per CU unless that splits the pairs into too many parts.
+static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &hm, int k, const char *force = nullptr)
+{
+    if (force && force[0] == 'o') {  // "one"
+        gp.build(hm, k, FBR_CFG_ONE_PER_CU);
+        return;
+    }
+    gp.build(hm, k, FBR_CFG_TWO_PER_CU);
+    if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) gp.build(hm, k, FBR_CFG_ONE_PER_CU);
+}

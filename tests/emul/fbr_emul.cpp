@@ -153,13 +153,21 @@ int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const 
     return 0;
 }
 
+// 0: the product's choice (fbr_gram_build_best), 1: force the one-workgroup-per-CU shape, 2: force the two-per-CU shape
+static int g_shape = 0;
+void emul_set_gram_shape(int shape) { g_shape = shape; }
+static void build_program(FbrGramProgram &gp, const FbrHostModel &hm, int k)
+{
+    fbr_gram_build_best(gp, hm, k, g_shape == 1 ? "one" : g_shape == 2 ? "two" : nullptr);
+}
+
 int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma, int *T, int *image_doubles,
                       int *items_total, long *mfma_uniform)
 {
     FbrHostModel hm;
     make(t, hm);
     FbrGramProgram gp;
-    gp.build(hm, k);
+    build_program(gp, hm, k);
     *NT = gp.NT; *npairs = (int)gp.pairs.size(); *mfma = gp.mfma_per_sample; *T = gp.T;
     *image_doubles = gp.part_image_max;
     long dma = 0;
@@ -167,6 +175,21 @@ int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma
     *items_total = (int)dma;  // doubles copied per sample summed over the parts
     *mfma_uniform = gp.mfma_uniform;
     return 0;
+}
+
+// per part: [load of the most loaded wave, MFMAs, image doubles]; out holds 3 * T ints
+int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrGramProgram gp;
+    build_program(gp, hm, k);
+    for (int p = 0; p < gp.T && p < cap; p++) {
+        out[3 * p] = gp.part_load[p];
+        out[3 * p + 1] = gp.part_mfma[p];
+        out[3 * p + 2] = gp.part_image[p];
+    }
+    return gp.T;
 }
 
 // mirrors fbr_pack_kernel + fbr_gram_kernel + fbr_gram_reduce_kernel: the packed image of each sample is
@@ -179,9 +202,10 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
     FbrHostModel hm;
     make(t, hm);
     FbrGramProgram gp;
-    gp.build(hm, k);
+    build_program(gp, hm, k);
     const int REC = hm.rec_size();
     const int Pa = gp.Pa;
+    const int FBR_NPW = gp.cfg.npw();
     std::vector<double> rec(REC), img(gp.image_doubles, 0.0), loc(gp.part_image_max, 0.0);
     std::vector<double> acc((size_t)gp.T * FBR_WPB * FBR_NPW * 256, 0.0);
     for (long s = 0; s < S; s++) {

@@ -36,7 +36,12 @@ def test_device_math_matches_oracle(cfg):
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=cfg_id)
 @pytest.mark.parametrize("k", [0, 3])
-def test_tile_program_reproduces_gram(cfg, k):
+@pytest.mark.parametrize("shape", [0, 1, 2], ids=["auto", "one_per_cu", "two_per_cu"])
+def test_tile_program_reproduces_gram(cfg, k, shape, request):
+    """Both compiled kernel shapes (FbrGramConfig) and the product's choice between them."""
+    import emul_lib
+    emul_lib.lib().emul_set_gram_shape(shape)
+    request.addfinalizer(lambda: emul_lib.lib().emul_set_gram_shape(0))
     t, om, em, st, sign, rng = _setup(cfg, 12, 2)
     Y = om.regressor(st, sign)
     rhs = rng.standard_normal((Y.shape[0], k)) if k else None
@@ -55,4 +60,21 @@ def test_walkman_program_is_sparse():
     em = Emul(t, floating=True)
     info = em.program_info(1)
     assert info["mfma"] < 0.4 * 4185  # vs 31*32/2 tiles x 9 k-steps of the dense tiling
-    assert info["T"] * 8 * 18 >= info["npairs"]
+    assert info["T"] * 8 * 10 >= info["npairs"]  # two-per-CU shape: 10 accumulators per wave
+    assert info["T"] <= 16
+
+
+def test_friction_layout_takes_the_large_image_shape():
+    """With friction columns the small-image shape would split WALK-MAN into > 16 parts: the chooser must fall back."""
+    import emul_lib
+    t = load_topo("walkman_apriori")
+    em = Emul(t, floating=True, fric=True, fric_sym=False)
+    try:
+        auto = em.program_info(1)
+        emul_lib.lib().emul_set_gram_shape(2)
+        two = em.program_info(1)
+        emul_lib.lib().emul_set_gram_shape(1)
+        one = em.program_info(1)
+    finally:
+        emul_lib.lib().emul_set_gram_shape(0)
+    assert two["T"] > 16 and auto["T"] == one["T"] < two["T"]
