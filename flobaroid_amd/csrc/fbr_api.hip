@@ -670,8 +670,8 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
                     const FbrPair &p = gp.pairs[pi];
                     offA = gp.part_tile_off[part][p.I];
                     const int offB = gp.part_tile_off[part][p.J];
-                    mm[1 + j] = (offB / 64) | (p.common << 10) | ((p.mode == 1 ? 1 : 0) << 18);
-                    nkmax = std::max(nkmax, p.nk4());
+                    mm[1 + j] = (offB / 64) | ((p.mode == 1 ? 1 : 0) << 10) | ((gp.masked ? (int)p.kmask : p.common) << 11);
+                    nkmax = std::max(nkmax, p.nkend());
                     cnt++;
                     slot_tiles[2 * s] = p.I;
                     slot_tiles[2 * s + 1] = p.J;
@@ -766,8 +766,12 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         const int FBR_NPW = h->prog.cfg.npw();
         const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
         typedef void (*gram_fn)(DevGram, long, int, const double *, double *, unsigned long long *);
-        const gram_fn gram_kernel = two_per_cu ? (timing ? fbr_gram_kernel<true, 5, 2> : fbr_gram_kernel<false, 5, 2>)
-                                               : (timing ? fbr_gram_kernel<true, 6, 3> : fbr_gram_kernel<false, 6, 3>);
+        const bool mk = h->prog.masked;
+        const gram_fn gram_kernel =
+            two_per_cu ? (timing ? (mk ? fbr_gram_kernel<true, 5, 2, true> : fbr_gram_kernel<true, 5, 2, false>)
+                                 : (mk ? fbr_gram_kernel<false, 5, 2, true> : fbr_gram_kernel<false, 5, 2, false>))
+                       : (timing ? (mk ? fbr_gram_kernel<true, 6, 3, true> : fbr_gram_kernel<true, 6, 3, false>)
+                                 : (mk ? fbr_gram_kernel<false, 6, 3, true> : fbr_gram_kernel<false, 6, 3, false>));
         HIPCHK(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)fbr_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->pack_lds_bytes));
@@ -798,23 +802,25 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         // producer (kinematics + tile-image packing of chunk i+1) runs on a second stream and shares the CUs with the
         // MFMA-bound Gram kernel of chunk i; the images are double buffered
         HIPCHK(hipEventRecord(m->ev_fork, m->stream));
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        // FBR_GRAM_SERIAL (diagnostic): producer on the main stream, i.e. no overlap with the Gram kernel
+        hipStream_t side = getenv("FBR_GRAM_SERIAL") ? m->stream : m->side;
+        HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
         auto produce = [&](long ci) -> int {
             const long s0 = items[ci].s0, cs = items[ci].cs;
             const int b = (int)(ci & 1);
-            if (ci >= 2) HIPCHK(hipStreamWaitEvent(m->side, m->ev_gram[b], 0));  // Gram of chunk ci-2 is done with this buffer
-            int rc2 = run_kin(m, d, s0, cs, m->side, &m->rec2);
+            if (ci >= 2) HIPCHK(hipStreamWaitEvent(side, m->ev_gram[b], 0));  // Gram of chunk ci-2 is done with this buffer
+            int rc2 = run_kin(m, d, s0, cs, side, &m->rec2);
             if (rc2) return rc2;
             {
-                ProfScope ps(m, FBR_PROF_REGRESSOR, m->side);
+                ProfScope ps(m, FBR_PROF_REGRESSOR, side);
                 const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
-                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, m->side, h->dev, m->dm, cs,
+                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs,
                                    m->rec2.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
                                    h->pimg[b].as<double>());
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(m->ev_pack[b], m->side));
+            HIPCHK(hipEventRecord(m->ev_pack[b], side));
             return FBR_OK;
         };
         if ((rc = produce(0))) return rc;
@@ -878,7 +884,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             }
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipStreamSynchronize(m->side));
+        HIPCHK(hipStreamSynchronize(side));
     }
     return finish_output(m, G, G_out, gcount, out_mem);
 }

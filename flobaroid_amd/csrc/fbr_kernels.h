@@ -28,7 +28,7 @@ struct DevGram {
     int npw;                  // accumulators per wave of the kernel shape the program was built for (segw * nseg)
     const int4 *items;        // every real column: image offset, kind, a, b
     const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | nkmax<<14 ;
-                              //   [1+j] = offB_j/64 | common_j<<10 | lookup_j<<18   (part-local offsets)
+                              //   [1+j] = offB_j/64 | lookup_j<<10 | (masked ? kmask_j : common_j)<<11   (part-local offsets)
     const int *piece_begin;   // [T+1]
     const int2 *pieces;       // x = offset in the global image, y = offset in the part image | half<<30  (doubles)
     const int *rid_begin;     // [T+1]
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, lo
                 const int r = m.fb + d.z;
                 double v = fbr_friction_value(d.w, rs[sg.o_dq + d.z], sign ? rs[sg.o_sign + d.z] : 0.0, m.stribeck);
                 if (ws) v *= ws[r];
-                img[d.x + r * FBR_TILE] = v;
+                img[d.x] = v;  // d.x points at the packed row of the joint
             } else {
                 for (int r = 0; r < m.rows; r++) {
                     double v = rs[sg.o_rhs + r * g.k + d.z];
@@ -458,7 +458,9 @@ typedef __attribute__((address_space(3))) void *fbr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_glb_ptr;
 
 // FBR_SEGW x FBR_NSEG: the wave's accumulator shape (FbrGramConfig, fbr_program.h); (5,2) must fit 128 VGPRs (two workgroups per CU).
-template <bool TIMING, int FBR_SEGW, int FBR_NSEG>
+// MASKED: k-step ks of a pair runs iff bit ks of its mask is set (friction layouts); otherwise iff 4 ks < common (every pair runs a
+// prefix of the k-steps: one scalar instruction less per pair and k-step, 3 % on WALK-MAN).
+template <bool TIMING, int FBR_SEGW, int FBR_NSEG, bool MASKED>
 __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) void fbr_gram_kernel(DevGram g, long S, int NG, const double *__restrict__ pimg,
                                                            double *__restrict__ partial, unsigned long long *__restrict__ dbg)
 {
@@ -561,16 +563,15 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
                 const int vlk = pr[4 * ks] * FBR_TILE + li;   // operand row through the row map (chain x dense pairs)
                 const int vpos = 64 * ks + lane;
                 double b[FBR_SEGW];
+                const int kbit = 2048 << ks;
+                auto runs = [&](int mjv) { return MASKED ? (mjv & kbit) != 0 : 4 * ks < ((mjv >> 11) & 0xff); };
+#pragma unroll
+                for (int j = 0; j < FBR_SEGW; j++)
+                    if (runs(mj[j])) b[j] = img[((mj[j] & 0x3ff) << 6) + (((mj[j] >> 10) & 1) ? vlk : vpos)];
 #pragma unroll
                 for (int j = 0; j < FBR_SEGW; j++) {
-                    const int common = (mj[j] >> 10) & 0xff;
-                    if (4 * ks < common) b[j] = img[((mj[j] & 0x3ff) << 6) + (((mj[j] >> 18) & 1) ? vlk : vpos)];
-                }
-#pragma unroll
-                for (int j = 0; j < FBR_SEGW; j++) {
-                    const int common = (mj[j] >> 10) & 0xff;
-                    // no operand masking: rows past `common` are zero in at least one tile (aligned packing)
-                    if (4 * ks < common)
+                    // no operand masking: a k-step either runs whole or is structurally zero (aligned packing, k-step masks)
+                    if (runs(mj[j]))
                         acc[sgi * FBR_SEGW + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[sgi * FBR_SEGW + j], 0, 0, 0);
                 }
             }

@@ -41,7 +41,8 @@ struct FbrGramConfig {
 };
 static const FbrGramConfig FBR_CFG_TWO_PER_CU = {5, 2, 4608, 1171.0, 29.0, 30.6, 0.27};
 static const FbrGramConfig FBR_CFG_ONE_PER_CU = {6, 3, 9472, 1873.0, 79.1, 0.0, 0.10};
-#define FBR_MAX_PARTS_TWO_PER_CU 16  // beyond this many parts the small-image shape loses to the large-image one
+#define FBR_MAX_PARTS_TWO_PER_CU 20  // beyond this many parts the small-image shape loses to the large-image one
+                                    // (WALK-MAN floating base, tools/gram_shape_probe.py: 18 parts 6.8 vs 5.8 M samples/s, 26 parts 4.2 vs 5.8)
 #define FBR_MAX_RHS 16
 
 struct FbrCol {
@@ -178,12 +179,19 @@ struct FbrTile {
     int off = 0;                  // offset (doubles) of the tile inside the per-sample LDS image
     int col[FBR_TILE];            // augmented column id per slot, -1 = padding
     std::vector<int> rowid;       // chain: global row of each packed position
+    int friction = 0;             // chain tile of friction columns
+    int okey = 0;                 // traversal position of the tile's last link (tile order)
+    std::vector<char> rowreal;    // chain: 1 = the packed position holds a regressor row (0 = alignment gap, always zero)
+    std::vector<char> posnz;      // chain: 1 = some column of the tile can be non-zero in that packed position
+    std::vector<char> rownz;      // dense: 1 = some column of the tile can be non-zero in that regressor row
     std::vector<int> tpath;       // chain: dof path of the deepest link
     std::vector<int> tpos;        // chain: packed position of each joint of tpath
 };
 struct FbrPair {
     int I, J, common, mode;  // mode 0: both packed by position; 1: B rows looked up through rowid_I; 2: dense x dense
-    int nk4() const { return (common + 3) / 4; }
+    unsigned kmask = 0;      // k-step ks (tile-I rows 4ks..4ks+3) runs iff bit ks is set: the others are structurally zero
+    int nk4() const { return __builtin_popcount(kmask); }              // MFMAs per sample
+    int nkend() const { return kmask ? 32 - __builtin_clz(kmask) : 0; }  // one past the last k-step that runs
 };
 struct FbrItem {  // one producer work item = one real column of one tile
     int off;      // LDS offset of (tile, slot): tile.off + slot
@@ -218,6 +226,7 @@ struct FbrGramProgram {
     std::vector<int> part_load;                   // per part: cost units of its most loaded wave (2 per MFMA + fixed costs)
     std::vector<int> part_mfma;                   // per part: MFMAs per sample (all waves)
     std::vector<double> part_cost;                // per part: modelled cycles per sample of one workgroup (FbrGramConfig)
+    bool masked = false;       // some pair skips k-steps inside its common rows (friction columns): the kernel tests k-step masks
     int64_t mfma_per_sample = 0;
     int64_t mfma_uniform = 0;  // k-steps that run in row segments whose pairs all share `common` and the operand mode
 
@@ -245,10 +254,15 @@ struct FbrGramProgram {
         if (k < 0 || k > FBR_MAX_RHS) throw std::runtime_error("rhs column count must be 0..16");
         Pa = hm.cols + k;
         rows_pad = (hm.rows + 3) / 4 * 4;
+        if (rows_pad > 60) throw std::runtime_error("more than 60 regressor rows per sample (15 MFMA k-steps) are not supported");
         tiles.clear();
         pairs.clear();
-        // ---- chain tiles over the inertial columns, links in traversal order
-        {
+        // ---- chain tiles, links in traversal order: first the inertial columns, then (own tiles) the friction columns.
+        //      A friction column of joint j is a chain column that is non-zero in one packed row only, the position of j
+        //      (model.py:459-503): stored like this it shares the positional addressing of the chain tiles and its
+        //      products with links that do not hang below j vanish from the pair list.
+        const int F = hm.n > 0 ? (hm.cols - hm.cpl * hm.L) / hm.n : 0;  // friction columns per joint
+        for (int pass = 0; pass < (F > 0 ? 2 : 1); pass++) {
             FbrTile cur;
             int fill = 0;
             bool open = false;
@@ -258,12 +272,16 @@ struct FbrGramProgram {
                 tiles.push_back(cur);
                 open = false;
             };
-            for (int l : hm.order) {
-                for (int p = 0; p < hm.cpl; p++) {
+            for (size_t oi = 0; oi < hm.order.size(); oi++) {
+                const int l = hm.order[oi];
+                if (pass == 1 && hm.dof[l] < 0) continue;
+                const int ncol = pass == 0 ? hm.cpl : F;
+                for (int p = 0; p < ncol; p++) {
                     if (open && (fill == FBR_TILE || !nested(cur.tpath, hm.path[l]))) close();
                     if (!open) {
                         cur = FbrTile();
                         cur.type = 0;
+                        cur.friction = pass;
                         cur.tpath = hm.path[l];
                         cur.tpos = hm.ppos[l];
                         cur.depth = hm.pdepth[l];
@@ -275,25 +293,47 @@ struct FbrGramProgram {
                         cur.tpos = hm.ppos[l];
                         cur.depth = hm.pdepth[l];
                     }
-                    cur.col[fill++] = hm.cpl * l + p;
+                    cur.col[fill++] = pass == 0 ? hm.cpl * l + p : hm.cpl * hm.L + p * hm.n + hm.dof[l];
+                    cur.okey = 2 * (int)oi + pass;
                 }
             }
             close();
         }
+        // a friction tile follows the inertial tile of the same links: the pairs that survive lie near the diagonal of the
+        // (I, J) triangle and a part of the pair list touches few tiles
+        std::stable_sort(tiles.begin(), tiles.end(), [](const FbrTile &a, const FbrTile &b) { return a.okey < b.okey; });
         for (auto &t : tiles) {
             // packed position -> regressor row (alignment gaps map to row 0; their image rows are zero)
             t.rowid.assign(t.depth, 0);
-            for (int i = 0; i < hm.fb; i++) t.rowid[i] = i;
-            for (size_t j = 0; j < t.tpath.size(); j++) t.rowid[t.tpos[j]] = hm.fb + t.tpath[j];
+            t.rowreal.assign(t.depth, 0);
+            for (int i = 0; i < hm.fb; i++) {
+                t.rowid[i] = i;
+                t.rowreal[i] = 1;
+            }
+            for (size_t j = 0; j < t.tpath.size(); j++) {
+                t.rowid[t.tpos[j]] = hm.fb + t.tpath[j];
+                t.rowreal[t.tpos[j]] = 1;
+            }
+            t.posnz = t.rowreal;
+            if (t.friction) {  // only the positions of the tile's own joints
+                t.posnz.assign(t.depth, 0);
+                for (int sl = 0; sl < FBR_TILE; sl++) {
+                    if (t.col[sl] < 0) continue;
+                    const int jnt = hm.coldesc[t.col[sl]].joint;
+                    for (size_t j = 0; j < t.tpath.size(); j++)
+                        if (t.tpath[j] == jnt) t.posnz[t.tpos[j]] = 1;
+                }
+            }
         }
-        // ---- dense tiles: friction columns then rhs columns
+        // ---- dense tiles: rhs columns, all rows in regressor order
         {
-            int c = hm.cpl * hm.L;
+            int c = hm.cols;
             while (c < Pa) {
                 FbrTile t;
                 t.type = 1;
                 t.depth = hm.rows;
                 for (int s = 0; s < FBR_TILE; s++) t.col[s] = (c < Pa) ? c++ : -1;
+                t.rownz.assign(hm.rows, 1);
                 tiles.push_back(t);
             }
         }
@@ -321,6 +361,9 @@ struct FbrGramProgram {
                     it.kind = 0; it.a = hm.coldesc[c].link; it.b = hm.coldesc[c].pidx;
                 } else {
                     it.kind = 1; it.a = hm.coldesc[c].joint; it.b = hm.coldesc[c].pidx;
+                    const FbrTile &t = tiles[ti];  // the one image row of the column: the packed position of its joint
+                    for (size_t j = 0; j < t.tpath.size(); j++)
+                        if (t.tpath[j] == it.a) it.off += t.tpos[j] * FBR_TILE;
                 }
                 items.push_back(it);
             }
@@ -332,6 +375,7 @@ struct FbrGramProgram {
         BE = std::max(FBR_SEGW, BE / FBR_SEGW * FBR_SEGW);  // block rows split into whole row segments
         mfma_per_sample = 0;
         mfma_uniform = 0;
+        masked = false;
         const int NB = (NT + BE - 1) / BE;
         for (int bi = 0; bi < NB; bi++)
             for (int bj = bi; bj < NB; bj++)
@@ -357,7 +401,22 @@ struct FbrGramProgram {
                         } else {
                             throw std::runtime_error("dense tile before chain tile");
                         }
-                        if (p.common == 0) continue;  // structurally zero block (fixed base, disjoint branches)
+                        // k-steps that can contribute: the ones holding a row in which both tiles can be non-zero (friction
+                        // columns: one row each)
+                        for (int ks = 0; 4 * ks < p.common; ks++) {
+                            bool on = false;
+                            for (int r = 4 * ks; r < std::min(4 * ks + 4, p.common) && !on; r++) {
+                                if (p.mode == 0)
+                                    on = a.posnz[r] && b.posnz[r];
+                                else if (p.mode == 1)
+                                    on = a.posnz[r] && b.rownz[a.rowid[r]];
+                                else
+                                    on = a.rownz[r] && b.rownz[r];
+                            }
+                            if (on) p.kmask |= 1u << ks;
+                        }
+                        if (p.kmask != (1u << ((p.common + 3) / 4)) - 1) masked = true;
+                        if (p.kmask == 0) continue;  // structurally zero block (fixed base, disjoint branches, friction of other joints)
                         pairs.push_back(p);
                         mfma_per_sample += p.nk4();
                     }
@@ -438,7 +497,7 @@ struct FbrGramProgram {
                         for (size_t j = o; j < std::min(v.size(), o + FBR_SEGW); j++) {
                             sgm.pr.push_back(v[j]);
                             sgm.w += 2 * pairs[v[j]].nk4();  // one MFMA = 2 cost units
-                            nkmax = std::max(nkmax, pairs[v[j]].nk4());
+                            nkmax = std::max(nkmax, pairs[v[j]].nkend());
                         }
                         sgm.w += 3 + 3 * nkmax;  // measured fixed cost: segment preamble + per-k-step A / row-map fetch
                         segs.push_back(sgm);
@@ -457,7 +516,7 @@ struct FbrGramProgram {
                 {
                     bool uni = true;
                     for (int pi : sgm.pr)
-                        uni = uni && pairs[pi].common == pairs[sgm.pr[0]].common && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
+                        uni = uni && pairs[pi].kmask == pairs[sgm.pr[0]].kmask && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
                     if (uni) for (int pi : sgm.pr) mfma_uniform += pairs[pi].nk4();
                 }
                 cnt[best]++;

@@ -225,7 +225,7 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                 }
             } else if (it.kind == 1) {
                 int r = hm.fb + it.a;
-                img[it.off + r * FBR_TILE] =
+                img[it.off] =
                     fbr_friction_value(it.b, dq[s * hm.n + it.a], sign ? sign[s * hm.n + it.a] : 0.0, hm.stribeck) *
                     (ws ? ws[r] : 1.0);
             } else {
@@ -251,7 +251,8 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                     const int oA = gp.part_tile_off[part][p.I], oB = gp.part_tile_off[part][p.J];
                     if (oA < 0 || oB < 0 || (oA % 64) || (oB % 64)) return -7;
                     double *a4 = &acc[(((size_t)part * FBR_WPB + w) * FBR_NPW + sl) * 256];
-                    for (int ks = 0; ks < p.nk4(); ks++) {
+                    for (int ks = 0; ks < p.nkend(); ks++) {
+                        if (!((p.kmask >> ks) & 1)) continue;
                         double A[16][4], B[4][16];
                         for (int lane = 0; lane < 64; lane++) {
                             int i = lane & 15, kk = lane >> 4;

@@ -51,7 +51,9 @@ def test_tile_program_reproduces_gram(cfg, k, shape, request):
     assert np.linalg.norm(G - A.T @ A) <= 1e-13 * np.linalg.norm(A.T @ A)
     info = em.program_info(k)
     dense = ((om.P + k + 15) // 16) * ((om.P + k + 15) // 16 + 1) // 2 * ((om.rows + 3) // 4)
-    assert info["mfma"] <= dense * 1.35  # the chain packing must never cost much more than the dense tiling
+    # the chain packing must never cost much more than the dense tiling (friction and rhs columns have tiles of their own:
+    # a few MFMAs of absolute slack for the two-joint toy model)
+    assert info["mfma"] <= dense * 1.35 + 6
     assert 2 * info["part_image_max"] * 8 <= 150 * 1024  # two DMA buffers of the largest part fit the LDS
 
 
@@ -61,14 +63,15 @@ def test_walkman_program_is_sparse():
     info = em.program_info(1)
     assert info["mfma"] < 0.4 * 4185  # vs 31*32/2 tiles x 9 k-steps of the dense tiling
     assert info["T"] * 8 * 10 >= info["npairs"]  # two-per-CU shape: 10 accumulators per wave
-    assert info["T"] <= 16
+    assert info["T"] <= 20
 
 
-def test_friction_layout_takes_the_large_image_shape():
-    """With friction columns the small-image shape would split WALK-MAN into > 16 parts: the chooser must fall back."""
+@pytest.mark.parametrize("fric,sym", [(False, True), (True, True), (True, False)])
+def test_shape_chooser_rule(fric, sym):
+    """fbr_gram_build_best: the two-workgroups-per-CU shape unless it splits the model into more than 20 parts."""
     import emul_lib
     t = load_topo("walkman_apriori")
-    em = Emul(t, floating=True, fric=True, fric_sym=False)
+    em = Emul(t, floating=True, fric=fric, fric_sym=sym)
     try:
         auto = em.program_info(1)
         emul_lib.lib().emul_set_gram_shape(2)
@@ -77,4 +80,7 @@ def test_friction_layout_takes_the_large_image_shape():
         one = em.program_info(1)
     finally:
         emul_lib.lib().emul_set_gram_shape(0)
-    assert two["T"] > 16 and auto["T"] == one["T"] < two["T"]
+    assert one["T"] < two["T"] and one["mfma"] == two["mfma"]
+    assert auto["T"] == (two["T"] if two["T"] <= 20 else one["T"])
+    if fric:  # friction columns cost few MFMAs: one packed row each, no products with links of other branches
+        assert auto["mfma"] < 1.1 * 1529
