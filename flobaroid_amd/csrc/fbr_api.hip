@@ -27,9 +27,29 @@ static void set_err(const std::string &s) { g_err = s; }
         }                                                                                       \
     } while (0)
 
-struct DevBuf {
+struct DevBuf {  // owning device allocation (move-only)
     void *p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes)
+    {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            p = o.p;
+            bytes = o.bytes;
+            o.p = nullptr;
+            o.bytes = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
     int ensure(size_t need)
     {
         if (need <= bytes) return FBR_OK;
@@ -124,6 +144,28 @@ struct fbr_model {
     std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
     double prof_ms[FBR_PROF_COUNT] = {0};
     int64_t prof_n[FBR_PROF_COUNT] = {0};
+
+    fbr_model() = default;
+    fbr_model(const fbr_model &) = delete;
+    fbr_model &operator=(const fbr_model &) = delete;
+    // Releases what the handle owns besides its DevBufs (also on the error paths of fbr_model_create, through unique_ptr).
+    ~fbr_model()
+    {
+        fbr_model *m = this;
+        (void)hipSetDevice(m->device);
+        m->tsqr.release();
+        for (auto &e : m->ev_pool) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        if (m->side) (void)hipStreamDestroy(m->side);
+        for (int i = 0; i < 2; i++) {
+            if (m->ev_pack[i]) (void)hipEventDestroy(m->ev_pack[i]);
+            if (m->ev_gram[i]) (void)hipEventDestroy(m->ev_gram[i]);
+        }
+        if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+        if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    }
 };
 
 // Bracket a launch with events (no-op unless profiling is on).
@@ -265,32 +307,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
 
 extern "C" void fbr_model_destroy(fbr_model *m)
 {
-    if (!m) return;
-    (void)hipSetDevice(m->device);
-    for (auto &b : m->tables) b.release();
-    for (auto &kv : m->gram) {
-        for (auto &b : kv.second->pool) b.release();
-        kv.second->pimg[0].release();
-        kv.second->pimg[1].release();
-    }
-    DevBuf *bufs[] = {&m->st_q, &m->st_dq, &m->st_ddq, &m->st_bv, &m->st_ba, &m->st_rpy, &m->st_sign, &m->st_aux,
-                      &m->st_aux2, &m->st_x, &m->rec, &m->partial, &m->out_tmp, &m->g_tmp};
-    for (DevBuf *b : bufs) b->release();
-    for (DevBuf &b : m->fd) b.release();
-    m->tsqr.release();
-    for (auto &e : m->ev_pool) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
-    if (m->side) (void)hipStreamDestroy(m->side);
-    for (int i = 0; i < 2; i++) {
-        if (m->ev_pack[i]) (void)hipEventDestroy(m->ev_pack[i]);
-        if (m->ev_gram[i]) (void)hipEventDestroy(m->ev_gram[i]);
-    }
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    m->rec2.release();
-    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
-    delete m;
+    delete m;  // ~fbr_model releases the device memory, streams and events
 }
 
 extern "C" int fbr_model_dims(const fbr_model *m, int32_t *rows, int32_t *cols)
@@ -862,19 +879,22 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                 HIPCHK(hipMemcpyAsync(hb.data(), dbg, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
                 HIPCHK(hipStreamSynchronize(m->stream));
                 static const char *names[3] = {"wait_dma+barrier", "dma_issue", "mfma"};
-                std::vector<double> sum((size_t)T * 3, 0.0), ns(T, 0.0), nw(T, 0.0);
+                std::vector<double> sum((size_t)T * 3, 0.0), ns(T, 0.0), nw(T, 0.0), wv((size_t)T * FBR_WPB, 0.0);
                 for (size_t e = 0; e + 8 <= hb.size(); e += 8) {
                     const int part = (int)hb[e + 6];
                     if (part < 0 || part >= T) continue;
                     for (int i = 0; i < 3; i++) sum[(size_t)part * 3 + i] += (double)hb[e + i];
                     ns[part] += (double)hb[e + 7];
                     nw[part] += 1.0;
+                    wv[(size_t)part * FBR_WPB + (e / 8) % FBR_WPB] += (double)hb[e + 2];
                 }
                 for (int part = 0; part < T; part++) {
                     fprintf(stderr, "[fbr gram timing] part %d (cycles per sample per wave):", part);
                     for (int i = 0; i < 3; i++) fprintf(stderr, " %s=%.0f", names[i], sum[(size_t)part * 3 + i] / std::max(ns[part], 1.0));
-                    fprintf(stderr, " | workgroups=%.0f cycles per workgroup=%.0f\n", nw[part] / FBR_WPB,
+                    fprintf(stderr, " | workgroups=%.0f cycles per workgroup=%.0f | mfma phase per wave:", nw[part] / FBR_WPB,
                             (sum[(size_t)part * 3] + sum[(size_t)part * 3 + 1] + sum[(size_t)part * 3 + 2]) / std::max(nw[part], 1.0));
+                    for (int w = 0; w < FBR_WPB; w++) fprintf(stderr, " %.0f", wv[(size_t)part * FBR_WPB + w] * FBR_WPB / std::max(ns[part], 1.0));
+                    fprintf(stderr, "\n");
                 }
             }
             {

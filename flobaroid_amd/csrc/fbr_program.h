@@ -13,6 +13,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -37,7 +39,7 @@ struct FbrGramConfig {
     // proportion to these costs (fbr_gram_deal).
     double c0, cload, cmfma, cimg;
     int npw() const { return segw * nseg; }  // tile pairs (MFMA accumulators) per wave
-    bool operator==(const FbrGramConfig &o) const { return segw == o.segw && nseg == o.nseg && img_budget == o.img_budget; }
+    bool operator==(const FbrGramConfig &o) const { return segw == o.segw && nseg == o.nseg && img_budget == o.img_budget; }  // same kernel shape
 };
 static const FbrGramConfig FBR_CFG_TWO_PER_CU = {5, 2, 4608, 1171.0, 29.0, 30.6, 0.27};
 static const FbrGramConfig FBR_CFG_ONE_PER_CU = {6, 3, 9472, 1873.0, 79.1, 0.0, 0.10};
@@ -422,52 +424,108 @@ struct FbrGramProgram {
                     }
         // ---- parts: contiguous chunks of the pair list.  Inside a part the pairs are grouped into ROW SEGMENTS
         //      (same tile I, <= SEGW tiles J, sorted by k-steps descending): a wave loads the A fragment of (I, ks)
-        //      once and feeds up to SEGW independent accumulators with it.  A part holds <= WPB*NSEG segments.
+        //      once and feeds up to SEGW independent accumulators with it.  A part holds <= WPB*NSEG segments, dealt to
+        //      the waves longest-first; two copies of its tile image must fit the LDS budget.
         const int np = (int)pairs.size();
         const int SEGCAP = FBR_WPB * FBR_NSEG;
-        // a part must fit its row segments in WPB*NSEG slots and two copies of its tile image in the LDS
         const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer (see FbrGramConfig)
-        auto seg_count = [&](int b, int e) {
-            std::vector<int> cnt(NT, 0);
-            std::vector<char> need(NT, 0);
-            for (int i = b; i < e; i++) {
-                cnt[pairs[i].I]++;
-                need[pairs[i].I] = need[pairs[i].J] = 1;
-            }
-            int n = 0, img = 4 * FBR_TILE;
-            for (int c : cnt) n += (c + FBR_SEGW - 1) / FBR_SEGW;
-            for (int ti = 0; ti < NT; ti++)
-                if (need[ti]) img += (tiles[ti].depth + 3) / 4 * 4 * FBR_TILE;
-            if (img > IMG_BUDGET) {
-                if (e - b <= 1) throw std::runtime_error("a single tile pair exceeds the LDS image budget (too many rows per sample)");
-                return SEGCAP + 1;
-            }
-            return n;
+        struct Seg { int I; std::vector<int> pr; int w; };
+        struct Plan {
+            std::vector<std::vector<Seg>> ws;  // per wave: its row segments
+            int load[FBR_WPB];                 // cost units per wave (incl. the late-wave penalty)
+            int maxload, mfma, img;
+            double cost;
         };
-        int64_t total_w = 0;
-        for (auto &p : pairs) total_w += p.nk4();
-        std::vector<int> part_begin;
-        for (T = std::max(1, (np + PPB - 1) / PPB);; T++) {
-            part_begin.assign(T + 1, 0);
-            int idx = 0;
-            int64_t done = 0;
-            bool ok = true;
-            for (int t = 0; t < T && ok; t++) {
-                part_begin[t] = idx;
-                const int64_t target = (total_w - done + (T - t) - 1) / (T - t);
-                int64_t acc = 0;
-                while (idx < np) {
-                    if (acc >= target && t + 1 < T) break;
-                    if (seg_count(part_begin[t], idx + 1) > SEGCAP) break;
-                    acc += pairs[idx].nk4();
-                    idx++;
-                }
-                done += acc;
+        // cost of a row segment: 2 units per MFMA + measured fixed cost (segment preamble, per-k-step A / row-map fetch)
+        auto seg_cost = [&](const Seg &sg) {
+            int c = 3, nkmax = 0;
+            for (int pi : sg.pr) {
+                c += 2 * pairs[pi].nk4();
+                nkmax = std::max(nkmax, pairs[pi].nkend());
             }
-            part_begin[T] = np;
-            if (idx == np) break;
-            if (T > np + 1) throw std::runtime_error("internal: pair partition failed");
-            (void)ok;
+            return c + 3 * nkmax;
+        };
+        std::vector<int> stamp(NT, -1);
+        int stamp_gen = 0;
+        std::vector<std::pair<int, int>> order_buf;
+        // plan of the part pairs[b..e): false if it does not fit.  Waves 4..7 share their SIMDs with the older waves 0..3, which
+        // the arbiter favours: measured, they finish the MFMA phase about 10 cost units later at equal load.
+        auto plan_part = [&](int b, int e, Plan &pl) -> bool {
+            stamp_gen++;
+            int img = 0;
+            auto need = [&](int ti) {
+                if (stamp[ti] != stamp_gen) {
+                    stamp[ti] = stamp_gen;
+                    img += (tiles[ti].depth + 3) / 4 * 4 * FBR_TILE;
+                }
+            };
+            order_buf.clear();
+            for (int i = b; i < e; i++) {
+                need(pairs[i].I);
+                need(pairs[i].J);
+                order_buf.emplace_back(pairs[i].I, i);
+            }
+            if (img + 4 * FBR_TILE > IMG_BUDGET) return false;
+            std::stable_sort(order_buf.begin(), order_buf.end(), [&](const std::pair<int, int> &x, const std::pair<int, int> &y) {
+                if (x.first != y.first) return x.first < y.first;
+                const FbrPair &px = pairs[x.second], &py = pairs[y.second];
+                if (px.common != py.common) return px.common > py.common;
+                return px.mode < py.mode;
+            });
+            std::vector<Seg> segs;
+            for (size_t o = 0; o < order_buf.size();) {
+                Seg sg{order_buf[o].first, {}, 0};
+                while (o < order_buf.size() && order_buf[o].first == sg.I && (int)sg.pr.size() < FBR_SEGW) sg.pr.push_back(order_buf[o++].second);
+                sg.w = seg_cost(sg);
+                segs.push_back(std::move(sg));
+            }
+            if ((int)segs.size() > SEGCAP) return false;
+            std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.w > y.w; });
+            pl.ws.assign(FBR_WPB, {});
+            pl.mfma = 0;
+            for (int w = 0; w < FBR_WPB; w++) pl.load[w] = w >= FBR_WPB / 2 ? 10 : 0;
+            for (Seg &sg : segs) {
+                int best = -1;
+                for (int w = 0; w < FBR_WPB; w++)
+                    if ((int)pl.ws[w].size() < FBR_NSEG && (best < 0 || pl.load[w] < pl.load[best])) best = w;
+                pl.load[best] += sg.w;
+                for (int pi : sg.pr) pl.mfma += pairs[pi].nk4();
+                pl.ws[best].push_back(std::move(sg));
+            }
+            pl.maxload = 0;
+            for (int w = 0; w < FBR_WPB; w++)
+                if (!pl.ws[w].empty()) pl.maxload = std::max(pl.maxload, pl.load[w]);
+            pl.img = img;
+            pl.cost = cfg.c0 + cfg.cload * pl.maxload + cfg.cmfma * pl.mfma + cfg.cimg * img;
+            return true;
+        };
+        // The cuts minimise the summed modelled cost of the parts (dynamic programme over the cut positions): workgroups are
+        // dealt to the parts in proportion to their cost, so the pass time is proportional to that sum.  It trades the
+        // number of parts (fixed cost per sample and part), the image volume and the balance of the waves inside a part
+        // (the per-sample barrier waits for the most loaded wave).
+        std::vector<int> part_begin;
+        {
+            const double INF = 1e300;
+            std::vector<double> best(np + 1, INF);
+            std::vector<int> from(np + 1, -1);
+            best[0] = 0.0;
+            Plan pl;
+            for (int i = 1; i <= np; i++)
+                for (int j = i - 1; j >= std::max(0, i - PPB); j--) {
+                    if (!plan_part(j, i, pl)) {
+                        if (i - j == 1) throw std::runtime_error("a single tile pair exceeds the LDS image budget (too many rows per sample)");
+                        break;  // a longer part ending at i cannot fit either
+                    }
+                    if (best[j] + pl.cost < best[i]) {
+                        best[i] = best[j] + pl.cost;
+                        from[i] = j;
+                    }
+                }
+            for (int i = np; i > 0; i = from[i]) part_begin.push_back(i);
+            part_begin.push_back(0);
+            std::reverse(part_begin.begin(), part_begin.end());
+            T = std::max(1, (int)part_begin.size() - 1);
+            if (np == 0) part_begin.assign(2, 0);
         }
         // ---- segments and slots: LPT assignment of each part's segments to its waves; part-local images, DMA pieces
         slots.assign((size_t)T * PPB, FbrSlot{-1});
@@ -480,49 +538,21 @@ struct FbrGramProgram {
         part_cost.assign(T, 0.0);
         part_image_max = 0;
         for (int t = 0; t < T; t++) {
-            struct Seg { int I; std::vector<int> pr; int w; };
-            std::vector<Seg> segs;
-            {
-                std::vector<std::vector<int>> byI(NT);
-                for (int i = part_begin[t]; i < part_begin[t + 1]; i++) byI[pairs[i].I].push_back(i);
-                for (int I = 0; I < NT; I++) {
-                    auto &v = byI[I];
-                    std::stable_sort(v.begin(), v.end(), [&](int x, int y) {
-                        if (pairs[x].common != pairs[y].common) return pairs[x].common > pairs[y].common;
-                        return pairs[x].mode < pairs[y].mode;
-                    });
-                    for (size_t o = 0; o < v.size(); o += FBR_SEGW) {
-                        Seg sgm{I, {}, 0};
-                        int nkmax = 0;
-                        for (size_t j = o; j < std::min(v.size(), o + FBR_SEGW); j++) {
-                            sgm.pr.push_back(v[j]);
-                            sgm.w += 2 * pairs[v[j]].nk4();  // one MFMA = 2 cost units
-                            nkmax = std::max(nkmax, pairs[v[j]].nkend());
-                        }
-                        sgm.w += 3 + 3 * nkmax;  // measured fixed cost: segment preamble + per-k-step A / row-map fetch
-                        segs.push_back(sgm);
-                    }
-                }
-            }
-            if ((int)segs.size() > SEGCAP) throw std::runtime_error("internal: too many row segments in a part");
-            std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.w > b.w; });
-            int load[FBR_WPB] = {0}, cnt[FBR_WPB] = {0};
-            for (auto &sgm : segs) {
-                int best = -1;
+            Plan pl;
+            if (part_begin[t + 1] > part_begin[t]) {
+                if (!plan_part(part_begin[t], part_begin[t + 1], pl)) throw std::runtime_error("internal: part does not fit");
                 for (int w = 0; w < FBR_WPB; w++)
-                    if (cnt[w] < FBR_NSEG && (best < 0 || load[w] < load[best])) best = w;
-                for (size_t j = 0; j < sgm.pr.size(); j++)
-                    slots[((size_t)t * FBR_WPB + best) * FBR_NPW + cnt[best] * FBR_SEGW + j].pair = sgm.pr[j];
-                {
-                    bool uni = true;
-                    for (int pi : sgm.pr)
-                        uni = uni && pairs[pi].kmask == pairs[sgm.pr[0]].kmask && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
-                    if (uni) for (int pi : sgm.pr) mfma_uniform += pairs[pi].nk4();
-                }
-                cnt[best]++;
-                load[best] += sgm.w;
-                part_load[t] = std::max(part_load[t], load[best]);
-                for (int pi : sgm.pr) part_mfma[t] += pairs[pi].nk4();
+                    for (int sgi = 0; sgi < (int)pl.ws[w].size(); sgi++) {
+                        const Seg &sgm = pl.ws[w][sgi];
+                        for (size_t j = 0; j < sgm.pr.size(); j++)
+                            slots[((size_t)t * FBR_WPB + w) * FBR_NPW + sgi * FBR_SEGW + j].pair = sgm.pr[j];
+                        bool uni = true;
+                        for (int pi : sgm.pr)
+                            uni = uni && pairs[pi].kmask == pairs[sgm.pr[0]].kmask && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
+                        if (uni) for (int pi : sgm.pr) mfma_uniform += pairs[pi].nk4();
+                    }
+                part_load[t] = pl.maxload;
+                part_mfma[t] = pl.mfma;
             }
             std::vector<char> need(NT, 0);
             for (int i = part_begin[t]; i < part_begin[t + 1]; i++) need[pairs[i].I] = need[pairs[i].J] = 1;
@@ -578,10 +608,14 @@ static inline std::vector<int> fbr_gram_deal(const FbrGramProgram &gp, int slots
 // Program for the shape that suits the model: small images / two workgroups per CU unless that splits the pairs into too many parts.
 static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &hm, int k, const char *force = nullptr)
 {
+    FbrGramConfig two = FBR_CFG_TWO_PER_CU, one = FBR_CFG_ONE_PER_CU;
+    if (const char *e = getenv("FBR_GRAM_COST")) {  // experiments: "c0,cload,cmfma,cimg" of the two-per-CU shape [; same for one]
+        sscanf(e, "%lf,%lf,%lf,%lf;%lf,%lf,%lf,%lf", &two.c0, &two.cload, &two.cmfma, &two.cimg, &one.c0, &one.cload, &one.cmfma, &one.cimg);
+    }
     if (force && force[0] == 'o') {  // "one"
-        gp.build(hm, k, FBR_CFG_ONE_PER_CU);
+        gp.build(hm, k, one);
         return;
     }
-    gp.build(hm, k, FBR_CFG_TWO_PER_CU);
-    if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) gp.build(hm, k, FBR_CFG_ONE_PER_CU);
+    gp.build(hm, k, two);
+    if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) gp.build(hm, k, one);
 }
