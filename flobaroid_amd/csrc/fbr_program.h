@@ -247,6 +247,13 @@ struct FbrGramProgram {
     }
 
     FbrGramConfig cfg = FBR_CFG_TWO_PER_CU;
+    int block_edge = 0;  // > 0: edge of the square blocks in which the pair triangle is enumerated (fbr_gram_build_best tries several)
+    double total_cost() const
+    {
+        double c = 0.0;
+        for (double x : part_cost) c += x;
+        return c;
+    }
 
     void build(const FbrHostModel &hm, int k_, const FbrGramConfig &cfg_)
     {
@@ -375,6 +382,7 @@ struct FbrGramProgram {
         int BE = 1;
         while ((BE + 1) * (BE + 1) <= PPB) BE++;
         BE = std::max(FBR_SEGW, BE / FBR_SEGW * FBR_SEGW);  // block rows split into whole row segments
+        if (block_edge > 0) BE = block_edge;
         mfma_per_sample = 0;
         mfma_uniform = 0;
         masked = false;
@@ -436,21 +444,13 @@ struct FbrGramProgram {
             int maxload, mfma, img;
             double cost;
         };
-        // cost of a row segment: 2 units per MFMA + measured fixed cost (segment preamble, per-k-step A / row-map fetch)
-        auto seg_cost = [&](const Seg &sg) {
-            int c = 3, nkmax = 0;
-            for (int pi : sg.pr) {
-                c += 2 * pairs[pi].nk4();
-                nkmax = std::max(nkmax, pairs[pi].nkend());
-            }
-            return c + 3 * nkmax;
-        };
         std::vector<int> stamp(NT, -1);
         int stamp_gen = 0;
         std::vector<std::pair<int, int>> order_buf;
-        // plan of the part pairs[b..e): false if it does not fit.  Waves 4..7 share their SIMDs with the older waves 0..3, which
+        // plan of the part pairs[b..e): false if it does not fit (materialise: also the wave -> segments -> pairs lists).  Waves 4..7 share their SIMDs with the older waves 0..3, which
         // the arbiter favours: measured, they finish the MFMA phase about 10 cost units later at equal load.
-        auto plan_part = [&](int b, int e, Plan &pl) -> bool {
+        std::vector<int> sg_begin, sg_w, sg_order;  // row segments of the part being planned: ranges of order_buf, cost units
+        auto plan_part = [&](int b, int e, Plan &pl, bool materialise) -> bool {
             stamp_gen++;
             int img = 0;
             auto need = [&](int ti) {
@@ -472,29 +472,47 @@ struct FbrGramProgram {
                 if (px.common != py.common) return px.common > py.common;
                 return px.mode < py.mode;
             });
-            std::vector<Seg> segs;
-            for (size_t o = 0; o < order_buf.size();) {
-                Seg sg{order_buf[o].first, {}, 0};
-                while (o < order_buf.size() && order_buf[o].first == sg.I && (int)sg.pr.size() < FBR_SEGW) sg.pr.push_back(order_buf[o++].second);
-                sg.w = seg_cost(sg);
-                segs.push_back(std::move(sg));
-            }
-            if ((int)segs.size() > SEGCAP) return false;
-            std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.w > y.w; });
-            pl.ws.assign(FBR_WPB, {});
+            sg_begin.clear();
+            sg_w.clear();
             pl.mfma = 0;
+            for (size_t o = 0; o < order_buf.size();) {
+                const int I = order_buf[o].first;
+                int c = 3, nkmax = 0, cnt = 0;
+                sg_begin.push_back((int)o);
+                while (o < order_buf.size() && order_buf[o].first == I && cnt < FBR_SEGW) {
+                    const FbrPair &pr = pairs[order_buf[o].second];
+                    c += 2 * pr.nk4();  // one MFMA = 2 cost units
+                    pl.mfma += pr.nk4();
+                    nkmax = std::max(nkmax, pr.nkend());
+                    cnt++;
+                    o++;
+                }
+                sg_w.push_back(c + 3 * nkmax);  // measured fixed cost: segment preamble + per-k-step A / row-map fetch
+            }
+            const int nsg = (int)sg_w.size();
+            if (nsg > SEGCAP) return false;
+            sg_begin.push_back((int)order_buf.size());
+            sg_order.resize(nsg);
+            for (int i = 0; i < nsg; i++) sg_order[i] = i;
+            std::stable_sort(sg_order.begin(), sg_order.end(), [&](int x, int y) { return sg_w[x] > sg_w[y]; });
+            int cnt[FBR_WPB] = {0};
+            if (materialise) pl.ws.assign(FBR_WPB, {});
             for (int w = 0; w < FBR_WPB; w++) pl.load[w] = w >= FBR_WPB / 2 ? 10 : 0;
-            for (Seg &sg : segs) {
+            for (int si : sg_order) {  // longest processing time first
                 int best = -1;
                 for (int w = 0; w < FBR_WPB; w++)
-                    if ((int)pl.ws[w].size() < FBR_NSEG && (best < 0 || pl.load[w] < pl.load[best])) best = w;
-                pl.load[best] += sg.w;
-                for (int pi : sg.pr) pl.mfma += pairs[pi].nk4();
-                pl.ws[best].push_back(std::move(sg));
+                    if (cnt[w] < FBR_NSEG && (best < 0 || pl.load[w] < pl.load[best])) best = w;
+                pl.load[best] += sg_w[si];
+                cnt[best]++;
+                if (materialise) {
+                    Seg sg{order_buf[sg_begin[si]].first, {}, sg_w[si]};
+                    for (int o = sg_begin[si]; o < sg_begin[si + 1]; o++) sg.pr.push_back(order_buf[o].second);
+                    pl.ws[best].push_back(std::move(sg));
+                }
             }
             pl.maxload = 0;
             for (int w = 0; w < FBR_WPB; w++)
-                if (!pl.ws[w].empty()) pl.maxload = std::max(pl.maxload, pl.load[w]);
+                if (cnt[w]) pl.maxload = std::max(pl.maxload, pl.load[w]);
             pl.img = img;
             pl.cost = cfg.c0 + cfg.cload * pl.maxload + cfg.cmfma * pl.mfma + cfg.cimg * img;
             return true;
@@ -512,7 +530,7 @@ struct FbrGramProgram {
             Plan pl;
             for (int i = 1; i <= np; i++)
                 for (int j = i - 1; j >= std::max(0, i - PPB); j--) {
-                    if (!plan_part(j, i, pl)) {
+                    if (!plan_part(j, i, pl, false)) {
                         if (i - j == 1) throw std::runtime_error("a single tile pair exceeds the LDS image budget (too many rows per sample)");
                         break;  // a longer part ending at i cannot fit either
                     }
@@ -540,7 +558,7 @@ struct FbrGramProgram {
         for (int t = 0; t < T; t++) {
             Plan pl;
             if (part_begin[t + 1] > part_begin[t]) {
-                if (!plan_part(part_begin[t], part_begin[t + 1], pl)) throw std::runtime_error("internal: part does not fit");
+                if (!plan_part(part_begin[t], part_begin[t + 1], pl, true)) throw std::runtime_error("internal: part does not fit");
                 for (int w = 0; w < FBR_WPB; w++)
                     for (int sgi = 0; sgi < (int)pl.ws[w].size(); sgi++) {
                         const Seg &sgm = pl.ws[w][sgi];
@@ -612,10 +630,36 @@ static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &h
     if (const char *e = getenv("FBR_GRAM_COST")) {  // experiments: "c0,cload,cmfma,cimg" of the two-per-CU shape [; same for one]
         sscanf(e, "%lf,%lf,%lf,%lf;%lf,%lf,%lf,%lf", &two.c0, &two.cload, &two.cmfma, &two.cimg, &one.c0, &one.cload, &one.cmfma, &one.cimg);
     }
+    // the order of the pair list decides which tiles a contiguous part touches: a few block edges are tried and the one with
+    // the lowest modelled cost kept (WALK-MAN: edge 6 instead of 5 saves one part and 7 % of the image traffic)
+    auto build_shape = [&](const FbrGramConfig &cfg) {
+        gp.block_edge = 0;
+        if (const char *e = getenv("FBR_GRAM_BE")) {  // experiments
+            gp.block_edge = std::max(1, atoi(e));
+            gp.build(hm, k, cfg);
+            return;
+        }
+        gp.build(hm, k, cfg);
+        if (gp.T == 1) return;
+        double best = gp.total_cost();
+        int best_edge = 0;
+        for (int edge = 4; edge <= 8; edge++) {
+            gp.block_edge = edge;
+            gp.build(hm, k, cfg);
+            if (gp.total_cost() < best) {
+                best = gp.total_cost();
+                best_edge = edge;
+            }
+        }
+        if (gp.block_edge != best_edge) {
+            gp.block_edge = best_edge;
+            gp.build(hm, k, cfg);
+        }
+    };
     if (force && force[0] == 'o') {  // "one"
-        gp.build(hm, k, one);
+        build_shape(one);
         return;
     }
-    gp.build(hm, k, two);
-    if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) gp.build(hm, k, one);
+    build_shape(two);
+    if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) build_shape(one);
 }
