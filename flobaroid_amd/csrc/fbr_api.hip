@@ -246,7 +246,18 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
     m->num_cus = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
     m->stream = m->own_stream;
-    HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    {
+        // The producer stream must not share a hardware queue with the stream the Gram kernel runs on, or the two serialise
+        // (seen under torch.distributed, where RCCL's streams shift HIP's round-robin stream -> queue assignment).  A stream of
+        // another priority level gets a queue of its own; the producer is the background work, so it takes the lowest.
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char *pe = getenv("FBR_SIDE_PRIORITY");  // experiments: "high" / "none"
+        if (pe && pe[0] == 'n')
+            HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+        else
+            HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, (pe && pe[0] == 'h') ? greatest : least));
+    }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipEventCreateWithFlags(&m->ev_pack[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_gram[i], hipEventDisableTiming));
