@@ -52,3 +52,36 @@ CONFIGS = [
 
 def cfg_id(c):
     return f"{c[0]}-fb{c[1]}-fr{c[2]}{'s' if c[3] else 'a'}-g{c[4]}-st{c[5]}"
+
+
+def random_topology(rng, num_links, p_fixed=0.2, branchiness=0.5):
+    """Random kinematic tree (revolute and fixed joints, random rest transforms and axes) for structure tests of the
+    tile program: nothing about it resembles a bundled robot."""
+    from scipy.spatial.transform import Rotation
+
+    L = num_links
+    parent, jtype, dof = [-1], [0], [-1]
+    names = ["l0"]
+    n = 0
+    for l in range(1, L):
+        par = l - 1 if rng.random() > branchiness else int(rng.integers(0, l))
+        fixed = rng.random() < p_fixed
+        parent.append(par)
+        jtype.append(0 if fixed else 1)
+        dof.append(-1 if fixed else n)
+        n += 0 if fixed else 1
+        names.append(f"l{l}")
+    rest_R = Rotation.random(L, random_state=int(rng.integers(1 << 30))).as_matrix()
+    rest_R[0] = np.eye(3)
+    rest_p = rng.standard_normal((L, 3)) * 0.3
+    rest_p[0] = 0
+    axis = rng.standard_normal((L, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    axis[[i for i in range(L) if dof[i] < 0]] = 0
+    params = np.zeros((L, 10))
+    params[:, 0] = 1 + rng.random(L)
+    params[:, 1:4] = 0.1 * rng.standard_normal((L, 3))
+    params[:, [4, 7, 9]] = 0.05 + 0.05 * rng.random((L, 3))
+    dof_names = [f"j{d}" for d in range(n)]
+    return Topology(name="random", link_names=names, parent=parent, joint_names=[""] + [f"jt{l}" for l in range(1, L)],
+                    joint_type=jtype, dof_index=dof, rest_R=rest_R, rest_p=rest_p, axis=axis, params=params, dof_names=dof_names)

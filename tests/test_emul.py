@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from common import CONFIGS, cfg_id, load_topo, random_states
+from common import CONFIGS, cfg_id, load_topo, random_states, random_topology
 from emul_lib import Emul
 from oracle.oracle import OracleModel
 
@@ -84,3 +84,29 @@ def test_shape_chooser_rule(fric, sym):
     assert auto["T"] == (two["T"] if two["T"] <= 20 else one["T"])
     if fric:  # friction columns cost few MFMAs: one packed row each, no products with links of other branches
         assert auto["mfma"] < 1.1 * 1529
+
+
+@pytest.mark.parametrize("seed,L,branch,floating,fric,sym", [
+    (1, 12, 0.5, 1, 1, 1), (2, 25, 0.3, 1, 0, 1), (3, 25, 0.8, 0, 1, 0), (4, 40, 0.15, 1, 1, 0), (5, 40, 0.6, 0, 0, 1),
+    (6, 55, 0.0, 1, 1, 1), (7, 60, 0.4, 0, 1, 0),
+])
+@pytest.mark.parametrize("shape", [1, 2], ids=["one_per_cu", "two_per_cu"])
+def test_random_trees(seed, L, branch, floating, fric, sym, shape, request):
+    """Tile program on random trees (deep chains, bushy trees, fixed joints, friction): emulated Gram == oracle Gram."""
+    import emul_lib
+    rng = np.random.default_rng(seed)
+    t = random_topology(rng, L, p_fixed=0.0 if seed == 6 else 0.25, branchiness=branch)
+    if t.num_dofs + (6 if floating else 0) > 60:
+        pytest.skip("more than 60 regressor rows")
+    emul_lib.lib().emul_set_gram_shape(shape)
+    request.addfinalizer(lambda: emul_lib.lib().emul_set_gram_shape(0))
+    om = OracleModel(t, floating=bool(floating), fric=bool(fric), fric_sym=bool(sym))
+    em = Emul(t, floating=bool(floating), fric=bool(fric), fric_sym=bool(sym))
+    S = 6
+    st = random_states(t, S, rng, floating)
+    sign = np.tanh(st["dq"] / 0.02)
+    Y = om.regressor(st, sign)
+    rhs = rng.standard_normal((Y.shape[0], 2))
+    A = np.hstack([Y, rhs])
+    G = em.gram(st, rhs, sign, None)
+    assert np.linalg.norm(G - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)

@@ -447,3 +447,41 @@ def test_tsqr_badly_scaled_and_tiny_columns():
     keep = np.arange(n) != 7
     E = (Rm.T @ Rm - G) * D[:, None] * D[None, :]
     assert np.abs(E[np.ix_(keep, keep)]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("seed,L,branch,floating,fric,sym", [
+    (11, 14, 0.5, 1, 1, 0), (12, 30, 0.3, 1, 1, 1), (13, 44, 0.7, 0, 1, 0), (14, 55, 0.0, 1, 0, 1), (15, 60, 0.4, 0, 1, 1),
+])
+def test_random_trees_all_entry_points(seed, L, branch, floating, fric, sym, monkeypatch):
+    """Random kinematic trees (nothing tuned to the bundled robots): regressor, fused Gram (both kernel shapes), TSQR and
+    prediction against the oracle."""
+    from common import random_topology
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(seed)
+    t = random_topology(rng, L, p_fixed=0.0 if branch == 0.0 else 0.25, branchiness=branch)
+    if t.num_dofs + (6 if floating else 0) > 60:
+        pytest.skip("more than 60 regressor rows")
+    om = OracleModel(t, floating=bool(floating), fric=bool(fric), fric_sym=bool(sym))
+    S = 300
+    st = random_states(t, S, rng, floating)
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    Yo = om.regressor(st, st["sign"])
+    rhs = rng.standard_normal((Yo.shape[0], 2))
+    A = np.hstack([Yo, rhs])
+    Go = A.T @ A
+    for shape in ("two", "one"):
+        monkeypatch.setenv("FBR_GRAM_SHAPE", shape)
+        eng = Engine(t, floating=bool(floating), friction=bool(fric), friction_symmetric=bool(sym))
+        G = eng.gram(st, rhs=rhs)
+        assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go), shape
+        if shape == "two":
+            Y = eng.regressor(st)
+            assert np.abs(Y - Yo).max() <= 1e-11 * np.abs(Yo).max()
+            R = eng.tsqr(st, rhs=rhs)
+            assert np.linalg.norm(R.T @ R - Go) <= 1e-10 * np.linalg.norm(Go)
+            x = rng.standard_normal(om.P)
+            tau = eng.predict(st, x)
+            assert np.abs(tau.reshape(-1) - Yo @ x).max() <= 1e-10 * np.abs(Yo @ x).max()
+        eng.close()
