@@ -690,21 +690,30 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
         for (int w = 0; w < FBR_WPB; w++)
             for (int sg = 0; sg < FBR_NSEG; sg++) {
                 int *mm = &meta[(((size_t)part * FBR_WPB + w) * FBR_NSEG + sg) * 8];
-                int cnt = 0, nkmax = 0, offA = 0;
+                int cnt = 0, nkmax = 0, offA = 0, kb = 0, last_nk = 1 << 30;
+                bool sorted = true;
                 for (int j = 0; j < FBR_SEGW; j++) {
                     const size_t s = ((size_t)part * FBR_WPB + w) * FBR_NPW + sg * FBR_SEGW + j;
                     const int pi = gp.slots[s].pair;
                     if (pi < 0) continue;
                     const FbrPair &p = gp.pairs[pi];
                     offA = gp.part_tile_off[part][p.I];
+                    kb = gp.slots[s].kb;
                     const int offB = gp.part_tile_off[part][p.J];
-                    mm[1 + j] = (offB / 64) | ((p.mode == 1 ? 1 : 0) << 10) | ((gp.masked ? (int)p.kmask : p.common) << 11);
+                    mm[1 + j] = (offB / 64) | ((p.mode == 1 ? 1 : 0) << 10) | (p.nkend() << 11);
                     nkmax = std::max(nkmax, p.nkend());
+                    // the kernel relies on: last k-steps falling along the slots, no holes before a slot, one start per segment
+                    if (p.nkend() > last_nk || cnt != j || p.kbegin() < kb) sorted = false;
+                    last_nk = p.nkend();
                     cnt++;
                     slot_tiles[2 * s] = p.I;
                     slot_tiles[2 * s + 1] = p.J;
                 }
-                mm[0] = (offA / 64) | (cnt << 10) | (nkmax << 14);
+                mm[0] = (offA / 64) | (cnt << 10) | (nkmax << 14) | (kb << 18);
+                if (cnt && !sorted) {
+                    set_err("internal: row segment is not sorted by k-steps");
+                    return FBR_E_INVALID;
+                }
             }
     std::vector<int> tilecol((size_t)gp.NT * FBR_TILE);
     for (int t = 0; t < gp.NT; t++)
@@ -794,12 +803,8 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         const int FBR_NPW = h->prog.cfg.npw();
         const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
         typedef void (*gram_fn)(DevGram, long, int, const double *, double *, unsigned long long *);
-        const bool mk = h->prog.masked;
-        const gram_fn gram_kernel =
-            two_per_cu ? (timing ? (mk ? fbr_gram_kernel<true, 5, 2, true> : fbr_gram_kernel<true, 5, 2, false>)
-                                 : (mk ? fbr_gram_kernel<false, 5, 2, true> : fbr_gram_kernel<false, 5, 2, false>))
-                       : (timing ? (mk ? fbr_gram_kernel<true, 6, 3, true> : fbr_gram_kernel<true, 6, 3, false>)
-                                 : (mk ? fbr_gram_kernel<false, 6, 3, true> : fbr_gram_kernel<false, 6, 3, false>));
+        const gram_fn gram_kernel = two_per_cu ? (timing ? fbr_gram_kernel<true, 5, 2> : fbr_gram_kernel<false, 5, 2>)
+                                               : (timing ? fbr_gram_kernel<true, 6, 3> : fbr_gram_kernel<false, 6, 3>);
         HIPCHK(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)fbr_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->pack_lds_bytes));

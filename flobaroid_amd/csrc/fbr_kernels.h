@@ -1,5 +1,6 @@
 // fbr_kernels.h -- device tables and HIP kernels of libfbr (gfx950).  Included once by fbr_api.hip.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "fbr_math.h"
@@ -27,8 +28,8 @@ struct DevGram {
     int T, NT, k, Pa, image_doubles, part_image_max, nitems;
     int npw;                  // accumulators per wave of the kernel shape the program was built for (segw * nseg)
     const int4 *items;        // every real column: image offset, kind, a, b
-    const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | nkmax<<14 ;
-                              //   [1+j] = offB_j/64 | lookup_j<<10 | (masked ? kmask_j : common_j)<<11   (part-local offsets)
+    const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | nkmax<<14 | kbegin<<18 ;
+                              //   [1+j] = offB_j/64 | lookup_j<<10 | kend_j<<11   (part-local offsets; the pair runs k-steps [kbegin, kend_j))
     const int *piece_begin;   // [T+1]
     const int2 *pieces;       // x = offset in the global image, y = offset in the part image | half<<30  (doubles)
     const int *rid_begin;     // [T+1]
@@ -458,9 +459,7 @@ typedef __attribute__((address_space(3))) void *fbr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_glb_ptr;
 
 // FBR_SEGW x FBR_NSEG: the wave's accumulator shape (FbrGramConfig, fbr_program.h); (5,2) must fit 128 VGPRs (two workgroups per CU).
-// MASKED: k-step ks of a pair runs iff bit ks of its mask is set (friction layouts); otherwise iff 4 ks < common (every pair runs a
-// prefix of the k-steps: one scalar instruction less per pair and k-step, 3 % on WALK-MAN).
-template <bool TIMING, int FBR_SEGW, int FBR_NSEG, bool MASKED>
+template <bool TIMING, int FBR_SEGW, int FBR_NSEG>
 __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) void fbr_gram_kernel(DevGram g, long S, int NG, const double *__restrict__ pimg,
                                                            double *__restrict__ partial, unsigned long long *__restrict__ dbg)
 {
@@ -552,28 +551,53 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
             const int m0 = __builtin_amdgcn_readlane(mv, 0);
             const int cnt = (m0 >> 10) & 15;
             if (cnt == 0) continue;
-            const int oA = (m0 & 0x3ff) << 6, nkmax = (m0 >> 14) & 15;
+            const int oA = (m0 & 0x3ff) << 6;
             int mj[FBR_SEGW];
 #pragma unroll
             for (int j = 0; j < FBR_SEGW; j++) mj[j] = __builtin_amdgcn_readlane(mv, 1 + j);
-            const double *pa = img + oA + lane;
-            const int *pr = ridl + (oA >> 4) + kk;
-            for (int ks = 0; ks < nkmax; ks++) {
-                const double a = pa[64 * ks];
-                const int vlk = pr[4 * ks] * FBR_TILE + li;   // operand row through the row map (chain x dense pairs)
-                const int vpos = 64 * ks + lane;
-                double b[FBR_SEGW];
-                const int kbit = 2048 << ks;
-                auto runs = [&](int mjv) { return MASKED ? (mjv & kbit) != 0 : 4 * ks < ((mjv >> 11) & 0xff); };
+            // lane-dependent addresses are rebuilt per sample: hoisted out of the sample loop they would cost the VGPRs that
+            // keep the kernel at 4 waves per SIMD
+            int lane_v = lane;
+            asm volatile("" : "+v"(lane_v));
+            const double *pa = img + oA + lane_v;
+            const int *pr = ridl + (oA >> 4) + (lane_v >> 4);
+            {
+                // every pair of the segment runs the k-steps [kb, its own end) and the pairs are sorted by their end descending:
+                // the pairs that run k-step ks are the first n(ks), n falling.  One branch-free loop per n.  (Friction pairs
+                // whose tiles meet in a few rows only start late and end early; k-steps inside the range that are structurally
+                // zero run anyway and add zeros.)
+                // The row-map entry of k-step ks + 1 (chain x dense pairs) is read during k-step ks: one LDS round trip per k-step.
+                // (Reading the operands of ks + 1 between the MFMAs of ks, into the registers just consumed, was measured 10 %
+                // slower than this read-all / wait / issue-all order.)
+                auto nksteps = [](int mjv) { return (mjv >> 11) & 0xff; };  // one past the last k-step of the pair
+                int ks = (m0 >> 18) & 15;
+                int rm = pr[4 * ks];
+                auto kstep = [&](auto nc, int ks) {
+                    constexpr int N = decltype(nc)::value;
+                    const int vlk = rm * FBR_TILE + (lane_v & 15);
+                    const int vpos = 64 * ks + lane_v;
+                    double b[N];
 #pragma unroll
-                for (int j = 0; j < FBR_SEGW; j++)
-                    if (runs(mj[j])) b[j] = img[((mj[j] & 0x3ff) << 6) + (((mj[j] >> 10) & 1) ? vlk : vpos)];
+                    for (int j = 0; j < N; j++) b[j] = img[((mj[j] & 0x3ff) << 6) + (((mj[j] >> 10) & 1) ? vlk : vpos)];
+                    __builtin_amdgcn_sched_barrier(0);  // keep the A read after the b reads: the wait for `rm` must not cover it
+                    const double a = pa[64 * ks];
+                    rm = pr[4 * ks + 4];  // may run a few entries past the tile's rows: still inside the LDS tables, never used
 #pragma unroll
-                for (int j = 0; j < FBR_SEGW; j++) {
-                    // no operand masking: a k-step either runs whole or is structurally zero (aligned packing, k-step masks)
-                    if (runs(mj[j]))
+                    for (int j = 0; j < N; j++)
                         acc[sgi * FBR_SEGW + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[sgi * FBR_SEGW + j], 0, 0, 0);
-                }
+                };
+#define FBR_RUN_PREFIX(N)                                                              \
+    if (N <= FBR_SEGW) {                                                               \
+        const int kend = nksteps(mj[(N) - 1 < FBR_SEGW ? (N) - 1 : 0]);                    \
+        for (; ks < kend; ks++) kstep(std::integral_constant<int, (N) <= FBR_SEGW ? (N) : 1>{}, ks); \
+    }
+                FBR_RUN_PREFIX(6)
+                FBR_RUN_PREFIX(5)
+                FBR_RUN_PREFIX(4)
+                FBR_RUN_PREFIX(3)
+                FBR_RUN_PREFIX(2)
+                FBR_RUN_PREFIX(1)
+#undef FBR_RUN_PREFIX
             }
         }
         if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[2] += t1 - t0; t0 = t1; }

@@ -191,9 +191,10 @@ struct FbrTile {
 };
 struct FbrPair {
     int I, J, common, mode;  // mode 0: both packed by position; 1: B rows looked up through rowid_I; 2: dense x dense
-    unsigned kmask = 0;      // k-step ks (tile-I rows 4ks..4ks+3) runs iff bit ks is set: the others are structurally zero
-    int nk4() const { return __builtin_popcount(kmask); }              // MFMAs per sample
-    int nkend() const { return kmask ? 32 - __builtin_clz(kmask) : 0; }  // one past the last k-step that runs
+    unsigned kmask = 0;      // k-step ks (tile-I rows 4ks..4ks+3) can contribute iff bit ks is set: the others are structurally zero
+    int kbegin() const { return kmask ? __builtin_ctz(kmask) : 0; }      // first k-step that can contribute
+    int nkend() const { return kmask ? 32 - __builtin_clz(kmask) : 0; }  // one past the last one
+    // The kernel runs the k-steps [kbegin of the pair's row segment, nkend): a superset of the mask (zeros add nothing).
 };
 struct FbrItem {  // one producer work item = one real column of one tile
     int off;      // LDS offset of (tile, slot): tile.off + slot
@@ -203,6 +204,7 @@ struct FbrItem {  // one producer work item = one real column of one tile
 };
 struct FbrSlot {  // one accumulator of one wave
     int pair;     // -1 = unused
+    int kb;       // first k-step its row segment runs
 };
 
 struct FbrPiece {  // one LDS-DMA piece of a part's per-sample image: 128 doubles (1 KiB, whole wave) or 64 (half wave)
@@ -228,7 +230,6 @@ struct FbrGramProgram {
     std::vector<int> part_load;                   // per part: cost units of its most loaded wave (2 per MFMA + fixed costs)
     std::vector<int> part_mfma;                   // per part: MFMAs per sample (all waves)
     std::vector<double> part_cost;                // per part: modelled cycles per sample of one workgroup (FbrGramConfig)
-    bool masked = false;       // some pair skips k-steps inside its common rows (friction columns): the kernel tests k-step masks
     int64_t mfma_per_sample = 0;
     int64_t mfma_uniform = 0;  // k-steps that run in row segments whose pairs all share `common` and the operand mode
 
@@ -385,7 +386,6 @@ struct FbrGramProgram {
         if (block_edge > 0) BE = block_edge;
         mfma_per_sample = 0;
         mfma_uniform = 0;
-        masked = false;
         const int NB = (NT + BE - 1) / BE;
         for (int bi = 0; bi < NB; bi++)
             for (int bj = bi; bj < NB; bj++)
@@ -425,10 +425,8 @@ struct FbrGramProgram {
                             }
                             if (on) p.kmask |= 1u << ks;
                         }
-                        if (p.kmask != (1u << ((p.common + 3) / 4)) - 1) masked = true;
                         if (p.kmask == 0) continue;  // structurally zero block (fixed base, disjoint branches, friction of other joints)
                         pairs.push_back(p);
-                        mfma_per_sample += p.nk4();
                     }
         // ---- parts: contiguous chunks of the pair list.  Inside a part the pairs are grouped into ROW SEGMENTS
         //      (same tile I, <= SEGW tiles J, sorted by k-steps descending): a wave loads the A fragment of (I, ks)
@@ -437,7 +435,7 @@ struct FbrGramProgram {
         const int np = (int)pairs.size();
         const int SEGCAP = FBR_WPB * FBR_NSEG;
         const int IMG_BUDGET = FBR_IMG_BUDGET;  // doubles per image buffer (see FbrGramConfig)
-        struct Seg { int I; std::vector<int> pr; int w; };
+        struct Seg { int I; std::vector<int> pr; int w; int kb; };
         struct Plan {
             std::vector<std::vector<Seg>> ws;  // per wave: its row segments
             int load[FBR_WPB];                 // cost units per wave (incl. the late-wave penalty)
@@ -466,24 +464,27 @@ struct FbrGramProgram {
                 order_buf.emplace_back(pairs[i].I, i);
             }
             if (img + 4 * FBR_TILE > IMG_BUDGET) return false;
+            // a row segment: pairs of one tile I that start at the same k-step, sorted by their last k-step descending (the
+            // kernel runs k-step ks for the first n(ks) pairs of the segment, n falling)
             std::stable_sort(order_buf.begin(), order_buf.end(), [&](const std::pair<int, int> &x, const std::pair<int, int> &y) {
                 if (x.first != y.first) return x.first < y.first;
                 const FbrPair &px = pairs[x.second], &py = pairs[y.second];
-                if (px.common != py.common) return px.common > py.common;
+                if (px.kbegin() != py.kbegin()) return px.kbegin() < py.kbegin();
+                if (px.nkend() != py.nkend()) return px.nkend() > py.nkend();
                 return px.mode < py.mode;
             });
             sg_begin.clear();
             sg_w.clear();
             pl.mfma = 0;
             for (size_t o = 0; o < order_buf.size();) {
-                const int I = order_buf[o].first;
+                const int I = order_buf[o].first, kb = pairs[order_buf[o].second].kbegin();
                 int c = 3, nkmax = 0, cnt = 0;
                 sg_begin.push_back((int)o);
-                while (o < order_buf.size() && order_buf[o].first == I && cnt < FBR_SEGW) {
+                while (o < order_buf.size() && order_buf[o].first == I && pairs[order_buf[o].second].kbegin() == kb && cnt < FBR_SEGW) {
                     const FbrPair &pr = pairs[order_buf[o].second];
-                    c += 2 * pr.nk4();  // one MFMA = 2 cost units
-                    pl.mfma += pr.nk4();
-                    nkmax = std::max(nkmax, pr.nkend());
+                    c += 2 * (pr.nkend() - kb);  // one MFMA = 2 cost units
+                    pl.mfma += pr.nkend() - kb;
+                    nkmax = std::max(nkmax, pr.nkend() - kb);
                     cnt++;
                     o++;
                 }
@@ -505,7 +506,7 @@ struct FbrGramProgram {
                 pl.load[best] += sg_w[si];
                 cnt[best]++;
                 if (materialise) {
-                    Seg sg{order_buf[sg_begin[si]].first, {}, sg_w[si]};
+                    Seg sg{order_buf[sg_begin[si]].first, {}, sg_w[si], pairs[order_buf[sg_begin[si]].second].kbegin()};
                     for (int o = sg_begin[si]; o < sg_begin[si + 1]; o++) sg.pr.push_back(order_buf[o].second);
                     pl.ws[best].push_back(std::move(sg));
                 }
@@ -546,7 +547,7 @@ struct FbrGramProgram {
             if (np == 0) part_begin.assign(2, 0);
         }
         // ---- segments and slots: LPT assignment of each part's segments to its waves; part-local images, DMA pieces
-        slots.assign((size_t)T * PPB, FbrSlot{-1});
+        slots.assign((size_t)T * PPB, FbrSlot{-1, 0});
         part_tiles.assign(T, {});
         part_tile_off.assign(T, std::vector<int>(NT, -1));
         pieces.assign(T, {});
@@ -563,14 +564,15 @@ struct FbrGramProgram {
                     for (int sgi = 0; sgi < (int)pl.ws[w].size(); sgi++) {
                         const Seg &sgm = pl.ws[w][sgi];
                         for (size_t j = 0; j < sgm.pr.size(); j++)
-                            slots[((size_t)t * FBR_WPB + w) * FBR_NPW + sgi * FBR_SEGW + j].pair = sgm.pr[j];
+                            slots[((size_t)t * FBR_WPB + w) * FBR_NPW + sgi * FBR_SEGW + j] = FbrSlot{sgm.pr[j], sgm.kb};
                         bool uni = true;
                         for (int pi : sgm.pr)
-                            uni = uni && pairs[pi].kmask == pairs[sgm.pr[0]].kmask && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
-                        if (uni) for (int pi : sgm.pr) mfma_uniform += pairs[pi].nk4();
+                            uni = uni && pairs[pi].nkend() == pairs[sgm.pr[0]].nkend() && (pairs[pi].mode == 1) == (pairs[sgm.pr[0]].mode == 1);
+                        if (uni) for (int pi : sgm.pr) mfma_uniform += pairs[pi].nkend() - sgm.kb;
                     }
                 part_load[t] = pl.maxload;
                 part_mfma[t] = pl.mfma;
+                mfma_per_sample += pl.mfma;
             }
             std::vector<char> need(NT, 0);
             for (int i = part_begin[t]; i < part_begin[t + 1]; i++) need[pairs[i].I] = need[pairs[i].J] = 1;

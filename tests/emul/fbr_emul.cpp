@@ -251,8 +251,9 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                     const int oA = gp.part_tile_off[part][p.I], oB = gp.part_tile_off[part][p.J];
                     if (oA < 0 || oB < 0 || (oA % 64) || (oB % 64)) return -7;
                     double *a4 = &acc[(((size_t)part * FBR_WPB + w) * FBR_NPW + sl) * 256];
-                    for (int ks = 0; ks < p.nkend(); ks++) {
-                        if (!((p.kmask >> ks) & 1)) continue;
+                    const int kb = gp.slots[((size_t)part * FBR_WPB + w) * FBR_NPW + sl].kb;
+                    if (kb > p.kbegin()) return -8;
+                    for (int ks = kb; ks < p.nkend(); ks++) {  // superset of the pair's k-step mask, like the kernel
                         double A[16][4], B[4][16];
                         for (int lane = 0; lane < 64; lane++) {
                             int i = lane & 15, kk = lane >> 4;
