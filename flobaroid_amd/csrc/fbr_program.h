@@ -34,17 +34,19 @@ struct FbrGramConfig {
     int nseg;        // row segments per wave
     int img_budget;  // doubles per LDS image buffer of a part
     // cycles per sample of a part's workgroup ~ c0 + cload * (cost units of its most loaded wave) + cmfma * (MFMAs of the part)
-    // + cimg * (image doubles): least squares over the per-part s_memtime phases of WALK-MAN with and without friction
-    // (FBR_GRAM_TIMING=1, tools/gram_shape_probe.py; 7 % / 3 % rms).  Only ratios matter: workgroups are dealt to the parts in
-    // proportion to these costs (fbr_gram_deal).
+    // + cimg * (image doubles): non-negative least squares over the per-part s_memtime phases of the six WALK-MAN layouts
+    // (tools/gram_timing_probe.py + tools/fit_gram_cost.py; 3.8 % / 2.8 % rms).  Only ratios matter: the cuts between the parts
+    // minimise the summed cost and workgroups are dealt to the parts in proportion to it (fbr_gram_deal).
     double c0, cload, cmfma, cimg;
     int npw() const { return segw * nseg; }  // tile pairs (MFMA accumulators) per wave
     bool operator==(const FbrGramConfig &o) const { return segw == o.segw && nseg == o.nseg && img_budget == o.img_budget; }  // same kernel shape
 };
-static const FbrGramConfig FBR_CFG_TWO_PER_CU = {5, 2, 4608, 1171.0, 29.0, 30.6, 0.27};
-static const FbrGramConfig FBR_CFG_ONE_PER_CU = {6, 3, 9472, 1873.0, 79.1, 0.0, 0.10};
-#define FBR_MAX_PARTS_TWO_PER_CU 20  // beyond this many parts the small-image shape loses to the large-image one
-                                    // (WALK-MAN floating base, tools/gram_shape_probe.py: 18 parts 6.8 vs 5.8 M samples/s, 26 parts 4.2 vs 5.8)
+static const FbrGramConfig FBR_CFG_TWO_PER_CU = {5, 2, 4608, 1171.0, 37.2, 22.4, 0.07};
+static const FbrGramConfig FBR_CFG_ONE_PER_CU = {6, 3, 9472, 1873.0, 7.7, 18.1, 0.15};
+#define FBR_MAX_PARTS_TWO_PER_CU 1   // a model that needs more than one part takes the large-image shape: measured with the branch-free
+                                     // kernel (tools/gram_shape_probe.py, profiles/r01k_gram_shapes.txt) the large images win every
+                                     // multi-part layout of WALK-MAN by 0-7 % (fewer image re-reads, room for the producer kernels
+                                     // beside the Gram kernel), the small ones the single-part robots by 8-12 %
 #define FBR_MAX_RHS 16
 
 struct FbrCol {
@@ -665,3 +667,4 @@ static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &h
     build_shape(two);
     if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) build_shape(one);
 }
+

@@ -62,13 +62,13 @@ def test_walkman_program_is_sparse():
     em = Emul(t, floating=True)
     info = em.program_info(1)
     assert info["mfma"] < 0.4 * 4185  # vs 31*32/2 tiles x 9 k-steps of the dense tiling
-    assert info["T"] * 8 * 10 >= info["npairs"]  # two-per-CU shape: 10 accumulators per wave
-    assert info["T"] <= 20
+    assert info["T"] * 8 * 18 >= info["npairs"]  # one-per-CU shape: 18 accumulators per wave
+    assert info["T"] <= 8
 
 
 @pytest.mark.parametrize("fric,sym", [(False, True), (True, True), (True, False)])
 def test_shape_chooser_rule(fric, sym):
-    """fbr_gram_build_best: the two-workgroups-per-CU shape unless it splits the model into more than 20 parts."""
+    """fbr_gram_build_best: the two-workgroups-per-CU shape only when the model fits a single part."""
     import emul_lib
     t = load_topo("walkman_apriori")
     em = Emul(t, floating=True, fric=fric, fric_sym=sym)
@@ -81,7 +81,7 @@ def test_shape_chooser_rule(fric, sym):
     finally:
         emul_lib.lib().emul_set_gram_shape(0)
     assert one["T"] < two["T"] and one["mfma"] == two["mfma"]
-    assert auto["T"] == (two["T"] if two["T"] <= 20 else one["T"])
+    assert auto["T"] == (two["T"] if two["T"] <= 1 else one["T"])
     if fric:  # friction columns cost few MFMAs: one packed row each, no products with links of other branches
         assert auto["mfma"] < 1.1 * 1529
 

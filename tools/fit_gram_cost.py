@@ -22,23 +22,23 @@ for path in sys.argv[1:]:
     cur, parts = None, {}
     runs = []
     for line in open(path):
-        m = re.search(r"=== friction=(\d) sym=(\d) shape=(\w+)", line)
+        m = re.search(r"=== floating=(\d) friction=(\d) sym=(\d) shape=(\w+)", line)
         if m:
-            cur = (int(m.group(1)), int(m.group(2)), m.group(3))
+            cur = (int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4))
             parts = {}
             runs.append((cur, parts))
         m = re.search(r"part (\d+) .*barrier=(\d+) dma_issue=(\d+) mfma=(\d+) \|", line)
         if m and cur:
             parts[int(m.group(1))] = sum(int(x) for x in m.groups()[1:])  # last launch wins
-    for (fr, sym, shape), parts in runs:
-        em = Emul(topo, floating=True, fric=bool(fr), fric_sym=bool(sym))
+    for (fl, fr, sym, shape), parts in runs:
+        em = Emul(topo, floating=bool(fl), fric=bool(fr), fric_sym=bool(sym))
         emul_lib.lib().emul_set_gram_shape({"two": 2, "one": 1}.get(shape, 0))
         out = (ctypes.c_int * 600)()
         T = emul_lib.lib().emul_part_stats(ctypes.byref(em.t), 1, out, 200)
         info = em.program_info(1)
         emul_lib.lib().emul_set_gram_shape(0)
         if T != len(parts):
-            print(f"skip {path} {fr, sym, shape}: {T} parts here, {len(parts)} in the log")
+            print(f"skip {path} {fl, fr, sym, shape}: {T} parts here, {len(parts)} in the log")
             continue
         key = shape if shape in data else ("two" if info["T"] == T and T > 0 and out[2] <= 4608 else "one")
         for p in range(T):

@@ -1,6 +1,6 @@
 """Per-part phase cycles of the streaming Gram kernel (FBR_GRAM_TIMING=1 diagnostic instantiation), WALK-MAN floating base.
 
-    gpurun -- 'python tools/gram_timing_probe.py [friction] [asym] > gpurun_out/gram_timing.txt 2>&1'
+    gpurun -- 'python tools/gram_timing_probe.py [fixed] [friction] [asym] > gpurun_out/gram_timing.txt 2>&1'
 
 FBR_GRAM_SHAPE=one|two forces a kernel shape.  tools/fit_gram_cost.py fits the part cost model (FbrGramConfig) to this output."""
 import os
@@ -17,17 +17,18 @@ from flobaroid_amd.topology import Topology  # noqa: E402
 
 fric = "friction" in sys.argv
 sym = "asym" not in sys.argv
+floating = "fixed" not in sys.argv
 topo = Topology.load(os.path.join(ROOT, "flobaroid_amd/robots/walkman_apriori.topology.json"))
-eng = Engine(topo, floating=True, friction=fric, friction_symmetric=sym)
+eng = Engine(topo, floating=floating, friction=fric, friction_symmetric=sym)
 S = 60000
-st_np, _ = synth_states(topo, S, 1, True)
+st_np, _ = synth_states(topo, S, 1, floating)
 st_np["sign"] = np.tanh(st_np["dq"] / 0.02)
 dev = torch.device("cuda", 0)
 st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
 rhs = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
 eng.gram(st, rhs=rhs)
 torch.cuda.synchronize()
-print(f"=== friction={int(fric)} sym={int(sym)} shape={os.environ.get('FBR_GRAM_SHAPE', 'auto')} {eng.gram_program_info(1)}", file=sys.stderr, flush=True)
+print(f"=== floating={int(floating)} friction={int(fric)} sym={int(sym)} shape={os.environ.get('FBR_GRAM_SHAPE', 'auto')} {eng.gram_program_info(1)}", file=sys.stderr, flush=True)
 os.environ["FBR_GRAM_TIMING"] = "1"
 eng.gram(st, rhs=rhs)
 torch.cuda.synchronize()
