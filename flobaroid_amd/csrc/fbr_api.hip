@@ -804,7 +804,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
         typedef void (*gram_fn)(DevGram, long, int, const double *, double *, unsigned long long *);
         const gram_fn gram_kernel = two_per_cu ? (timing ? fbr_gram_kernel<true, 5, 2> : fbr_gram_kernel<false, 5, 2>)
-                                               : (timing ? fbr_gram_kernel<true, 6, 3> : fbr_gram_kernel<false, 6, 3>);
+                                               : (timing ? fbr_gram_kernel<true, FBR_ONE_SEGW, FBR_ONE_NSEG> : fbr_gram_kernel<false, FBR_ONE_SEGW, FBR_ONE_NSEG>);
         HIPCHK(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(hipFuncSetAttribute((const void *)fbr_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->pack_lds_bytes));

@@ -592,6 +592,8 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
         const int kend = nksteps(mj[(N) - 1 < FBR_SEGW ? (N) - 1 : 0]);                    \
         for (; ks < kend; ks++) kstep(std::integral_constant<int, (N) <= FBR_SEGW ? (N) : 1>{}, ks); \
     }
+                FBR_RUN_PREFIX(8)
+                FBR_RUN_PREFIX(7)
                 FBR_RUN_PREFIX(6)
                 FBR_RUN_PREFIX(5)
                 FBR_RUN_PREFIX(4)
