@@ -92,6 +92,24 @@ __global__ __launch_bounds__(256) void fbr_kin_kernel(DevModel m, long S, const 
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)): in
+// the per-sample producer loops below that made every sample wait for the write acknowledgements of the one before.
+__device__ __forceinline__ void fbr_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Copy n doubles global -> LDS with all of a thread's loads in flight together (a plain `for (i = tid; ...) dst[i] = src[i]` loop is
+// compiled to load / wait / store per element: with 5 elements per thread that was 5 serial memory latencies per sample).
+template <int NT_, int U_ = 6> __device__ __forceinline__ void fbr_stage_copy(double *dst, const double *__restrict__ src, int n, int tid)
+{
+    for (int base = tid; base < n; base += NT_ * U_) {
+        double v[U_];
+#pragma unroll
+        for (int u = 0; u < U_; u++) v[u] = src[min(base + NT_ * u, n - 1)];  // clamped: unconditional loads
+#pragma unroll
+        for (int u = 0; u < U_; u++)
+            if (base + NT_ * u < n) dst[base + NT_ * u] = v[u];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: materialised standard regressor  Y[s][rows][cols]; one workgroup per sample (grid-stride), one
 // thread per column, every row of a sample written as one contiguous, coalesced run of `cols` doubles.
@@ -106,9 +124,9 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
     double *rs = smem;  // [rec]
     const int tid = threadIdx.x;
     for (long s = blockIdx.x; s < S; s += gridDim.x) {
-        __syncthreads();
-        for (int i = tid; i < m.rec; i += blockDim.x) rs[i] = rec[s * (long)m.rec + i];
-        __syncthreads();
+        fbr_barrier_lds();
+        fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        fbr_barrier_lds();
         double *Ys = Y + s * (long)m.rows * ldy;
         for (int c = tid; c < m.cols; c += blockDim.x) {
             const int4 cd = m.coldesc[c];
@@ -179,9 +197,9 @@ __global__ __launch_bounds__(256) void fbr_score_kernel(DevModel m, long SE, int
     double *red = smem + m.rec;
     const int tid = threadIdx.x;
     for (long e = blockIdx.x; e < SE; e += gridDim.x) {
-        __syncthreads();
-        for (int i = tid; i < m.rec; i += blockDim.x) rs[i] = rec[e * (long)m.rec + i];
-        __syncthreads();
+        fbr_barrier_lds();
+        fbr_stage_copy<256>(rs, rec + e * (long)m.rec, m.rec, tid);
+        fbr_barrier_lds();
         const double *Ws = W + (e / nper) * (long)m.rows * m.cols;
         double acc = 0.0;
         for (int c = tid; c < m.cols; c += blockDim.x) {
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(256) void fbr_score_kernel(DevModel m, long SE, int
         // deterministic block reduction: wave sums by xor butterflies, then 4 partials in fixed order
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if ((tid & 63) == 0) red[tid >> 6] = acc;
-        __syncthreads();
+        fbr_barrier_lds();
         if (tid == 0) out[e] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
@@ -221,9 +239,9 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
     for (long gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
         const long sb = gi * spb;
         const int ns = (int)min((long)spb, S - sb);
-        __syncthreads();
-        for (int i = tid; i < ns * m.rec; i += blockDim.x) smem[i] = rec[sb * (long)m.rec + i];
-        __syncthreads();
+        fbr_barrier_lds();
+        fbr_stage_copy<256>(smem, rec + sb * (long)m.rec, ns * m.rec, tid);
+        fbr_barrier_lds();
         if (ls >= ns) continue;
         const long s = sb + ls;
         const double *rs = smem + (long)ls * m.rec;
@@ -414,9 +432,11 @@ __global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, lo
     }
     const double *ws = wts ? rs + sg.o_w : nullptr;
     for (long s = blockIdx.x; s < S; s += gridDim.x) {
-        __syncthreads();
-        for (int i = tid; i < sg.total; i += 256) rs[i] = fbr_stage_load(sg, i, s, m.rec, m.rows, g.k, m.n, rec, rhs, wts, dq, sign);
-        __syncthreads();
+        fbr_barrier_lds();
+        fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        for (int i = sg.o_rhs + tid; i < sg.total; i += 256)  // rhs, weights, dq, sign: usually one element per thread
+            rs[i] = fbr_stage_load(sg, i, s, m.rec, m.rows, g.k, m.n, rec, rhs, wts, dq, sign);
+        fbr_barrier_lds();
         double *img = pimg + s * (long)g.image_doubles;
         for (int it = tid; it < g.nitems; it += 256) {
             const int4 d = g.items[it];
