@@ -588,8 +588,9 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
                 // zero run anyway and add zeros.)
                 // The row-map entry of k-step ks + 1 (chain x dense pairs) is read during k-step ks: one LDS round trip per k-step.
                 // (Reading the operands of ks + 1 between the MFMAs of ks, into the registers just consumed, was measured 10 %
-                // slower than this read-all / wait / issue-all order; hand-issued reads with s_waitcnt lgkmcnt(N - j) before
-                // MFMA j instead of the compiler's lgkmcnt(0) before the first one: no difference.)
+                // slower than this read-all / wait / issue-all order, a second register set for the operands of ks + 1 15 % slower
+                // (LDS reads between the MFMAs delay their issue); hand-issued reads with s_waitcnt lgkmcnt(N - j) before MFMA j
+                // instead of the compiler's lgkmcnt(0) before the first one: no difference.)
                 auto nksteps = [](int mjv) { return (mjv >> 11) & 0xff; };  // one past the last k-step of the pair
                 int ks = (m0 >> 18) & 15;
                 int rm = pr[4 * ks];
