@@ -485,3 +485,38 @@ def test_random_trees_all_entry_points(seed, L, branch, floating, fric, sym, mon
             tau = eng.predict(st, x)
             assert np.abs(tau.reshape(-1) - Yo @ x).max() <= 1e-10 * np.abs(Yo @ x).max()
         eng.close()
+
+
+@pytest.mark.parametrize("name,fl,fric,S", [("kuka_lwr4", 0, 1, 50_000), ("walkman_left_arm", 1, 1, 500_000), ("walkman_apriori", 1, 0, 1_000_000)])
+def test_baseline_sizes_through_size_independent_properties(name, fl, fric, S):
+    """BASELINE.json configs 2-4 at their full sample counts (the CPU oracle cannot get there inside a test): the fused Gram
+    must satisfy, for random x,  x^T G_YY x = |Y x|^2  and  x^T G_Y,tau = (Y x) . tau  with Y x from the streaming prediction
+    kernel (a different kernel, itself pinned on the oracle above), additivity over a split of the samples (the accumulate
+    path) and symmetry."""
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo(name)
+    eng = Engine(t, floating=bool(fl), friction=bool(fric))
+    rng = np.random.default_rng(2024)
+    st = random_states(t, S, rng, fl, use_limits=True)
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    tau = rng.standard_normal((S * eng.rows, 1))
+    P = eng.cols
+    G = eng.gram(st, rhs=tau)
+    assert G.shape == (P + 1, P + 1) and np.all(np.isfinite(G))
+    assert np.abs(G - G.T).max() <= 1e-13 * np.abs(G).max()
+    assert abs(G[P, P] - float(tau[:, 0] @ tau[:, 0])) <= 1e-11 * G[P, P]
+    for _ in range(3):
+        x = rng.standard_normal(P)
+        yx = eng.predict(st, x).reshape(-1)
+        assert abs(x @ G[:P, :P] @ x - yx @ yx) <= 1e-10 * (yx @ yx)
+        assert abs(x @ G[:P, P] - yx @ tau[:, 0]) <= 1e-10 * np.linalg.norm(yx) * np.linalg.norm(tau)
+    h = S // 3
+    G1 = eng.gram({k: v[:h] for k, v in st.items()}, rhs=tau[: h * eng.rows])
+    G2 = eng.gram({k: v[h:] for k, v in st.items()}, rhs=tau[h * eng.rows:], out=G1.copy(), accumulate=True)
+    assert np.linalg.norm(G2 - G) <= 1e-12 * np.linalg.norm(G)
+    # the Householder TSQR factor of the same stream (config 5's route to the SDP inputs): R^T R = G, R upper triangular
+    R = eng.tsqr(st, rhs=tau)
+    assert np.all(np.tril(R, -1) == 0.0) and np.all(np.isfinite(R))
+    assert np.linalg.norm(R.T @ R - G) <= 1e-11 * np.linalg.norm(G)
+    eng.close()
