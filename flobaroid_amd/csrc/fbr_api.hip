@@ -683,6 +683,7 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     rid_begin[gp.T] = (int)ridl.size();
     const int FBR_SEGW = gp.cfg.segw, FBR_NSEG = gp.cfg.nseg, FBR_NPW = gp.cfg.npw();
     dg.npw = FBR_NPW;
+    dg.base_ks = gp.base_ks;
     const size_t nslots = gp.slots.size();
     std::vector<int> meta((size_t)gp.T * FBR_WPB * FBR_NSEG * 8, 0);
     std::vector<int> slot_tiles(2 * nslots, -1);
@@ -690,7 +691,7 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
         for (int w = 0; w < FBR_WPB; w++)
             for (int sg = 0; sg < FBR_NSEG; sg++) {
                 int *mm = &meta[(((size_t)part * FBR_WPB + w) * FBR_NSEG + sg) * 8];
-                int cnt = 0, nkmax = 0, offA = 0, kb = 0, last_nk = 1 << 30;
+                int cnt = 0, offA = 0, kb = 0, last_nk = 1 << 30, chainA = 0;
                 bool sorted = true;
                 for (int j = 0; j < FBR_SEGW; j++) {
                     const size_t s = ((size_t)part * FBR_WPB + w) * FBR_NPW + sg * FBR_SEGW + j;
@@ -698,10 +699,10 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
                     if (pi < 0) continue;
                     const FbrPair &p = gp.pairs[pi];
                     offA = gp.part_tile_off[part][p.I];
+                    chainA = gp.tiles[p.I].type == 0;  // packed positions: the odd sample of a pair skips the base k-steps
                     kb = gp.slots[s].kb;
                     const int offB = gp.part_tile_off[part][p.J];
                     mm[1 + j] = (offB / 64) | ((p.mode == 1 ? 1 : 0) << 10) | (p.nkend() << 11);
-                    nkmax = std::max(nkmax, p.nkend());
                     // the kernel relies on: last k-steps falling along the slots, no holes before a slot, one start per segment
                     if (p.nkend() > last_nk || cnt != j || p.kbegin() < kb) sorted = false;
                     last_nk = p.nkend();
@@ -709,7 +710,7 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
                     slot_tiles[2 * s] = p.I;
                     slot_tiles[2 * s + 1] = p.J;
                 }
-                mm[0] = (offA / 64) | (cnt << 10) | (nkmax << 14) | (kb << 18);
+                mm[0] = (offA / 64) | (cnt << 10) | (kb << 18) | (chainA << 23);
                 if (cnt && !sorted) {
                     set_err("internal: row segment is not sorted by k-steps");
                     return FBR_E_INVALID;
@@ -847,7 +848,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             {
                 ProfScope ps(m, FBR_PROF_REGRESSOR, side);
                 const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
-                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs,
+                hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs, cs / items[ci].ng,
                                    m->rec2.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
                                    h->pimg[b].as<double>());

@@ -27,8 +27,9 @@ struct DevModel {
 struct DevGram {
     int T, NT, k, Pa, image_doubles, part_image_max, nitems;
     int npw;                  // accumulators per wave of the kernel shape the program was built for (segw * nseg)
+    int base_ks;              // k-steps of the paired base rows (3 with a floating base, else 0): skipped by the odd sample of a pair
     const int4 *items;        // every real column: image offset, kind, a, b
-    const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | nkmax<<14 | kbegin<<18 ;
+    const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | kbegin<<18 | (tile I is a chain tile)<<23 ;
                               //   [1+j] = offB_j/64 | lookup_j<<10 | kend_j<<11   (part-local offsets; the pair runs k-steps [kbegin, kend_j))
     const int *piece_begin;   // [T+1]
     const int2 *pieces;       // x = offset in the global image, y = offset in the part image | half<<30  (doubles)
@@ -408,7 +409,11 @@ __device__ __forceinline__ double fbr_stage_load(const FbrStage &sg, int i, long
     return 0.0;
 }
 
-__global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, long S, const double *__restrict__ rec,
+// Floating base: the 6 base-wrench rows of two consecutive samples of a group share 3 MFMA k-steps (FbrHostModel::fbp).  Packed
+// base position of row r of a sample: even sample -> r of its own image; odd sample -> r < 2: 6 + r of its partner's image (written
+// from this workgroup), else 2 + r of its own.  Dense tiles use the same base rows, joint row j at fbp + j.  The Gram kernel skips
+// k-step 0 of the chain tiles of odd samples.  Sg = samples per group of this launch (pairs never straddle groups).
+__global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, long S, long Sg, const double *__restrict__ rec,
                                                         const double *__restrict__ dq, const double *__restrict__ sign,
                                                         const double *__restrict__ rhs, const double *__restrict__ wts,
                                                         double *__restrict__ pimg)
@@ -438,12 +443,19 @@ __global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, lo
             rs[i] = fbr_stage_load(sg, i, s, m.rec, m.rows, g.k, m.n, rec, rhs, wts, dq, sign);
         fbr_barrier_lds();
         double *img = pimg + s * (long)g.image_doubles;
+        const long local = s % Sg;
+        const bool odd = (local & 1) != 0, partner = !odd && local + 1 < Sg;
+        const int fbp = m.fb ? 8 : 0;
+        // packed base position of base row r and the image it goes to
+        auto bpos = [&](int r) { return odd ? (r < 2 ? 6 + r : 2 + r) : r; };
+        auto bimg = [&](int r) { return (odd && r < 2) ? img - g.image_doubles : img; };
         for (int it = tid; it < g.nitems; it += 256) {
             const int4 d = g.items[it];
             if (d.y == 0) {
                 double w6[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * d.z, d.w, w6);
-                for (int r = 0; r < m.fb; r++) img[d.x + r * FBR_TILE] = ws ? w6[r] * ws[r] : w6[r];
+                for (int r = 0; r < m.fb; r++) bimg(r)[d.x + bpos(r) * FBR_TILE] = ws ? w6[r] * ws[r] : w6[r];
+                if (m.fb && !odd && !partner) img[d.x + 6 * FBR_TILE] = img[d.x + 7 * FBR_TILE] = 0.0;  // no partner: clear stale ghost rows
                 const int len = plen[d.z];
                 for (int j = 0; j < len; j++) {
                     const int dd = ptab[d.z * m.maxd + j];
@@ -460,8 +472,15 @@ __global__ __launch_bounds__(256) void fbr_pack_kernel(DevGram g, DevModel m, lo
                 for (int r = 0; r < m.rows; r++) {
                     double v = rs[sg.o_rhs + r * g.k + d.z];
                     if (ws) v *= ws[r];
-                    img[d.x + r * FBR_TILE] = v;
+                    if (r < m.fb)
+                        bimg(r)[d.x + bpos(r) * FBR_TILE] = v;
+                    else
+                        img[d.x + (fbp + r - m.fb) * FBR_TILE] = v;
                 }
+                // dense x dense pairs run every k-step of every sample: rows this sample does not own must be zero
+                if (m.fb && odd)
+                    for (int r = 0; r < 4; r++) img[d.x + r * FBR_TILE] = 0.0;
+                if (m.fb && !odd && !partner) img[d.x + 6 * FBR_TILE] = img[d.x + 7 * FBR_TILE] = 0.0;
             }
         }
     }
@@ -563,6 +582,7 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
         if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
         if (s + 1 < s1) dma(s + 1, ((s - s0) & 1) ? buf0 : buf1);
         if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
+        const int kskip = ((s - gs0) & 1) ? g.base_ks : 0;  // the base rows of an odd sample sit in its partner's image
         // ---- MFMA phase: per row segment the A fragment of (I, ks) is loaded once and feeds up to SEGW
         //      independent accumulators (tiles J, sorted by k-steps descending)
 #pragma unroll
@@ -592,7 +612,8 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
                 // (LDS reads between the MFMAs delay their issue); hand-issued reads with s_waitcnt lgkmcnt(N - j) before MFMA j
                 // instead of the compiler's lgkmcnt(0) before the first one: no difference.)
                 auto nksteps = [](int mjv) { return (mjv >> 11) & 0xff; };  // one past the last k-step of the pair
-                int ks = (m0 >> 18) & 15;
+                int ks = (m0 >> 18) & 31;
+                if ((m0 >> 23) & 1) ks = max(ks, kskip);  // tile I is packed by position: its base k-steps belong to even samples
                 int rm = pr[4 * ks];
                 auto kstep = [&](auto nc, int ks) {
                     constexpr int N = decltype(nc)::value;

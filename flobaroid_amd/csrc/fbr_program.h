@@ -62,6 +62,12 @@ struct FbrCol {
 
 struct FbrHostModel {
     int L = 0, n = 0, fb = 0, rows = 0, cols = 0, cpl = 10;
+    // Packed base positions of the tile images.  Floating base: 8 = two MFMA k-steps.  The 6 base-wrench rows of two consecutive
+    // samples of a group fill 3 k-steps instead of 2 x 2 with two padding rows each: the even sample's image holds its own
+    // rows b0..b5 in positions 0..5 and its partner's b0, b1 in positions 6, 7 ("ghost rows", written by the partner's
+    // workgroup); the odd sample's image holds its b2..b5 in positions 4..7 and the Gram kernel skips its k-step 0.
+    // Dense (rhs) tiles use the same 8 base rows, then the joint rows.
+    int fbp = 0;
     int floating = 0, fric = 0, fric_sym = 0, grav_only = 0;
     double stribeck = 0.0;
     double gravity[3] = {0, 0, -9.81};
@@ -82,6 +88,7 @@ struct FbrHostModel {
         if (L <= 0 || n < 0) throw std::runtime_error("bad model size");
         fb = floating ? 6 : 0;
         rows = n + fb;
+        fbp = fb ? 8 : 0;
         cpl = grav_only ? 4 : 10;
         for (int i = 0; i < 3; i++) gravity[i] = g[i];
         parent.assign(parent_, parent_ + L);
@@ -144,9 +151,9 @@ struct FbrHostModel {
             ppos.assign(L, {});
             pdepth.assign(L, 0);
             for (int l = 0; l < L; l++) {
-                int cur = fb;
+                int cur = fbp;
                 if (nchild[n] >= 2) cur = (cur + 3) & ~3;
-                int depth = fb;
+                int depth = fbp;
                 for (int d : path[l]) {
                     ppos[l].push_back(cur);
                     depth = cur + 1;
@@ -236,7 +243,8 @@ struct FbrGramProgram {
     std::vector<int> part_load;                   // per part: cost units of its most loaded wave (2 per MFMA + fixed costs)
     std::vector<int> part_mfma;                   // per part: MFMAs per sample (all waves)
     std::vector<double> part_cost;                // per part: modelled cycles per sample of one workgroup (FbrGramConfig)
-    int64_t mfma_per_sample = 0;
+    int base_ks = 0;           // 1 with a floating base: the odd sample of a pair skips k-step 0 (its b0, b1 sit in its partner's image)
+    int64_t mfma_per_sample = 0;  // average over an even / odd pair of samples (rounded up)
     int64_t mfma_uniform = 0;  // k-steps that run in row segments whose pairs all share `common` and the operand mode
 
     static bool nested(const std::vector<int> &a, const std::vector<int> &b)
@@ -270,6 +278,7 @@ struct FbrGramProgram {
         if (k < 0 || k > FBR_MAX_RHS) throw std::runtime_error("rhs column count must be 0..16");
         Pa = hm.cols + k;
         rows_pad = (hm.rows + 3) / 4 * 4;
+        base_ks = hm.fb ? 1 : 0;
         if (rows_pad > 60) throw std::runtime_error("more than 60 regressor rows per sample (15 MFMA k-steps) are not supported");
         tiles.clear();
         pairs.clear();
@@ -322,12 +331,12 @@ struct FbrGramProgram {
             // packed position -> regressor row (alignment gaps map to row 0; their image rows are zero)
             t.rowid.assign(t.depth, 0);
             t.rowreal.assign(t.depth, 0);
-            for (int i = 0; i < hm.fb; i++) {
+            for (int i = 0; i < hm.fbp; i++) {  // the dense tiles keep the same 8 base rows
                 t.rowid[i] = i;
                 t.rowreal[i] = 1;
             }
             for (size_t j = 0; j < t.tpath.size(); j++) {
-                t.rowid[t.tpos[j]] = hm.fb + t.tpath[j];
+                t.rowid[t.tpos[j]] = hm.fbp + t.tpath[j];
                 t.rowreal[t.tpos[j]] = 1;
             }
             t.posnz = t.rowreal;
@@ -347,9 +356,9 @@ struct FbrGramProgram {
             while (c < Pa) {
                 FbrTile t;
                 t.type = 1;
-                t.depth = hm.rows;
+                t.depth = hm.fbp + hm.n;  // base rows in the packed order of the chain tiles, then the joint rows
                 for (int s = 0; s < FBR_TILE; s++) t.col[s] = (c < Pa) ? c++ : -1;
-                t.rownz.assign(hm.rows, 1);
+                t.rownz.assign(t.depth, 1);
                 tiles.push_back(t);
             }
         }
@@ -392,6 +401,7 @@ struct FbrGramProgram {
         if (block_edge > 0) BE = block_edge;
         mfma_per_sample = 0;
         mfma_uniform = 0;
+        int64_t mfma_pair = 0;
         const int NB = (NT + BE - 1) / BE;
         for (int bi = 0; bi < NB; bi++)
             for (int bj = bi; bj < NB; bj++)
@@ -412,7 +422,7 @@ struct FbrGramProgram {
                             p.common = a.depth;
                             p.mode = 1;
                         } else if (a.type == 1 && b.type == 1) {
-                            p.common = hm.rows;
+                            p.common = a.depth;
                             p.mode = 2;
                         } else {
                             throw std::runtime_error("dense tile before chain tile");
@@ -445,7 +455,7 @@ struct FbrGramProgram {
         struct Plan {
             std::vector<std::vector<Seg>> ws;  // per wave: its row segments
             int load[FBR_WPB];                 // cost units per wave (incl. the late-wave penalty)
-            int maxload, mfma, img;
+            int maxload, mfma, mfma_odd, img;  // mfma: MFMAs of an even sample (all k-steps), mfma_odd: of an odd one
             double cost;
         };
         std::vector<int> stamp(NT, -1);
@@ -482,6 +492,7 @@ struct FbrGramProgram {
             sg_begin.clear();
             sg_w.clear();
             pl.mfma = 0;
+            pl.mfma_odd = 0;
             for (size_t o = 0; o < order_buf.size();) {
                 const int I = order_buf[o].first, kb = pairs[order_buf[o].second].kbegin();
                 int c = 3, nkmax = 0, cnt = 0;
@@ -490,6 +501,7 @@ struct FbrGramProgram {
                     const FbrPair &pr = pairs[order_buf[o].second];
                     c += 2 * (pr.nkend() - kb);  // one MFMA = 2 cost units
                     pl.mfma += pr.nkend() - kb;
+                    pl.mfma_odd += std::max(0, pr.nkend() - std::max(kb, base_ks));
                     nkmax = std::max(nkmax, pr.nkend() - kb);
                     cnt++;
                     o++;
@@ -578,7 +590,7 @@ struct FbrGramProgram {
                     }
                 part_load[t] = pl.maxload;
                 part_mfma[t] = pl.mfma;
-                mfma_per_sample += pl.mfma;
+                mfma_pair += pl.mfma + pl.mfma_odd;
             }
             std::vector<char> need(NT, 0);
             for (int i = part_begin[t]; i < part_begin[t + 1]; i++) need[pairs[i].I] = need[pairs[i].J] = 1;
@@ -613,6 +625,7 @@ struct FbrGramProgram {
                 i = j;
             }
         }
+        mfma_per_sample = (mfma_pair + 1) / 2;
     }
 };
 

@@ -206,18 +206,32 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
     const int REC = hm.rec_size();
     const int Pa = gp.Pa;
     const int FBR_NPW = gp.cfg.npw();
-    std::vector<double> rec(REC), img(gp.image_doubles, 0.0), loc(gp.part_image_max, 0.0);
-    std::vector<double> acc((size_t)gp.T * FBR_WPB * FBR_NPW * 256, 0.0);
+    std::vector<double> rec(REC), loc(gp.part_image_max, 0.0);
+    // pack kernel: the images of all samples first (an odd sample writes its base rows into its partner's image); every image
+    // starts as garbage where the kernel never writes and never reads ... except the structural zeros, which are zero
+    std::vector<double> imgs((size_t)S * gp.image_doubles, 0.0);
     for (long s = 0; s < S; s++) {
         kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
                    hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
         const double *ws = wts ? wts + (size_t)s * hm.rows : nullptr;
-        // pack kernel: image zeroed once, only real entries rewritten
+        double *img = &imgs[(size_t)s * gp.image_doubles];
+        const bool odd = (s & 1) != 0, partner = !odd && s + 1 < S;
+        auto bpos = [&](int r) { return odd ? (r < 2 ? 6 + r : 2 + r) : r; };
+        auto bimg = [&](int r) { return (odd && r < 2) ? img - gp.image_doubles : img; };
+        // poison what a stale image could hold: the mirror must overwrite, clear or never read it, like the kernel
+        for (const FbrItem &it : gp.items) {
+            if (it.kind == 0 && hm.fb && !odd) img[it.off + 6 * FBR_TILE] = img[it.off + 7 * FBR_TILE] = 1e300;
+            if (it.kind == 0 && hm.fb && odd)
+                for (int r = 0; r < 4; r++) img[it.off + r * FBR_TILE] = 1e300;  // never read: k-step 0 skipped
+            if (it.kind == 2 && hm.fb)
+                for (int r = 0; r < 8; r++) img[it.off + r * FBR_TILE] = 1e300;
+        }
         for (const FbrItem &it : gp.items) {
             if (it.kind == 0) {
                 double w6[6];
                 fbr_unit_wrench(&rec[21 * it.a], it.b, w6);
-                for (int r = 0; r < hm.fb; r++) img[it.off + r * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
+                for (int r = 0; r < hm.fb; r++) bimg(r)[it.off + bpos(r) * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
+                if (hm.fb && !odd && !partner) img[it.off + 6 * FBR_TILE] = img[it.off + 7 * FBR_TILE] = 0.0;
                 int j = 0;
                 for (int d : hm.path[it.a]) {
                     img[it.off + hm.ppos[it.a][j] * FBR_TILE] = fbr_dot6(&rec[21 * hm.L + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
@@ -229,10 +243,23 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                     fbr_friction_value(it.b, dq[s * hm.n + it.a], sign ? sign[s * hm.n + it.a] : 0.0, hm.stribeck) *
                     (ws ? ws[r] : 1.0);
             } else {
-                for (int r = 0; r < hm.rows; r++)
-                    img[it.off + r * FBR_TILE] = rhs[((size_t)s * hm.rows + r) * k + it.a] * (ws ? ws[r] : 1.0);
+                for (int r = 0; r < hm.rows; r++) {
+                    const double v = rhs[((size_t)s * hm.rows + r) * k + it.a] * (ws ? ws[r] : 1.0);
+                    if (r < hm.fb)
+                        bimg(r)[it.off + bpos(r) * FBR_TILE] = v;
+                    else
+                        img[it.off + (hm.fbp + r - hm.fb) * FBR_TILE] = v;
+                }
+                if (hm.fb && odd)
+                    for (int r = 0; r < 4; r++) img[it.off + r * FBR_TILE] = 0.0;
+                if (hm.fb && !odd && !partner) img[it.off + 6 * FBR_TILE] = img[it.off + 7 * FBR_TILE] = 0.0;
             }
         }
+    }
+    std::vector<double> acc((size_t)gp.T * FBR_WPB * FBR_NPW * 256, 0.0);
+    for (long s = 0; s < S; s++) {
+        const double *img = &imgs[(size_t)s * gp.image_doubles];
+        const int kskip = (s & 1) ? gp.base_ks : 0;
         for (int part = 0; part < gp.T; part++) {
             std::fill(loc.begin(), loc.end(), 0.0);
             for (const FbrPiece &pc : gp.pieces[part]) {
@@ -253,7 +280,7 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                     double *a4 = &acc[(((size_t)part * FBR_WPB + w) * FBR_NPW + sl) * 256];
                     const int kb = gp.slots[((size_t)part * FBR_WPB + w) * FBR_NPW + sl].kb;
                     if (kb > p.kbegin()) return -8;
-                    for (int ks = kb; ks < p.nkend(); ks++) {  // superset of the pair's k-step mask, like the kernel
+                    for (int ks = (gp.tiles[p.I].type == 0) ? std::max(kb, kskip) : kb; ks < p.nkend(); ks++) {  // superset of the pair's k-step mask, like the kernel
                         double A[16][4], B[4][16];
                         for (int lane = 0; lane < 64; lane++) {
                             int i = lane & 15, kk = lane >> 4;
