@@ -263,6 +263,29 @@ def test_grouped_gram_equals_one_gram_per_group(cfg):
         eng.gram_grouped(st, 4)  # 630 samples are not a multiple of 4
 
 
+@pytest.mark.parametrize("Sg", [1, 3, 7])
+def test_grouped_gram_odd_group_sizes_floating_base(Sg):
+    """The base-wrench rows of sample pairs share MFMA k-steps (even sample: its own rows + two of its partner's): pairs must
+    not straddle groups, and the last sample of an odd-sized group has no partner.  Each group against the oracle."""
+    cfg = CONFIGS[7]  # WALK-MAN, floating base
+    t, eng, om = _engine_oracle(cfg)
+    ng = 9
+    st, rng = _states(t, cfg, ng * Sg, 57)
+    rhs = rng.standard_normal((ng * Sg * om.rows, 2))
+    w = rng.random(ng * Sg * om.rows) + 0.5
+    for _ in range(2):  # twice: the second pass runs over images whose ghost rows hold the first pass's values
+        Gg = eng.gram_grouped(st, ng, rhs=rhs, w=w)
+        for g in range(ng):
+            sl = slice(g * Sg, (g + 1) * Sg)
+            rs = slice(g * Sg * om.rows, (g + 1) * Sg * om.rows)
+            A = _aug(om, {k: v[sl] for k, v in st.items()}, rhs[rs], w[rs])
+            assert np.linalg.norm(Gg[g] - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A), (Sg, g)
+    # a different grouping of the same buffers afterwards (slots change parity)
+    G = eng.gram(st, rhs=rhs, w=w)
+    A = _aug(om, st, rhs, w)
+    assert np.linalg.norm(G - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
+
+
 def test_multi_chunk_paths_at_small_sizes(monkeypatch):
     """FBR_CHUNK_SAMPLES forces the chunked code paths (double-buffered producer stream of the Gram, groups larger /
     smaller than a chunk, several TSQR chunks, chunked regressor / inverse dynamics) at sizes the oracle can check."""
