@@ -138,6 +138,7 @@ struct fbr_model {
     DevBuf rec, partial, out_tmp, g_tmp;
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     FbrTsqrWork tsqr;
+    DevBuf tsqr_rowfc;        // first supported column of every regressor row (row-sorted TSQR chunks)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -504,10 +505,10 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
             // even column count (and a 16-byte aligned output): paired columns, 16-byte stores
             if ((hm.cols & 1) == 0 && (((uintptr_t)dst) & 15) == 0)
                 hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2, m->stream, m->dm, cs, spb,
-                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols);
+                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L);
             else
                 hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols);
+                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L);
         }
         HIPCHK(hipGetLastError());
         if (out_mem == FBR_HOST) {
@@ -1055,6 +1056,29 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
     if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
+    if (S > 0 && !m->tsqr.narrow) {
+        // first column (in the order of the factorised columns) in which regressor row r can be non-zero: base-wrench rows
+        // meet every inertial column, the row of joint d the columns of the links below d and its own friction columns
+        std::vector<int> fc(hm.rows, Psel);  // nothing but the rhs columns
+        for (int r = 0; r < hm.rows; r++)
+            for (int c = 0; c < Psel; c++) {
+                const FbrCol &cd = hm.coldesc[cols ? cols[c] : c];
+                bool on;
+                if (r < hm.fb)
+                    on = cd.kind == 0;
+                else if (cd.kind == 0)
+                    on = std::find(hm.path[cd.link].begin(), hm.path[cd.link].end(), r - hm.fb) != hm.path[cd.link].end();
+                else
+                    on = cd.joint == r - hm.fb;
+                if (on) {
+                    fc[r] = c;
+                    break;
+                }
+            }
+        if ((rc = m->tsqr_rowfc.ensure(fc.size() * sizeof(int)))) return rc;
+        HIPCHK(hipMemcpyAsync(m->tsqr_rowfc.p, fc.data(), fc.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));  // fc is a local
+    }
     if (S > 0) {
         // materialise Y chunk by chunk (K1 + K2) and fold each chunk into the per-workgroup factors.  Without row
         // weights / column subset the regressor kernel writes straight into the padded chunk [Y | rhs | 0] of the
@@ -1075,26 +1099,40 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
             const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
             double *dst = m->out_tmp.as<double>();
             int ldy = hm.cols;
+            // The chunk is stacked by regressor row (all samples' row r together): R does not depend on the order of the rows,
+            // and a 64-row block of one regressor row is zero left of that row's first supported column, so its fold starts
+            // there (rows of joints deep in the tree touch a fraction of the panels).  Wave-private narrow kernels: sample-major.
+            FbrTsqrRowOrder ro;
+            if (!m->tsqr.narrow) {
+                ro.first_col = m->tsqr_rowfc.as<int>();
+                ro.rows = hm.rows;
+                ro.group = cs;
+            }
+            long rs_s = hm.rows, rs_r = 1;
             if (direct) {
                 if ((rc = fbr_tsqr_chunk_buffer(m->tsqr, cs * hm.rows, &dst))) return tsqr_fail(rc, "tsqr chunk");
                 ldy = m->tsqr.n;
+                if (ro.rows) {
+                    rs_s = 1;
+                    rs_r = cs;
+                }
             }
             {
                 ProfScope ps(m, FBR_PROF_REGRESSOR);
                 if ((hm.cols & 1) == 0)
                     hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2,
-                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy);
+                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r);
                 else
                     hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy);
+                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r);
             }
             HIPCHK(hipGetLastError());
             ProfScope ps(m, FBR_PROF_TSQR);
             if (direct)
-                rc = fbr_tsqr_fold_chunk(m->tsqr, m->stream, cs * hm.rows, Psel, k, drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr);
+                rc = fbr_tsqr_fold_chunk(m->tsqr, m->stream, cs * hm.rows, Psel, k, drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, ro);
             else
                 rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, cs * hm.rows, Psel, m->out_tmp.as<double>(), k,
-                                        drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr, hm.cols, dcols);
+                                        drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr, hm.cols, dcols, ro);
             if (rc) return tsqr_fail(rc, "tsqr fold");
         }
     }

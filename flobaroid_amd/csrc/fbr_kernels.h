@@ -121,8 +121,11 @@ template <int NT_, int U_ = 6> __device__ __forceinline__ void fbr_stage_copy(do
 // ldy = leading dimension of Y in doubles (>= cols; the TSQR path writes straight into its padded chunk)
 __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, const double *__restrict__ rec,
                                                              const double *__restrict__ dq,
-                                                             const double *__restrict__ sign, double *__restrict__ Y, int ldy)
+                                                             const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
+                                                             long rs_r)
 {
+    // row (s, r) of the output is row s * rs_s + r * rs_r: (rows, 1) = the reference's sample-major stack; (1, S) = row-major by
+    // regressor row (the TSQR chunks: all samples' row r together, see fbr_tsqr.h)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *rs = smem;  // [rec]
     const int tid = threadIdx.x;
@@ -130,23 +133,24 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
         fbr_barrier_lds();
         fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
         fbr_barrier_lds();
-        double *Ys = Y + s * (long)m.rows * ldy;
+        double *Ys = Y + s * rs_s * ldy;
+        const long rl = rs_r * ldy;
         for (int c = tid; c < m.cols; c += blockDim.x) {
             const int4 cd = m.coldesc[c];
             if (cd.x == 0) {
                 double w6[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
-                for (int r = 0; r < m.fb; r++) Ys[(long)r * ldy + c] = w6[r];
+                for (int r = 0; r < m.fb; r++) Ys[r * rl + c] = w6[r];
                 for (int d = 0; d < m.n; d++) {
                     const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
                     double v = 0.0;
                     if (bit) v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
-                    Ys[(long)(m.fb + d) * ldy + c] = v;
+                    Ys[(m.fb + d) * rl + c] = v;
                 }
             } else {
                 const int j = cd.w;
                 const double v = fbr_friction_value(cd.z, dq[s * m.n + j], sign ? sign[s * m.n + j] : 0.0, m.stribeck);
-                for (int r = 0; r < m.rows; r++) Ys[(long)r * ldy + c] = (r == m.fb + j) ? v : 0.0;
+                for (int r = 0; r < m.rows; r++) Ys[r * rl + c] = (r == m.fb + j) ? v : 0.0;
             }
         }
     }
@@ -231,7 +235,8 @@ __global__ __launch_bounds__(256) void fbr_score_kernel(DevModel m, long SE, int
 typedef double fbr_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
                                                               const double *__restrict__ dq,
-                                                              const double *__restrict__ sign, double *__restrict__ Y, int ldy)
+                                                              const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
+                                                              long rs_r)
 {
     // spb samples per workgroup pass (small robots: 256 / (cols/2) samples side by side)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -248,12 +253,12 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
         if (ls >= ns) continue;
         const long s = sb + ls;
         const double *rs = smem + (long)ls * m.rec;
-        double *Ys = Y + s * (long)m.rows * ldy;
+        double *Ys = Y + s * rs_s * ldy;
         for (int prr = pr; prr < npairs; prr += (spb > 1 ? npairs : (int)blockDim.x)) {
             const int c = 2 * prr;
             const int4 ca = m.coldesc[c], cb = m.coldesc[c + 1];
             fbr_d2 *dst = (fbr_d2 *)(Ys + c);
-            const long rstride = ldy >> 1;  // in double2 units (ldy even)
+            const long rstride = rs_r * (ldy >> 1);  // in double2 units (ldy even)
             if (ca.x == 0) {
                 double wa[6], wb[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, ca.z, wa);

@@ -37,19 +37,36 @@ typedef double fbr_td4 __attribute__((ext_vector_type(4)));
 static thread_local std::string g_tsqr_err;
 static inline const char *fbr_tsqr_error() { return g_tsqr_err.c_str(); }
 
+// Row order of a chunk handed to the factorisation.  rows == 0: as given (sample-major stack).  Otherwise the chunk holds `group`
+// samples of `rows` regressor rows each and is stacked by regressor row: chunk row r * group + s is row r of sample s, and a
+// block of rows is zero left of first_col[r] (device table) of the regressor rows it spans.
+struct FbrTsqrRowOrder {
+    const int *first_col = nullptr;
+    int rows = 0;
+    long group = 0;
+};
+// input row (sample-major) of chunk row o
+__device__ __forceinline__ long fbr_tsqr_in_row(long o, int rows, long group)
+{
+    if (rows == 0) return o;
+    const long r = o / group;
+    return (o - r * group) * rows + r;
+}
+
 // A[r][c] (ld) = w[r] * [Y | rhs][r][c], zero in the padding columns / rows
 // cols (optional, device): gather columns cols[0..P) of a Y with leading dimension ldy
 __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, int P, int k, int ld,
                                                              const double *__restrict__ Y, int ldy, const int *__restrict__ cols,
                                                              const double *__restrict__ rhs, const double *__restrict__ w,
-                                                             double *__restrict__ A)
+                                                             double *__restrict__ A, int orows, long ogroup)
 {
     const long total = Mpad * ld;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / ld;
-        const int c = (int)(i - r * ld);
+        const long o = i / ld;
+        const int c = (int)(i - o * ld);
         double v = 0.0;
-        if (r < M) {
+        if (o < M) {
+            const long r = fbr_tsqr_in_row(o, orows, ogroup);
             if (c < P)
                 v = Y[r * ldy + (cols ? cols[c] : c)];
             else if (c < P + k)
@@ -62,7 +79,8 @@ __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, i
 
 // columns [P, ld) of rows < M: rhs then zeros; rows M..Mpad: all zeros  (completes a chunk whose first P columns were
 // written in place by the regressor kernel)
-__global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, int P, int k, int ld, const double *__restrict__ rhs, double *__restrict__ A)
+__global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, int P, int k, int ld, const double *__restrict__ rhs, double *__restrict__ A,
+                                                             int orows, long ogroup)
 {
     const int tw = ld - P;
     const long t1 = M * tw, total = t1 + (Mpad - M) * ld;
@@ -70,7 +88,7 @@ __global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, i
         if (i < t1) {
             const long r = i / tw;
             const int c = (int)(i - r * tw);
-            A[r * ld + P + c] = (c < k) ? rhs[r * k + c] : 0.0;
+            A[r * ld + P + c] = (c < k) ? rhs[fbr_tsqr_in_row(r, orows, ogroup) * k + c] : 0.0;
         } else {
             A[M * ld + (i - t1)] = 0.0;
         }
@@ -547,7 +565,8 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
 template <int TPW, int SUB>
 __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
                                                                                double *__restrict__ Rw, long nblocks, unsigned *errflag,
-                                                                               unsigned long long *dbg)
+                                                                               unsigned long long *dbg, const int *__restrict__ rowfc, int orows,
+                                                                               long ogroup, long M)
 {
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -557,7 +576,15 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
     const int nfolds = (int)((nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
     auto fold_of = [&](int f) {
         const long r0 = ((long)blockIdx.x + (long)f * gridDim.x) * MB;
-        return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), 0};
+        int fc = 0;
+        if (orows) {  // chunk stacked by regressor row: the block is zero left of the first supported column of the rows it spans
+            fc = n;
+            if (r0 < M) {
+                const int ra = (int)(r0 / ogroup), rb = (int)((std::min<long>(r0 + MB, M) - 1) / ogroup);
+                for (int r = ra; r <= rb; r++) fc = min(fc, rowfc[r]);
+            }
+        }
+        return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc};
     };
     fbr_tsqr_stream<TPW, SUB>(R, n, LD, nfolds, fold_of, smem, errflag, dbg ? tacc : nullptr);
     if (dbg && (threadIdx.x & 63) == 0) {
@@ -865,7 +892,7 @@ static inline int fbr_tsqr_chunk_buffer(FbrTsqrWork &wk, long M, double **A)
 }
 
 // level 0 over the packed chunk wk.A (M rows)
-static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M)
+static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, const FbrTsqrRowOrder &ro = FbrTsqrRowOrder())
 {
     const int n = wk.n;
     const long Mpad = (M + 15) & ~15L;
@@ -888,7 +915,7 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M)
     FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
     FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                 (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg));
+                                                 (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
     TSQR_HIP(hipGetLastError());
     if (dbg) {
         std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 8);
@@ -906,7 +933,7 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M)
 
 // Fold M rows of [Y (M x P) | rhs (M x k)] (row weights w optional, column gather optional) into the working factors.
 static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, int P, const double *Y, int k, const double *rhs,
-                                     const double *w, int ldy = 0, const int *cols = nullptr)
+                                     const double *w, int ldy = 0, const int *cols = nullptr, const FbrTsqrRowOrder &ro = FbrTsqrRowOrder())
 {
     if (ldy <= 0) ldy = P;
     if (!wk.active || P + k != wk.Pa) {
@@ -918,14 +945,15 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
     int rc = fbr_tsqr_chunk_buffer(wk, M, &A);
     if (rc) return rc;
     const long Mpad = (M + 15) & ~15L;
-    hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(2048), dim3(256), 0, st, M, Mpad, P, k, wk.n, Y, ldy, cols, rhs, w, A);
+    hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(2048), dim3(256), 0, st, M, Mpad, P, k, wk.n, Y, ldy, cols, rhs, w, A, ro.rows, ro.group);
     TSQR_HIP(hipGetLastError());
-    return fbr_tsqr_fold_packed(wk, st, M);
+    return fbr_tsqr_fold_packed(wk, st, M, ro);
 }
 
 // Fold the chunk whose first P columns were already written into fbr_tsqr_chunk_buffer() (leading dimension wk.n):
 // append the rhs columns and the zero padding, then level 0.
-static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, int P, int k, const double *rhs)
+static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, int P, int k, const double *rhs,
+                                      const FbrTsqrRowOrder &ro = FbrTsqrRowOrder())
 {
     if (!wk.active || P + k != wk.Pa) {
         g_tsqr_err = "tsqr fold without matching begin";
@@ -933,9 +961,9 @@ static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, i
     }
     if (M <= 0) return 0;
     const long Mpad = (M + 15) & ~15L;
-    hipLaunchKernelGGL(fbr_tsqr_tail_kernel, dim3(1024), dim3(256), 0, st, M, Mpad, P, k, wk.n, rhs, wk.A);
+    hipLaunchKernelGGL(fbr_tsqr_tail_kernel, dim3(1024), dim3(256), 0, st, M, Mpad, P, k, wk.n, rhs, wk.A, ro.rows, ro.group);
     TSQR_HIP(hipGetLastError());
-    return fbr_tsqr_fold_packed(wk, st, M);
+    return fbr_tsqr_fold_packed(wk, st, M, ro);
 }
 
 // Binary tree over the working factors, result (Pa x Pa, upper triangular) to R_out (device).
