@@ -1056,7 +1056,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
     if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
-    if (S > 0 && !m->tsqr.narrow) {
+    if (S > 0) {
         // first column (in the order of the factorised columns) in which regressor row r can be non-zero: base-wrench rows
         // meet every inertial column, the row of joint d the columns of the links below d and its own friction columns
         std::vector<int> fc(hm.rows, Psel);  // nothing but the rhs columns
@@ -1101,13 +1101,11 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
             int ldy = hm.cols;
             // The chunk is stacked by regressor row (all samples' row r together): R does not depend on the order of the rows,
             // and a 64-row block of one regressor row is zero left of that row's first supported column, so its fold starts
-            // there (rows of joints deep in the tree touch a fraction of the panels).  Wave-private narrow kernels: sample-major.
+            // there (rows of joints deep in the tree touch a fraction of the panels).
             FbrTsqrRowOrder ro;
-            if (!m->tsqr.narrow) {
-                ro.first_col = m->tsqr_rowfc.as<int>();
-                ro.rows = hm.rows;
-                ro.group = cs;
-            }
+            ro.first_col = m->tsqr_rowfc.as<int>();
+            ro.rows = hm.rows;
+            ro.group = cs;
             long rs_s = hm.rows, rs_r = 1;
             if (direct) {
                 if ((rc = fbr_tsqr_chunk_buffer(m->tsqr, cs * hm.rows, &dst))) return tsqr_fail(rc, "tsqr chunk");

@@ -728,7 +728,8 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
 // level 0: wave g folds blocks g, g + NWV, ... of A into its private Rw[g]
 template <int NPT, int SUB>
 __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow_level0_kernel(const double *__restrict__ A, long Mpad,
-                                                                                                 double *__restrict__ Rw, long nblocks, int nwaves)
+                                                                                                 double *__restrict__ Rw, long nblocks, int nwaves,
+                                                                                                 const int *__restrict__ rowfc, int orows, long ogroup, long M)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB, n = 16 * NPT;
@@ -739,7 +740,15 @@ __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow
     double *R = Rw + (long)g * n * n;
     for (long b = g; b < nblocks; b += nwaves) {
         const long r0 = b * MB;
-        fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), 0, lds, lane);
+        int fc = 0;
+        if (orows) {  // chunk stacked by regressor row (FbrTsqrRowOrder)
+            fc = n;
+            if (r0 < M) {
+                const int ra = (int)(r0 / ogroup), rb = (int)((std::min<long>(r0 + MB, M) - 1) / ogroup);
+                for (int r = ra; r <= rb; r++) fc = min(fc, rowfc[r]);
+            }
+        }
+        fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc, lds, lane);
     }
 }
 
@@ -902,7 +911,7 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         const int grid = (nwaves + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
         FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
                                                             (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, wk.A, Mpad,
-                                                            wk.Rw, nblocks, nwaves));
+                                                            wk.Rw, nblocks, nwaves, ro.first_col, ro.rows, ro.group, M));
         TSQR_HIP(hipGetLastError());
         return 0;
     }
