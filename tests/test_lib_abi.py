@@ -48,3 +48,31 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(txt), (f, "references the oracle")
+
+
+def test_register_budget_for_co_residency(tmp_path):
+    """The fused pass relies on the producer kernels running beside the Gram waves: per SIMD two Gram waves of <= 176 VGPRs leave
+    160 of the 512 for one kin wave (<= 96) and one pack wave (<= 64) -- measured: 6 more VGPRs in the Gram kernel cost 5 % of the
+    pass.  Read the counts from the code object inside the built library."""
+    import re
+    import subprocess
+
+    from flobaroid_amd import build as fbuild
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("ROCm LLVM tools not available")
+    lib = fbuild.build_lib()
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co], text=True)
+    vgprs = {}
+    for m in re.finditer(r"\.name:\s+(\S+).*?\.vgpr_count:\s+(\d+)", notes, re.S):
+        vgprs[m.group(1)] = int(m.group(2))
+    find = lambda frag: [v for k, v in vgprs.items() if frag in k]
+    assert find("fbr_gram_kernelILb0ELi6ELi3E") and max(find("fbr_gram_kernelILb0ELi6ELi3E")) <= 176
+    assert find("fbr_gram_kernelILb0ELi5ELi2E") and max(find("fbr_gram_kernelILb0ELi5ELi2E")) <= 128  # two workgroups per CU
+    assert max(find("fbr_kin_kernel")) <= 96
+    assert max(find("fbr_pack_kernel")) <= 64
