@@ -51,7 +51,7 @@ static const FbrGramConfig FBR_CFG_TWO_PER_CU = {5, 2, 4608, 1171.0, 37.2, 22.4,
 #endif
 static const FbrGramConfig FBR_CFG_ONE_PER_CU = {FBR_ONE_SEGW, FBR_ONE_NSEG, FBR_ONE_IMG, 1873.0, 7.7, 18.1, 0.15};
 #define FBR_MAX_PARTS_TWO_PER_CU 1   // a model that needs more than one part takes the large-image shape: measured with the branch-free
-                                     // kernel (tools/gram_shape_probe.py, profiles/r01k_gram_shapes.txt) the large images win every
+                                     // kernel (tools/gram_shape_probe.py, profiles/r01n_gram_shapes.txt) the large images win every
                                      // multi-part layout of WALK-MAN by 0-7 % (fewer image re-reads, room for the producer kernels
                                      // beside the Gram kernel), the small ones the single-part robots by 8-12 %
 #define FBR_MAX_RHS 16
