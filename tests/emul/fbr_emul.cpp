@@ -177,6 +177,36 @@ int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma
     return 0;
 }
 
+// row statistics of the executed k-steps: out[0] = executed rows (4 per k-step, even-sample count), out[1] = rows that are real in
+// both tiles, out[2] = base-section rows executed, out[3] = base-section rows real in both
+int emul_row_stats(const EmulTopo *t, int k, long *out)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrGramProgram gp;
+    build_program(gp, hm, k);
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (size_t s = 0; s < gp.slots.size(); s++) {
+        const int pi = gp.slots[s].pair;
+        if (pi < 0) continue;
+        const FbrPair &p = gp.pairs[pi];
+        const FbrTile &a = gp.tiles[p.I], &b = gp.tiles[p.J];
+        for (int ks = gp.slots[s].kb; ks < p.nkend(); ks++)
+            for (int r = 4 * ks; r < 4 * ks + 4; r++) {
+                bool real = false;
+                if (r < p.common) {
+                    if (p.mode == 0) real = a.posnz[r] && b.posnz[r];
+                    else if (p.mode == 1) real = a.posnz[r] && b.rownz[a.rowid[r]];
+                    else real = a.rownz[r] && b.rownz[r];
+                }
+                out[0]++;
+                out[1] += real;
+                if (r < hm.fbp && p.mode != 2) { out[2]++; out[3] += real; }
+            }
+    }
+    return 0;
+}
+
 // per part: [load of the most loaded wave, MFMAs, image doubles]; out holds 3 * T ints
 int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
 {
