@@ -1,15 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- regressor samples/s of the fused hot path on MI355X (contract: see the task statement).
+"""bench.py -- regressor samples/s + TSQR TFLOP/s of the fused hot path on MI355X (contract: see the task statement).
 
-A step = one pass of the hot path over this rank's batch of synthetic WALK-MAN floating-base samples
-that are already resident in HBM: link kinematics + fused regressor -> [Y|tau]^T[Y|tau] Gram (fp64 MFMA),
-reduced deterministically on the device, then (N > 1) an RCCL all-reduce of the (P+1)^2 Gram.
+    python bench.py --gpus N --steps K --warmup W
+
+starts N ranks ITSELF (re-executes under ``python -m torch.distributed.run --nproc-per-node N``; a launch that already
+runs under torchrun is used as is) and fails loudly when fewer than N devices / ranks come up.  One process per GPU,
+RCCL (backend "nccl") over xGMI.
+
+A step = one pass of the hot path over BASELINE.json configs[3] -- WALK-MAN floating base, 1 M synthetic samples SHARDED
+over the N ranks (125 k per GPU at 8), inputs resident in HBM: link kinematics + fused regressor -> [Y|tau]^T[Y|tau] Gram
+(fp64 MFMA), reduced deterministically on the device, then ONE RCCL all-reduce of the (P+1)^2 fp64 Gram.  ``value`` =
+1 M / (max-over-ranks seconds per step): strong scaling, identical to the one-GPU workload at N = 1.  The same JSON line
+carries the weak-scaling figure (1 M samples PER GPU), the Householder-TSQR legs (per-rank ``fbr_tsqr`` + binary tree of
+``fbr_tsqr_merge`` over the ranks, checked against the all-reduced Gram inside the bench), and at N = 1 the other
+BASELINE configs, the PCIe-inclusive rate, the roofline of the dominant kernel and the CPU baselines.
+
+The global data set is made of 8 seeded blocks (seeds 42..49), so every world size sees the same 1 M samples and
+``gram_checksum`` must agree across the N = 1, 2, 4, 8 lines.
 """
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,70 +36,158 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # vendor dense fp64 matrix peak of MI355X; not in MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+MFMA_FLOP = 2 * 16 * 16 * 4   # one v_mfma_f64_16x16x4_f64
+NUM_BLOCKS = 8                # seeded blocks of the global data set
 
 
-def synth_states(topo, S, seed, floating=True):
-    """Synthetic inputs of SURVEY.md §8(d): seeded, the distributions of model.py:696-725."""
+# ----------------------------------------------------------------------------------------------------------------------
+# launch
+# ----------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=1_000_000, help="samples of the whole job per step (sharded over the ranks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="only the timed steps (profiling runs)")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0, help="N = 1: length of the sustained leg after the timed steps")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: CPU tensors; only meaningful with --engine (the test-suite's stand-in), the product has no CPU path")
+    ap.add_argument("--engine", default=None,
+                    help="module:factory returning an Engine-like object (tests inject a CPU stand-in to exercise the launch / "
+                         "sharding / reduction logic without a GPU); default: flobaroid_amd._lib.Engine (HIP, fails without a device)")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args) -> None:
+    """``--gpus N`` without a torchrun environment: start the N ranks here and exit with their status."""
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "RANK" in os.environ or args.gpus == 1:
+        return
+    if args.backend == "nccl":
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible; refusing to run fewer ranks")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# synthetic inputs (SURVEY.md §8(d): the distributions of model.py:696-725, tau = ID(state; xStdModel) + N(0, 0.05^2))
+# ----------------------------------------------------------------------------------------------------------------------
+def synth_block(topo, S, seed, dev, floating=True):
+    import torch
+
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+
+    def rand(*shape):
+        return torch.rand(shape, dtype=torch.float64, device=dev, generator=g)
+
+    n = topo.num_dofs
+    lo = torch.tensor([topo.limits[j]["lower"] for j in topo.dof_names], dtype=torch.float64, device=dev)
+    hi = torch.tensor([topo.limits[j]["upper"] for j in topo.dof_names], dtype=torch.float64, device=dev)
+    vm = torch.tensor([topo.limits[j]["velocity"] for j in topo.dof_names], dtype=torch.float64, device=dev)
+    st = dict(q=lo + (hi - lo) * rand(S, n), dq=(rand(S, n) - 0.5) * 2 * vm, ddq=(rand(S, n) - 0.5) * 2 * np.pi)
+    if floating:
+        st.update(base_vel=np.pi * rand(S, 6), base_acc=np.pi * rand(S, 6), rpy=0.1 * rand(S, 3))
+    st["_noise"] = 0.05 * torch.randn((S, n + (6 if floating else 0)), dtype=torch.float64, device=dev, generator=g)
+    return st
+
+
+def synth_range(topo, total, a, b, dev, floating=True, seed0=42):
+    """Samples [a, b) of the global data set of ``total`` samples = NUM_BLOCKS seeded blocks (seed0 + block)."""
+    import torch
+
+    bounds = [(total * i) // NUM_BLOCKS for i in range(NUM_BLOCKS + 1)]
+    parts = []
+    for i in range(NUM_BLOCKS):
+        lo, hi = max(a, bounds[i]), min(b, bounds[i + 1])
+        if lo >= hi:
+            continue
+        blk = synth_block(topo, bounds[i + 1] - bounds[i], seed0 + i, dev, floating)
+        parts.append({k: v[lo - bounds[i]:hi - bounds[i]] for k, v in blk.items()})
+    if not parts:
+        parts = [{k: v[:0] for k, v in synth_block(topo, 1, seed0, dev, floating).items()}]
+    return {k: torch.cat([p[k] for p in parts]).contiguous() for k in parts[0]}
+
+
+def with_tau(eng, topo, st):
+    """states dict (without the noise entry) and rhs = tau (S*rows, 1) on the device."""
+    noise = st.pop("_noise")
+    tau = eng.inverse_dynamics(st, topo.x_std())
+    tau = tau + noise
+    return st, tau.reshape(-1, 1).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = test infrastructure; used here only as the timed / checking CPU leg)
+# ----------------------------------------------------------------------------------------------------------------------
+def _np_states(topo, S, seed, floating=True):
     rng = np.random.default_rng(seed)
     n = topo.num_dofs
     lo = np.array([topo.limits[j]["lower"] for j in topo.dof_names])
     hi = np.array([topo.limits[j]["upper"] for j in topo.dof_names])
     vm = np.array([topo.limits[j]["velocity"] for j in topo.dof_names])
-    st = dict(q=lo + (hi - lo) * rng.random((S, n)), dq=(rng.random((S, n)) - 0.5) * 2 * vm,
-              ddq=(rng.random((S, n)) - 0.5) * 2 * np.pi)
+    st = dict(q=lo + (hi - lo) * rng.random((S, n)), dq=(rng.random((S, n)) - 0.5) * 2 * vm, ddq=(rng.random((S, n)) - 0.5) * 2 * np.pi)
     if floating:
         st.update(base_vel=np.pi * rng.random((S, 6)), base_acc=np.pi * rng.random((S, 6)), rpy=0.1 * rng.random((S, 3)))
-    return st, rng
+    return st
 
 
-def cpu_baseline(topo, budget_s=15.0):
-    """Oracle (C restatement, 1 thread) timed on the host: per-sample regressor + RNEA torques + the
-    A^T A accumulation of the stacked block with NumPy (BLAS pinned to 1 thread)."""
+def cpu_baseline(topo, budget_s=12.0):
+    """Phase A of BASELINE.md §3 on ONE host thread: oracle (C restatement) per-sample regressor + RNEA torques + the A^T A
+    accumulation of the stacked block with NumPy (BLAS pinned to 1 thread)."""
     from oracle.oracle import OracleModel
+    from threadpoolctl import threadpool_limits
 
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
     om = OracleModel(topo, floating=True)
     x = topo.x_std()
     block = 256
-    st, _ = synth_states(topo, block, 1234)
+    st = _np_states(topo, block, 1234)
     done = 0
     G = np.zeros((om.P + 1, om.P + 1))
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    t0 = time.perf_counter()
-    while True:
-        Y = om.regressor(st)
-        tau = om.inverse_dynamics(st, x).reshape(-1, 1)
-        Ya = np.hstack([Y, tau])
-        G += Ya.T @ Ya
-        done += block
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    if ctx is not None:
-        ctx.unregister() if hasattr(ctx, "unregister") else None
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        while True:
+            Y = om.regressor(st)
+            tau = om.inverse_dynamics(st, x).reshape(-1, 1)
+            Ya = np.hstack([Y, tau])
+            G += Ya.T @ Ya
+            done += block
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "samples/s", "cores": 1, "kind": "port",
             "sample": f"{done} WALK-MAN floating-base samples: oracle regressor + RNEA (C, 1 thread) + NumPy A^T A (1 BLAS thread), {dt:.1f} s"}
 
 
 def cpu_baseline_all_cores(topo, budget_s=8.0):
     """The same port on every host core: one Python thread per core, each running the C oracle (ctypes releases the GIL)
-    and its own 1-thread NumPy A^T A on private sample blocks, Grams summed at the end ("1 thread, then all
-    host cores").  The reference itself is single-threaded on this path."""
+    and its own 1-thread NumPy A^T A on private sample blocks ("1 thread, then all host cores")."""
     import concurrent.futures as cf
 
     from oracle.oracle import OracleModel
+    from threadpoolctl import threadpool_limits
 
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
     cores = os.cpu_count() or 1
     x = topo.x_std()
     block = 256
-    st, _ = synth_states(topo, block, 4321)
+    st = _np_states(topo, block, 4321)
     oms = [OracleModel(topo, floating=True) for _ in range(cores)]
     t_end = time.perf_counter() + budget_s
 
@@ -97,133 +201,175 @@ def cpu_baseline_all_cores(topo, budget_s=8.0):
             Ya = np.hstack([Y, tau])
             G += Ya.T @ Ya
             done += block
-        return done, G
+        return done
 
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:
-        res = list(ex.map(work, range(cores)))
-    dt = time.perf_counter() - t0
-    if ctx is not None and hasattr(ctx, "unregister"):
-        ctx.unregister()
-    done = sum(r[0] for r in res)
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(work, range(cores)))
+        dt = time.perf_counter() - t0
+    done = sum(res)
     return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{done} WALK-MAN floating-base samples over {cores} threads (C oracle + 1-thread NumPy A^T A each), {dt:.1f} s"}
 
 
-def other_configs(dev):
-    """BASELINE.json configs[1] and configs[2] on this GPU (secondary figures, outside the timed steps):
-    KUKA LWR4 fixed base, 50 k samples: regressor assembly + fused Gram + base-parameter QR (host, 80 x 80);
-    WALK-MAN left arm (floating base, 13 x 90 block), 500 k samples: Householder TSQR."""
-    import torch
+def cpu_phases_bc_and_parity(eng, topo, Sc=4000):
+    """Phases B and C of BASELINE.md §3 -- the reference's ACTUAL dense-LA calls through SciPy / NumPy on the host (all BLAS
+    threads) -- and, from the same inputs, the end-to-end parity figure of SURVEY 8(d): standard parameters identified from the
+    GPU reductions (structural Gram -> pivoted QR -> independent columns; TSQR factor -> lstsq -> pinv(K)) against the CPU path
+    (oracle-materialised YStd, numpy.linalg.lstsq on the tall YBase), relative Frobenius error.
 
-    from flobaroid_amd._lib import Engine
-    from flobaroid_amd.topology import Topology
-    from flobaroid_amd import estimation as est
-
-    res = {}
-
-    def timed(fn, reps=3):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
-
-    # configs[1]
-    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "kuka_lwr4.topology.json"))
-    eng = Engine(topo, floating=False, device=dev.index or 0)
-    S = 50_000
-    st_np, rng = synth_states(topo, S, 7, False)
-    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
-    tau = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
-    Y = torch.empty((S * eng.rows, eng.cols), dtype=torch.float64, device=dev)
-    t_reg = timed(lambda: eng.regressor(st, out=Y))
-    t_gram = timed(lambda: eng.gram(st, rhs=tau))
-    G = eng.gram(st, rhs=tau).cpu().numpy()
-    t0 = time.perf_counter()
+    B: scipy.linalg.qr(pivoting=True, mode="economic") on the structural Gram (model.py:809) -> P, rank, K (model.py:871-894).
+    C: numpy.linalg.lstsq / pinv / qr on the materialised YBase (identifier.py:709-712, sdp.py:470) at Sc samples."""
+    import numpy.linalg as la
+    import scipy
     import scipy.linalg as sla
 
-    Gs = G[: eng.cols, : eng.cols]
-    Rq = sla.qr(Gs, pivoting=True, mode="economic")[1]
-    nb = int(np.count_nonzero(np.abs(np.diag(Rq)) > 1e-4 * np.abs(Rq[0, 0])))
-    t_qr = time.perf_counter() - t0
-    res["kuka_lwr4_fixed_50k"] = {"samples": S, "block": [eng.rows, eng.cols], "regressor_ms": t_reg * 1e3,
-                                  "regressor_GB_per_s": 8.0 * S * eng.rows * eng.cols / t_reg / 1e9, "fused_gram_ms": t_gram * 1e3,
-                                  "fused_gram_samples_per_s": S / t_gram, "base_param_qr_host_ms": t_qr * 1e3, "base_rank": nb}
-    eng.close()
-    del Y, st
-    # configs[2]
-    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "walkman_left_arm.topology.json"))
-    eng = Engine(topo, floating=True, device=dev.index or 0)
-    S = 500_000
-    st_np, rng = synth_states(topo, S, 8, True)
-    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
-    tau = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
-    t_q = timed(lambda: eng.tsqr(st, rhs=tau), reps=2)
-    t_g = timed(lambda: eng.gram(st, rhs=tau), reps=2)
-    fl = 2.0 * S * eng.rows * (eng.cols + 1) ** 2
-    res["walkman_left_arm_floating_500k"] = {"samples": S, "block": [eng.rows, eng.cols], "tsqr_ms": t_q * 1e3, "tsqr_TFLOP_per_s": fl / t_q / 1e12,
-                                             "tsqr_samples_per_s": S / t_q, "fused_gram_ms": t_g * 1e3, "fused_gram_samples_per_s": S / t_g}
-    eng.close()
-    torch.cuda.empty_cache()
-    return res
+    from flobaroid_amd import estimation as est
+    from oracle.oracle import OracleModel
+
+    def np_(x):
+        return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+    out = {"numpy": np.__version__, "scipy": scipy.__version__, "host_threads": os.cpu_count()}
+    # structural Gram on the GPU from the reference's random-state distributions (model.py:696-725), randomSamples = 10000
+    R_struct = np_(eng.gram(_np_states(topo, 10000, 99)))
+    t0 = time.perf_counter()
+    Q, RQ, PQ = sla.qr(R_struct, pivoting=True, mode="economic")
+    tB = time.perf_counter() - t0
+    P = R_struct.shape[0]
+    r = int(np.count_nonzero(np.abs(np.diag(RQ)) > 0.005))  # minTol of configs/walkman_full.yaml
+    ic = PQ[:r]
+    Pp = np.zeros((P, P))
+    Pp[np.arange(P), PQ] = 1.0  # Pp[i, P[i]] = 1 (model.py:876-878)
+    deps = sla.solve_triangular(RQ[:r, :r], RQ[:r, r:])
+    deps[np.abs(deps) < 0.005] = 0.0
+    K = Pp.T[:, :r].T + deps @ Pp.T[:, r:].T
+    out["phase_B"] = {"call": "scipy.linalg.qr(R, pivoting=True, mode='economic')", "matrix": [P, P], "seconds": tB,
+                      "GFLOP_per_s": (4.0 / 3.0) * P ** 3 / tB / 1e9, "base_rank": r}
+    # phase C on the tall matrix
+    om = OracleModel(topo, floating=True)
+    st = _np_states(topo, Sc, 77)
+    x_true = topo.x_std()
+    rng = np.random.default_rng(5)
+    Y = om.regressor(st)
+    tau = om.inverse_dynamics(st, x_true).reshape(-1) + 0.05 * rng.standard_normal(Sc * om.rows)
+    YB = np.ascontiguousarray(Y[:, ic])
+    M, nb = YB.shape
+    fl = 2.0 * M * nb * nb - (2.0 / 3.0) * nb ** 3
+    res = {}
+    t0 = time.perf_counter()
+    xb_cpu = la.lstsq(YB, tau, rcond=None)[0]
+    res["lstsq"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    la.pinv(YB)
+    res["pinv"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    la.qr(YB)
+    res["qr"] = time.perf_counter() - t0
+    out["phase_C"] = {"samples": Sc, "matrix": [M, nb], "seconds": res,
+                      "qr_GFLOP_per_s": fl / res["qr"] / 1e9, "flop_model": "2 M P^2 - 2/3 P^3",
+                      "note": "costs are linear in the sample count; 1 M samples = x%d" % (1_000_000 // Sc)}
+    xstd_cpu = la.pinv(K) @ xb_cpu
+    # the same through the GPU reductions
+    R_aug = np_(eng.tsqr(st, rhs=tau.reshape(-1, 1)))
+    xb_gpu, _, _ = est.identify_base_parameters(R_aug, ic, P, M, add_contacts=False)
+    xstd_gpu = est.find_std_from_base(K, xb_gpu)
+    out["parity"] = {"samples": Sc, "xstd_rel_fro_err_gpu_vs_cpu": float(la.norm(xstd_gpu - xstd_cpu) / la.norm(xstd_cpu)),
+                     "xbase_rel_err": float(la.norm(xb_gpu - xb_cpu) / la.norm(xb_cpu)), "bar": 1e-6, "num_base_params": r}
+    return out, ic, K
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--samples", type=int, default=1_000_000, help="samples per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--other-configs", action="store_true",
-                    help="also time BASELINE.json configs[1] (KUKA 50 k) and configs[2] (left arm 500 k) as secondary figures; "
-                         "off by default so that the kernel statistics of the default command contain the headline workload only")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------------------------------
+# rank body
+# ----------------------------------------------------------------------------------------------------------------------
+def make_engine(args, topo, floating, device, **kw):
+    if args.engine:
+        mod, fn = args.engine.split(":")
+        return getattr(importlib.import_module(mod), fn)(topo, floating=floating, device=device, **kw)
+    from flobaroid_amd._lib import Engine
 
+    return Engine(topo, floating=floating, device=device, **kw)
+
+
+def run_rank(args) -> int:
     import torch
+    import torch.distributed as dist
+
+    from flobaroid_amd.dist import shard_range, tsqr_tree
+    from flobaroid_amd.topology import Topology
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = "RANK" in os.environ  # launched by torch.distributed.run: one process per GPU over RCCL
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    use_dist = "RANK" in os.environ
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to mislabel the run", file=sys.stderr)
+        return 2
+    on_gpu = args.backend == "nccl"
+    if on_gpu:
+        if torch.cuda.device_count() <= local:
+            print(f"bench.py: rank {rank} has no HIP device {local}", file=sys.stderr)
+            return 2
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device("cpu")
     if use_dist:
-        import torch.distributed as dist
-
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise RuntimeError("process group came up with the wrong size")
 
-    from flobaroid_amd._lib import Engine
-    from flobaroid_amd.topology import Topology
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if use_dist:
+            dist.barrier()
+        sync()
+
+    def max_over_ranks(x: float) -> float:
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "walkman_apriori.topology.json"))
-    eng = Engine(topo, floating=True, device=local)
-    eng.use_torch_stream()
-    S = args.samples
-    st_np, rng = synth_states(topo, S, 42 + rank)
-    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
-    # tau = ID(state; xStdModel) + N(0, 0.05^2)  (tests/test_identification.py:79), computed on the device
-    tau = eng.inverse_dynamics(st, topo.x_std())
-    tau += 0.05 * torch.randn(tau.shape, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(7 + rank))
-    rhs = tau.reshape(-1, 1).contiguous()
-    Pa = eng.cols + 1
+    eng = make_engine(args, topo, True, local)
+    if on_gpu:
+        eng.use_torch_stream()
+    rows, P = eng.rows, eng.cols
+    Pa = P + 1
+    S_total = args.samples
+    a, b = shard_range(S_total, rank, world)
+    S = b - a
+    st, rhs = with_tau(eng, topo, synth_range(topo, S_total, a, b, dev))
     G = torch.zeros((Pa, Pa), dtype=torch.float64, device=dev)
 
     def step():
         eng.gram(st, rhs=rhs, out=G)
         if use_dist:
-            dist.all_reduce(G)  # (P+1)^2 fp64 = 1.85 MB: the only exchange step of the pass
+            dist.all_reduce(G)  # (P+1)^2 fp64 = 1.86 MB: the only exchange step of the pass
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
 
+    # ---- the timed steps of the contract
     for _ in range(args.warmup):
         step()
     barrier()
@@ -233,98 +379,200 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = max_over_ranks(time.perf_counter() - t0)
     prof = eng.profile_get()
     eng.profile_enable(False)
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    if rank != 0:
-        dist.destroy_process_group()
-        return
+    G_sharded = G.clone()
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * S / (dt / args.steps)
-    rows, P = eng.rows, eng.cols
+    value = S_total / (dt / args.steps)
     info = eng.gram_program_info(1)
     gram_ms, gram_n = prof["gram"]
     samples_per_launch = S * args.steps / max(gram_n, 1)
-    # symmetric Gram count rows*P*(P+1) + 2*rows*P per rhs column, per sample
-    alg_flop_per_sample = rows * P * (P + 1) + 2 * rows * P * 1
+    alg_flop_per_sample = rows * P * (P + 1) + 2 * rows * P * 1  # symmetric Gram count + 1 rhs column
     avg_launch_s = gram_ms / max(gram_n, 1) * 1e-3
-    achieved = alg_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-    executed_flop_per_sample = info["mfma_per_sample"] * 2 * 16 * 16 * 4
+    executed_flop_per_sample = info["mfma_per_sample"] * MFMA_FLOP
+    executed = executed_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
     out = {
-        "metric": "regressor samples/s (fused regressor->Gram pass), WALK-MAN float-base",
+        "metric": "regressor samples/s (fused regressor->Gram pass) + TSQR TFLOP/s, WALK-MAN 31-DOF float-base",
         "value": value,
         "unit": "samples/s",
         "n_gpus": world,
+        "ranks_seen_by_process_group": dist.get_world_size() if use_dist else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"walkman_apriori floating base (29 DOF, 48 links, {rows}x{P} regressor block), "
-                        f"{S} samples per GPU per step, fused kinematics + [Y|tau]^T[Y|tau] Gram"
-                        + (" + RCCL all-reduce" if world > 1 else ""),
+            "workload": f"BASELINE configs[3]: walkman_apriori floating base (29 DOF, 48 links, {rows}x{P} regressor block), "
+                        f"{S_total} samples per step sharded over {world} GPU(s) ({S} on rank 0), fused kinematics + "
+                        "[Y|tau]^T[Y|tau] Gram" + (" + RCCL all-reduce of the Gram" if world > 1 else ""),
+            "samples_per_step": S_total,
             "samples_per_gpu": S,
             "rhs_columns": 1,
-            "parallelism": f"samples sharded over {world} GPU(s)",
+            "parallelism": f"samples sharded over {world} GPU(s), one all-reduce of the (P+1)^2 fp64 Gram per step",
+            "backend": args.backend,
         },
+        # all world sizes reduce the same 1 M samples: these must agree (to rounding) between the N = 1, 2, 4, 8 lines
+        "gram_checksum": {"trace": float(torch.trace(G_sharded).item()), "fro": float(torch.linalg.norm(G_sharded).item())},
         "roofline": {
             "bound": "mfma",
             "kernel": "fbr_gram_kernel",
-            "achieved": achieved,
+            # what the MFMA pipe executed (the kernel skips the structurally zero k-steps of the tile pairs; the PMC pass counts
+            # exactly mfma_per_sample x samples): executed flop / launch time measured with HIP events on the launch stream
+            "achieved": executed,
             "peak": PEAK_FP64_MFMA_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            "frac": executed / PEAK_FP64_MFMA_TFLOPS,
             "traffic": None,
+            "executed_mfma_per_sample": info["mfma_per_sample"],
+            "executed_flop_per_sample": executed_flop_per_sample,
             "algorithmic_flop_per_sample": alg_flop_per_sample,
-            "executed_mfma_flop_per_sample": executed_flop_per_sample,
-            # what the MFMA pipe really ran: the kernel skips the structurally zero k-steps of the tile pairs, so `achieved`
-            # (contract definition: dense-symmetric algorithmic flops / launch time) can exceed the hardware peak
-            "executed": executed_flop_per_sample * samples_per_launch / avg_launch_s / 1e12,
-            "executed_frac": executed_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            # SURVEY 8(d)'s dense-symmetric flop count over the same launch time (exceeds what the hardware ran: not a fraction)
+            "effective_dense_TFLOP_per_s": alg_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
             "avg_launch_ms": avg_launch_s * 1e3,
             "launches": gram_n,
             "samples_per_launch": samples_per_launch,
         },
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
     }
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2
-    # correction of FETCH_SIZE) are committed under profiles/; scaled here to this run's samples per launch
-    try:
+    try:  # HBM traffic of the dominant kernel: committed rocprofv3 PMC passes, scaled to this run's samples per launch
         import glob
 
-        src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gram_pmc_traffic.json")))[-1]  # latest committed PMC summary
+        src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gram_pmc_traffic.json")))[-1]
         pm = json.load(open(src))
         out["roofline"]["traffic"] = pm["hbm_bytes_per_sample"] * samples_per_launch
         out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(src)} (HBM bytes per sample x samples per launch)"
     except Exception:
         pass
-    if world == 1:
-        # secondary figures of the path (not part of the timed steps): Householder TSQR GF/s and the
+
+    if not args.no_secondary:
+        secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_dist, on_gpu, timed, barrier, sync, max_over_ranks)
+    if rank == 0:
+        print(json.dumps(out))
+    if use_dist:
+        dist.destroy_process_group()
+    return 0
+
+
+def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_dist, on_gpu, timed, barrier, sync, max_over_ranks):
+    """Everything outside the contract's timed region (all ranks take part in the distributed legs)."""
+    import torch
+    import torch.distributed as dist
+
+    from flobaroid_amd.dist import shard_range, tsqr_tree
+
+    rows, P = eng.rows, eng.cols
+    S_total = args.samples
+    S = st["q"].shape[0]
+    reps = 3
+
+    # ---- Householder TSQR of the same sharded 1 M samples: per-rank fbr_tsqr, binary tree of fbr_tsqr_merge over the ranks
+    def tsqr_sharded():
+        R = eng.tsqr(st, rhs=rhs)
+        return tsqr_tree(R, eng.tsqr_merge) if use_dist else R
+
+    R = tsqr_sharded()
+    RtR = R.T @ R
+    err = float((torch.linalg.norm(RtR - G_sharded) / torch.linalg.norm(G_sharded)).item())
+    if not err <= 1e-11:
+        raise AssertionError(f"TSQR tree: ||R^T R - all-reduced Gram|| / ||Gram|| = {err:.3e} > 1e-11")
+    eng.profile_enable(True)
+    eng.profile_get()
+    dt = timed(tsqr_sharded, reps, 0) / reps
+    pr = eng.profile_get()
+    eng.profile_enable(False)
+    wi = eng.tsqr_work_info(S, k=1)
+    merges = 0
+    stp = 1
+    while stp < world:  # merges on the critical path of the rank tree (one per level)
+        merges += 1
+        stp *= 2
+    wm = eng.tsqr_work_info(0, k=1)  # (no samples: only the shape)
+    n_pad, mb = wm["n_padded"], wm["block_rows"]
+    NPt = n_pad // 16
+    per_update = 8 * (mb // 16) + 4
+    merge_mfma = sum(per_update * ((NPt - i0 // 16) * (NPt - i0 // 16 - 1) // 2) for i0 in range(0, n_pad, mb))
+    executed_flop = world * wi["flop"] + (world - 1) * merge_mfma * MFMA_FLOP  # all ranks' folds + every merge of the rank tree
+    dense_flop = 2.0 * S_total * rows * (P + 1) ** 2
+    out["tsqr"] = {
+        "workload": f"configs[3] data: {S_total} samples sharded over {world} GPU(s), {rows * S_total} x {P + 1} rows x columns",
+        "seconds": dt, "repetitions": reps, "samples_per_s": S_total / dt,
+        "executed_TFLOP_per_s": executed_flop / dt / 1e12,
+        "executed_frac_of_fp64_mfma_peak": executed_flop / dt / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world),
+        "dense_model_TFLOP_per_s": dense_flop / dt / 1e12,
+        "flop_models": "executed: 512 flop x MFMAs the folds run (fbr_tsqr_work_info: row-sorted chunks fold from their first supported "
+                       "column); dense: 2*rows*(P+k)^2 per sample (SURVEY 8d)",
+        "rank_tree_levels": merges, "relerr_RtR_vs_allreduced_gram": err,
+        "kernel_ms_per_call_rank0": {k: v[0] / reps for k, v in pr.items() if v[1]},
+    }
+
+    # ---- weak scaling: 1 M samples PER GPU (N = 1: identical to the timed steps)
+    if world > 1:
+        off = (rank * S_total) // world  # every rank takes the whole data set, rotated by its shard offset
+        stw_a, rhsw_a = with_tau(eng, topo, synth_range(topo, S_total, off, S_total, dev))
+        stw_b, rhsw_b = with_tau(eng, topo, synth_range(topo, S_total, 0, off, dev))
+        stw = {k: torch.cat([stw_a[k], stw_b[k]]).contiguous() for k in stw_a}
+        rhsw = torch.cat([rhsw_a, rhsw_b]).contiguous()
+        del stw_a, stw_b, rhsw_a, rhsw_b
+        Gw = torch.zeros_like(G_sharded)
+
+        def step_w():
+            eng.gram(stw, rhs=rhsw, out=Gw)
+            dist.all_reduce(Gw)
+
+        ksteps = max(3, args.steps // 4)
+        dtw = timed(step_w, ksteps, 1) / ksteps
+        ok = float((torch.linalg.norm(Gw - world * G_sharded) / torch.linalg.norm(Gw)).item())
+        out["weak_scaling"] = {"samples_per_gpu": S_total, "steps": ksteps, "ms_per_step": dtw * 1e3, "value": world * S_total / dtw,
+                               "unit": "samples/s", "relerr_vs_world_x_sharded_gram": ok}
+        del stw, rhsw
+        return  # the single-GPU legs below are reported by the N = 1 line
+
+    # ---- N = 1 only ---------------------------------------------------------------------------------------------------
+    if args.sustain_seconds > 0:  # a long steady run of the same step (the driver's own GPU-busy sampling sees it)
+        G2 = torch.zeros_like(G_sharded)
+        sync()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < args.sustain_seconds:
+            for _ in range(5):
+                eng.gram(st, rhs=rhs, out=G2)
+            sync()
+            n += 5
+        ds = time.perf_counter() - t0
+        out["sustained"] = {"seconds": ds, "steps": n, "samples_per_s": n * S / ds}
+
+    if on_gpu:
+        # PCIe-inclusive rate (SURVEY 8(d) "incl. H2D of states"): pinned host inputs, staged chunk by chunk on the producer stream
+        hst = {k: v.cpu().pin_memory() for k, v in st.items()}
+        hrhs = rhs.cpu().pin_memory()
+        Gh = np.zeros((P + 1, P + 1))
+        eng.gram(hst, rhs=hrhs, out=Gh)
+        eng.profile_enable(True)
+        eng.profile_get()
+        k2 = 5
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            eng.gram(hst, rhs=hrhs, out=Gh)
+        dth = (time.perf_counter() - t0) / k2
+        prh = eng.profile_get()
+        eng.profile_enable(False)
+        nbytes = sum(v.numel() * 8 for v in hst.values()) + hrhs.numel() * 8
+        out["value_incl_h2d"] = S / dth
+        out["h2d"] = {"ms_per_step": dth * 1e3, "bytes_per_step": nbytes, "copy_ms_per_step": prh["h2d"][0] / k2,
+                      "copy_GB_per_s": nbytes / (prh["h2d"][0] / k2 * 1e-3) / 1e9 if prh["h2d"][0] > 0 else None,
+                      "relerr_vs_resident": float(np.linalg.norm(Gh - G_sharded.cpu().numpy()) / np.linalg.norm(Gh)),
+                      "how": "pinned host states + tau, hipMemcpyAsync per chunk on the producer stream (overlaps the Gram kernel of the previous chunk), host Gram out"}
+        del hst, hrhs
+
         # materialising regressor kernel against the HBM roofline
-        S2 = min(S, 150_000)
-        sub = {k2: v[:S2].contiguous() for k2, v in st.items()}
-        rhs2 = rhs[: S2 * rows].contiguous()
-        eng.tsqr(sub, rhs=rhs2)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        eng.tsqr(sub, rhs=rhs2)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        tflop = 2.0 * S2 * rows * (P + 1) ** 2 / dt2 / 1e12
-        out["tsqr"] = {"samples": S2, "columns": P + 1, "seconds": dt2, "samples_per_s": S2 / dt2, "TFLOP_per_s": tflop,
-                       "frac_of_fp64_mfma_peak": tflop / PEAK_FP64_MFMA_TFLOPS,
-                       "flop_model": "2*rows*(P+k)^2 per sample (SURVEY 8d)"}
         S3 = min(S, 60_000)
-        sub3 = {k2: v[:S3].contiguous() for k2, v in st.items()}
+        sub3 = {k2_: v[:S3].contiguous() for k2_, v in st.items()}
         Y = torch.empty((S3 * rows, P), dtype=torch.float64, device=dev)
         eng.regressor(sub3, out=Y)
         eng.profile_enable(True)
@@ -334,22 +582,138 @@ def main():
         eng.profile_enable(False)
         kms = pr3["regressor"][0]
         gbs = 8.0 * rows * P * S3 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        out["assembly"] = {"samples": S3, "kernel": "fbr_regressor_kernel", "kernel_ms": kms, "GB_per_s": gbs,
+        out["assembly"] = {"samples": S3, "kernel": "fbr_regressor2_kernel", "kernel_ms": kms, "GB_per_s": gbs,
                            "frac_of_hbm_peak": gbs / PEAK_HBM_GBS, "bytes_per_sample": 8 * rows * P}
-        del Y
-        if args.other_configs:
-            out["other_configs"] = other_configs(dev)
-    if not args.no_cpu_baseline and world == 1:
+        del Y, sub3
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(args, dev, eng, topo, st, rhs)
+    if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo)
         try:
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(topo)
         except Exception as e:  # secondary figure: never lose the bench line over it
             out["cpu_baseline_all_cores"] = {"error": repr(e)}
-    elif world == 1:
+        try:
+            bc, _, _ = cpu_phases_bc_and_parity(eng, topo)
+            out["cpu_baseline_phases"] = bc
+        except Exception as e:
+            out["cpu_baseline_phases"] = {"error": repr(e)}
+    else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+
+
+def other_configs(args, dev, eng4, topo4, st4, rhs4):
+    """BASELINE.json configs[1], [2] and [4] on this GPU (secondary figures, HIP-event / wall timed, >= 3 repetitions)."""
+    import scipy.linalg as sla
+    import torch
+
+    from flobaroid_amd import estimation as est
+    from flobaroid_amd.topology import Topology
+
+    res = {}
+    reps = 3
+
+    def timed(fn, reps=reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # configs[1]: KUKA LWR4 fixed base, 50 k samples: regressor + fused Gram + base-parameter QR
+    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "kuka_lwr4.topology.json"))
+    eng = make_engine(args, topo, False, dev.index or 0)
+    S = 50_000
+    st = synth_range(topo, S, 0, S, dev, floating=False, seed0=7)
+    st.pop("_noise")
+    tau = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
+    Y = torch.empty((S * eng.rows, eng.cols), dtype=torch.float64, device=dev)
+    t_reg = timed(lambda: eng.regressor(st, out=Y))
+    t_gram = timed(lambda: eng.gram(st, rhs=tau))
+    Gs = eng.gram(_np_states(topo, 5000, 3, floating=False))
+    t0 = time.perf_counter()
+    Rq = sla.qr(Gs, pivoting=True, mode="economic")[1]
+    nb = int(np.count_nonzero(np.abs(np.diag(Rq)) > 1e-4))
+    t_qr = time.perf_counter() - t0
+    res["kuka_lwr4_fixed_50k"] = {"samples": S, "block": [eng.rows, eng.cols], "regressor_ms": t_reg * 1e3,
+                                  "regressor_GB_per_s": 8.0 * S * eng.rows * eng.cols / t_reg / 1e9, "fused_gram_ms": t_gram * 1e3,
+                                  "fused_gram_samples_per_s": S / t_gram, "base_param_qr_host_ms": t_qr * 1e3, "base_rank": nb}
+    eng.close()
+    del Y, st
+    # configs[2]: WALK-MAN left arm (floating base per configs/walkman_left_arm.yaml: 13 x 90 block), 500 k samples: TSQR
+    topo = Topology.load(os.path.join(ROOT, "flobaroid_amd", "robots", "walkman_left_arm.topology.json"))
+    eng = make_engine(args, topo, True, dev.index or 0)
+    S = 500_000
+    st = synth_range(topo, S, 0, S, dev, floating=True, seed0=8)
+    st.pop("_noise")
+    tau = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
+    t_q = timed(lambda: eng.tsqr(st, rhs=tau))
+    t_g = timed(lambda: eng.gram(st, rhs=tau))
+    wi = eng.tsqr_work_info(S, k=1)
+    fl = 2.0 * S * eng.rows * (eng.cols + 1) ** 2
+    res["walkman_left_arm_floating_500k"] = {
+        "samples": S, "block": [eng.rows, eng.cols], "tsqr_ms": t_q * 1e3, "repetitions": reps,
+        "tsqr_executed_TFLOP_per_s": wi["flop"] / t_q / 1e12, "tsqr_executed_frac_of_fp64_mfma_peak": wi["flop"] / t_q / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+        "tsqr_dense_model_TFLOP_per_s": fl / t_q / 1e12, "tsqr_samples_per_s": S / t_q,
+        "tsqr_hbm_floor_ms": 2 * 8.0 * S * eng.rows * wi["n_padded"] / (PEAK_HBM_GBS * 1e9) * 1e3,
+        "fused_gram_ms": t_g * 1e3, "fused_gram_samples_per_s": S / t_g}
+    eng.close()
+    del st, tau
+    torch.cuda.empty_cache()
+    # configs[4]: WALK-MAN, 4 M samples: fused Gram + TSQR of the base regressor [YBase | tau] -> SDP inputs -> xStd
+    S1 = st4["q"].shape[0]
+    mult = max(1, 4_000_000 // S1)
+    Rs = eng4.gram(_np_states(topo4, 10000, 99))
+    Rs = Rs.cpu().numpy() if hasattr(Rs, "cpu") else Rs
+    Q, RQ, PQ = sla.qr(Rs, pivoting=True, mode="economic")
+    r = int(np.count_nonzero(np.abs(np.diag(RQ)) > 0.005))
+    ic = np.sort(PQ[:r]).astype(np.int32)
+    P = eng4.cols
+    # 4 M samples = the 1 M resident ones and three more seeded blocks, streamed through R_in / accumulate (what a host with less
+    # memory than the data set does); every pass is timed
+    R_b = None
+    G5 = torch.zeros((P + 1, P + 1), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t_tsqr = t_gram = 0.0
+    for i in range(mult):
+        if i == 0:
+            sti, rhsi = st4, rhs4
+        else:
+            sti, rhsi = with_tau(eng4, topo4, synth_range(topo4, S1, 0, S1, dev, seed0=1000 + 8 * i))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng4.gram(sti, rhs=rhsi, out=G5, accumulate=i > 0)
+        torch.cuda.synchronize()
+        t_gram += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        R_b = eng4.tsqr(sti, rhs=rhsi, cols=ic, R_in=R_b)
+        torch.cuda.synchronize()
+        t_tsqr += time.perf_counter() - t0
+    Rb = R_b.cpu().numpy()
+    G5n = G5.cpu().numpy()
+    sel = np.concatenate((ic, [P]))
+    Gb = G5n[np.ix_(sel, sel)]
+    relerr = float(np.linalg.norm(Rb.T @ Rb - Gb) / np.linalg.norm(Gb))
+    M = mult * S1 * eng4.rows
+    nbp = len(ic)
+    xb, _ = est.lstsq_from_R(Rb, nbp, 0, M)
+    wi = eng4.tsqr_work_info(S1, k=1, cols=ic)
+    res["walkman_full_4M_gram_tsqr_sdp_inputs"] = {
+        "samples": mult * S1, "passes": mult, "base_params": nbp, "gram_seconds": t_gram, "gram_samples_per_s": mult * S1 / t_gram,
+        "tsqr_base_columns": nbp + 1, "tsqr_seconds": t_tsqr, "tsqr_samples_per_s": mult * S1 / t_tsqr,
+        "tsqr_executed_TFLOP_per_s": mult * wi["flop"] / t_tsqr / 1e12,
+        "tsqr_dense_model_TFLOP_per_s": 2.0 * M * (nbp + 1) ** 2 / t_tsqr / 1e12,
+        "relerr_RtR_vs_gram": relerr, "rho2_norm_sqr": est.residual_sq_from_R(Rb, nbp, xb),
+        "note": "R1 = R[:nb,:nb], rho1 = R[:nb,nb] are the SDP inputs of sdp.py:470-487 (estimation.sdp_inputs)"}
+    return res
+
+
+def main():
+    args = parse_args()
+    maybe_spawn(args)
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -104,6 +104,11 @@ _SIGNATURES = {
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32],
     ),
     "fbr_tsqr_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "fbr_tsqr_work_info": (
+        ctypes.c_int,
+        [ctypes.c_void_p, _ip, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
+         ctypes.POINTER(ctypes.c_int64), _ip, _ip],
+    ),
     "fbr_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "fbr_profile_get": (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.POINTER(ctypes.c_int64)]),
     "fbr_gram_program_info": (
@@ -428,7 +433,20 @@ class Engine:
         _check(self._lib.fbr_tsqr_merge(self._h, n, a.ptr, b.ptr, r.ptr, a.mem), "fbr_tsqr_merge")
         return ret
 
-    PROF_CLASSES = ("kin", "regressor", "gram", "reduce", "id", "tsqr")
+    def tsqr_work_info(self, num_samples: int, k: int = 0, cols=None) -> dict:
+        """Executed MFMA instructions of ``tsqr(..)`` for ``num_samples`` samples (level-0 folds, merge tree), 512 flop each."""
+        ca = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+        l0, tr = ctypes.c_int64(), ctypes.c_int64()
+        mb, npad = ctypes.c_int32(), ctypes.c_int32()
+        _check(
+            self._lib.fbr_tsqr_work_info(self._h, None if ca is None else ca.ctypes.data_as(_ip), 0 if ca is None else int(ca.size), int(k),
+                                         int(num_samples), ctypes.byref(l0), ctypes.byref(tr), ctypes.byref(mb), ctypes.byref(npad)),
+            "fbr_tsqr_work_info",
+        )
+        return {"mfma_level0": l0.value, "mfma_tree": tr.value, "block_rows": mb.value, "n_padded": npad.value,
+                "flop": 512 * (l0.value + tr.value)}
+
+    PROF_CLASSES = ("kin", "regressor", "gram", "reduce", "id", "tsqr", "pack", "h2d")
 
     def profile_enable(self, on: bool = True) -> None:
         _check(self._lib.fbr_profile_enable(self._h, int(bool(on))), "fbr_profile_enable")

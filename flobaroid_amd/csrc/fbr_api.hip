@@ -136,6 +136,7 @@ struct fbr_model {
     // workspace
     DevBuf st_q, st_dq, st_ddq, st_bv, st_ba, st_rpy, st_sign, st_aux, st_aux2, st_x;
     DevBuf rec, partial, out_tmp, g_tmp;
+    DevBuf st_chunk[2];       // per-chunk staging of pinned host inputs (fused Gram pass), double buffered with the tile images
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     FbrTsqrWork tsqr;
     DevBuf tsqr_rowfc;        // first supported column of every regressor row (row-sorted TSQR chunks)
@@ -393,7 +394,20 @@ static int stage_one(fbr_model *m, DevBuf &buf, const double *src, size_t count,
     return FBR_OK;
 }
 
-static int stage_states(fbr_model *m, const fbr_states *st, DevStates *d, bool need_vel = true)
+// true iff p is pinned (page-locked / registered) host memory: hipMemcpyAsync from it is asynchronous
+static bool is_pinned_host(const void *p)
+{
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// defer_host: leave HOST inputs where they are (d receives the host pointers): the caller stages them chunk by chunk
+static int stage_states(fbr_model *m, const fbr_states *st, DevStates *d, bool need_vel = true, bool defer_host = false)
 {
     if (!m || !st) {
         set_err("null argument");
@@ -420,6 +434,16 @@ static int stage_states(fbr_model *m, const fbr_states *st, DevStates *d, bool n
     const size_t S = (size_t)st->num_samples;
     d->S = (long)S;
     int rc;
+    if (defer_host && st->mem == FBR_HOST) {
+        d->q = st->q;
+        d->dq = st->dq;
+        d->ddq = st->ddq;
+        d->rpy = hm.floating ? st->base_rpy : nullptr;
+        d->bv = hm.floating ? st->base_vel : nullptr;
+        d->ba = hm.floating ? st->base_acc : nullptr;
+        d->sign = hm.fric ? st->sign : nullptr;
+        return FBR_OK;
+    }
     if ((rc = stage_one(m, m->st_q, st->q, S * hm.n, st->mem, &d->q))) return rc;
     if ((rc = stage_one(m, m->st_dq, st->dq ? st->dq : st->q, S * hm.n, st->mem, &d->dq))) return rc;
     if ((rc = stage_one(m, m->st_ddq, st->ddq ? st->ddq : st->q, S * hm.n, st->mem, &d->ddq))) return rc;
@@ -771,8 +795,14 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
 static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
                      int32_t out_mem, int32_t accumulate, int32_t ngroups)
 {
+    // Pinned host inputs are staged chunk by chunk on the producer stream, overlapped with the Gram kernel of the previous chunk
+    // (the PCIe-inclusive rate of the pass); pageable ones up front (an asynchronous copy from pageable memory blocks
+    // the host thread and was measured slower when interleaved with the launches).
+    const bool h2d_chunked = st && st->mem == FBR_HOST && !getenv("FBR_NO_CHUNKED_H2D") && is_pinned_host(st->q) && is_pinned_host(st->dq) &&
+                             is_pinned_host(st->ddq) && is_pinned_host(st->base_vel) && is_pinned_host(st->base_acc) &&
+                             is_pinned_host(st->base_rpy) && is_pinned_host(st->sign) && is_pinned_host(rhs) && is_pinned_host(w);
     DevStates d;
-    int rc = stage_states(m, st, &d);
+    int rc = stage_states(m, st, &d, true, h2d_chunked);
     if (rc) return rc;
     if (!G_out || k < 0 || k > FBR_MAX_RHS || (k > 0 && !rhs)) {
         set_err("bad rhs / G_out arguments");
@@ -789,8 +819,13 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     const size_t gcount = (size_t)Pa * Pa * ngroups;
     const long S = d.S;
     const double *drhs = nullptr, *dw = nullptr;
-    if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
-    if ((rc = stage_one(m, m->st_aux2, w, (size_t)S * hm.rows, st->mem, &dw))) return rc;
+    if (h2d_chunked) {
+        drhs = rhs;  // host pointers: staged per chunk in produce()
+        dw = w;
+    } else {
+        if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
+        if ((rc = stage_one(m, m->st_aux2, w, (size_t)S * hm.rows, st->mem, &dw))) return rc;
+    }
     double *G = G_out;
     if (out_mem == FBR_HOST) {
         if ((rc = m->g_tmp.ensure(gcount * sizeof(double)))) return rc;
@@ -813,6 +848,12 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         const size_t img_bytes = (size_t)h->prog.image_doubles * sizeof(double);
         long ch = chunk_size(m, S);
         ch = std::max(1L, std::min(ch, (long)((size_t)4 * 1024 * 1024 * 1024 / img_bytes)));
+        if (ngroups == 1 && !getenv("FBR_CHUNK_SAMPLES")) {
+            // a short batch (e.g. one rank's shard of a multi-GPU run) is still cut into several chunks, so that only a small first
+            // chunk's producer work runs before the first Gram launch instead of half the batch's
+            static const long min_chunks = getenv("FBR_MIN_CHUNKS") ? std::max(1L, atol(getenv("FBR_MIN_CHUNKS"))) : 8;
+            ch = std::max(std::min(ch, 8192L), std::min(ch, (S + min_chunks - 1) / min_chunks));
+        }
         // work items: several whole groups per launch, or (groups larger than a chunk) pieces of one group
         struct Item { long s0, cs; int g0, ng; };
         std::vector<Item> items;
@@ -840,18 +881,45 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         // FBR_GRAM_SERIAL (diagnostic): producer on the main stream, i.e. no overlap with the Gram kernel
         hipStream_t side = getenv("FBR_GRAM_SERIAL") ? m->stream : m->side;
         HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
+        // per-sample doubles of one staged chunk (pinned host inputs): q dq ddq [bv ba rpy] [sign] [rhs] [w]
+        const size_t stage_per = (size_t)3 * hm.n + (hm.floating ? 15 : 0) + (d.sign ? hm.n : 0) + (size_t)hm.rows * k + (dw ? hm.rows : 0);
+        if (h2d_chunked)
+            for (int b = 0; b < (nchunks > 1 ? 2 : 1); b++)
+                if ((rc = m->st_chunk[b].ensure(std::max<size_t>(1, (size_t)ch * stage_per) * sizeof(double)))) return rc;
         auto produce = [&](long ci) -> int {
             const long s0 = items[ci].s0, cs = items[ci].cs;
             const int b = (int)(ci & 1);
             if (ci >= 2) HIPCHK(hipStreamWaitEvent(side, m->ev_gram[b], 0));  // Gram of chunk ci-2 is done with this buffer
-            int rc2 = run_kin(m, d, s0, cs, side, &m->rec2);
+            DevStates dc = d;     // what the kernels of this chunk read, and the sample offset into it
+            long o = s0;
+            const double *crhs = drhs, *cw = dw;
+            if (h2d_chunked) {
+                // (the pack kernel of chunk ci-2, the last reader of this staging buffer, precedes these copies on the side stream)
+                ProfScope ps(m, FBR_PROF_H2D, side);
+                double *p = m->st_chunk[b].as<double>();
+                auto put = [&](const double *src, size_t per, const double **dst) -> int {
+                    *dst = nullptr;
+                    if (!src || per == 0) return FBR_OK;
+                    HIPCHK(hipMemcpyAsync(p, src + (size_t)s0 * per, (size_t)cs * per * sizeof(double), hipMemcpyHostToDevice, side));
+                    *dst = p;
+                    p += (size_t)cs * per;
+                    return FBR_OK;
+                };
+                int r3;
+                if ((r3 = put(d.q, hm.n, &dc.q)) || (r3 = put(d.dq, hm.n, &dc.dq)) || (r3 = put(d.ddq, hm.n, &dc.ddq)) ||
+                    (r3 = put(d.bv, 6, &dc.bv)) || (r3 = put(d.ba, 6, &dc.ba)) || (r3 = put(d.rpy, 3, &dc.rpy)) ||
+                    (r3 = put(d.sign, hm.n, &dc.sign)) || (r3 = put(drhs, (size_t)hm.rows * k, &crhs)) || (r3 = put(dw, hm.rows, &cw)))
+                    return r3;
+                o = 0;
+            }
+            int rc2 = run_kin(m, dc, o, cs, side, &m->rec2);
             if (rc2) return rc2;
             {
-                ProfScope ps(m, FBR_PROF_REGRESSOR, side);
+                ProfScope ps(m, FBR_PROF_PACK, side);
                 const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
                 hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs, cs / items[ci].ng,
-                                   m->rec2.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
-                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,
+                                   m->rec2.as<double>(), dc.dq + o * hm.n, dc.sign ? dc.sign + o * hm.n : nullptr,
+                                   crhs ? crhs + (size_t)o * hm.rows * k : nullptr, cw ? cw + (size_t)o * hm.rows : nullptr,
                                    h->pimg[b].as<double>());
             }
             HIPCHK(hipGetLastError());
@@ -1000,6 +1068,29 @@ extern "C" int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W
 // ------------------------------------------------------------------------------------------------
 // TSQR (fbr_tsqr.h)
 // ------------------------------------------------------------------------------------------------
+// first column (in the order of the factorised columns) in which regressor row r can be non-zero: base-wrench rows meet every
+// inertial column, the row of joint d the columns of the links below d and its own friction columns; Psel = only the rhs columns
+static std::vector<int> tsqr_first_cols(const FbrHostModel &hm, const int32_t *cols, int Psel)
+{
+    std::vector<int> fc(hm.rows, Psel);
+    for (int r = 0; r < hm.rows; r++)
+        for (int c = 0; c < Psel; c++) {
+            const FbrCol &cd = hm.coldesc[cols ? cols[c] : c];
+            bool on;
+            if (r < hm.fb)
+                on = cd.kind == 0;
+            else if (cd.kind == 0)
+                on = std::find(hm.path[cd.link].begin(), hm.path[cd.link].end(), r - hm.fb) != hm.path[cd.link].end();
+            else
+                on = cd.joint == r - hm.fb;
+            if (on) {
+                fc[r] = c;
+                break;
+            }
+        }
+    return fc;
+}
+
 static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
                      const double *w, const double *R_in, double *R_out, int32_t out_mem)
 {
@@ -1059,22 +1150,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
     if (S > 0) {
         // first column (in the order of the factorised columns) in which regressor row r can be non-zero: base-wrench rows
         // meet every inertial column, the row of joint d the columns of the links below d and its own friction columns
-        std::vector<int> fc(hm.rows, Psel);  // nothing but the rhs columns
-        for (int r = 0; r < hm.rows; r++)
-            for (int c = 0; c < Psel; c++) {
-                const FbrCol &cd = hm.coldesc[cols ? cols[c] : c];
-                bool on;
-                if (r < hm.fb)
-                    on = cd.kind == 0;
-                else if (cd.kind == 0)
-                    on = std::find(hm.path[cd.link].begin(), hm.path[cd.link].end(), r - hm.fb) != hm.path[cd.link].end();
-                else
-                    on = cd.joint == r - hm.fb;
-                if (on) {
-                    fc[r] = c;
-                    break;
-                }
-            }
+        const std::vector<int> fc = tsqr_first_cols(hm, cols, Psel);
         if ((rc = m->tsqr_rowfc.ensure(fc.size() * sizeof(int)))) return rc;
         HIPCHK(hipMemcpyAsync(m->tsqr_rowfc.p, fc.data(), fc.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));  // fc is a local
@@ -1157,6 +1233,55 @@ extern "C" int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *
     return tsqr_impl(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem);
 }
 
+extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t ncols, int32_t k, int64_t num_samples, int64_t *mfma_level0,
+                                  int64_t *mfma_tree, int32_t *block_rows, int32_t *n_padded)
+{
+    if (!m || k < 0 || k > FBR_MAX_RHS || num_samples < 0 || (cols && (ncols <= 0 || ncols > m->hm.cols))) {
+        set_err("bad arguments");
+        return FBR_E_INVALID;
+    }
+    const FbrHostModel &hm = m->hm;
+    const int Psel = cols ? ncols : hm.cols, Pa = Psel + k;
+    FbrTsqrShape sh;
+    if (fbr_tsqr_shape(Pa, m->num_cus, num_samples * (long)hm.rows, &sh)) {
+        set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
+        return FBR_E_UNSUPPORTED;
+    }
+    const std::vector<int> fc = tsqr_first_cols(hm, cols, Psel);
+    const int NP = sh.n / 16;
+    const long per_update = 8L * sh.sub + 4;  // V^T C (4 SUB) + T (4) + C -= V W (4 SUB) MFMAs per (panel, tile right of it)
+    auto fold_mfma = [&](int first_col) -> long {
+        const long np_ = NP - first_col / 16;
+        return np_ > 0 ? per_update * (np_ * (np_ - 1) / 2) : 0;
+    };
+    long l0 = 0, tr = 0;
+    if (num_samples > 0) {
+        long ch = std::min(fbr_tsqr_chunk_samples(hm.rows, Pa), chunk_size(m, num_samples));
+        for (long s0 = 0; s0 < num_samples; s0 += ch) {
+            const long cs = std::min(ch, (long)num_samples - s0), M = cs * hm.rows, Mpad = (M + 15) & ~15L;
+            const long nblocks = (Mpad + sh.mb - 1) / sh.mb;
+            for (long b = 0; b < nblocks; b++) {
+                const long r0 = b * sh.mb;
+                int f = sh.n;
+                if (r0 < M) {
+                    const int ra = (int)(r0 / cs), rb = (int)((std::min<long>(r0 + sh.mb, M) - 1) / cs);
+                    for (int r = ra; r <= rb; r++) f = std::min(f, fc[r]);
+                }
+                l0 += fold_mfma(f);
+            }
+        }
+    }
+    long merge = 0;  // one node of the tree: the partner's triangular factor folded in block_rows-row pieces
+    for (int i0 = 0; i0 < sh.n; i0 += sh.mb) merge += fold_mfma(i0);
+    for (int stride = 1; stride < sh.NW; stride *= 2)
+        for (long a = 0; a + stride < sh.NW; a += 2L * stride) tr += merge;
+    if (mfma_level0) *mfma_level0 = l0;
+    if (mfma_tree) *mfma_tree = tr;
+    if (block_rows) *block_rows = sh.mb;
+    if (n_padded) *n_padded = sh.n;
+    return FBR_OK;
+}
+
 extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem)
 {
     if (!m || n <= 0 || !R_a || !R_b || !R_out) {
@@ -1174,7 +1299,12 @@ extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const 
         if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
         R = m->g_tmp.as<double>();
     }
-    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, n, da, m->num_cus, n)) || (rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, n, n, db, 0, nullptr, nullptr)) ||
+    // one workgroup (narrow factors: one wave) folds the partner's factor, 64 (32) rows at a time, into a working factor seeded with
+    // R_a; a block of the triangular R_b is folded from its first non-zero column.  (rows_hint = 1: a single working factor, no tree.)
+    FbrTsqrRowOrder tri;
+    tri.rows = -1;
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, n, da, m->num_cus, 1)) ||
+        (rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, n, n, db, 0, nullptr, nullptr, 0, nullptr, tri)) ||
         (rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) {
         set_err(std::string("tsqr merge: ") + fbr_tsqr_error());
         return rc == -4 ? FBR_E_UNSUPPORTED : (rc == -3 ? FBR_E_HIP : FBR_E_INVALID);

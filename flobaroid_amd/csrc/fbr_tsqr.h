@@ -37,9 +37,10 @@ typedef double fbr_td4 __attribute__((ext_vector_type(4)));
 static thread_local std::string g_tsqr_err;
 static inline const char *fbr_tsqr_error() { return g_tsqr_err.c_str(); }
 
-// Row order of a chunk handed to the factorisation.  rows == 0: as given (sample-major stack).  Otherwise the chunk holds `group`
+// Row order of a chunk handed to the factorisation.  rows == 0: as given (sample-major stack).  rows > 0: the chunk holds `group`
 // samples of `rows` regressor rows each and is stacked by regressor row: chunk row r * group + s is row r of sample s, and a
-// block of rows is zero left of first_col[r] (device table) of the regressor rows it spans.
+// block of rows is zero left of first_col[r] (device table) of the regressor rows it spans.  rows < 0: as given, and the input is
+// upper triangular (a factor handed to fbr_tsqr_merge): the block that starts at row r0 is zero left of column r0.
 struct FbrTsqrRowOrder {
     const int *first_col = nullptr;
     int rows = 0;
@@ -48,7 +49,7 @@ struct FbrTsqrRowOrder {
 // input row (sample-major) of chunk row o
 __device__ __forceinline__ long fbr_tsqr_in_row(long o, int rows, long group)
 {
-    if (rows == 0) return o;
+    if (rows <= 0) return o;
     const long r = o / group;
     return (o - r * group) * rows + r;
 }
@@ -577,12 +578,14 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
     auto fold_of = [&](int f) {
         const long r0 = ((long)blockIdx.x + (long)f * gridDim.x) * MB;
         int fc = 0;
-        if (orows) {  // chunk stacked by regressor row: the block is zero left of the first supported column of the rows it spans
+        if (orows > 0) {  // chunk stacked by regressor row: the block is zero left of the first supported column of the rows it spans
             fc = n;
             if (r0 < M) {
                 const int ra = (int)(r0 / ogroup), rb = (int)((std::min<long>(r0 + MB, M) - 1) / ogroup);
                 for (int r = ra; r <= rb; r++) fc = min(fc, rowfc[r]);
             }
+        } else if (orows < 0) {  // upper-triangular input
+            fc = (int)std::min<long>(r0, n);
         }
         return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc};
     };
@@ -741,12 +744,14 @@ __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow
     for (long b = g; b < nblocks; b += nwaves) {
         const long r0 = b * MB;
         int fc = 0;
-        if (orows) {  // chunk stacked by regressor row (FbrTsqrRowOrder)
+        if (orows > 0) {  // chunk stacked by regressor row (FbrTsqrRowOrder)
             fc = n;
             if (r0 < M) {
                 const int ra = (int)(r0 / ogroup), rb = (int)((std::min<long>(r0 + MB, M) - 1) / ogroup);
                 for (int r = ra; r <= rb; r++) fc = min(fc, rowfc[r]);
             }
+        } else if (orows < 0) {  // upper-triangular input
+            fc = (int)std::min<long>(r0, n);
         }
         fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc, lds, lane);
     }
@@ -843,8 +848,12 @@ static inline int fbr_tsqr_sub_for(int tpw) { return tpw <= 4 ? 4 : (tpw == 5 ? 
     default: { constexpr int NPT = 8, SUB = 2; CALL; } break; \
     }
 
-// Start a factorisation of width Pa: working factors zeroed, R_in (device, Pa x Pa, may be null) seeded into slot 0.
-static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint)
+// Kernel shape of a factorisation of width Pa over about rows_hint rows (shared by fbr_tsqr_begin and the work counter)
+struct FbrTsqrShape {
+    int n, tpw, sub, mb, NW, ld;
+    bool narrow;
+};
+static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrShape *out)
 {
     const int n = (Pa + 15) & ~15;
     if (n > FBR_TSQR_MAXN) {
@@ -860,6 +869,17 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
     const long per_cu = envw ? std::max(1, atoi(envw)) : (narrow ? 2 * FBR_TSQR_NARROW_WAVES : 1);  // narrow: private R per WAVE
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
     const int ld = narrow ? n : 16 * FBR_TSQR_WAVES * tpw;
+    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow};
+    return 0;
+}
+
+// Start a factorisation of width Pa: working factors zeroed, R_in (device, Pa x Pa, may be null) seeded into slot 0.
+static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint)
+{
+    FbrTsqrShape sh;
+    if (int rc = fbr_tsqr_shape(Pa, num_cus, rows_hint, &sh)) return rc;
+    const int n = sh.n, tpw = sh.tpw, sub = sh.sub, mb = sh.mb, NW = sh.NW, ld = sh.ld;
+    const bool narrow = sh.narrow;
     const size_t need = (size_t)NW * n * ld * sizeof(double);
     if (need > wk.rw_bytes) {
         if (wk.Rw) (void)hipFree(wk.Rw);

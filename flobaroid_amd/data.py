@@ -52,7 +52,8 @@ class Data:
         Every file drops its first ``startOffset`` samples.  Per key: 2-D arrays are stacked along the sample axis, 1-D
         arrays appended, scalars (e.g. ``frequency``) keep the last file's value; ``times`` of a later file continue the
         running clock: t - t[so] + (t[so+1] - t[so]) + last time so far.  ``file_boundaries`` records the sample index
-        at which every file starts.  Contact dictionaries are concatenated per frame (the reference keeps the last file's)."""
+        at which every file starts.  Contact dictionaries are concatenated per frame, zero-padded for the files that do not
+        carry a frame, so every frame has one row per loaded sample (the reference keeps the last file's dict only)."""
         with Timer() as timer:
             so = self.opt["startOffset"]
             bounds = [0]
@@ -71,14 +72,28 @@ class Data:
                                 v = v - v[so] + (v[so + 1] - v[so]) + merged[key][-1]
                             append(key, v[so:])
                         elif isinstance(v.item(0), dict):  # contact wrenches: {frame: (S, 6)}
+                            # (the reference keeps only the LAST file's dict, data.py:55-146; here every frame gets one row per
+                            # loaded sample: files that do not know a frame contribute zero wrenches for their samples)
+                            nrows = f["positions"].shape[0] - so
+                            before = bounds[-2]  # samples merged before this file
                             frames = {c: w[so:, :] for c, w in v.item(0).items() if c != "dummy_sim"}
-                            if key in merged and isinstance(merged[key].item(0), dict):
-                                old = merged[key].item(0)
-                                frames = {c: np.concatenate((old[c], w), axis=0) if c in old else w for c, w in frames.items()}
-                            merged[key] = np.array(frames)
+                            old = merged[key].item(0) if key in merged and isinstance(merged[key].item(0), dict) else {}
+                            out = {}
+                            for c in list(old.keys()) + [c for c in frames if c not in old]:
+                                prev = old[c] if c in old else np.zeros((before, 6))
+                                if prev.shape[0] < before:  # frame absent from intermediate files
+                                    prev = np.concatenate((prev, np.zeros((before - prev.shape[0], 6))), axis=0)
+                                out[c] = np.concatenate((prev, frames[c] if c in frames else np.zeros((nrows, 6))), axis=0)
+                            merged[key] = np.array(out)
                         else:
                             merged[key] = v
             self.file_boundaries = bounds
+            for key, v in merged.items():  # frames missing from the trailing files: zero wrenches up to the last sample
+                if isinstance(v, np.ndarray) and v.ndim == 0 and isinstance(v.item(0), dict):
+                    d = v.item(0)
+                    for c, w in d.items():
+                        if w.shape[0] < bounds[-1]:
+                            d[c] = np.concatenate((w, np.zeros((bounds[-1] - w.shape[0], 6))), axis=0)
             self._validate_required_keys(merged)
             self.num_loaded_samples = merged["positions"].shape[0]
             self.num_used_samples = self.num_loaded_samples // (self.opt["skipSamples"] + 1)

@@ -40,17 +40,19 @@ def tsqr_tree(R: torch.Tensor, merge: Callable[[torch.Tensor, torch.Tensor], tor
     if world == 1:
         return R
     R = R.contiguous()
+    # rank arithmetic is group-local; send / recv / broadcast take GLOBAL ranks
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     step = 1
     while step < world:
         if rank % (2 * step) == 0:
             src = rank + step
             if src < world:
                 other = torch.empty_like(R)
-                dist.recv(other, src=src, group=group)
+                dist.recv(other, src=g(src), group=group)
                 R = merge(R, other).contiguous()
         elif rank % (2 * step) == step:
-            dist.send(R, dst=rank - step, group=group)
+            dist.send(R, dst=g(rank - step), group=group)
             break
         step *= 2
-    dist.broadcast(R, src=0, group=group)
+    dist.broadcast(R, src=g(0), group=group)
     return R

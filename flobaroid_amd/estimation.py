@@ -156,20 +156,42 @@ def wls_row_weights(p_sigma_x: np.ndarray, num_used_samples: int, rows_total: in
     return d[:rows_total].copy()
 
 
-def d_optimality(G_aug: np.ndarray, independent_cols, delta: float = 0.0) -> float:
-    """Excitation criterion of the trajectory optimiser (excitation/trajectoryOptimizer.py:263-272):
-    -sum(log(eig(YBase^T YBase) + delta)) from the fused Gram, YBase^T YBase = G[ic, ic]."""
+def _regularized_neg_log_det(ev: np.ndarray, dopt_regularization: float) -> np.ndarray:
+    """-sum(log(max(ev + delta, 1e-300))) along the last axis with the reference's per-trajectory
+    delta = doptRegularization * max(lambda_max, 1e-30) (trajectoryOptimizer.py:267-272; eigvalsh returns ascending values)."""
+    delta = float(dopt_regularization) * np.maximum(ev[..., -1:], 1e-30)
+    return -np.sum(np.log(np.maximum(ev + delta, 1e-300)), axis=-1)
+
+
+def d_optimality(G_aug: np.ndarray, independent_cols, dopt_regularization: float = 1e-4, YtY_prior: np.ndarray | None = None) -> float:
+    """Excitation criterion of the trajectory optimiser (excitation/trajectoryOptimizer.py:259-272), same expression:
+    YtY = YBase^T YBase (= G[ic, ic] of the fused Gram) [+ YtY_prior, the sequential-design term :263-265],
+    delta = doptRegularization (config default 1e-4) * max(lambda_max, 1e-30), -sum(log(max(eig + delta, 1e-300)))."""
+    ic = np.asarray(independent_cols, dtype=np.int64)
+    YtY = G_aug[np.ix_(ic, ic)]
+    if YtY_prior is not None:
+        YtY = YtY + np.asarray(YtY_prior, dtype=np.float64)
+    return float(_regularized_neg_log_det(la.eigvalsh(YtY), dopt_regularization))
+
+
+def d_optimality_batch(G_groups: np.ndarray, independent_cols, dopt_regularization: float = 1e-4,
+                       YtY_prior: np.ndarray | None = None) -> np.ndarray:
+    """``d_optimality`` of every candidate trajectory of a batch: ``G_groups`` (ngroups, Pa, Pa) from
+    ``Engine.gram_grouped`` (one pass over all candidates; the optimiser's inner loop, trajectoryOptimizer.py:248-272).
+    delta is taken per candidate from that candidate's own largest eigenvalue, as the reference does per trajectory."""
+    ic = np.asarray(independent_cols, dtype=np.int64)
+    YtY = G_groups[:, ic[:, None], ic[None, :]]
+    if YtY_prior is not None:
+        YtY = YtY + np.asarray(YtY_prior, dtype=np.float64)[None]
+    return _regularized_neg_log_det(la.eigvalsh(YtY), dopt_regularization)
+
+
+def n_observable_base_params(G_aug: np.ndarray, independent_cols, dopt_regularization: float = 1e-4) -> int:
+    """Eigenvalues of YBase^T YBase above the regularisation threshold (trajectoryOptimizer.py:275; the count
+    trajectory.py:225-264 stores as ``n_observable_base_params``)."""
     ic = np.asarray(independent_cols, dtype=np.int64)
     ev = la.eigvalsh(G_aug[np.ix_(ic, ic)])
-    return float(-np.sum(np.log(np.maximum(ev, 0.0) + delta)))
-
-
-def d_optimality_batch(G_groups: np.ndarray, independent_cols, delta: float = 0.0) -> np.ndarray:
-    """``d_optimality`` of every candidate trajectory of a batch: ``G_groups`` (ngroups, Pa, Pa) from
-    ``Engine.gram_grouped`` (one pass over all candidates; the optimiser's inner loop, trajectoryOptimizer.py:248-272)."""
-    ic = np.asarray(independent_cols, dtype=np.int64)
-    ev = la.eigvalsh(G_groups[:, ic[:, None], ic[None, :]])
-    return -np.sum(np.log(np.maximum(ev, 0.0) + delta), axis=1)
+    return int(np.sum(ev > float(dopt_regularization) * max(float(ev[-1]), 1e-30)))
 
 
 def base_wrench_row_mask(num_samples: int, rows: int) -> np.ndarray:

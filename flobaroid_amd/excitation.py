@@ -14,12 +14,14 @@ import numpy as np
 from . import estimation as est
 
 
-def candidate_dopt(engine, states: dict, num_candidates: int, independent_cols, delta: float = 0.0, w=None) -> np.ndarray:
-    """-sum(log(eig(YBase^T YBase) + delta)) of ``num_candidates`` trajectories stacked along the sample axis
-    (equal length each), one fused pass (trajectoryOptimizer.py:263-272 per candidate)."""
+def candidate_dopt(engine, states: dict, num_candidates: int, independent_cols, dopt_regularization: float = 1e-4, w=None,
+                   YtY_prior=None) -> np.ndarray:
+    """Regularised D-optimality -sum(log(max(eig(YBase^T YBase [+ YtY_prior]) + delta, 1e-300))), delta = doptRegularization *
+    lambda_max per candidate, of ``num_candidates`` trajectories stacked along the sample axis (equal length each), one fused
+    pass (trajectoryOptimizer.py:259-272 per candidate)."""
     G = engine.gram_grouped(states, int(num_candidates), w=w)
     G = G.cpu().numpy() if hasattr(G, "cpu") else G
-    return est.d_optimality_batch(G, independent_cols, delta)
+    return est.d_optimality_batch(G, independent_cols, dopt_regularization, YtY_prior)
 
 
 def dopt_sensitivities(engine, states: dict, W_iner, epsilon: float, W_visc=None, reference_state_carryover: bool = False):

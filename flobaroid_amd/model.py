@@ -371,6 +371,13 @@ class Model:
             st["sign"] = np.tanh(dq / float(self.opt.get("frictionSignThreshold", 0.02)))  # model.py:757-758
         return st
 
+    CACHE_PRODUCER = "flobaroid_amd/1"
+
+    def _dof_hash(self) -> str:
+        import hashlib
+
+        return hashlib.sha1("\n".join(self.jointNames + ["|"] + self.linkNames).encode()).hexdigest()
+
     def getRandomRegressor(self, n_samples=None):
         """Structural Gram R = sum A^T A over random states + its pivoted QR, with the reference's npz
         cache (model.py:634-830).  The Gram is the raw sum (never normalised): minTol applies to it."""
@@ -379,14 +386,22 @@ class Model:
         regr_filename = self.urdf_file + suffix
         fb = opt["floatingBase"]
         generate_new = False
+        # The file name and the reference's keys are kept (model.py:811-822) so the tools around it find the cache, but a cache
+        # is only trusted when it was written by this implementation for the same DOF serialisation and friction layout:
+        # iDynTree's DOF order can differ from ours (URDF document order), which permutes the friction columns, and the
+        # reference's own validity check ignores both that and stribeckVelocity.
+        dof_hash = self._dof_hash()
+        stribeck = float(opt.get("stribeckVelocity", 0) or 0.0)
         try:
             f = np.load(regr_filename)
             R, Q, RQ, PQ = f["R"], f["Q"], f["RQ"], f["PQ"]
             if (f["n"] != n_samples or f["fb"] != fb or R.shape[0] != self.num_identified_params
                     or opt["identifyGravityParamsOnly"] != f["grav_only"] or f["fric"] != opt["identifyFrictionSimultaneously"]
-                    or f["fric_sym"] != opt["identifySymmetricVelFriction"]):
+                    or f["fric_sym"] != opt["identifySymmetricVelFriction"]
+                    or "producer" not in f or str(f["producer"]) != self.CACHE_PRODUCER or str(f["dof_hash"]) != dof_hash
+                    or float(f["stribeck"]) != stribeck):
                 generate_new = True
-        except (OSError, KeyError):
+        except (OSError, KeyError, ValueError):
             generate_new = True
         if generate_new:
             if not n_samples:
@@ -397,7 +412,8 @@ class Model:
             try:
                 np.savez(regr_filename, R=R, Q=Q, RQ=RQ, PQ=PQ, n=n_samples, fb=opt["floatingBase"],
                          grav_only=opt["identifyGravityParamsOnly"], fric=opt["identifyFrictionSimultaneously"],
-                         fric_sym=opt["identifySymmetricVelFriction"])
+                         fric_sym=opt["identifySymmetricVelFriction"], producer=self.CACHE_PRODUCER, dof_hash=dof_hash,
+                         stribeck=stribeck)
             except OSError:
                 pass  # read-only model directory: skip the cache
         return R, Q, RQ, PQ

@@ -184,8 +184,10 @@ int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b
 #define FBR_PROF_GRAM 2      /* fused regressor->Gram MFMA kernel */
 #define FBR_PROF_REDUCE 3    /* slice reduction / scatter of the Gram partials */
 #define FBR_PROF_ID 4        /* inverse dynamics / predict kernel */
-#define FBR_PROF_TSQR 5      /* TSQR fold kernels (whole fold) */
-#define FBR_PROF_COUNT 6
+#define FBR_PROF_TSQR 5      /* TSQR fold kernels (level 0 per chunk, merge tree) */
+#define FBR_PROF_PACK 6      /* tile-image packing kernel of the fused Gram pass (producer stream) */
+#define FBR_PROF_H2D 7       /* host -> device staging copies of the chunked fused pass (pinned host inputs) */
+#define FBR_PROF_COUNT 8
 /* When enabled, every kernel launch is bracketed by hipEvents on the launch stream; fbr_profile_get
    returns, per kernel class, the summed device time in ms and the launch count since the last reset
    (the counters are reset by the call).  Used by bench.py for the live roofline figures. */
@@ -193,6 +195,16 @@ int fbr_profile_enable(fbr_model *m, int32_t on);
 int fbr_profile_get(fbr_model *m, double *ms_out /*[FBR_PROF_COUNT]*/, int64_t *launches_out /*[FBR_PROF_COUNT]*/);
 
 /* ---- introspection (tests, tooling) ------------------------------------------------------------ */
+/*
+ * MFMA instructions (v_mfma_f64_16x16x4_f64, 512 flop each) that fbr_tsqr / fbr_tsqr_cols executes for num_samples
+ * samples and k rhs columns: the level-0 folds of the row-sorted chunks (a block is folded from the first column its rows
+ * can touch) and the merge tree over the per-workgroup factors -- counted on the host from the same chunking and fold
+ * rules the kernels use, so bench.py can report executed (not dense-model) flops.  cols == NULL: every identified column.
+ * block_rows / n_padded (optional): rows per fold and padded factor width.
+ */
+int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t ncols, int32_t k, int64_t num_samples, int64_t *mfma_level0,
+                       int64_t *mfma_tree, int32_t *block_rows, int32_t *n_padded);
+
 /* Tile program of the fused Gram kernel: counts of padded column tiles / tile pairs / MFMA k-steps per
    sample, so tests and bench.py can report executed vs algorithmic flops. */
 int fbr_gram_program_info(const fbr_model *m, int32_t k, int32_t *num_tiles, int32_t *num_pairs,

@@ -51,6 +51,13 @@ assert np.linalg.norm(R.numpy().T @ R.numpy() - A.T @ A) <= 1e-12 * np.linalg.no
 Rs = [torch.empty_like(R) for _ in range(world)]
 dist.all_gather(Rs, R)
 assert all(torch.equal(Rs[0], r) for r in Rs)
+# sub-group (1, 2) of a 3-rank world: group-local ranks 0, 1 are global ranks 1, 2 (send / recv / broadcast take global ranks)
+if world == 3:
+    sub = dist.new_group([1, 2])
+    if rank in (1, 2):
+        Ab = A[om.rows * (0 if rank == 1 else 150):om.rows * (150 if rank == 1 else S)]
+        Rg = tsqr_tree(torch.from_numpy(np.linalg.qr(Ab, mode="r")), merge, group=sub)
+        assert np.linalg.norm(Rg.numpy().T @ Rg.numpy() - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -76,3 +83,45 @@ def test_two_rank_gloo(tmp_path):
         outs = [p.communicate(timeout=240)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
         procs = []
+
+
+def _run_bench(extra, env_extra=None, timeout=600):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    if env_extra:
+        env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--engine", "cpu_engine:make_engine", "--samples", "192",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sustain-seconds", "0"] + extra
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_bench_gpus_2_spawns_two_ranks_end_to_end():
+    """``python bench.py --gpus 2`` starts its two ranks itself (re-exec under torch.distributed.run), shards the samples,
+    all-reduces the Gram, runs the TSQR rank tree with its in-bench check and the weak-scaling leg, and prints ONE JSON line
+    whose n_gpus is the process group's size.  gloo + the CPU stand-in engine: the launch logic is the product's, the arithmetic
+    is the oracle's.  The one-rank run must reduce the same 192 samples to the same Gram."""
+    import json
+
+    lines = {}
+    for n in (1, 2):
+        r = _run_bench(["--gpus", str(n)])
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        js = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(js) == 1, r.stdout.decode()
+        lines[n] = json.loads(js[0])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and two["ranks_seen_by_process_group"] == 2 and one["n_gpus"] == 1
+    assert two["scaling"] == "strong" and two["config"]["samples_per_gpu"] == 96 and two["config"]["samples_per_step"] == 192
+    for key in ("trace", "fro"):
+        assert abs(one["gram_checksum"][key] - two["gram_checksum"][key]) <= 1e-11 * abs(one["gram_checksum"][key])
+    assert two["tsqr"]["rank_tree_levels"] == 1 and two["tsqr"]["relerr_RtR_vs_allreduced_gram"] <= 1e-11
+    assert two["weak_scaling"]["samples_per_gpu"] == 192 and two["weak_scaling"]["relerr_vs_world_x_sharded_gram"] <= 1e-11
+    assert "weak_scaling" not in one and one["tsqr"]["rank_tree_levels"] == 0
+
+
+def test_bench_refuses_a_mislabelled_world():
+    """Launched by hand with fewer ranks than --gpus says, the bench fails instead of printing n_gpus: N for one rank."""
+    r = _run_bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert r.returncode != 0 and b"refusing" in r.stderr
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]

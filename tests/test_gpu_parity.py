@@ -44,8 +44,25 @@ def test_regressor_matches_oracle(cfg):
     Yo = om.regressor(st, st["sign"])
     assert Y.shape == Yo.shape
     assert np.abs(Y - Yo).max() <= 1e-11 * np.abs(Yo).max()
-    # structural zeros must be exact zeros
-    assert np.all(Y[Yo == 0.0] == 0.0) or np.abs(Y[Yo == 0.0]).max() < 1e-9
+    # STRUCTURAL zeros -- decided by the topology: the row of joint d in the columns of a link that does not hang below d, every
+    # row but its joint's in a friction column -- are exact zeros.  Entries the oracle evaluates to exactly 0.0 for another reason
+    # (an analytic cancellation of its body-frame formulation, e.g. a link origin on its joint axis) only have to vanish to
+    # rounding in the base-frame formulation of the kernels.
+    fb = 6 if cfg[1] else 0
+    cpl = 4 if cfg[4] else 10
+    anc = t.ancestors_dofs()
+    mask = np.zeros((eng.rows, eng.cols), dtype=bool)
+    for l in range(t.num_links):
+        for d in range(t.num_dofs):
+            if d not in anc[l]:
+                mask[fb + d, cpl * l:cpl * (l + 1)] = True
+    for c in range(cpl * t.num_links, eng.cols):
+        j = (c - cpl * t.num_links) % t.num_dofs
+        mask[:, c] = True
+        mask[fb + j, c] = False
+    Y3, Yo3 = Y.reshape(37, eng.rows, eng.cols), Yo.reshape(37, eng.rows, eng.cols)
+    assert np.all(Yo3[:, mask] == 0.0) and np.all(Y3[:, mask] == 0.0)
+    assert np.abs(Y[Yo == 0.0]).max(initial=0.0) <= 1e-13 * np.abs(Yo).max()
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=cfg_id)
@@ -256,9 +273,9 @@ def test_grouped_gram_equals_one_gram_per_group(cfg):
     A = _aug(om, {k: v[:Sg] for k, v in st.items()}, rhs[: Sg * om.rows], w[: Sg * om.rows])
     assert np.linalg.norm(Gg[0] - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
     ic = np.flatnonzero(np.diag(Gg.sum(axis=0))[: om.P] > 0)[:20]
-    dopt = est.d_optimality_batch(Gg, ic, 1e-6)
+    dopt = est.d_optimality_batch(Gg, ic, 1e-4)
     for g in range(ng):
-        assert abs(dopt[g] - est.d_optimality(Gg[g], ic, 1e-6)) <= 1e-9 * abs(dopt[g])
+        assert abs(dopt[g] - est.d_optimality(Gg[g], ic, 1e-4)) <= 1e-9 * abs(dopt[g])
     with pytest.raises(Exception):
         eng.gram_grouped(st, 4)  # 630 samples are not a multiple of 4
 

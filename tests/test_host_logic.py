@@ -48,6 +48,30 @@ def test_data_container(tmp_path):
         Data(_opt()).init_from_data({"positions": np.zeros((3, 2))})
 
 
+def test_contact_frames_of_several_files_are_aligned_with_the_samples(tmp_path):
+    """Every contact frame has one row per loaded sample, whichever files carry it (zero wrenches elsewhere), so that
+    contact_dict[frame][idx] in computeRegressors (model.py:535-560) stays aligned with ``positions``."""
+    rng = np.random.default_rng(1)
+    files, wr = [], {}
+    layout = [("a", ["l_foot", "r_foot"]), ("b", ["r_foot"]), ("c", []), ("d", ["l_foot", "hand"])]
+    for name, frames in layout:
+        m = _meas(20, 3, rng)
+        if frames:
+            wr[name] = {fr: rng.random((20, 6)) for fr in frames}
+            m["contacts"] = np.array(dict(wr[name], dummy_sim=np.zeros((20, 6))))
+        files.append(str(tmp_path / f"{name}.npz"))
+        np.savez(files[-1], **m)
+    d = Data(_opt(startOffset=2))
+    d.init_from_files([files[:2], files[2:]])
+    assert d.file_boundaries == [0, 18, 36, 54, 72]
+    c = d.samples["contacts"].item(0)
+    assert sorted(c) == ["hand", "l_foot", "r_foot"] and all(w.shape == (72, 6) for w in c.values())
+    z = np.zeros((18, 6))
+    assert np.array_equal(c["l_foot"], np.concatenate((wr["a"]["l_foot"][2:], z, z, wr["d"]["l_foot"][2:])))
+    assert np.array_equal(c["r_foot"], np.concatenate((wr["a"]["r_foot"][2:], wr["b"]["r_foot"][2:], z, z)))
+    assert np.array_equal(c["hand"], np.concatenate((z, z, z, wr["d"]["hand"][2:])))
+
+
 def test_friction_sign_helpers():
     """tests/test_friction_helpers.py:27-83: tanh(v/thr) identity, caching, raw-velocity filtering, fallbacks."""
     rng = np.random.default_rng(1)
@@ -193,9 +217,28 @@ def test_direct_std_identification_dopt_and_row_weights():
     # D-optimality from the Gram (trajectoryOptimizer.py:263-272)
     ic = d["independent_cols"]
     YB = Y[:, ic]
-    ref = -np.sum(np.log(la.eigvalsh(YB.T @ YB) + 1e-6))
     G = np.column_stack([Y, tau]).T @ np.column_stack([Y, tau])
-    assert abs(est.d_optimality(G, ic, 1e-6) - ref) <= 1e-8 * abs(ref)
+
+    def ref_dopt(YtY, reg=1e-4):  # the reference's expression, trajectoryOptimizer.py:262-272
+        eigvals = np.linalg.eigvalsh(YtY)
+        delta = reg * max(float(eigvals[-1]), 1e-30)
+        return -np.sum(np.log(np.maximum(eigvals + delta, 1e-300))), int(np.sum(eigvals > delta))
+
+    ref, nobs = ref_dopt(YB.T @ YB)
+    assert abs(est.d_optimality(G, ic) - ref) <= 1e-8 * abs(ref)
+    assert est.n_observable_base_params(G, ic) == nobs
+    prior = 3.0 * (YB[:70].T @ YB[:70])
+    ref_p, _ = ref_dopt(YB.T @ YB + prior, 1e-3)
+    assert abs(est.d_optimality(G, ic, 1e-3, YtY_prior=prior) - ref_p) <= 1e-8 * abs(ref_p)
+    # rank-deficient candidate Gram (a trajectory that does not excite some base directions): finite, as in the reference,
+    # and delta scales with each candidate's own lambda_max in the batch form
+    Gd = G.copy()
+    Gd[ic[:5], :] = 0.0
+    Gd[:, ic[:5]] = 0.0
+    ref_d, _ = ref_dopt(Gd[np.ix_(ic, ic)])
+    assert np.isfinite(ref_d) and abs(est.d_optimality(Gd, ic) - ref_d) <= 1e-8 * abs(ref_d)
+    batch = est.d_optimality_batch(np.stack([G, 100.0 * G, Gd]), ic)
+    assert np.allclose(batch, [ref, ref_dopt(100.0 * (YB.T @ YB))[0], ref_d], rtol=1e-8)
     # per-trajectory row weights (identifier.py:654-679)
     S = 300
     res = rng.standard_normal((S, 6)) * np.array([1, 2, 3, 1, 1, 1.0])
