@@ -149,6 +149,11 @@ def _np_states(topo, S, seed, floating=True):
     return st
 
 
+def synth_states(topo, S, seed, floating=True):
+    """NumPy states + the generator (tools/*_probe.py)."""
+    return _np_states(topo, S, seed, floating), np.random.default_rng(seed + 1)
+
+
 def cpu_baseline(topo, budget_s=12.0):
     """Phase A of BASELINE.md §3 on ONE host thread: oracle (C restatement) per-sample regressor + RNEA torques + the A^T A
     accumulation of the stacked block with NumPy (BLAS pinned to 1 thread)."""
@@ -505,7 +510,7 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
         "executed_TFLOP_per_s": executed_flop / dt / 1e12,
         "executed_frac_of_fp64_mfma_peak": executed_flop / dt / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world),
         "dense_model_TFLOP_per_s": dense_flop / dt / 1e12,
-        "flop_models": "executed: 512 flop x MFMAs the folds run (fbr_tsqr_work_info: row-sorted chunks fold from their first supported "
+        "flop_models": "executed: 2048 flop x MFMAs the folds run (fbr_tsqr_work_info: row-sorted chunks fold from their first supported "
                        "column); dense: 2*rows*(P+k)^2 per sample (SURVEY 8d)",
         "rank_tree_levels": merges, "relerr_RtR_vs_allreduced_gram": err,
         "kernel_ms_per_call_rank0": {k: v[0] / reps for k, v in pr.items() if v[1]},
@@ -698,14 +703,18 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
     relerr = float(np.linalg.norm(Rb.T @ Rb - Gb) / np.linalg.norm(Gb))
     M = mult * S1 * eng4.rows
     nbp = len(ic)
-    xb, _ = est.lstsq_from_R(Rb, nbp, 0, M)
+    xb, sv = est.lstsq_from_R(Rb, nbp, 0, M)
     wi = eng4.tsqr_work_info(S1, k=1, cols=ic)
     res["walkman_full_4M_gram_tsqr_sdp_inputs"] = {
         "samples": mult * S1, "passes": mult, "base_params": nbp, "gram_seconds": t_gram, "gram_samples_per_s": mult * S1 / t_gram,
         "tsqr_base_columns": nbp + 1, "tsqr_seconds": t_tsqr, "tsqr_samples_per_s": mult * S1 / t_tsqr,
         "tsqr_executed_TFLOP_per_s": mult * wi["flop"] / t_tsqr / 1e12,
         "tsqr_dense_model_TFLOP_per_s": 2.0 * M * (nbp + 1) ** 2 / t_tsqr / 1e12,
-        "relerr_RtR_vs_gram": relerr, "rho2_norm_sqr": est.residual_sq_from_R(Rb, nbp, xb),
+        "relerr_RtR_vs_gram": relerr,
+        # ||tau - YBase xBase||^2 of the least-squares fit = the square of the last diagonal entry of the augmented factor; the
+        # synthetic torques carry N(0, 0.05^2) noise per row (rho2_norm_sqr of sdp.py:482-485 without contacts)
+        "rho2_norm_sqr": float(Rb[nbp, nbp] ** 2), "rho2_expected_from_noise": 0.05 ** 2 * (M - nbp),
+        "lstsq_default_rcond_kept_singular_values": int(np.count_nonzero(sv > np.finfo(float).eps * M * sv[0])),
         "note": "R1 = R[:nb,:nb], rho1 = R[:nb,nb] are the SDP inputs of sdp.py:470-487 (estimation.sdp_inputs)"}
     return res
 

@@ -434,7 +434,7 @@ class Engine:
         return ret
 
     def tsqr_work_info(self, num_samples: int, k: int = 0, cols=None) -> dict:
-        """Executed MFMA instructions of ``tsqr(..)`` for ``num_samples`` samples (level-0 folds, merge tree), 512 flop each."""
+        """Executed MFMA instructions of ``tsqr(..)`` for ``num_samples`` samples (level-0 folds, merge tree), 2 * 16 * 16 * 4 = 2048 flop each."""
         ca = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
         l0, tr = ctypes.c_int64(), ctypes.c_int64()
         mb, npad = ctypes.c_int32(), ctypes.c_int32()
@@ -444,7 +444,7 @@ class Engine:
             "fbr_tsqr_work_info",
         )
         return {"mfma_level0": l0.value, "mfma_tree": tr.value, "block_rows": mb.value, "n_padded": npad.value,
-                "flop": 512 * (l0.value + tr.value)}
+                "flop": 2048 * (l0.value + tr.value)}
 
     PROF_CLASSES = ("kin", "regressor", "gram", "reduce", "id", "tsqr", "pack", "h2d")
 

@@ -465,6 +465,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         // factorise panel p = tile p of this wave (global index G): Householder QR of [R_pp ; tile] in registers,
         // publish V, T in ring slot G % RING
         auto chain = [&](int p, int G) {
+            unsigned long long tc0 = tacc ? __builtin_readcyclecounter() : 0;
             const int tp = p / W;
             fbr_td4 v[SUB];
 #pragma unroll
@@ -481,6 +482,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             double trow[16];
             double myscale = 0.0;
             unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
+            if (tacc) tacc[7] += tq - tc0;  // tile copy, R_pp staging
             fbr_tsqr_panel_steps<SUB>(v, Rp, rq, trow, myscale, li, kk, std::make_integer_sequence<int, 16>{});
             if (tacc) tacc[4] += __builtin_readcyclecounter() - tq;
             // the ring slot is free once no wave needs panel G - RING any more
@@ -509,6 +511,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             }
             // panels are published in order (the previous one may belong to the previous fold and still be in flight)
             tq = tacc ? __builtin_readcyclecounter() : 0;
+            if (tacc) tacc[8] += tq - tc0;  // (cumulative up to here: + ring wait + V, T writes)
             ok = ok && fbr_tsqr_wait_ge(pub, G);
             if (tacc) tacc[6] += __builtin_readcyclecounter() - tq;
             fbr_lds_release();
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
                                                                                unsigned long long *dbg, const int *__restrict__ rowfc, int orows,
                                                                                long ogroup, long M)
 {
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
     constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;  // leading dimension of the working factors (>= n)
@@ -591,8 +594,8 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
     };
     fbr_tsqr_stream<TPW, SUB>(R, n, LD, nfolds, fold_of, smem, errflag, dbg ? tacc : nullptr);
     if (dbg && (threadIdx.x & 63) == 0) {
-        unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 8;
-        for (int i = 0; i < 8; i++) d[i] = tacc[i];
+        unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 16;
+        for (int i = 0; i < 16; i++) d[i] = tacc[i];
     }
 }
 
@@ -938,8 +941,8 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
     const int grid = (int)std::min<long>(wk.NW, nblocks);
     unsigned long long *dbg = nullptr;
     if (getenv("FBR_TSQR_TIMING")) {
-        TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 8 * 8));
-        TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 8 * 8, st));
+        TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 16 * 8));
+        TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 16 * 8, st));
     }
     FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
@@ -947,14 +950,14 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
                                                  (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
     TSQR_HIP(hipGetLastError());
     if (dbg) {
-        std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 8);
+        std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 16);
         TSQR_HIP(hipMemcpyAsync(hb.data(), dbg, hb.size() * 8, hipMemcpyDeviceToHost, st));
         TSQR_HIP(hipStreamSynchronize(st));
-        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t i = 0; i < hb.size(); i++) sum[i & 7] += (double)hb[i];
+        double sum[16] = {0};
+        for (size_t i = 0; i < hb.size(); i++) sum[i & 15] += (double)hb[i];
         const double folds = (double)nblocks * FBR_TSQR_WAVES;
-        fprintf(stderr, "[fbr tsqr timing] cycles per fold per wave: load+init=%.0f chain=%.0f (16 steps %.0f, ring wait %.0f, order wait %.0f) wait_panel=%.0f update=%.0f  (mb=%d n=%d, %ld folds)\n",
-                sum[0] / folds, sum[1] / folds, sum[4] / folds, sum[5] / folds, sum[6] / folds, sum[2] / folds, sum[3] / folds, wk.mb, n, nblocks);
+        fprintf(stderr, "[fbr tsqr timing] cycles per fold per wave: load+init=%.0f chain=%.0f (before steps %.0f, 16 steps %.0f, ring wait %.0f, up to V/T written %.0f, order wait %.0f) wait_panel=%.0f update=%.0f  (mb=%d n=%d, %ld folds)\n",
+                sum[0] / folds, sum[1] / folds, sum[7] / folds, sum[4] / folds, sum[5] / folds, sum[8] / folds, sum[6] / folds, sum[2] / folds, sum[3] / folds, wk.mb, n, nblocks);
         (void)hipFree(dbg);
     }
     return 0;

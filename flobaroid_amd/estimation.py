@@ -116,6 +116,62 @@ def sdp_inputs(R_aug: np.ndarray, independent_cols, K: np.ndarray, P: int, xBase
     return {"R1": R1, "rho1": rho1, "contactForces": cf, "rho2_norm_sqr": rho2, "R1_K": R1 @ K}
 
 
+def observability_weights(R1_K: np.ndarray) -> np.ndarray:
+    """Per-parameter CAD-pull weights of ``SDP._observabilityWeights`` (sdp.py:295-315), same expression: with the reduced
+    normal matrix M = (R1 K)^T (R1 K) and the ridge eps = 1e-6 * trace(M) / n, obs_std = sqrt(clip(diag((M + eps I)^-1), 0)),
+    normalised by the median of its positive entries and clipped to [0.1, 100].  Ordered like the columns of ``R1_K``."""
+    M = R1_K.T @ R1_K
+    eps = 1e-6 * float(np.trace(M)) / M.shape[0]
+    cov_diag = np.clip(np.diag(la.inv(M + eps * np.eye(M.shape[0]))), 0.0, None)
+    obs_std = np.sqrt(cov_diag)
+    positive = obs_std[obs_std > 0]
+    med = float(np.median(positive)) if positive.size else 1.0
+    return np.clip(obs_std / med, 0.1, 100.0)
+
+
+def sdp_regularized_system(sdp_in: dict, xStdModel: np.ndarray, identified_params, non_id, base_error: float, regularization_factor: float,
+                           mode: str = "uniform", delete_cols=()) -> dict:
+    """The linear system the SDP's Schur block is built from (sdp.py:487-531): the residual is
+    e = rho1_hat - contactForces_hat - Y_combined @ x  over the identifiable standard parameters x, with
+    [R1 K; diag(w)] x ~ [rho1; diag(w) xStdModel] -- the CAD regularisation rows that keep the null-space part near the a-priori
+    model.  ``mode`` = opt['cadRegularizationMode']: 'uniform' pulls the non-identifiable parameters with one weight
+    base_error / len * regularizationFactor, 'observability' every identifiable parameter with ``observability_weights``,
+    'geometric' / regularisation off (``regularization_factor`` = 0 or None) adds no rows.
+
+    ``sdp_in``: the dict of ``sdp_inputs`` (R1_K's columns must already exclude ``delete_cols``); ``identified_params`` /
+    ``non_id`` as on the Model.  Returns Y_combined, rho1_hat, contactForces_hat, reg_params, reg_weights (dict)."""
+    delete_cols = set(int(c) for c in delete_cols)
+    idable = sorted(set(int(p) for p in identified_params).difference(delete_cols))
+    index = {p: i for i, p in enumerate(idable)}
+    R1_K, rho1, cf = sdp_in["R1_K"], sdp_in["rho1"], sdp_in["contactForces"]
+    if R1_K.shape[1] != len(idable):
+        raise ValueError("R1_K must have one column per identifiable parameter (delete_cols removed)")
+    reg_params: list[int] = []
+    reg_weights: dict[int, float] = {}
+    if regularization_factor:
+        p_nid = sorted(set(int(p) for p in non_id).difference(delete_cols).intersection(idable))
+        if mode == "observability":
+            w = observability_weights(R1_K)
+            reg_params = idable
+            base = (float(base_error) / len(reg_params)) * regularization_factor
+            reg_weights = {p: base * float(w[index[p]]) for p in reg_params}
+        elif mode == "geometric":
+            pass  # a log-det prior in the objective (sdp.py:506-510), no residual rows
+        elif p_nid:
+            reg_params = p_nid
+            base = (float(base_error) / len(p_nid)) * regularization_factor
+            reg_weights = {p: base for p in p_nid}
+    if not reg_params:
+        return {"Y_combined": R1_K, "rho1_hat": rho1, "contactForces_hat": cf, "reg_params": [], "reg_weights": {}}
+    Y_bot = np.zeros((len(reg_params), len(idable)))
+    rho_bot = np.zeros(len(reg_params))
+    for i, p in enumerate(reg_params):
+        Y_bot[i, index[p]] = reg_weights[p]
+        rho_bot[i] = reg_weights[p] * xStdModel[p]
+    return {"Y_combined": np.vstack([R1_K, Y_bot]), "rho1_hat": np.concatenate((rho1, rho_bot)),
+            "contactForces_hat": np.concatenate((cf, np.zeros(len(reg_params)))), "reg_params": reg_params, "reg_weights": reg_weights}
+
+
 def find_std_from_base(K: np.ndarray, xBase: np.ndarray) -> np.ndarray:
     """``findStdFromBaseParameters`` (identifier.py:328-341): xStd = pinv(K) xBase."""
     return la.pinv(K).dot(xBase)

@@ -23,6 +23,27 @@ from . import helpers
 from .topology import Topology, parse_urdf
 
 
+def pivoted_qr(A: np.ndarray, tie_eps: float = 1e-9):
+    """``scipy.linalg.qr(A, pivoting=True, mode="economic")`` (model.py:809,841) with a DETERMINISTIC rule for ties.
+
+    The structural regressor has columns whose pivoting norms are equal in exact arithmetic (e.g. inertia columns of a link that
+    the joint symmetry maps onto each other): which one LAPACK's dgeqp3 takes is decided by the last bits of the Gram, i.e. by the
+    summation order -- it differs between the reference's sample loop, the CPU oracle and the GPU reduction, and with it the
+    base-parameter index set.  Rule: norms within a relative ``tie_eps`` count as tied and the LOWEST column index wins.  It is
+    imposed without leaving LAPACK: the pivots are taken from dgeqp3 on A with column j scaled by 1 + tie_eps * (P - j) / P
+    (column scaling multiplies the trailing column norms of every step by exactly that factor, so it only reorders ties), then the
+    factor is recomputed from the UNSCALED matrix with that column order.  Outside ties the pivots, and to rounding R, are what
+    the reference's call returns."""
+    A = np.asarray(A)
+    Pn = A.shape[1]
+    if tie_eps and Pn > 0:
+        d = 1.0 + float(tie_eps) * (Pn - np.arange(Pn)) / Pn
+        piv = sla.qr(A * d[None, :], pivoting=True, mode="r")[1]
+        Q, R = sla.qr(A[:, piv], mode="economic")
+        return Q, R, piv
+    return sla.qr(A, pivoting=True, mode="economic")
+
+
 class LazyRegressor:
     """Stand-in for a (S*rows) x cols regressor that is too large to hold on the host.
 
@@ -371,7 +392,11 @@ class Model:
             st["sign"] = np.tanh(dq / float(self.opt.get("frictionSignThreshold", 0.02)))  # model.py:757-758
         return st
 
-    CACHE_PRODUCER = "flobaroid_amd/1"
+    CACHE_PRODUCER = "flobaroid_amd/2"  # /2: pivots follow the lowest-index tie rule
+
+    def _tie_eps(self) -> float:
+        """opt['pivotTieTolerance'] (default 1e-9; 0 = LAPACK's own last-bit tie breaking, as the reference)."""
+        return float(self.opt.get("pivotTieTolerance", 1e-9))
 
     def _dof_hash(self) -> str:
         import hashlib
@@ -408,7 +433,7 @@ class Model:
                 n_samples = self.num_dofs * 1000
             st = self._random_states(int(n_samples))
             R = self.engine.gram(st)
-            Q, RQ, PQ = sla.qr(R, pivoting=True, mode="economic")  # model.py:809
+            Q, RQ, PQ = pivoted_qr(R, self._tie_eps())  # model.py:809
             try:
                 np.savez(regr_filename, R=R, Q=Q, RQ=RQ, PQ=PQ, n=n_samples, fb=opt["floatingBase"],
                          grav_only=opt["identifyGravityParamsOnly"], fric=opt["identifyFrictionSimultaneously"],
@@ -427,9 +452,9 @@ class Model:
             if isinstance(Y, LazyRegressor):
                 # pivots and |diag R| of a pivoted QR depend on Y only through R with R^T R = Y^T Y
                 Rt = self.engine.tsqr(Y._st)
-                self.Q, self.R, self.P = sla.qr(Rt, pivoting=True, mode="economic")
+                self.Q, self.R, self.P = pivoted_qr(Rt, self._tie_eps())
             else:
-                self.Q, self.R, self.P = sla.qr(Y, pivoting=True, mode="economic")  # model.py:841
+                self.Q, self.R, self.P = pivoted_qr(Y, self._tie_eps())  # model.py:841
         else:
             Y, self.Q, self.R, self.P = self.getRandomRegressor(n_samples=opt["randomSamples"])
 

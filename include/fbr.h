@@ -196,7 +196,7 @@ int fbr_profile_get(fbr_model *m, double *ms_out /*[FBR_PROF_COUNT]*/, int64_t *
 
 /* ---- introspection (tests, tooling) ------------------------------------------------------------ */
 /*
- * MFMA instructions (v_mfma_f64_16x16x4_f64, 512 flop each) that fbr_tsqr / fbr_tsqr_cols executes for num_samples
+ * MFMA instructions (v_mfma_f64_16x16x4_f64, 2 * 16 * 16 * 4 = 2048 flop each) that fbr_tsqr / fbr_tsqr_cols executes for num_samples
  * samples and k rhs columns: the level-0 folds of the row-sorted chunks (a block is folded from the first column its rows
  * can touch) and the merge tree over the per-workgroup factors -- counted on the host from the same chunking and fold
  * rules the kernels use, so bench.py can report executed (not dense-model) flops.  cols == NULL: every identified column.

@@ -120,7 +120,8 @@ def test_lin_deps_qr_on_given_regressor_matches_reference_algorithm():
     st = random_states(t, 300, rng, 0, use_limits=True)
     om = OracleModel(t, fric=1, fric_sym=True)
     Y = om.regressor(st, np.tanh(st["dq"] / 0.02))
-    m = Model(_opt(identifyFrictionSimultaneously=1), path, regressor_init=False)
+    # pivotTieTolerance = 0: LAPACK's own tie breaking, i.e. the reference's call bit for bit
+    m = Model(_opt(identifyFrictionSimultaneously=1, pivotTieTolerance=0), path, regressor_init=False)
     m.computeRegressorLinDepsQR(Y)
     d = lin_deps_qr(Y, 1e-4)
     assert m.num_base_params == d["r"] == 64 and m.num_base_inertial_params == 57
@@ -136,6 +137,36 @@ def test_lin_deps_qr_on_given_regressor_matches_reference_algorithm():
     for i in range(deps.shape[0]):
         syms |= deps[i].free_symbols
     assert [p for p in range(m.num_all_params) if m.param_syms[p] not in syms] == m.non_id
+    _check_tie_rule(Y, m, _opt(identifyFrictionSimultaneously=1), path)
+
+
+def _check_tie_rule(Y, m_lapack, opt, path):
+    """The default pivot rule (model.pivoted_qr: ties of the pivoting norms go to the lowest column index) against LAPACK's own
+    order ``m_lapack``: same rank and spanned space, the pivots differ only where the competing columns tie, and the outcome does
+    not depend on rounding-level perturbations of the input (a different summation order) -- LAPACK's does."""
+    mt = Model(dict(opt), path, regressor_init=False)
+    mt.computeRegressorLinDepsQR(Y)
+    r = mt.num_base_params
+    assert r == m_lapack.num_base_params
+    da, db = np.abs(np.diag(mt.R)), np.abs(np.diag(m_lapack.R))
+    Pa, Pb_ = np.asarray(mt.P), np.asarray(m_lapack.P)
+    ties = np.flatnonzero(Pa[:r] != Pb_[:r])
+    for i in ties:   # where the orders part, the two candidates have the same pivoting norm ...
+        assert abs(da[i] - db[i]) <= 1e-9 * db[i]
+        j = int(np.flatnonzero(Pb_ == Pa[i])[0])
+        assert Pa[i] < Pb_[i] or j < i   # ... and the rule took the lower column index of the tie
+    assert np.abs(np.sort(da[:r]) - np.sort(db[:r])).max() <= 1e-8 * db.max()
+    assert la.matrix_rank(Y[:, np.union1d(Pa[:r], Pb_[:r])], tol=1e-8 * db.max()) == r   # same column space
+    assert np.abs(Y[:, Pa[r:]] - Y[:, Pa[:r]] @ mt.linear_deps).max() <= 1e-6 * np.abs(Y).max() + 10 * mt.opt["minTol"] * np.abs(Y).max()
+    rng = np.random.default_rng(0)
+    sets = set()
+    for _ in range(4):   # rounding-level noise: the rule's index set does not move
+        Yn = Y * (1.0 + 4e-16 * rng.standard_normal(Y.shape))
+        mn = Model(dict(opt), path, regressor_init=False)
+        mn.computeRegressorLinDepsQR(Yn)
+        sets.add(tuple(np.asarray(mn.P)[:r]))
+    assert sets == {tuple(Pa[:r])}
+    return len(ties)
 
 
 def test_estimators_from_small_reductions_match_the_tall_problem():
@@ -402,8 +433,10 @@ def test_lin_deps_qr_matches_the_reference_code_outputs(tag):
     z = _ref_est()
     meta, t, st, Y = _golden_regressor(z, tag)
     path = os.path.join(ROBOTS, meta["robot"] + ".topology.json")
-    m = Model(_opt(identifyFrictionSimultaneously=meta["friction"], floatingBase=meta["floating"], minTol=meta["minTol"]), path, regressor_init=False)
+    o = _opt(identifyFrictionSimultaneously=meta["friction"], floatingBase=meta["floating"], minTol=meta["minTol"])
+    m = Model(dict(o, pivotTieTolerance=0), path, regressor_init=False)  # LAPACK's tie breaking = the reference's run on the same bits
     m.computeRegressorLinDepsQR(Y)
+    _check_tie_rule(Y, m, o, path)
     assert m.num_base_params == int(z[tag + "_num_base_params"])
     assert np.array_equal(np.asarray(m.P), z[tag + "_P"])
     assert np.array_equal(np.asarray(m.independent_cols), z[tag + "_independent_cols"])
@@ -453,3 +486,103 @@ def test_estimators_match_the_reference_code_outputs():
     assert np.allclose(YB[bw] * w6.reshape(-1)[:, None], z["id_bw_YBase"], rtol=0, atol=1e-10)
     assert np.allclose(tau[bw] * w6.reshape(-1), z["id_bw_tau"], rtol=0, atol=1e-10)
     assert np.allclose(cf[bw] * w6.reshape(-1), z["id_bw_cf"], rtol=0, atol=1e-10)
+
+
+def _ref_walkman():
+    return np.load(os.path.join(GOLDEN, "ref_walkman.npz"), allow_pickle=True)
+
+
+def test_walkman_lin_deps_match_the_reference_code_outputs(monkeypatch):
+    """Model.computeRegressorLinDepsQR() on WALK-MAN's structural Gram (480 columns, randomSamples 10000, minTol 0.005 as in
+    configs/walkman_full.yaml) against the outputs of the REFERENCE'S OWN method on the same Gram (tests/golden/ref_walkman.npz,
+    tools/make_fixtures.py): with LAPACK's tie breaking (pivotTieTolerance = 0) bit-exact P / index sets / non_id, K to 1e-10, rank
+    213 (documentation/design_notes.md:98-104); with the default tie rule the same rank and space, pivots differing at ties only."""
+    import scipy.linalg as sla
+
+    z = _ref_walkman()
+    Pn = 480
+    R = np.zeros((Pn, Pn))
+    R[np.triu_indices(Pn)] = z["rrW_R_triu"]
+    R = R + np.triu(R, 1).T
+    path = os.path.join(ROBOTS, "walkman_apriori.topology.json")
+    o = _opt(floatingBase=1, minTol=0.005, randomSamples=10000)
+    m = Model(dict(o, pivotTieTolerance=0), path, regressor_init=False)
+    monkeypatch.setattr(Model, "getRandomRegressor", lambda self, n_samples=None: (R,) + tuple(
+        __import__("flobaroid_amd.model", fromlist=["pivoted_qr"]).pivoted_qr(R, self._tie_eps())))
+    m.computeRegressorLinDepsQR()
+    assert m.num_base_params == int(z["ldW_num_base_params"]) == 213
+    assert np.array_equal(np.asarray(m.P), z["ldW_P"]) and np.array_equal(np.asarray(m.independent_cols), z["ldW_independent_cols"])
+    assert list(m.non_id) == list(z["ldW_non_id"]) and list(m.identifiable) == list(z["ldW_identifiable"])
+    assert np.abs(np.diag(m.R) - z["ldW_Rdiag"]).max() <= 1e-12 * np.abs(z["ldW_Rdiag"]).max()
+    assert np.abs(m.K - z["ldW_K"]).max() <= 1e-10
+    mt = Model(dict(o), path, regressor_init=False)
+    mt.computeRegressorLinDepsQR()
+    assert mt.num_base_params == 213 and list(mt.non_id) == list(m.non_id)
+    da, db = np.abs(np.diag(mt.R)), np.abs(np.diag(m.R))
+    diff = np.flatnonzero(np.asarray(mt.P)[:213] != np.asarray(m.P)[:213])
+    assert len(diff) > 0   # WALK-MAN does have tied pivots: the rule matters
+    for i in diff:
+        assert abs(da[i] - db[i]) <= 1e-9 * db[i]
+    # rounding-level perturbations of the Gram (a different summation order) move LAPACK's choice but not the rule's
+    rng = np.random.default_rng(1)
+    lap, rule = set(), set()
+    for _ in range(4):
+        E = 4e-16 * rng.standard_normal(R.shape)
+        Rn = R * (1.0 + E + E.T)
+        lap.add(tuple(np.sort(sla.qr(Rn, pivoting=True, mode="r")[1][:213])))
+        from flobaroid_amd.model import pivoted_qr
+
+        rule.add(tuple(np.sort(pivoted_qr(Rn)[2][:213])))
+    assert rule == {tuple(np.sort(np.asarray(mt.P)[:213]))}
+
+
+def test_observability_weights_and_regularisation_rows_match_reference():
+    """estimation.observability_weights == the reference's SDP._observabilityWeights (sdp.py:295-315) on R1 K of a WALK-MAN problem
+    (output of the reference's own method, tests/golden/ref_walkman.npz); estimation.sdp_regularized_system == the augmented
+    system of sdp.py:487-531, restated literally below."""
+    from flobaroid_amd import estimation as est
+
+    z = _ref_walkman()
+    R1_K = z["owW_R1_K"]
+    w = est.observability_weights(R1_K)
+    assert np.abs(w - z["owW_weights"]).max() <= 1e-12 * np.abs(z["owW_weights"]).max()
+    assert w.min() >= 0.1 and w.max() <= 100.0 and w.shape == (480,)
+    nb, P = R1_K.shape
+    rng = np.random.default_rng(3)
+    sdp_in = {"R1_K": R1_K, "rho1": rng.standard_normal(nb), "contactForces": rng.standard_normal(nb)}
+    xStdModel = rng.standard_normal(P)
+    identified = list(range(P))
+    non_id = [int(p) for p in z["ldW_non_id"]]
+    base_error, factor = 3.7, 1000.0
+    for mode in ("uniform", "observability", "geometric"):
+        got = est.sdp_regularized_system(sdp_in, xStdModel, identified, non_id, base_error, factor, mode)
+        # sdp.py:497-531, literally
+        idable_params = sorted(identified)
+        index = {p: i for i, p in enumerate(idable_params)}
+        reg_params, reg_weights = [], {}
+        p_nid = list(set(non_id).intersection(identified))
+        if mode == "observability":
+            ww = z["owW_weights"]
+            reg_params = idable_params
+            base = (float(base_error) / len(reg_params)) * factor
+            reg_weights = {p: base * float(ww[index[p]]) for p in reg_params}
+        elif mode == "geometric":
+            pass
+        elif len(p_nid):
+            reg_params = p_nid
+            base = (float(base_error) / len(p_nid)) * factor
+            reg_weights = {p: base for p in p_nid}
+        if reg_params:
+            cf = np.concatenate((sdp_in["contactForces"], np.zeros(len(reg_params))))
+            Y_bot = np.zeros((len(reg_params), len(idable_params)))
+            rho_bot = np.zeros(len(reg_params))
+            for i, p in enumerate(sorted(reg_params)):
+                Y_bot[i, index[p]] = reg_weights[p]
+                rho_bot[i] = reg_weights[p] * xStdModel[p]
+            Yc, rh = np.vstack([R1_K, Y_bot]), np.concatenate((sdp_in["rho1"], rho_bot))
+        else:
+            Yc, rh, cf = R1_K, sdp_in["rho1"], sdp_in["contactForces"]
+        assert got["Y_combined"].shape == Yc.shape and np.allclose(got["Y_combined"], Yc, rtol=1e-12, atol=0)
+        assert np.allclose(got["rho1_hat"], rh, rtol=1e-12, atol=0) and np.array_equal(got["contactForces_hat"], cf)
+        assert sorted(got["reg_params"]) == sorted(reg_params)
+    assert est.sdp_regularized_system(sdp_in, xStdModel, identified, non_id, base_error, 0, "uniform")["Y_combined"] is R1_K

@@ -28,6 +28,10 @@ npz) and writes small derived fixtures; no reference source code is copied.
                                               (identifier.py:328-370,617-855), called as unbound methods on plain attribute
                                               holders (the real constructors need iDynTree).  The regressor matrices come
                                               from this repository's CPU oracle; the fixture stores the states, not Y.
+  tests/golden/ref_walkman.npz                the same reference code paths on WALK-MAN (48 links, 29 DOF, floating base): computeRegressors with
+                                              contacts on both feet + friction + a-priori torques, getRandomRegressor (10000 random states),
+                                              computeRegressorLinDepsQR (minTol 0.005: P, rank, independent columns, K, non_id) and
+                                              SDP._observabilityWeights (identification/sdp.py:295-315)
   tests/golden/ref_compute_regressors.npz     the reference's own Model.computeRegressors + simulateDynamicsIDynTree
                                               (identification/model.py:239-632) executed on small sample sets with the
                                               iDynTree calls answered by this repository's CPU oracle (a minimal object shim:
@@ -397,9 +401,10 @@ def reference_compute_regressors(golden):
               Transform=lambda rot, pos: NS(inverse=lambda: NS(rpy=rot.rpy)), Twist=NS(FromPython=lambda v: NS(v=np.asarray(v, float))),
               LinkWrenches=lambda model: NS(), FreeFloatingGeneralizedTorques=Gen)
     rmodel.iDynTree = shim
-    out = {}
+    out = out_main = {}
 
-    def run(tag, robot, floating, S, seed, opt_over, contacts=None, torques_with_base=False):
+    def run(tag, robot, floating, S, seed, opt_over, contacts=None, torques_with_base=False, dst=None):
+        out = out_main if dst is None else dst
         t = load_topo(robot)
         n, L = t.num_dofs, t.num_links
         rng = np.random.default_rng(seed)
@@ -459,7 +464,8 @@ def reference_compute_regressors(golden):
     # ---- getRandomRegressor (model.py:634-830): global-RNG call order, raw Gram, pivoted QR, cache file keys
     import tempfile
 
-    def run_random(tag, robot, floating, n_samples, seed, opt_over):
+    def run_random(tag, robot, floating, n_samples, seed, opt_over, dst=None, triu_only=False):
+        out = out_main if dst is None else dst
         t = load_topo(robot)
         n, L = t.num_dofs, t.num_links
         opt = {"floatingBase": int(floating), "identifyGravityParamsOnly": 0, "identifyFrictionSimultaneously": 0, "identifySymmetricVelFriction": 1,
@@ -476,9 +482,14 @@ def reference_compute_regressors(golden):
         np.random.seed(seed)
         R, Q, RQ, PQ = rmodel.Model.getRandomRegressor(fm, n_samples=n_samples)
         cache = np.load(fm.urdf_file + ".regressor.npz")
+        if triu_only:  # symmetric: the upper triangle is the matrix
+            out[tag + "_R_triu"] = R[np.triu_indices(R.shape[0])]
+        else:
+            out[tag + "_R"] = R
         out.update({tag + "_meta": json.dumps({"robot": robot, "floating": int(floating), "n_samples": n_samples, "seed": seed, "opt": opt}),
-                    tag + "_R": R, tag + "_PQ": PQ, tag + "_RQdiag": np.diag(RQ), tag + "_cache_keys": np.array(sorted(cache.files)),
+                    tag + "_PQ": PQ, tag + "_RQdiag": np.diag(RQ), tag + "_cache_keys": np.array(sorted(cache.files)),
                     tag + "_cache_n": cache["n"], tag + "_cache_fb": cache["fb"], tag + "_cache_fric": cache["fric"]})
+        return fm, (R, Q, RQ, PQ)
 
     # ---- the D-optimality gradient worker (excitation/analyticalGradient.py:46-185), same shim
     rgrad = _import_reference("excitation.analyticalGradient")
@@ -507,6 +518,34 @@ def reference_compute_regressors(golden):
     run_random("rrB", "threeLinks", 1, 30, 8, {})
     np.savez_compressed(os.path.join(golden, "ref_compute_regressors.npz"), **out)
     print("ref_compute_regressors.npz:", len(out), "arrays")
+
+    # ---- WALK-MAN (48 links, 29 DOF, floating base), the robot of BASELINE configs[3..4], through the same reference code:
+    #      computeRegressors with the option set of configs/walkman_full.yaml that matters on this path (floating base, a-priori
+    #      torques, simultaneous friction, contacts on the two foot FT frames, joint-only torque measurements -> simulated base wrench),
+    #      getRandomRegressor with randomSamples = 10000 and computeRegressorLinDepsQR with minTol = 0.005 (walkman_full.yaml:243-247)
+    outW = {}
+    run("crW", "walkman_apriori", 1, 14, 41, {"useAPriori": 1, "identifyFrictionSimultaneously": 1, "skipSamples": 1}, contacts=["l_leg_ft", "r_leg_ft"], dst=outW)
+    fmr, (R, Q, RQ, PQ) = run_random("rrW", "walkman_apriori", 1, 10000, 42, {}, dst=outW, triu_only=True)
+    t = load_topo("walkman_apriori")
+    fm = NS(opt={"minTol": 0.005, "useBasisProjection": 0, "orthogonalizeBasis": 1, "identifyGravityParamsOnly": 0, "identifyFrictionSimultaneously": 0,
+                 "identifySymmetricVelFriction": 1, "stribeckVelocity": 0, "randomSamples": 10000},
+            num_dofs=t.num_dofs, num_links=t.num_links, num_model_params=480, num_all_params=480, num_identified_params=480,
+            getRandomRegressor=lambda n_samples=None: (R, Q, RQ, PQ))
+    rmodel.Model.computeRegressorLinDepsQR(fm)
+    outW.update(ldW_P=np.asarray(fm.P), ldW_num_base_params=fm.num_base_params, ldW_independent_cols=np.asarray(fm.independent_cols),
+                ldW_K=fm.K, ldW_Rdiag=np.diag(fm.R), ldW_non_id=np.asarray(fm.non_id, dtype=np.int64),
+                ldW_identifiable=np.asarray(fm.identifiable, dtype=np.int64), ldW_minTol=0.005)
+    # ---- SDP._observabilityWeights (sdp.py:295-315) on R1 K of a seeded WALK-MAN least-squares problem (R1 from numpy.linalg.qr of
+    #      the oracle's YBase, as sdp.py:470-487 builds it)
+    rsdp = _import_reference("identification.sdp")
+    rng = np.random.default_rng(43)
+    stw = random_states(t, 400, rng, 1, use_limits=True)
+    Yw = OracleModel(t, floating=True).regressor(stw)
+    R1 = np.linalg.qr(Yw[:, fm.independent_cols], mode="r")
+    R1_K = R1 @ fm.K
+    outW.update(owW_R1_K=R1_K, owW_weights=rsdp.SDP._observabilityWeights(None, R1_K), owW_seed=43, owW_S=400)
+    np.savez_compressed(os.path.join(golden, "ref_walkman.npz"), **outW)
+    print("ref_walkman.npz:", len(outW), "arrays, rank", fm.num_base_params)
 
 
 if __name__ == "__main__":
