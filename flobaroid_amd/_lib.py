@@ -250,9 +250,22 @@ class Engine:
         _check(self._lib.fbr_model_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), "fbr_model_set_stream")
 
     def use_torch_stream(self) -> None:
+        """Run on torch's current stream when that is a real stream object.  torch's DEFAULT stream is the null stream (handle 0),
+        which the C-ABI reads as "the model's own stream": the engine then keeps its own non-blocking stream and every call with
+        CUDA tensors first waits for torch's stream (``_sync_torch``), so inputs produced by torch kernels are complete."""
         import torch
 
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        h = torch.cuda.current_stream(self.device).cuda_stream
+        self.set_stream(h)
+        self._shares_torch_stream = bool(h)
+
+    def _sync_torch(self) -> None:
+        # calls are blocking and the library synchronises its own stream on return; what is missing is the other direction:
+        # torch kernels still writing the inputs on a stream the library does not run on
+        if not getattr(self, "_shares_torch_stream", False):
+            import torch
+
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _states(self, st: dict, need_vel: bool = True):
         q = _Ref(st["q"], name="q")
@@ -273,6 +286,8 @@ class Engine:
             sg = _Ref(st.get("sign"), (S, n), "sign")
         refs += [dq, ddq, bv, ba, rpy, sg]
         mem = _same_space(refs)
+        if mem == FBR_DEVICE:
+            self._sync_torch()
         s = fbr_states()
         s.num_samples = S
         s.mem = mem
@@ -429,6 +444,8 @@ class Engine:
         b = _Ref(R_b, (n, n), "R_b")
         if a.mem != b.mem:
             raise ValueError("R_a and R_b must live in the same memory space")
+        if a.mem == FBR_DEVICE:
+            self._sync_torch()  # (a factor just received by torch.distributed lands on torch's stream)
         r, ret = self._out(out, (n, n), a.mem)
         _check(self._lib.fbr_tsqr_merge(self._h, n, a.ptr, b.ptr, r.ptr, a.mem), "fbr_tsqr_merge")
         return ret

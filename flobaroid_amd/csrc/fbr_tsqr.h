@@ -28,7 +28,11 @@
 
 #define FBR_TSQR_THREADS 512
 #define FBR_TSQR_WAVES (FBR_TSQR_THREADS / 64)
-#define FBR_TSQR_RING 6            // published panels (V, T) kept in the LDS: how far the waves may drift apart
+#ifndef FBR_TSQR_SUB2
+#define FBR_TSQR_SUB2 6           // 16-row sub-blocks per fold of the two-tiles-per-wave kernels (n <= 256): 96-row blocks
+#endif
+#define FBR_TSQR_RING_MAX 6        // published panels (V, T) kept in the LDS: how far the waves may drift apart (fewer for tall blocks)
+template <int SUB> __host__ __device__ constexpr int fbr_tsqr_ring() { return SUB > 6 ? 5 : FBR_TSQR_RING_MAX; }  // 128-row blocks: 5 slots fit the 160 KiB
 #define FBR_TSQR_MAXN 768          // widest supported factor (columns incl. rhs, padded to 16)
 #define FBR_TSQR_SPIN_LIMIT (1 << 20)  // ~50 ms of polling: far beyond any legitimate wait (a fold tail is ~0.1 ms)
 
@@ -109,11 +113,13 @@ __global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, i
 //   * only R (the panel's 16 rows) is streamed from global memory: each wave copies the R rows under its own tiles
 //     to the LDS with LDS-DMA one panel ahead, and writes them back after the update.
 #define FBR_TSQR_LDV 17  // LDS row stride of the published V panel (conflict-free for both operand walks)
+#define FBR_TSQR_LDT 17  // LDS row stride of the published T (16 lanes write one row each: stride 16 would put them on two banks)
+#define FBR_TSQR_TSZ (16 * FBR_TSQR_LDT)
 
 // LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vr[RING][MB*17] | Tr[RING][256] | Rp[WAVES][256] | flags[16]
 template <int TPW, int SUB> static inline size_t fbr_tsqr_lds_doubles()
 {
-    return (size_t)FBR_TSQR_WAVES * TPW * 256 + (size_t)FBR_TSQR_RING * (16 * SUB * FBR_TSQR_LDV + 256) + (size_t)FBR_TSQR_WAVES * 256 + 16;
+    return (size_t)FBR_TSQR_WAVES * TPW * 256 + (size_t)fbr_tsqr_ring<SUB>() * (16 * SUB * FBR_TSQR_LDV + FBR_TSQR_TSZ) + (size_t)FBR_TSQR_WAVES * 256 + 16 + FBR_TSQR_RING_MAX;
 }
 typedef __attribute__((address_space(3))) void *fbr_tsqr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_tsqr_glb_ptr;
@@ -189,8 +195,11 @@ template <int J, int L = 0> struct FbrTAcc {
 // The vectors stay unscaled in v (scaled by myscale when published), so one fused multiply-add per element per step.
 template <int SUB, int J>
 __device__ __forceinline__ void fbr_tsqr_panel_step(fbr_td4 (&v)[SUB], const double *Rp, fbr_td4 &rq, double (&trow)[16],
-                                                    double &myscale, int li, int kk)
+                                                    double &myscale, int li, int kk)  // (li, kk by value: private opaque copies)
 {
+    // the lane masks of this step (li == J, li > J, ...) are rebuilt from an opaque copy of li: hoisted out of the panel / fold loops
+    // (they are loop invariant) the 16 x 4 masks do not fit the SGPR file and come back as v_readlane pairs from spill lanes
+    asm volatile("" : "+v"(li));
     const double rjc = Rp[J * 16 + li];
     const double alpha = fbr_dpp_bcast<J>(rjc);
     // s_c = x . B[:, c] with x = B[:, J] (lane J's registers, read through the DPP operand); lane J's own s is |x|^2
@@ -249,6 +258,7 @@ __device__ __forceinline__ void fbr_tsqr_panel_step(fbr_td4 (&v)[SUB], const dou
         }
     if (li == J) myscale = scale;
     const double newr = (li > J) ? rjc - tau * wc : beta;
+    asm volatile("" : "+v"(kk));
     if (kk == (J & 3)) rq[J >> 2] = newr;
     // pin the step's results here: otherwise their computation is sunk to the stores after the chain and every step's
     // inputs stay live (spills)
@@ -293,7 +303,7 @@ __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], con
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li], C[T][sb][reg], acc, 0, 0, 0);
         }
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * 16 + li], acc[ks], w2, 0, 0, 0);
+    for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * FBR_TSQR_LDT + li], acc[ks], w2, 0, 0, 0);
     {
         // uniform (scalar) base + one per-lane offset shared by every store of the kernel
         const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * T);
@@ -388,25 +398,27 @@ struct FbrTsqrFoldDesc {
     int ldb, mrows, first_col;
 };
 
-template <int TPW, int SUB, class FoldFn>
+// TIMING: diagnostic instantiation (s_memtime cycles per phase into tacc[16]); the production kernels carry none of it
+template <int TPW, int SUB, bool TIMING, class FoldFn>
 __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, int ldr, int nfolds, FoldFn fold_of, double *smem, unsigned *errflag,
                                                 unsigned long long *tacc = nullptr)
 {
-    unsigned long long tk = tacc ? __builtin_readcyclecounter() : 0;
+    unsigned long long tk = TIMING ? __builtin_readcyclecounter() : 0;
 #define FBR_TT(i)                                                         \
-    if (tacc) {                                                           \
+    if constexpr (TIMING) {                                               \
         const unsigned long long t1 = __builtin_readcyclecounter();       \
         tacc[i] += t1 - tk;                                               \
         tk = t1;                                                          \
     }
     constexpr int MB = 16 * SUB;
     constexpr int W = FBR_TSQR_WAVES;
+    constexpr int FBR_TSQR_RING = fbr_tsqr_ring<SUB>();
     double *Rl = smem;  // 16-byte aligned tiles for the LDS-DMA
     double *Vr = Rl + W * TPW * 256;
     double *Tr = Vr + FBR_TSQR_RING * MB * FBR_TSQR_LDV;
-    double *Rps = Tr + FBR_TSQR_RING * 256;
-    int *pub = (int *)(Rps + W * 256);  // panels (global index) < *pub are published
-    int *done = pub + 1;                // done[w]: wave w needs no panel < done[w] any more
+    double *Rps = Tr + FBR_TSQR_RING * FBR_TSQR_TSZ;
+    int *done = (int *)(Rps + W * 256);  // done[w]: wave w needs no panel < done[w] any more
+    int *seq = done + 16;                // seq[slot]: 1 + global index of the panel published in ring slot `slot` (0 = none yet)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kk = lane >> 4;
@@ -415,7 +427,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
     double *Rp = Rps + wave * 256;  // R_pp staging of this wave's panel factorisations
     const int t1 = (NP - wave + W - 1) / W;  // this wave's tiles t < t1 are real column tiles (the rest is padding)
 
-    if (tid == 0) *pub = 0;
+    if (tid < FBR_TSQR_RING) seq[tid] = 0;
     if (tid < W) done[tid] = 0;
     __syncthreads();  // the only workgroup barrier
 
@@ -464,16 +476,10 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
 
         // factorise panel p = tile p of this wave (global index G): Householder QR of [R_pp ; tile] in registers,
         // publish V, T in ring slot G % RING
-        auto chain = [&](int p, int G) {
-            unsigned long long tc0 = tacc ? __builtin_readcyclecounter() : 0;
-            const int tp = p / W;
-            fbr_td4 v[SUB];
-#pragma unroll
-            for (int t = 0; t < TPW; t++)
-                if (t == tp) {
-#pragma unroll
-                    for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
-                }
+        // (v: the panel's tile -- for TPW <= 2 the wave's own registers C[t], which the factorisation consumes: the tile is dead
+        // afterwards, and a copy of a tall tile would not fit the register file; else a copy selected from the wave's tiles, so that
+        // the unrolled 16-step chain exists once in the code)
+        auto chain_on = [&](fbr_td4 (&v)[SUB], int p, int G, unsigned long long tc0) __attribute__((always_inline)) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) Rp[(4 * reg + kk) * 16 + li] = (li >= 4 * reg + kk) ? rpp[reg] : 0.0;
             fbr_lds_release();
@@ -481,14 +487,14 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             fbr_td4 rq = {0.0, 0.0, 0.0, 0.0};
             double trow[16];
             double myscale = 0.0;
-            unsigned long long tq = tacc ? __builtin_readcyclecounter() : 0;
-            if (tacc) tacc[7] += tq - tc0;  // tile copy, R_pp staging
+            unsigned long long tq = TIMING ? __builtin_readcyclecounter() : 0;
+            if constexpr (TIMING) tacc[7] += tq - tc0;  // tile copy, R_pp staging
             fbr_tsqr_panel_steps<SUB>(v, Rp, rq, trow, myscale, li, kk, std::make_integer_sequence<int, 16>{});
-            if (tacc) tacc[4] += __builtin_readcyclecounter() - tq;
+            if constexpr (TIMING) tacc[4] += __builtin_readcyclecounter() - tq;
             // the ring slot is free once no wave needs panel G - RING any more
             {
                 const int need = G - FBR_TSQR_RING + 1;
-                tq = tacc ? __builtin_readcyclecounter() : 0;
+                tq = TIMING ? __builtin_readcyclecounter() : 0;
                 bool free_ = !ok;
                 for (int it = 0; it < FBR_TSQR_SPIN_LIMIT && !free_; it++) {
                     const int d = __atomic_load_n(done + (lane & (W - 1)), __ATOMIC_RELAXED);
@@ -497,25 +503,22 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 }
                 fbr_lds_acquire();
                 ok = ok && free_;
-                if (tacc) tacc[5] += __builtin_readcyclecounter() - tq;
+                if constexpr (TIMING) tacc[5] += __builtin_readcyclecounter() - tq;
             }
             double *Vl = Vr + (G % FBR_TSQR_RING) * (MB * FBR_TSQR_LDV);
-            double *Tm = Tr + (G % FBR_TSQR_RING) * 256;
+            double *Tm = Tr + (G % FBR_TSQR_RING) * FBR_TSQR_TSZ;
 #pragma unroll
             for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li] = v[sb][reg] * myscale;
             if (kk == 0) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) Tm[li * 16 + j] = trow[j];
+                for (int j = 0; j < 16; j++) Tm[li * FBR_TSQR_LDT + j] = trow[j];
             }
-            // panels are published in order (the previous one may belong to the previous fold and still be in flight)
-            tq = tacc ? __builtin_readcyclecounter() : 0;
-            if (tacc) tacc[8] += tq - tc0;  // (cumulative up to here: + ring wait + V, T writes)
-            ok = ok && fbr_tsqr_wait_ge(pub, G);
-            if (tacc) tacc[6] += __builtin_readcyclecounter() - tq;
+            // published per ring slot: seq[slot] = G + 1 (the consumers take the panels in order anyway; the publisher does not have
+            // to wait for its predecessor, which may belong to the previous fold and still be in flight)
             fbr_lds_release();
-            if (lane == 0) __atomic_store_n(pub, G + 1, __ATOMIC_RELAXED);
+            if (lane == 0) __atomic_store_n(seq + G % FBR_TSQR_RING, G + 1, __ATOMIC_RELAXED);
             // R_pp back to global (upper triangle), then the R_pp of the next panel this wave owns
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
@@ -525,6 +528,27 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             }
             fetch_rpp(p + W);
         };
+        auto chain = [&](int p, int G) __attribute__((always_inline)) {
+            const unsigned long long tc0 = TIMING ? __builtin_readcyclecounter() : 0;
+            const int tp = p / W;
+            if constexpr (TPW == 1) {
+                chain_on(C[0], p, G, tc0);
+            } else if constexpr (TPW == 2) {
+                if (tp == 0)
+                    chain_on(C[0], p, G, tc0);
+                else
+                    chain_on(C[1], p, G, tc0);
+            } else {
+                fbr_td4 v[SUB];
+#pragma unroll
+                for (int t = 0; t < TPW; t++)
+                    if (t == tp) {
+#pragma unroll
+                        for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
+                    }
+                chain_on(v, p, G, tc0);
+            }
+        };
 
         // iteration q applies panel q; the owner of panel q + 1 factorises it inside iteration q (q = q0 - 1: only that)
         for (int q = q0 - 1; q < NP; q++) {
@@ -533,12 +557,12 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             const bool next_owner = q + 1 < NP && wave == (q + 1) % W;
             int t0 = (q >= wave) ? (q - wave) / W + 1 : 0;  // this wave's first tile right of panel q
             const bool need_panel = apply && (next_owner || t0 < t1);
-            if (need_panel) ok = ok && fbr_tsqr_wait_ge(pub, G + 1);
+            if (need_panel) ok = ok && fbr_tsqr_wait_ge(seq + (G + FBR_TSQR_RING) % FBR_TSQR_RING, G + 1);
             if (need_panel || next_owner) fbr_dma_wait();  // vmcnt(0): this wave's R rows (LDS-DMA) / R_pp have landed
             FBR_TT(2)
             const int slot = (G + FBR_TSQR_RING) % FBR_TSQR_RING;
             const double *Vl = Vr + slot * (MB * FBR_TSQR_LDV);
-            const double *Tm = Tr + slot * 256;
+            const double *Tm = Tr + slot * FBR_TSQR_TSZ;
             if (next_owner) {
                 // next panel's owner: its tile first, then its factorisation, then the rest of panel q.  This is the
                 // serial dependency chain of the fold: raise the wave's issue priority over the waves that only update
@@ -566,7 +590,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
 }
 
 // level 0: workgroup w folds blocks w, w+NW, ... of A into Rw[w]
-template <int TPW, int SUB>
+template <int TPW, int SUB, bool TIMING>
 __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
                                                                                double *__restrict__ Rw, long nblocks, unsigned *errflag,
                                                                                unsigned long long *dbg, const int *__restrict__ rowfc, int orows,
@@ -592,8 +616,8 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
         }
         return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc};
     };
-    fbr_tsqr_stream<TPW, SUB>(R, n, LD, nfolds, fold_of, smem, errflag, dbg ? tacc : nullptr);
-    if (dbg && (threadIdx.x & 63) == 0) {
+    fbr_tsqr_stream<TPW, SUB, TIMING>(R, n, LD, nfolds, fold_of, smem, errflag, tacc);
+    if (TIMING && (threadIdx.x & 63) == 0) {
         unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 16;
         for (int i = 0; i < 16; i++) d[i] = tacc[i];
     }
@@ -613,7 +637,7 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_tree_kernel(doub
         const int i0 = f * MB;
         return FbrTsqrFoldDesc{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), i0};
     };
-    fbr_tsqr_stream<TPW, SUB>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
+    fbr_tsqr_stream<TPW, SUB, false>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -698,14 +722,20 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
         __builtin_amdgcn_wave_barrier();
         // ---- trailing update of the tiles right of the panel (static register indexing, uniform branch per tile).
         //      The A operands (V for V^T C, V for V W, T) are the same for every tile: read from the LDS once per panel.
-        double va[SUB][4], vb[SUB][4], ta[4];
+        // (CACHE: the operands stay in registers for all tiles of the panel; tall blocks of many tiles have no room for them and read
+        // them from the LDS in front of every MFMA instead)
+        constexpr bool CACHE = NPT * SUB <= 12;
+        constexpr int CS = CACHE ? SUB : 1;
+        double va[CS][4], vb[CS][4], ta[4];
+        if constexpr (CACHE) {
 #pragma unroll
-        for (int sb = 0; sb < SUB; sb++)
+            for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                va[sb][r4] = Vl[(16 * sb + 4 * r4 + kk) * FBR_TSQR_LDV + li];
-                vb[sb][r4] = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * r4 + kk];
-            }
+                for (int r4 = 0; r4 < 4; r4++) {
+                    va[sb][r4] = Vl[(16 * sb + 4 * r4 + kk) * FBR_TSQR_LDV + li];
+                    vb[sb][r4] = Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * r4 + kk];
+                }
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) ta[ks] = Tm[(4 * ks + kk) * 16 + li];
 #pragma unroll
@@ -717,7 +747,8 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
 #pragma unroll
                 for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[sb][reg], C[t][sb][reg], acc, 0, 0, 0);
+                    for (int reg = 0; reg < 4; reg++)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(CACHE ? va[CACHE ? sb : 0][reg] : Vl[(16 * sb + 4 * reg + kk) * FBR_TSQR_LDV + li], C[t][sb][reg], acc, 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks], acc[ks], w2, 0, 0, 0);
 #pragma unroll
@@ -725,7 +756,8 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
 #pragma unroll
                 for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ks++) C[t][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(vb[sb][ks], -w2[ks], C[t][sb], 0, 0, 0);
+                    for (int ks = 0; ks < 4; ks++)
+                        C[t][sb] = __builtin_amdgcn_mfma_f64_16x16x4f64(CACHE ? vb[CACHE ? sb : 0][ks] : Vl[(16 * sb + li) * FBR_TSQR_LDV + 4 * ks + kk], -w2[ks], C[t][sb], 0, 0, 0);
             }
         __builtin_amdgcn_wave_barrier();  // (the wave's own LDS reads are in order with the next panel's writes)
     }
@@ -825,28 +857,34 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
 }
 
 // kernel instantiations: 8 waves per workgroup, one workgroup per CU; tiles per wave 1..6 (n <= 768); block rows
-// 64 / 48 / 32 so that the block (TPW * SUB * 8 VGPRs) and the panel chain fit the 256 VGPRs of a wave
+// 128 (n <= 256: the base regressor [YBase | tau] of WALK-MAN) / 64 / 48 / 32 so that the block (TPW * SUB * 8 VGPRs) and the panel
+// chain fit the 256 VGPRs of a wave.  The panel chain costs ~120 VALU instructions per Householder step of which only 2 * 4 SUB
+// depend on the block height, so taller blocks amortise it (fbr_tsqr_panel_step)
 #define FBR_TSQR_DISPATCH(TPWV, CALL)                  \
     switch (TPWV) {                                    \
     case 1: { constexpr int TPW = 1, SUB = 4; CALL; } break; \
-    case 2: { constexpr int TPW = 2, SUB = 4; CALL; } break; \
+    case 2: { constexpr int TPW = 2, SUB = FBR_TSQR_SUB2; CALL; } break; \
     case 3: { constexpr int TPW = 3, SUB = 4; CALL; } break; \
     case 4: { constexpr int TPW = 4, SUB = 4; CALL; } break; \
     case 5: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
     default: { constexpr int TPW = 6, SUB = 2; CALL; } break; \
     }
-static inline int fbr_tsqr_sub_for(int tpw) { return tpw <= 4 ? 4 : (tpw == 5 ? 3 : 2); }
+static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : (tpw <= 4 ? 4 : (tpw == 5 ? 3 : 2)); }
 
 // narrow (wave-private) kernels: column tiles 1..8, 32-row blocks
 #define FBR_TSQR_NARROW_MAX_TILES 8
+#ifndef FBR_TSQR_NARROW_SUB_LE6
+#define FBR_TSQR_NARROW_SUB_LE6 3  // <= 6 column tiles (left arm, KUKA): 48-row blocks still fit the 256 VGPRs of a wave
+#endif
+static inline int fbr_tsqr_narrow_sub_for(int npt) { return npt <= 6 ? FBR_TSQR_NARROW_SUB_LE6 : 2; }
 #define FBR_TSQR_NARROW_DISPATCH(NPTV, CALL)           \
     switch (NPTV) {                                    \
-    case 1: { constexpr int NPT = 1, SUB = 2; CALL; } break; \
-    case 2: { constexpr int NPT = 2, SUB = 2; CALL; } break; \
-    case 3: { constexpr int NPT = 3, SUB = 2; CALL; } break; \
-    case 4: { constexpr int NPT = 4, SUB = 2; CALL; } break; \
-    case 5: { constexpr int NPT = 5, SUB = 2; CALL; } break; \
-    case 6: { constexpr int NPT = 6, SUB = 2; CALL; } break; \
+    case 1: { constexpr int NPT = 1, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
+    case 2: { constexpr int NPT = 2, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
+    case 3: { constexpr int NPT = 3, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
+    case 4: { constexpr int NPT = 4, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
+    case 5: { constexpr int NPT = 5, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
+    case 6: { constexpr int NPT = 6, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
     case 7: { constexpr int NPT = 7, SUB = 2; CALL; } break; \
     default: { constexpr int NPT = 8, SUB = 2; CALL; } break; \
     }
@@ -865,7 +903,7 @@ static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrSha
     }
     const bool narrow = n / 16 <= FBR_TSQR_NARROW_MAX_TILES && !getenv("FBR_TSQR_NO_NARROW");
     const int tpw = narrow ? n / 16 : (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
-    const int sub = narrow ? 2 : fbr_tsqr_sub_for(tpw);
+    const int sub = narrow ? fbr_tsqr_narrow_sub_for(tpw) : fbr_tsqr_sub_for(tpw);
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
     const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
@@ -944,10 +982,17 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 16 * 8));
         TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 16 * 8, st));
     }
-    FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
-    FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                 (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+    if (dbg) {
+        FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
+        FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, true>), dim3(grid), dim3(FBR_TSQR_THREADS),
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+    } else {
+        FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
+        FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, false>), dim3(grid), dim3(FBR_TSQR_THREADS),
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+    }
     TSQR_HIP(hipGetLastError());
     if (dbg) {
         std::vector<unsigned long long> hb((size_t)grid * FBR_TSQR_WAVES * 16);

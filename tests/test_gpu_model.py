@@ -264,7 +264,8 @@ def test_random_regressor_matches_the_reference_logic_outputs(tag, tmp_path):
     assert np.abs(np.sort(dm[:r]) - np.sort(dw[:r])).max() <= 1e-9 * dw.max()
     for i in np.flatnonzero(mine[:r] != ref[:r]):                                          # (b)
         assert abs(dm[i] - dw[i]) <= 1e-9 * dw[i]
-    assert np.array_equal(pivoted_qr(Rw, 0.0)[2], ref)                                     # (c)
+    if tag + "_R" in z.files:   # (c) needs the reference's Gram bit for bit; and LAPACK's tie breaking is itself machine dependent for
+        assert np.array_equal(pivoted_qr(Rw, 0.0)[2], ref)   # large matrices (blocked / threaded dgeqp3): one more reason for the rule
     # either choice spans the same column space: the Gram restricted to each independent set has full rank r
     for ic in (mine[:r], ref[:r]):
         assert la.matrix_rank(Rw[np.ix_(ic, ic)], tol=1e-9 * dw.max()) == r
