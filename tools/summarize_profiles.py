@@ -41,16 +41,21 @@ line = [l for l in open(os.path.join(src, "bench_default.json")) if l.startswith
 bench = json.loads(line)
 json.dump(bench, open(os.path.join(dst, tag + "_bench_default.json"), "w"), indent=1)
 
-oc = os.path.join(src, "bench_other_configs.json")
-if os.path.exists(oc):
-    lines = [l for l in open(oc) if l.startswith("{")]
-    if lines:
-        json.dump(json.loads(lines[-1]).get("other_configs", {}), open(os.path.join(dst, tag + "_other_configs.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "tsqr_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "tsqr_kernel_stats.csv"), os.path.join(dst, tag + "_tsqr_kernel_stats.csv"))
 
 pmc = {}
 for prefix in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_sq"):
     pmc.update(counters(prefix))
-json.dump({"command": "rocprofv3 --pmc <set> --kernel-trace -- python bench.py --samples 200000 --steps 1 --warmup 0 --no-cpu-baseline "
+tpmc = {}
+for prefix in ("tsqr_pmc_mfma", "tsqr_pmc_sq", "tsqr_pmc_fetch"):
+    tpmc.update(counters(prefix))
+if tpmc:
+    json.dump({"command": "rocprofv3 --pmc <set> --kernel-trace -- python tools/tsqr_pmc_probe.py (one pass per set; WALK-MAN 150 k samples x 481 columns, "
+                          "left arm 500 k x 91; two tsqr calls each -> launches)",
+               "unit": "raw counts per launch; SQ_INSTS_VALU_MFMA_MOPS_F64 = 4 per v_mfma_f64_16x16x4_f64 (2048 flop); FETCH_SIZE in KB (x2 on gfx950)",
+               "counters": tpmc}, open(os.path.join(dst, tag + "_tsqr_pmc.json"), "w"), indent=1)
+json.dump({"command": "rocprofv3 --pmc <set> --kernel-trace -- python bench.py --samples 200000 --steps 1 --warmup 0 --no-secondary "
                       "(one pass per set: FETCH_SIZE | WRITE_SIZE | MFMA | SQ; tools/profile_round.sh)",
            "unit": "FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE needs x2 on gfx950), others raw counts", "counters": pmc},
           open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
@@ -71,4 +76,4 @@ if gk:
            "correction": "FETCH_SIZE x2 on gfx950 for 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported"}
     json.dump(out, open(os.path.join(dst, tag + "_gram_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
-print("bench:", bench["value"], bench["roofline"]["avg_launch_ms"], bench.get("tsqr", {}).get("TFLOP_per_s"))
+print("bench:", bench["value"], bench["roofline"]["avg_launch_ms"], bench.get("tsqr", {}).get("executed_TFLOP_per_s"))
