@@ -327,14 +327,25 @@ class Model:
 
         if not only_simulate:
             if opt["useBasisProjection"]:
-                self.YBase = np.dot(np.asarray(self.YStd), self.B)
+                if isinstance(self.YStd, LazyRegressor):
+                    raise ValueError("useBasisProjection needs the materialised YStd (raise opt['materializeLimitBytes'])")
+                self.YBase = np.dot(self.YStd, self.B)  # model.py:603-604
             elif isinstance(self.YStd, LazyRegressor):
                 self.YBase = LazyRegressor(self.engine, st, cols=self.independent_cols)
             else:
                 # YStd @ Pb is a column gather (Pb[:, i] = e_{P[i]}, model.py:876-880, 606)
                 self.YBase = np.ascontiguousarray(self.YStd[:, self.independent_cols])
             if opt["filterRegressor"]:
-                raise NotImplementedError("filterRegressor (model.py:608-615) is off in every shipped config; unpinned")
+                # model.py:608-615, literally (including its stride of num_dofs where the rows of a sample are N_OUT apart: the two
+                # agree for fixed-base models, the only ones the option makes sense for)
+                if isinstance(self.YBase, LazyRegressor):
+                    raise ValueError("filterRegressor needs the materialised YBase (raise opt['materializeLimitBytes'])")
+                from scipy import signal
+
+                b, a = signal.butter(5, opt["filterRegCutoff"] / (samples["frequency"] / 2), btype="low", analog=False)
+                for j in range(self.num_base_inertial_params):
+                    for i in range(self.num_dofs):
+                        self.YBase[i::self.num_dofs, j] = signal.filtfilt(b, a, self.YBase[i::self.num_dofs, j])
 
         self.sample_end = samples["positions"].shape[0]
         if opt["skipSamples"] > 0:
@@ -474,7 +485,27 @@ class Model:
         self.Kd = self.linear_deps
         self.K = self.Pb.T + self.Kd.dot(self.Pd.T)
         if opt["useBasisProjection"]:
-            raise NotImplementedError("useBasisProjection is forced off by identifier.py:57")
+            # grouped columns of every independent column -> basis B (model.py:896-929; identifier.py:57 forces the option off, the
+            # method still supports it for the other callers)
+            self.B = np.zeros((self.num_identified_params, self.num_base_params))
+            big = np.abs(self.linear_deps) > opt["minTol"]
+            for j in range(self.linear_deps.shape[0]):
+                kk = np.flatnonzero(big[j])
+                self.B[self.P[r + kk], j] = self.linear_deps[j, kk]
+                self.B[self.independent_cols[j], j] = 1
+            if opt["orthogonalizeBasis"]:
+                import numpy.linalg as la
+
+                Q_B_qr, R_B_qr = la.qr(self.B)
+                Q_B_qr[np.abs(Q_B_qr) < opt["minTol"]] = 0
+                d = np.diag(R_B_qr)
+                sgn = np.where(np.abs(d) < opt["minTol"], 0.0, np.sign(d))
+                self.B = Q_B_qr.dot(np.diag(sgn))
+                self.Binv = self.B.T
+            else:
+                import numpy.linalg as la
+
+                self.Binv = la.pinv(self.B)
 
         # indices of the identified parameters within the full vector (model.py:936-1022)
         self.identified_params = []
@@ -493,7 +524,17 @@ class Model:
                     self.identified_params.extend(range(fs, fs + nd))
         # parameters without any influence on a base parameter (model.py:1043-1052): a symbol is free in
         # base_deps = K * syms iff its column of K is not identically zero
-        used = np.any(self.K != 0, axis=0)
+        if opt["useBasisProjection"]:  # base_deps = syms . B, or syms . pinv(B)^T thresholded (model.py:1029-1037)
+            if opt["orthogonalizeBasis"]:
+                used = np.any(self.B != 0, axis=1)
+            else:
+                import numpy.linalg as la
+
+                Bz = la.pinv(self.B)
+                Bz[np.abs(Bz) < opt["minTol"]] = 0
+                used = np.any(Bz != 0, axis=0)
+        else:
+            used = np.any(self.K != 0, axis=0)
         idp = np.array(self.identified_params)
         ident = set(idp[used].tolist())
         self.non_id = [p for p in range(self.num_all_params) if p not in ident]
@@ -530,7 +571,17 @@ class Model:
                     syms.append(s)
                     self.friction_syms.append(s)
         self._param_syms = np.array(syms)
-        self._base_deps = Matrix(self.K) * Matrix(self._param_syms[self.identified_params])
+        if self.opt["useBasisProjection"]:  # model.py:1029-1037
+            if self.opt["orthogonalizeBasis"]:
+                self._base_deps = np.dot(self._param_syms[self.identified_params], self.B)
+            else:
+                import numpy.linalg as la
+
+                Bz = la.pinv(self.B)
+                Bz[np.abs(Bz) < self.opt["minTol"]] = 0
+                self._base_deps = np.dot(self._param_syms[self.identified_params], Bz.T)
+        else:
+            self._base_deps = Matrix(self.K) * Matrix(self._param_syms[self.identified_params])
         self._syms_ready = True
 
     @property

@@ -172,13 +172,14 @@ class _Golden:
         raise KeyError(k)
 
 
-@pytest.mark.parametrize("tag", ["crA", "crB", "crC", "crD", "crW"])
+@pytest.mark.parametrize("tag", ["crA", "crB", "crC", "crD", "crF", "crW"])
 def test_compute_regressors_matches_the_reference_logic_outputs(tag, tmp_path):
     """Model.computeRegressors on the GPU against the arrays the REFERENCE'S OWN computeRegressors /
     simulateDynamicsIDynTree (model.py:239-632) produced on the same samples (tests/golden/ref_compute_regressors.npz,
     tools/make_fixtures.py: the iDynTree calls were answered by the CPU oracle, everything else is the reference's code):
     crA KUKA, friction + Stribeck, skipSamples, a-priori torques; crB threeLinks floating with a contact and a simulated
-    base wrench; crC gravity-only columns; crD floating, simulated torques, asymmetric friction, two contacts; crW WALK-MAN
+    base wrench; crC gravity-only columns; crD floating, simulated torques, asymmetric friction, two contacts; crF the
+    filterRegressor option (zero-phase 5th-order Butterworth over the base regressor columns, model.py:608-615); crW WALK-MAN
     (48 links, 29 DOF) floating base with friction, a-priori torques, skipSamples, contacts on both foot FT frames and joint-only
     torque measurements (simulated base wrench) -- the option set of configs/walkman_full.yaml on this path."""
     import json
@@ -204,6 +205,7 @@ def test_compute_regressors_matches_the_reference_logic_outputs(tag, tmp_path):
     model.Pb = np.eye(model.num_identified_params)[:, :nb]
     model.independent_cols = np.arange(nb)
     model.num_base_params = nb
+    model.num_base_inertial_params = nb - 1
     data = Data(opt)
     data.init_from_data(samples)
     model.computeRegressors(data)

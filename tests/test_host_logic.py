@@ -591,3 +591,26 @@ def test_observability_weights_and_regularisation_rows_match_reference():
         assert np.allclose(got["rho1_hat"], rh, rtol=1e-12, atol=0) and np.array_equal(got["contactForces_hat"], cf)
         assert sorted(got["reg_params"]) == sorted(reg_params)
     assert est.sdp_regularized_system(sdp_in, xStdModel, identified, non_id, base_error, 0, "uniform")["Y_combined"] is R1_K
+
+
+@pytest.mark.parametrize("tag", ["ldD", "ldE"])
+def test_basis_projection_matches_the_reference_code_outputs(tag):
+    """useBasisProjection (model.py:896-929, 1029-1037): the basis B of grouped columns, its (pseudo-)inverse and the non_id
+    bookkeeping derived from it, against the outputs of the REFERENCE'S OWN computeRegressorLinDepsQR (ldD: orthogonalised basis,
+    ldE: pseudo-inverse), on the same regressor."""
+    z = _ref_est()
+    meta, t, st, Y = _golden_regressor(z, tag)
+    path = os.path.join(ROBOTS, meta["robot"] + ".topology.json")
+    o = _opt(identifyFrictionSimultaneously=meta["friction"], floatingBase=meta["floating"], minTol=meta["minTol"], pivotTieTolerance=0,
+             useBasisProjection=1, orthogonalizeBasis=1 if tag == "ldD" else 0)
+    m = Model(o, path, regressor_init=False)
+    m.computeRegressorLinDepsQR(Y)
+    assert m.num_base_params == int(z[tag + "_num_base_params"]) and np.array_equal(np.asarray(m.P), z[tag + "_P"])
+    assert np.abs(m.B - z[tag + "_B"]).max() <= 1e-10 and np.abs(m.Binv - z[tag + "_Binv"]).max() <= 1e-9
+    assert list(m.non_id) == list(z[tag + "_non_id"]) and list(m.identifiable) == list(z[tag + "_identifiable"])
+    # the symbolic form agrees with the numeric rule
+    deps = np.asarray(m.base_deps).reshape(-1)
+    syms = set()
+    for e in deps:
+        syms |= getattr(e, "free_symbols", set())
+    assert [p for p in range(m.num_all_params) if m.param_syms[p] not in syms] == list(m.non_id)

@@ -248,7 +248,7 @@ def reference_estimators(golden):
     rident = _import_reference("identifier")
     out = {}
 
-    def lin_deps(tag, topo_name, floating, fric, S, seed, minTol):
+    def lin_deps(tag, topo_name, floating, fric, S, seed, minTol, basis=0, orth=1):
         t = load_topo(topo_name)
         rng = np.random.default_rng(seed)
         st = random_states(t, S, rng, floating, use_limits=True)
@@ -257,7 +257,7 @@ def reference_estimators(golden):
         Y = om.regressor(st, sign if fric else None)
         L, n = t.num_links, t.num_dofs
         nall = 10 * L + (3 * n if fric else 0)
-        fm = NS(opt={"minTol": minTol, "useBasisProjection": 0, "orthogonalizeBasis": 1, "identifyGravityParamsOnly": 0,
+        fm = NS(opt={"minTol": minTol, "useBasisProjection": basis, "orthogonalizeBasis": orth, "identifyGravityParamsOnly": 0,
                      "identifyFrictionSimultaneously": int(fric), "identifySymmetricVelFriction": 1, "stribeckVelocity": 0, "randomSamples": 0},
                 num_dofs=n, num_links=L, num_model_params=10 * L, num_all_params=nall, num_identified_params=nall)
         rmodel.Model.computeRegressorLinDepsQR(fm, regressor=Y)
@@ -269,10 +269,14 @@ def reference_estimators(golden):
                     tag + "_linear_deps": fm.linear_deps, tag + "_K": fm.K, tag + "_Pb": fm.Pb, tag + "_Rdiag": np.diag(fm.R),
                     tag + "_identified_params": np.asarray(fm.identified_params), tag + "_non_id": np.asarray(fm.non_id, dtype=np.int64),
                     tag + "_identifiable": np.asarray(fm.identifiable, dtype=np.int64)})
+        if basis:
+            out.update({tag + "_B": fm.B, tag + "_Binv": fm.Binv})
         return t, st, Y, fm, rng
 
     lin_deps("ldA", "kuka_lwr4", 0, 0, 60, 11, 1e-8)
     lin_deps("ldB", "kuka_lwr4", 0, 1, 60, 12, 1e-8)
+    lin_deps("ldD", "kuka_lwr4", 0, 0, 60, 14, 1e-8, basis=1, orth=1)   # useBasisProjection (model.py:896-929), orthogonalised
+    lin_deps("ldE", "threeLinks", 1, 0, 50, 15, 1e-8, basis=1, orth=0)  # and with the pseudo-inverse
     t, st, Y, fm, rng = lin_deps("ldC", "threeLinks", 1, 0, 50, 13, 1e-8)
 
     # ---- Identification methods on the threeLinks floating problem (two "files", contact forces, a-priori vector)
@@ -446,7 +450,7 @@ def reference_compute_regressors(golden):
         nb = 5
         fm = NS(opt=opt, num_dofs=n, num_links=L, num_model_params=10 * L, num_all_params=nall, num_identified_params=len(identified),
                 identified_params=identified, inertia_params=inertia_params, xStdModel=xStdModel, friction_params_start=10 * L, kinDyn=kd,
-                gravity_vec=None, idyn_model=None, progress=lambda it: it, Pb=np.eye(len(identified))[:, :nb])
+                gravity_vec=None, idyn_model=None, progress=lambda it: it, Pb=np.eye(len(identified))[:, :nb], num_base_inertial_params=nb - 1)
         fm.simulateDynamicsIDynTree = lambda samples_, idx, kinDyn=None, xStdModel=None: rmodel.Model.simulateDynamicsIDynTree(fm, samples_, idx, kinDyn, xStdModel)
         data = NS(samples=samples, num_used_samples=used)
         rmodel.Model.computeRegressors(fm, data)
@@ -459,6 +463,7 @@ def reference_compute_regressors(golden):
     run("crA", "kuka_lwr4", 0, 20, 21, {"identifyFrictionSimultaneously": 1, "stribeckVelocity": 0.05, "skipSamples": 1, "useAPriori": 1})
     run("crB", "threeLinks", 1, 10, 22, {}, contacts=["link3"])
     run("crC", "kuka_lwr4", 0, 16, 23, {"identifyGravityParamsOnly": 1, "identifyFrictionSimultaneously": 1})
+    run("crF", "kuka_lwr4", 0, 48, 25, {"filterRegressor": 1, "filterRegCutoff": 10.0})  # model.py:608-615 (5th-order Butterworth filtfilt)
     run("crD", "threeLinks", 1, 16, 24, {"simulateTorques": 1, "useAPriori": 1, "identifyFrictionSimultaneously": 1, "identifySymmetricVelFriction": 0},
         contacts=["link2", "link3"], torques_with_base=True)
     # ---- getRandomRegressor (model.py:634-830): global-RNG call order, raw Gram, pivoted QR, cache file keys
