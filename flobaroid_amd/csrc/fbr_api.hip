@@ -129,7 +129,8 @@ struct fbr_model {
     int num_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side = nullptr;                 // producer stream: kinematics + tile-image packing of the next chunk
-    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_gram[2] = {nullptr, nullptr}, ev_fork = nullptr;
+    hipStream_t copy = nullptr;                 // staging stream: host -> device copies of the chunk after next (pinned host inputs)
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_gram[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_h2d[2] = {nullptr, nullptr};
     DevBuf rec2;
     std::vector<DevBuf> tables;
     std::map<int, std::unique_ptr<GramHolder>> gram;
@@ -139,7 +140,7 @@ struct fbr_model {
     DevBuf st_chunk[2];       // per-chunk staging of pinned host inputs (fused Gram pass), double buffered with the tile images
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     FbrTsqrWork tsqr;
-    DevBuf tsqr_rowfc;        // first supported column of every regressor row (row-sorted TSQR chunks)
+    DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -161,7 +162,9 @@ struct fbr_model {
             (void)hipEventDestroy(e.second);
         }
         if (m->side) (void)hipStreamDestroy(m->side);
+        if (m->copy) (void)hipStreamDestroy(m->copy);
         for (int i = 0; i < 2; i++) {
+            if (m->ev_h2d[i]) (void)hipEventDestroy(m->ev_h2d[i]);
             if (m->ev_pack[i]) (void)hipEventDestroy(m->ev_pack[i]);
             if (m->ev_gram[i]) (void)hipEventDestroy(m->ev_gram[i]);
         }
@@ -261,6 +264,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
             HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, (pe && pe[0] == 'h') ? greatest : least));
     }
     for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&m->ev_h2d[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_pack[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_gram[i], hipEventDisableTiming));
     }
@@ -529,10 +533,10 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
             // even column count (and a 16-byte aligned output): paired columns, 16-byte stores
             if ((hm.cols & 1) == 0 && (((uintptr_t)dst) & 15) == 0)
                 hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2, m->stream, m->dm, cs, spb,
-                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L);
+                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L, (const int *)nullptr);
             else
                 hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L);
+                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L, (const int *)nullptr);
         }
         HIPCHK(hipGetLastError());
         if (out_mem == FBR_HOST) {
@@ -894,13 +898,24 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             long o = s0;
             const double *crhs = drhs, *cw = dw;
             if (h2d_chunked) {
-                // (the pack kernel of chunk ci-2, the last reader of this staging buffer, precedes these copies on the side stream)
-                ProfScope ps(m, FBR_PROF_H2D, side);
+                // copies run on their own stream so that the copy of this chunk overlaps the kinematics / packing of the one before:
+                // they wait for the pack kernel of chunk ci-2 (the last reader of this staging buffer), the producer waits for them
+                // (created on first use: HIP maps streams to hardware queues in creation order, and the producer stream's queue must
+                // stay what it is for device-resident inputs)
+                if (!m->copy && !getenv("FBR_H2D_ON_SIDE")) HIPCHK(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
+                hipStream_t cps = m->copy ? m->copy : side;
+                if (cps != side) {
+                    if (ci >= 2)
+                        HIPCHK(hipStreamWaitEvent(cps, m->ev_pack[b], 0));
+                    else
+                        HIPCHK(hipStreamWaitEvent(cps, m->ev_fork, 0));
+                }
+                ProfScope ps(m, FBR_PROF_H2D, cps);
                 double *p = m->st_chunk[b].as<double>();
                 auto put = [&](const double *src, size_t per, const double **dst) -> int {
                     *dst = nullptr;
                     if (!src || per == 0) return FBR_OK;
-                    HIPCHK(hipMemcpyAsync(p, src + (size_t)s0 * per, (size_t)cs * per * sizeof(double), hipMemcpyHostToDevice, side));
+                    HIPCHK(hipMemcpyAsync(p, src + (size_t)s0 * per, (size_t)cs * per * sizeof(double), hipMemcpyHostToDevice, cps));
                     *dst = p;
                     p += (size_t)cs * per;
                     return FBR_OK;
@@ -911,6 +926,10 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                     (r3 = put(d.sign, hm.n, &dc.sign)) || (r3 = put(drhs, (size_t)hm.rows * k, &crhs)) || (r3 = put(dw, hm.rows, &cw)))
                     return r3;
                 o = 0;
+                if (cps != side) {
+                    HIPCHK(hipEventRecord(m->ev_h2d[b], cps));
+                    HIPCHK(hipStreamWaitEvent(side, m->ev_h2d[b], 0));
+                }
             }
             int rc2 = run_kin(m, dc, o, cs, side, &m->rec2);
             if (rc2) return rc2;
@@ -991,6 +1010,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(side));
+        if (h2d_chunked && m->copy) HIPCHK(hipStreamSynchronize(m->copy));
     }
     return finish_output(m, G, G_out, gcount, out_mem);
 }
@@ -1091,6 +1111,62 @@ static std::vector<int> tsqr_first_cols(const FbrHostModel &hm, const int32_t *c
     return fc;
 }
 
+// Column order of a factorisation.  R^T R = A^T A holds for any column order of A, and a block of one regressor row is folded from
+// the first column it can touch (tsqr_first_cols): with the inertial columns ordered by the DEPTH of their link (number of movable
+// joints above it), every joint row starts behind all shallower links.  WALK-MAN: the folds run 0.44 instead of 0.55 of the dense
+// tile updates and 0.60 instead of 0.71 of the panel chains.  The factor is computed in that order and brought back to the caller's
+// column order by one small re-triangularisation (QR of the column-permuted n x n factor).  Friction columns keep their place behind
+// the inertial ones.
+struct TsqrPlan {
+    int Psel = 0, Pa = 0;
+    bool reorder = false;
+    std::vector<int> fcols;    // [Psel] regressor column of factor column j
+    std::vector<int> perm;     // [Pa]   caller's factor column of internal factor column j (rhs columns: identity)
+    std::vector<int> inv;      // [Pa]   internal position of the caller's column j
+    std::vector<int> linkpos;  // [L]    (all columns, no subset) block position of every link's columns
+    std::vector<int> fc;       // [rows] first supported internal column of every regressor row
+};
+static long tsqr_plan_work(const std::vector<int> &fc, int n)
+{
+    long w = 0;
+    const int NP = n / 16;
+    for (int f : fc) {
+        const long np_ = NP - std::min(f, n) / 16;
+        w += np_ * (np_ - 1) / 2 + np_;
+    }
+    return w;
+}
+static TsqrPlan tsqr_plan(const FbrHostModel &hm, const int32_t *cols, int32_t ncols, int k, long S)
+{
+    TsqrPlan p;
+    p.Psel = cols ? ncols : hm.cols;
+    p.Pa = p.Psel + k;
+    const int n = (p.Pa + 15) & ~15;
+    std::vector<int> ucols(p.Psel);
+    for (int j = 0; j < p.Psel; j++) ucols[j] = cols ? cols[j] : j;
+    std::vector<int> order(p.Psel);
+    for (int j = 0; j < p.Psel; j++) order[j] = j;
+    auto depth = [&](int j) { return hm.coldesc[ucols[j]].kind == 0 ? (int)hm.path[hm.coldesc[ucols[j]].link].size() : (1 << 20); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth(a) < depth(b); });
+    std::vector<int> sorted(p.Psel);
+    for (int j = 0; j < p.Psel; j++) sorted[j] = ucols[order[j]];
+    const std::vector<int> fc_user = tsqr_first_cols(hm, ucols.data(), p.Psel), fc_sorted = tsqr_first_cols(hm, sorted.data(), p.Psel);
+    // worth it for wide factors and enough rows to pay for the final n x n re-triangularisation
+    p.reorder = !getenv("FBR_TSQR_NO_REORDER") && n > 16 * FBR_TSQR_NARROW_MAX_TILES && S * (long)hm.rows >= 64L * n &&
+                tsqr_plan_work(fc_sorted, n) * 100 < tsqr_plan_work(fc_user, n) * 97;
+    p.perm.resize(p.Pa);
+    p.inv.resize(p.Pa);
+    for (int j = 0; j < p.Pa; j++) p.perm[j] = (p.reorder && j < p.Psel) ? order[j] : j;
+    for (int j = 0; j < p.Pa; j++) p.inv[p.perm[j]] = j;
+    p.fcols = p.reorder ? sorted : ucols;
+    p.fc = p.reorder ? fc_sorted : fc_user;
+    if (!cols) {
+        p.linkpos.assign(hm.L, 0);
+        for (int l = 0; l < hm.L; l++) p.linkpos[l] = p.inv[hm.cpl * l] / hm.cpl;
+    }
+    return p;
+}
+
 static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
                      const double *w, const double *R_in, double *R_out, int32_t out_mem)
 {
@@ -1102,8 +1178,6 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         return FBR_E_INVALID;
     }
     const FbrHostModel &hm = m->hm;
-    const int *dcols = nullptr;
-    int Psel = hm.cols;
     if (cols) {
         if (ncols <= 0 || ncols > hm.cols) {
             set_err("bad column subset size");
@@ -1117,14 +1191,30 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
             }
             seen[cols[i]] = 1;
         }
-        if ((rc = m->st_x.ensure((size_t)ncols * sizeof(int)))) return rc;
-        HIPCHK(hipMemcpyAsync(m->st_x.p, cols, (size_t)ncols * sizeof(int), hipMemcpyHostToDevice, m->stream));
-        dcols = m->st_x.as<int>();
-        Psel = ncols;
     }
-    const int Pa = Psel + k;
-    const size_t rcount = (size_t)Pa * Pa;
     const long S = d.S;
+    const TsqrPlan plan = tsqr_plan(hm, cols, ncols, k, S);
+    const int Psel = plan.Psel, Pa = plan.Pa;
+    // device tables: [fcols (Psel) | perm (Pa) | inv (Pa) | linkpos (L) | row first columns (rows)]
+    const int *dcols = nullptr, *dperm = nullptr, *dinv = nullptr, *dlinkpos = nullptr, *dfc = nullptr;
+    {
+        std::vector<int> tab;
+        tab.insert(tab.end(), plan.fcols.begin(), plan.fcols.end());
+        tab.insert(tab.end(), plan.perm.begin(), plan.perm.end());
+        tab.insert(tab.end(), plan.inv.begin(), plan.inv.end());
+        tab.insert(tab.end(), plan.linkpos.begin(), plan.linkpos.end());
+        tab.insert(tab.end(), plan.fc.begin(), plan.fc.end());
+        if ((rc = m->st_x.ensure(tab.size() * sizeof(int)))) return rc;
+        HIPCHK(hipMemcpyAsync(m->st_x.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));  // tab is a local
+        const int *t = m->st_x.as<int>();
+        if (cols || (plan.reorder)) dcols = t;  // gather list of the materialised path
+        dperm = t + Psel;
+        dinv = dperm + Pa;
+        if (!cols && plan.reorder) dlinkpos = dinv + Pa;
+        dfc = dinv + Pa + plan.linkpos.size();
+    }
+    const size_t rcount = (size_t)Pa * Pa;
     const double *drhs = nullptr, *dw = nullptr;
     if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
     if ((rc = stage_one(m, m->st_aux2, w, (size_t)S * hm.rows, st->mem, &dw))) return rc;
@@ -1146,14 +1236,12 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         set_err(std::string(what) + ": " + fbr_tsqr_error());
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
-    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
-    if (S > 0) {
-        // first column (in the order of the factorised columns) in which regressor row r can be non-zero: base-wrench rows
-        // meet every inertial column, the row of joint d the columns of the links below d and its own friction columns
-        const std::vector<int> fc = tsqr_first_cols(hm, cols, Psel);
-        if ((rc = m->tsqr_rowfc.ensure(fc.size() * sizeof(int)))) return rc;
-        HIPCHK(hipMemcpyAsync(m->tsqr_rowfc.p, fc.data(), fc.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));  // fc is a local
+    // an existing factor seeds working factor 0 directly when the column order is the caller's; in the internal order its rows are
+    // folded in like data rows (column gather)
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, plan.reorder ? nullptr : Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
+    if (plan.reorder && Rin_dev) {
+        ProfScope ps(m, FBR_PROF_TSQR);
+        if ((rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pa, Pa, Rin_dev, 0, nullptr, nullptr, Pa, dperm))) return tsqr_fail(rc, "tsqr fold R_in");
     }
     if (S > 0) {
         // materialise Y chunk by chunk (K1 + K2) and fold each chunk into the per-workgroup factors.  Without row
@@ -1167,7 +1255,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         const int spb = std::max(1, std::min(16, 256 / std::max(1, hm.cols / 2)));
         const size_t lds2 = lds * spb;
         HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        const bool direct = !dcols && !dw;
+        const bool direct = !cols && !dw;
         if (!direct && (rc = m->out_tmp.ensure((size_t)ch * per * sizeof(double)))) return rc;
         for (long s0 = 0; s0 < S; s0 += ch) {
             const long cs = std::min(ch, S - s0);
@@ -1179,7 +1267,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
             // and a 64-row block of one regressor row is zero left of that row's first supported column, so its fold starts
             // there (rows of joints deep in the tree touch a fraction of the panels).
             FbrTsqrRowOrder ro;
-            ro.first_col = m->tsqr_rowfc.as<int>();
+            ro.first_col = dfc;
             ro.rows = hm.rows;
             ro.group = cs;
             long rs_s = hm.rows, rs_r = 1;
@@ -1191,14 +1279,15 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
                     rs_r = cs;
                 }
             }
+            const int *lp = direct ? dlinkpos : nullptr;  // (the materialised path gathers the columns when it packs the chunk)
             {
                 ProfScope ps(m, FBR_PROF_REGRESSOR);
                 if ((hm.cols & 1) == 0)
                     hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2,
-                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r);
+                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r, lp);
                 else
                     hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r);
+                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r, lp);
             }
             HIPCHK(hipGetLastError());
             ProfScope ps(m, FBR_PROF_TSQR);
@@ -1212,7 +1301,17 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
     }
     {
         ProfScope ps(m, FBR_PROF_TSQR);
-        if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
+        if (!plan.reorder) {
+            if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
+        } else {
+            // factor in the internal column order -> the caller's: R = qr(R' [:, inv]) (one workgroup, Pa dense rows)
+            if ((rc = m->tsqr_rtmp.ensure(rcount * sizeof(double)))) return rc;
+            if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, m->tsqr_rtmp.as<double>()))) return tsqr_fail(rc, "tsqr finish");
+            if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, nullptr, m->num_cus, 1)) ||
+                (rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pa, Pa, m->tsqr_rtmp.as<double>(), 0, nullptr, nullptr, Pa, dinv)) ||
+                (rc = fbr_tsqr_finish(m->tsqr, m->stream, R)))
+                return tsqr_fail(rc, "tsqr column order");
+        }
     }
     return finish_output(m, R, R_out, rcount, out_mem);
 }
@@ -1241,13 +1340,15 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
         return FBR_E_INVALID;
     }
     const FbrHostModel &hm = m->hm;
-    const int Psel = cols ? ncols : hm.cols, Pa = Psel + k;
+    const TsqrPlan plan = tsqr_plan(hm, cols, ncols, k, (long)num_samples);
+    const int Psel = plan.Psel, Pa = plan.Pa;
+    (void)Psel;
     FbrTsqrShape sh;
     if (fbr_tsqr_shape(Pa, m->num_cus, num_samples * (long)hm.rows, &sh)) {
         set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
         return FBR_E_UNSUPPORTED;
     }
-    const std::vector<int> fc = tsqr_first_cols(hm, cols, Psel);
+    const std::vector<int> &fc = plan.fc;
     const int NP = sh.n / 16;
     const long per_update = 8L * sh.sub + 4;  // V^T C (4 SUB) + T (4) + C -= V W (4 SUB) MFMAs per (panel, tile right of it)
     auto fold_mfma = [&](int first_col) -> long {
@@ -1275,6 +1376,8 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
     for (int i0 = 0; i0 < sh.n; i0 += sh.mb) merge += fold_mfma(i0);
     for (int stride = 1; stride < sh.NW; stride *= 2)
         for (long a = 0; a + stride < sh.NW; a += 2L * stride) tr += merge;
+    if (plan.reorder)  // the factor is brought back to the caller's column order: Pa dense rows folded by one workgroup
+        for (long r0 = 0; r0 < ((Pa + 15) & ~15); r0 += sh.mb) tr += fold_mfma(0);
     if (mfma_level0) *mfma_level0 = l0;
     if (mfma_tree) *mfma_tree = tr;
     if (block_rows) *block_rows = sh.mb;

@@ -122,8 +122,9 @@ template <int NT_, int U_ = 6> __device__ __forceinline__ void fbr_stage_copy(do
 __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, const double *__restrict__ rec,
                                                              const double *__restrict__ dq,
                                                              const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
-                                                             long rs_r)
+                                                             long rs_r, const int *__restrict__ linkpos)
 {
+    // linkpos (optional): the cpl columns of link l are written at column cpl * linkpos[l] (the TSQR chunks order the links by depth)
     // row (s, r) of the output is row s * rs_s + r * rs_r: (rows, 1) = the reference's sample-major stack; (1, S) = row-major by
     // regressor row (the TSQR chunks: all samples' row r together, see fbr_tsqr.h)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -138,14 +139,15 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
         for (int c = tid; c < m.cols; c += blockDim.x) {
             const int4 cd = m.coldesc[c];
             if (cd.x == 0) {
+                const int co = linkpos ? m.cpl * linkpos[cd.y] + (c - m.cpl * cd.y) : c;
                 double w6[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
-                for (int r = 0; r < m.fb; r++) Ys[r * rl + c] = w6[r];
+                for (int r = 0; r < m.fb; r++) Ys[r * rl + co] = w6[r];
                 for (int d = 0; d < m.n; d++) {
                     const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
                     double v = 0.0;
                     if (bit) v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
-                    Ys[(m.fb + d) * rl + c] = v;
+                    Ys[(m.fb + d) * rl + co] = v;
                 }
             } else {
                 const int j = cd.w;
@@ -236,7 +238,7 @@ typedef double fbr_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
                                                               const double *__restrict__ dq,
                                                               const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
-                                                              long rs_r)
+                                                              long rs_r, const int *__restrict__ linkpos)
 {
     // spb samples per workgroup pass (small robots: 256 / (cols/2) samples side by side)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
         for (int prr = pr; prr < npairs; prr += (spb > 1 ? npairs : (int)blockDim.x)) {
             const int c = 2 * prr;
             const int4 ca = m.coldesc[c], cb = m.coldesc[c + 1];
-            fbr_d2 *dst = (fbr_d2 *)(Ys + c);
+            // (a pair of adjacent inertial columns belongs to one link: it moves with the link's column block, cpl is even)
+            fbr_d2 *dst = (fbr_d2 *)(Ys + ((linkpos && ca.x == 0) ? m.cpl * linkpos[ca.y] + (c - m.cpl * ca.y) : c));
             const long rstride = rs_r * (ldy >> 1);  // in double2 units (ldy even)
             if (ca.x == 0) {
                 double wa[6], wb[6];
