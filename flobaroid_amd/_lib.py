@@ -13,7 +13,7 @@ from typing import Any
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfbr.so")
+LIB_PATH = os.environ.get("FBR_LIB_PATH") or os.path.join(_HERE, "libfbr.so")  # (FBR_LIB_PATH: kernel-shape experiments, tools/)
 
 FBR_HOST = 0
 FBR_DEVICE = 1

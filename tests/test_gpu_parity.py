@@ -333,6 +333,79 @@ def test_multi_chunk_paths_at_small_sizes(monkeypatch):
             assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * np.linalg.norm(Ag.T @ Ag)
 
 
+def test_pinned_host_inputs_are_staged_chunk_by_chunk(monkeypatch):
+    """Pinned host states / rhs / weights take the chunked staging path of fbr_gram_accumulate (copy stream, double-buffered staging
+    buffers, events against the producer stream); pageable ones the up-front copy.  Both must give the device-resident result bit for
+    bit (same chunking, same kernels), also for grouped Grams and with a friction layout (sign series staged as well)."""
+    import torch
+
+    for cfg in (CONFIGS[7], CONFIGS[6]):
+        t, eng, om = _engine_oracle(cfg)
+        S = 660
+        st, rng = _states(t, cfg, S, 17)
+        rhs = rng.standard_normal((S * om.rows, 2))
+        w = 0.5 + rng.random(S * om.rows)
+        monkeypatch.setenv("FBR_CHUNK_SAMPLES", "90")   # 8 chunks: both staging buffers are reused several times
+        G_pageable = eng.gram(st, rhs=rhs, w=w)
+        pin = {k: torch.from_numpy(v).pin_memory() for k, v in st.items()}
+        G_pinned = eng.gram(pin, rhs=torch.from_numpy(rhs).pin_memory(), w=torch.from_numpy(w).pin_memory())
+        dev = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+        G_dev = eng.gram(dev, rhs=torch.from_numpy(rhs).cuda(), w=torch.from_numpy(w).cuda()).cpu().numpy()
+        assert np.array_equal(G_pinned, G_dev) and np.array_equal(G_pageable, G_dev)
+        A = _aug(om, st, rhs, w)
+        assert np.linalg.norm(G_dev - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
+        Gg = eng.gram_grouped(pin, 3, rhs=torch.from_numpy(rhs).pin_memory())
+        Gg_dev = eng.gram_grouped(dev, 3, rhs=torch.from_numpy(rhs).cuda()).cpu().numpy()
+        assert np.array_equal(Gg, Gg_dev)
+        pr = None
+        eng.profile_enable(True)
+        eng.profile_get()
+        eng.gram(pin, rhs=torch.from_numpy(rhs).pin_memory())
+        pr = eng.profile_get()
+        eng.profile_enable(False)
+        assert pr["h2d"][1] == 8 and pr["pack"][1] == 8   # one staging copy group and one packing launch per chunk
+        eng.close()
+
+
+def test_tsqr_column_order_is_internal(monkeypatch):
+    """The wide factorisation orders the inertial columns by link depth internally and returns the factor in the caller's
+    order: with the reordering switched off the same R^T R and, for a full-rank column subset, the same sign-normalised R; an R_in
+    in the caller's order streams through either way; the executed-work counter reports the saving."""
+    cfg = CONFIGS[7]
+    t, eng, om = _engine_oracle(cfg)
+    S = 1200   # (35 S rows >= 64 n: below that the final re-triangularisation is not worth it and the caller's order is kept)
+    st, rng = _states(t, cfg, S, 23)
+    rhs = rng.standard_normal((S * om.rows, 1))
+    A = _aug(om, st, rhs)
+    Go = A.T @ A
+    import scipy.linalg as sla
+
+    # 150 linearly independent columns (the first pivots of the Gram): 151 columns with the rhs -> the wide kernels, unique R up to signs
+    cols = np.sort(sla.qr(Go[: om.P, : om.P], pivoting=True, mode="r")[1][:150]).astype(np.int32)
+    sel = np.r_[cols, om.P]
+    h = S // 2
+    first = {k: v[:h] for k, v in st.items()}
+    second = {k: v[h:] for k, v in st.items()}
+
+    def run():
+        R = eng.tsqr(st, rhs=rhs)
+        Rc = eng.tsqr(st, rhs=rhs, cols=cols)
+        Rs = eng.tsqr(second, rhs=rhs[h * om.rows:], cols=cols, R_in=eng.tsqr(first, rhs=rhs[: h * om.rows], cols=cols))
+        return R, Rc, Rs, eng.tsqr_work_info(S, k=1)
+
+    R1, Rc1, Rs1, wi1 = run()
+    monkeypatch.setenv("FBR_TSQR_NO_REORDER", "1")
+    R0, Rc0, Rs0, wi0 = run()
+    for R in (R0, R1):
+        assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
+    norm = lambda R: R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
+    Gc = Go[np.ix_(sel, sel)]
+    for R in (Rc0, Rc1, Rs0, Rs1):
+        assert np.linalg.norm(R.T @ R - Gc) <= 1e-11 * np.linalg.norm(Gc)
+        assert np.linalg.norm(norm(R) - norm(Rc0)) <= 1e-9 * np.linalg.norm(Rc0)
+    assert wi1["mfma_level0"] < 0.9 * wi0["mfma_level0"] and wi1["mfma_tree"] > wi0["mfma_tree"]
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[7]], ids=cfg_id)
 def test_fd_sweep_scores_match_oracle_regressors(cfg):
     """fbr_fd_scores == sum(W_t * Y(state_t + eps e_d)) with the oracle's regressor on every perturbed state
