@@ -109,6 +109,9 @@ _SIGNATURES = {
         [ctypes.c_void_p, _ip, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
          ctypes.POINTER(ctypes.c_int64), _ip, _ip],
     ),
+    "fbr_filtfilt": (ctypes.c_int, [ctypes.c_void_p, _dp, _dp, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "fbr_medfilt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "fbr_central_diff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
     "fbr_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "fbr_profile_get": (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.POINTER(ctypes.c_int64)]),
     "fbr_gram_program_info": (
@@ -448,6 +451,47 @@ class Engine:
             self._sync_torch()  # (a factor just received by torch.distributed lands on torch's stream)
         r, ret = self._out(out, (n, n), a.mem)
         _check(self._lib.fbr_tsqr_merge(self._h, n, a.ptr, b.ptr, r.ptr, a.mem), "fbr_tsqr_merge")
+        return ret
+
+    # ------------------------------------------------------------------ signal conditioning (Data.preprocess on the device)
+    def _sig_array(self, X, ncols):
+        """(pointer, mem, S, ld, keep-alive) of a 2-D C-contiguous float64 array (NumPy, changed in place, or CUDA tensor)."""
+        if _is_torch(X):
+            if X.dim() != 2 or not X.is_contiguous() or str(X.dtype) != "torch.float64" or X.device.type != "cuda":
+                raise ValueError("expected a contiguous 2-D float64 CUDA tensor")
+            self._sync_torch()
+            return X.data_ptr(), FBR_DEVICE, int(X.shape[0]), int(X.shape[1]), X
+        if not (isinstance(X, np.ndarray) and X.ndim == 2 and X.flags.c_contiguous and X.dtype == np.float64):
+            raise ValueError("expected a C-contiguous 2-D float64 ndarray (it is filtered in place)")
+        return X.ctypes.data, FBR_HOST, int(X.shape[0]), int(X.shape[1]), X
+
+    def filtfilt(self, b, a, X, ncols=None):
+        """In place ``X[:, :ncols] = scipy.signal.filtfilt(b, a, X[:, :ncols], axis=0)`` (zero-phase low-pass of every channel)."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if b.size != a.size:  # scipy pads the shorter one with zeros
+            n = max(b.size, a.size)
+            b, a = np.r_[b, np.zeros(n - b.size)], np.r_[a, np.zeros(n - a.size)]
+        ptr, mem, S, ld, keep = self._sig_array(X, ncols)
+        nc = ld if ncols is None else int(ncols)
+        _check(self._lib.fbr_filtfilt(self._h, b.ctypes.data_as(_dp), a.ctypes.data_as(_dp), int(b.size), ptr, S, nc, ld, mem), "fbr_filtfilt")
+        return X
+
+    def medfilt(self, k: int, X, ncols=None):
+        """In place ``X[:, :ncols] = scipy.signal.medfilt(X[:, :ncols], (k, 1))``."""
+        ptr, mem, S, ld, keep = self._sig_array(X, ncols)
+        nc = ld if ncols is None else int(ncols)
+        _check(self._lib.fbr_medfilt(self._h, int(k), ptr, S, nc, ld, mem), "fbr_medfilt")
+        return X
+
+    def central_diff(self, A, times, out=None):
+        """4th-order central difference of the columns of A over the time stamps (data.py:396-418)."""
+        ptr, mem, S, ld, keep = self._sig_array(A, None)
+        t = _Ref(times, (S,), "times")
+        if t.mem != mem:
+            raise ValueError("times must live in the same memory space as A")
+        r, ret = self._out(out, (S, ld), mem)
+        _check(self._lib.fbr_central_diff(self._h, ptr, t.ptr, r.ptr, S, ld, mem), "fbr_central_diff")
         return ret
 
     def tsqr_work_info(self, num_samples: int, k: int = 0, cols=None) -> dict:

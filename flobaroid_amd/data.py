@@ -141,11 +141,16 @@ class Data:
         return d
 
     def preprocess(self, Q, V, Vdot, Tau, T, Fs, Q_raw=None, V_raw=None, Tau_raw=None, IMUlinVel=None, IMUrotVel=None,
-                   IMUlinAcc=None, IMUrotAcc=None, IMUrpy=None, FT=None) -> None:
+                   IMUlinAcc=None, IMUrotAcc=None, IMUrpy=None, FT=None, engine=None) -> None:
         """Derivation and filtering of measurements, arrays changed in place like the reference (data.py:369-619):
         Q, Tau filtered; V, Vdot, *_raw overwritten; IMUrotVel, IMUlinAcc, IMUrpy filtered; IMUlinVel, IMUrotAcc
         overwritten; every FT array median + low-pass filtered (first three columns).  All columns of an array are
-        filtered in one SciPy call (identical per-column arithmetic)."""
+        filtered in one SciPy call (identical per-column arithmetic).
+
+        ``engine`` (a ``flobaroid_amd._lib.Engine``): the zero-phase low-passes, the median filters and the central differences run on
+        the GPU (``fbr_filtfilt`` / ``fbr_medfilt`` / ``fbr_central_diff``: time-parallel blocked scan of the filter state, all
+        channels of an array at once) -- same results to rounding, the filter design (``scipy.signal.butter``, a handful of
+        coefficients) and the IMU frame bookkeeping stay on the host."""
         import scipy.integrate
         import scipy.signal as sig
 
@@ -153,7 +158,14 @@ class Data:
 
         k = self.opt["filterMedianSize"]
         n = self.opt["num_dofs"]
-        med = lambda X: sig.medfilt(X, (k, 1))
+        if engine is None:
+            med = lambda X: sig.medfilt(X, (k, 1))
+            filtfilt = lambda b, a, X: sig.filtfilt(b, a, X, axis=0)
+            cdiff = self._central_diff
+        else:
+            med = lambda X: engine.medfilt(k, np.ascontiguousarray(X, dtype=np.float64).copy())
+            filtfilt = lambda b, a, X: engine.filtfilt(b, a, np.ascontiguousarray(X, dtype=np.float64).copy())
+            cdiff = lambda A, times: engine.central_diff(np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(times, dtype=np.float64))
         if self.opt["useDeg"]:
             np.copyto(Q, np.deg2rad(Q))
             np.copyto(V, np.deg2rad(V))
@@ -166,31 +178,31 @@ class Data:
         b3, a3 = lp["filterLowPass3"]
         # joint positions: low-pass
         Q_orig = Q.copy()
-        Q[:, :n] = sig.filtfilt(b8, a8, Q_orig[:, :n], axis=0)
+        Q[:, :n] = filtfilt(b8, a8, Q_orig[:, :n])
         if Q_raw is not None:
             np.copyto(Q_raw, Q_orig)
         # joint velocities: derivative of the filtered positions, median, low-pass
-        Vs = self._central_diff(Q, T)
+        Vs = cdiff(Q, T)
         if V_raw is not None:
             np.copyto(V_raw, Vs)
         Vs[:, :n] = med(Vs[:, :n].copy())
-        Vs[:, :n] = sig.filtfilt(b6, a6, Vs[:, :n].copy(), axis=0)
+        Vs[:, :n] = filtfilt(b6, a6, Vs[:, :n].copy())
         np.copyto(V, Vs)
         # joint accelerations: derivative of the velocities, median
-        np.copyto(Vdot, self._central_diff(Vs, T))
+        np.copyto(Vdot, cdiff(Vs, T))
         Vdot[:, :n] = med(Vdot[:, :n].copy())
         # joint torques: median, low-pass
         if Tau_raw is not None:
             np.copyto(Tau_raw, Tau)
         Tau[:, :n] = med(Tau[:, :n].copy())
-        Tau[:, :n] = sig.filtfilt(b8, a8, Tau[:, :n].copy(), axis=0)
+        Tau[:, :n] = filtfilt(b8, a8, Tau[:, :n].copy())
         # IMU
         if IMUlinAcc is not None and IMUrotVel is not None:
             IMUlinAcc[:, :3] = med(IMUlinAcc[:, :3].copy())
             IMUrotVel[:, :3] = med(IMUrotVel[:, :3].copy())
-            IMUlinAcc[:, :3] = sig.filtfilt(b8, a8, IMUlinAcc[:, :3].copy(), axis=0)
-            IMUrotVel[:, :3] = sig.filtfilt(b8, a8, IMUrotVel[:, :3].copy(), axis=0)
-            IMUrpy[:, :3] = sig.filtfilt(b3, a3, IMUrpy[:, :3].copy(), axis=0)
+            IMUlinAcc[:, :3] = filtfilt(b8, a8, IMUlinAcc[:, :3].copy())
+            IMUrotVel[:, :3] = filtfilt(b8, a8, IMUrotVel[:, :3].copy())
+            IMUrpy[:, :3] = filtfilt(b3, a3, IMUrpy[:, :3].copy())
             if IMUlinVel is not None:
                 # rotate to the (estimated) world frame
                 R = np.stack([rpy_to_matrix(r) for r in IMUrpy])
@@ -225,4 +237,4 @@ class Data:
         if FT is not None:
             for ft in FT:
                 ft[:, :3] = med(ft[:, :3].copy())
-                ft[:, :3] = sig.filtfilt(b3, a3, ft[:, :3].copy(), axis=0)
+                ft[:, :3] = filtfilt(b3, a3, ft[:, :3].copy())

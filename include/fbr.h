@@ -178,6 +178,21 @@ int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *cols, int32
 /* R_out = R factor of [R_a; R_b] (both n x n upper triangular, row-major) -- one node of the TSQR tree. */
 int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem);
 
+/* ---- the step before the path: signal conditioning of measurement channels ---------------------------- */
+/*
+ * The array operations of Data.preprocess (identification/data.py:369-619) on channel arrays X [S][ld] (row-major, the first ncols
+ * columns are processed, in place), in `mem` space; `m` only supplies the device and the stream.
+ *   fbr_filtfilt      scipy.signal.filtfilt(b, a, X, axis=0) with its defaults (odd extension of 3*ncoef samples, steady-state
+ *                     initial conditions): the zero-phase Butterworth low-passes of positions / velocities / torques / IMU / FT
+ *                     channels (data.py:430-436, 470-480, 505-520, 600-615).  ncoef = order + 1 <= 12, S > 3*ncoef.
+ *   fbr_medfilt       scipy.signal.medfilt(X, (k, 1)) (zero padding at the ends), k odd <= 31 (data.py:466, 485, 500, 598).
+ *   fbr_central_diff  D [S][ncols] = 4th-order central difference of A [S][ncols] (dense) over the time stamps T [S] with the
+ *                     reference's edge rules (data.py:396-418).  S >= 5.
+ */
+int fbr_filtfilt(fbr_model *m, const double *b, const double *a, int32_t ncoef, double *X, int64_t S, int32_t ncols, int32_t ld, int32_t mem);
+int fbr_medfilt(fbr_model *m, int32_t k, double *X, int64_t S, int32_t ncols, int32_t ld, int32_t mem);
+int fbr_central_diff(fbr_model *m, const double *A, const double *T, double *D, int64_t S, int32_t ncols, int32_t mem);
+
 /* ---- profiling ---------------------------------------------------------------------------------- */
 #define FBR_PROF_KIN 0       /* link kinematics kernel */
 #define FBR_PROF_REGRESSOR 1 /* materialising regressor kernel */

@@ -1,0 +1,113 @@
+"""The step before the path on the device: fbr_filtfilt / fbr_medfilt / fbr_central_diff against SciPy and, through
+Data.preprocess(engine=...), against the outputs of the REFERENCE'S OWN Data.preprocess (tests/golden/ref_host_functions.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, load_topo
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from flobaroid_amd._lib import Engine
+
+    return Engine(load_topo("threeLinks"))
+
+
+@pytest.mark.parametrize("S", [40, 2030, 2048, 2049, 50_000])
+@pytest.mark.parametrize("order,fc", [(3, 0.05), (5, 0.08), (8, 0.2)])
+def test_filtfilt_matches_scipy(S, order, fc):
+    """Zero-phase Butterworth low-pass of every channel == scipy.signal.filtfilt(b, a, X, axis=0) (odd extension, lfilter_zi start
+    states), across the block boundaries of the state scan (2048 samples), strided arrays and device tensors."""
+    import scipy.signal as sig
+    import torch
+
+    if S <= 3 * (order + 1):
+        pytest.skip("shorter than scipy's padding")
+    eng = _engine()
+    rng = np.random.default_rng(S + order)
+    X = np.cumsum(rng.standard_normal((S, 7)), axis=0) * 0.1 + 3.0 * rng.standard_normal(7)
+    b, a = sig.butter(order, fc)
+    want = sig.filtfilt(b, a, X, axis=0)
+    got = eng.filtfilt(b, a, X.copy())
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-10 * scale
+    # only the first 4 of 7 columns (ld = 7), the rest untouched
+    Y = X.copy()
+    eng.filtfilt(b, a, Y, ncols=4)
+    assert np.abs(Y[:, :4] - want[:, :4]).max() <= 1e-10 * scale and np.array_equal(Y[:, 4:], X[:, 4:])
+    Xd = torch.from_numpy(X.copy()).cuda()
+    eng.filtfilt(b, a, Xd)
+    assert np.array_equal(Xd.cpu().numpy(), got)
+
+
+def test_filtfilt_rejects_short_signals_like_scipy():
+    import scipy.signal as sig
+
+    from flobaroid_amd._lib import FbrError
+
+    b, a = sig.butter(5, 0.1)
+    with pytest.raises(FbrError, match="longer than the padding"):
+        _engine().filtfilt(b, a, np.zeros((18, 2)))
+
+
+@pytest.mark.parametrize("k", [1, 3, 5, 9])
+def test_medfilt_and_central_diff_match_the_host_versions(k):
+    import scipy.signal as sig
+
+    from flobaroid_amd.data import Data
+
+    eng = _engine()
+    rng = np.random.default_rng(k)
+    S = 3001
+    X = rng.standard_normal((S, 6))
+    assert np.array_equal(eng.medfilt(k, X.copy()), sig.medfilt(X, (k, 1)))
+    Y = X.copy()
+    eng.medfilt(k, Y, ncols=2)
+    assert np.array_equal(Y[:, :2], sig.medfilt(X[:, :2], (k, 1))) and np.array_equal(Y[:, 2:], X[:, 2:])
+    T = np.cumsum(0.005 + 1e-4 * rng.random(S))
+    want = Data._central_diff(X, T)
+    got = eng.central_diff(X, T)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_preprocess_on_the_device_matches_the_reference_outputs():
+    """Data.preprocess(engine=...) == the reference's Data.preprocess (identification/data.py:369-619): same fixture and checks as the
+    host version in tests/test_host_logic.py, with the array operations on the GPU."""
+    from flobaroid_amd.data import Data
+
+    z = np.load(os.path.join(GOLDEN, "ref_host_functions.npz"), allow_pickle=True)
+    opt = json.loads(str(z["pre_opt"]))
+    eng = _engine()
+    Q, V, Tau, T = z["pre_Q"].copy(), z["pre_V"].copy(), z["pre_Tau"].copy(), z["pre_T"].copy()
+    FT = [z["pre_FT0"].copy(), z["pre_FT1"].copy()]
+    Vdot = np.zeros_like(Q)
+    Qr, Vr, Tr = np.zeros_like(Q), np.zeros_like(Q), np.zeros_like(Q)
+    Data(opt).preprocess(Q, V, Vdot, Tau, T, float(z["pre_Fs"]), Q_raw=Qr, V_raw=Vr, Tau_raw=Tr, FT=FT, engine=eng)
+    for name, got in [("Q", Q), ("V", V), ("Vdot", Vdot), ("Tau", Tau), ("Q_raw", Qr), ("V_raw", Vr), ("Tau_raw", Tr), ("FT0", FT[0]), ("FT1", FT[1])]:
+        want = z["pre_out_" + name]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), name
+
+
+def test_preprocess_large_file_device_equals_host():
+    """A long recording (400 k samples x 29 channels: several hundred scan blocks per channel): device == host SciPy to rounding."""
+    from flobaroid_amd.data import Data
+
+    rng = np.random.default_rng(0)
+    S, n, Fs = 400_000, 29, 200.0
+    T = np.arange(S) / Fs
+    Q0 = np.sin(T[:, None] * (0.3 + 0.1 * np.arange(n))) + 0.01 * rng.standard_normal((S, n))
+    Tau0 = 5 * np.cos(T[:, None] * (0.2 + 0.05 * np.arange(n))) + 0.3 * rng.standard_normal((S, n))
+    opt = {"filterMedianSize": 5, "useDeg": 0, "num_dofs": n, "filterLowPass1": [8.0, 5], "filterLowPass2": [6.0, 5], "filterLowPass3": [3.0, 4],
+           "waitForZeroAcc": 0, "zeroAccThresh": 0.1}
+    res = []
+    for engine in (None, _engine()):
+        Q, V, Vdot, Tau = Q0.copy(), np.zeros((S, n)), np.zeros((S, n)), Tau0.copy()
+        Data(opt).preprocess(Q, V, Vdot, Tau, T, Fs, engine=engine)
+        res.append((Q, V, Vdot, Tau))
+    for name, h, d in zip(("Q", "V", "Vdot", "Tau"), res[0], res[1]):
+        assert np.abs(h - d).max() <= 1e-9 * max(1.0, np.abs(h).max()), name
