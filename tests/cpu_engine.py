@@ -98,5 +98,59 @@ class OracleEngine:
         return p
 
 
+class NumpyOracleEngine:
+    """The same stand-in for host-side callers (``Model`` / ``Data`` with NumPy arrays): NumPy in, NumPy out, friction layouts included.
+    Used by the drop-in test that runs the REFERENCE'S identifier.py against the work-alike classes in the build container."""
+
+    def __init__(self, topo, floating=False, friction=False, friction_symmetric=True, gravity_only=False, stribeck_velocity=0.0, **kw):
+        self.topo = topo
+        self.om = OracleModel(topo, floating=bool(floating), fric=bool(friction), fric_sym=bool(friction_symmetric), grav_only=bool(gravity_only),
+                              stribeck=float(stribeck_velocity))
+        self.rows, self.cols, self.n = self.om.rows, self.om.P, topo.num_dofs
+        self.friction = bool(friction)
+
+    def _st(self, st):
+        return {("rpy" if k == "base_rpy" else k): np.ascontiguousarray(v, dtype=np.float64) for k, v in st.items() if k != "sign"}
+
+    def regressor(self, st, out=None):
+        return self.om.regressor(self._st(st), st.get("sign"))
+
+    def inverse_dynamics(self, st, x_std, vel_sign=None, out=None):
+        return self.om.inverse_dynamics(self._st(st), np.asarray(x_std), st.get("sign"), vel_sign)
+
+    def predict(self, st, x, out=None):
+        return (self.regressor(st) @ np.asarray(x)).reshape(-1, self.rows)
+
+    def contact_torques(self, st, frame, wrench, out=None):
+        s2 = self._st(st)
+        S = s2["q"].shape[0]
+        s2.setdefault("dq", np.zeros_like(s2["q"]))
+        s2.setdefault("ddq", np.zeros_like(s2["q"]))
+        if self.om.floating:
+            s2.setdefault("base_vel", np.zeros((S, 6)))
+            s2.setdefault("base_acc", np.zeros((S, 6)))
+        return self.om.contact_torques(s2, frame, np.asarray(wrench))
+
+    def gram(self, st, rhs=None, w=None, out=None, accumulate=False):
+        A = self.regressor(st)
+        if rhs is not None:
+            A = np.hstack([A, np.asarray(rhs).reshape(A.shape[0], -1)])
+        if w is not None:
+            A = A * np.asarray(w).reshape(-1, 1)
+        return A.T @ A
+
+    def tsqr(self, st, rhs=None, w=None, R_in=None, out=None, cols=None):
+        A = self.regressor(st)
+        if cols is not None:
+            A = A[:, np.asarray(cols)]
+        if rhs is not None:
+            A = np.hstack([A, np.asarray(rhs).reshape(A.shape[0], -1)])
+        if w is not None:
+            A = A * np.asarray(w).reshape(-1, 1)
+        if R_in is not None:
+            A = np.vstack([np.asarray(R_in), A])
+        return np.triu(np.linalg.qr(A, mode="r"))
+
+
 def make_engine(topo, floating=False, device=0, **kw):
     return OracleEngine(topo, floating=floating, device=device, **kw)
