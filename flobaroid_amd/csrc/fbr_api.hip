@@ -534,10 +534,10 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
             // even column count (and a 16-byte aligned output): paired columns, 16-byte stores
             if ((hm.cols & 1) == 0 && (((uintptr_t)dst) & 15) == 0)
                 hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2, m->stream, m->dm, cs, spb,
-                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L, (const int *)nullptr);
+                                   m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L, (const int *)nullptr, (const int *)nullptr);
             else
                 hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L, (const int *)nullptr);
+                                   d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, hm.cols, (long)hm.rows, 1L, (const int *)nullptr, (const int *)nullptr);
         }
         HIPCHK(hipGetLastError());
         if (out_mem == FBR_HOST) {
@@ -1261,6 +1261,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         const size_t per = (size_t)hm.rows * hm.cols;
         long ch = fbr_tsqr_chunk_samples(hm.rows, Pa);
         ch = std::min(ch, chunk_size(m, S));
+        if (ch > m->tsqr.mb) ch -= ch % m->tsqr.mb;  // whole blocks per regressor row in the row-sorted chunks
         const size_t lds = (size_t)hm.rec_size() * sizeof(double);
         HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int spb = std::max(1, std::min(16, 256 / std::max(1, hm.cols / 2)));
@@ -1291,14 +1292,17 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
                 }
             }
             const int *lp = direct ? dlinkpos : nullptr;  // (the materialised path gathers the columns when it packs the chunk)
+            // structural zeros left of a row's first supported column tile are not written when every block holds rows of ONE regressor
+            // row (the chunk is a whole number of blocks per row): the folds never read them
+            const int *skipfc = (direct && cs % m->tsqr.mb == 0) ? dfc : nullptr;
             {
                 ProfScope ps(m, FBR_PROF_REGRESSOR);
                 if ((hm.cols & 1) == 0)
                     hipLaunchKernelGGL(fbr_regressor2_kernel, dim3((unsigned)std::min<long>((cs + spb - 1) / spb, (long)m->num_cus * 8)), dim3(256), lds2,
-                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r, lp);
+                                       m->stream, m->dm, cs, spb, m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r, lp, skipfc);
                 else
                     hipLaunchKernelGGL(fbr_regressor_kernel, dim3(blocks), dim3(256), lds, m->stream, m->dm, cs, m->rec.as<double>(),
-                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r, lp);
+                                       d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr, dst, ldy, rs_s, rs_r, lp, skipfc);
             }
             HIPCHK(hipGetLastError());
             ProfScope ps(m, FBR_PROF_TSQR);
@@ -1369,6 +1373,7 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
     long l0 = 0, tr = 0;
     if (num_samples > 0) {
         long ch = std::min(fbr_tsqr_chunk_samples(hm.rows, Pa), chunk_size(m, num_samples));
+        if (ch > sh.mb) ch -= ch % sh.mb;
         for (long s0 = 0; s0 < num_samples; s0 += ch) {
             const long cs = std::min(ch, (long)num_samples - s0), M = cs * hm.rows, Mpad = (M + 15) & ~15L;
             const long nblocks = (Mpad + sh.mb - 1) / sh.mb;

@@ -122,9 +122,10 @@ template <int NT_, int U_ = 6> __device__ __forceinline__ void fbr_stage_copy(do
 __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, const double *__restrict__ rec,
                                                              const double *__restrict__ dq,
                                                              const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
-                                                             long rs_r, const int *__restrict__ linkpos)
+                                                             long rs_r, const int *__restrict__ linkpos, const int *__restrict__ rowfc)
 {
     // linkpos (optional): the cpl columns of link l are written at column cpl * linkpos[l] (the TSQR chunks order the links by depth)
+    // rowfc (optional): regressor row r is only written from the column tile of rowfc[r] on (the TSQR folds never read left of it)
     // row (s, r) of the output is row s * rs_s + r * rs_r: (rows, 1) = the reference's sample-major stack; (1, S) = row-major by
     // regressor row (the TSQR chunks: all samples' row r together, see fbr_tsqr.h)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
                     const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
                     double v = 0.0;
                     if (bit) v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
-                    Ys[(m.fb + d) * rl + co] = v;
+                    if (!rowfc || co >= (rowfc[m.fb + d] & ~15)) Ys[(m.fb + d) * rl + co] = v;
                 }
             } else {
                 const int j = cd.w;
@@ -238,7 +239,7 @@ typedef double fbr_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
                                                               const double *__restrict__ dq,
                                                               const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
-                                                              long rs_r, const int *__restrict__ linkpos)
+                                                              long rs_r, const int *__restrict__ linkpos, const int *__restrict__ rowfc)
 {
     // spb samples per workgroup pass (small robots: 256 / (cols/2) samples side by side)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
             const int c = 2 * prr;
             const int4 ca = m.coldesc[c], cb = m.coldesc[c + 1];
             // (a pair of adjacent inertial columns belongs to one link: it moves with the link's column block, cpl is even)
-            fbr_d2 *dst = (fbr_d2 *)(Ys + ((linkpos && ca.x == 0) ? m.cpl * linkpos[ca.y] + (c - m.cpl * ca.y) : c));
+            const int cout = (linkpos && ca.x == 0) ? m.cpl * linkpos[ca.y] + (c - m.cpl * ca.y) : c;
+            fbr_d2 *dst = (fbr_d2 *)(Ys + cout);
             const long rstride = rs_r * (ldy >> 1);  // in double2 units (ldy even)
             if (ca.x == 0) {
                 double wa[6], wb[6];
@@ -278,6 +280,8 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
                             const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d;
                             v[0] = fbr_dot6(Sd, wa);
                             v[1] = fbr_dot6(Sd, wb);
+                        } else if (rowfc && cout < (rowfc[m.fb + d] & ~15)) {
+                            continue;  // structural zero left of the row's first supported column tile: never read by the folds
                         }
                         dst[(m.fb + d) * rstride] = v;
                     }
