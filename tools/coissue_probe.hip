@@ -17,7 +17,8 @@ __global__ __launch_bounds__(512, 2) void k(double *out, unsigned long long *cyc
     double s = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
     const bool mf = (wave < 4 && (mode & 1)) || (wave >= 4 && (mode & 4));
-    const bool va = wave >= 4 && (mode & 2);
+    const int lanes = (mode & 16) ? 16 : (mode & 32) ? 32 : 64;  // active lanes of the VALU waves (EXEC mask)
+    const bool va = wave >= 4 && (mode & 2) && (int)(threadIdx.x & 63) < lanes;
     if (mf) {
         d4 acc[4];
 #pragma unroll
@@ -62,8 +63,9 @@ int main()
     hipMalloc(&cyc, (size_t)blocks * 8 * 8);
     const int iters = 20000;
     const char *names[] = {"", "MFMA on waves 0-3 only", "fp64 VALU on waves 4-7 only", "MFMA (0-3) beside fp64 VALU (4-7)", "", "MFMA on all 8 waves", "", "",
-                           "", "", "VALU + LDS reads only", "MFMA beside VALU + LDS reads"};
-    for (int mode : {1, 2, 3, 5, 10, 11}) {
+                           "", "", "VALU + LDS reads only", "MFMA beside VALU + LDS reads", "", "", "", "", "", "", "fp64 VALU, 16 active lanes", "MFMA beside fp64 VALU of 16 lanes",
+                           "", "", "", "", "", "", "", "", "", "", "", "", "", "", "fp64 VALU, 32 active lanes", "MFMA beside fp64 VALU of 32 lanes"};
+    for (int mode : {1, 2, 3, 5, 10, 11, 18, 19, 34, 35}) {
         hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 0, 0, out, cyc, 100, mode, 1.0);
         hipDeviceSynchronize();
         hipEvent_t e0, e1;
