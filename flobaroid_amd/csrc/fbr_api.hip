@@ -966,7 +966,13 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             // every resident workgroup slot is used: the slots of a sample group are dealt to the parts by cost (fbr_gram_deal),
             // a part's workgroups split the group's samples evenly.  Tiny batches: no more workgroups than samples per part.
             const long spg_max = std::max(1L, cs / ng);
-            int wpg = std::max(T, (m->num_cus * blocks_per_cu) / ng);
+            // Grouped launches (many short candidates) are oversubscribed: with one round of resident workgroups a group gets too few
+            // of them to follow the parts' costs (WALK-MAN, 64 groups x 2000 samples: 5 per group, 15.4 ms; 4 rounds: 11.8 ms; KUKA
+            // 0.92 -> 0.90 ms with 2 rounds) and the hardware dispatcher evens out the rest.  Bulk launches lose 17 % when
+            // oversubscribed (late workgroups run beside the producer kernels of the next chunk): one round, dealt by cost.
+            static const int oversub_env = getenv("FBR_GROUP_OVERSUB") ? std::max(1, atoi(getenv("FBR_GROUP_OVERSUB"))) : 0;
+            const int rounds = ng > 1 ? (oversub_env ? oversub_env : (T > 1 ? 4 : 2)) : 1;
+            int wpg = std::max(T, (rounds * m->num_cus * blocks_per_cu) / ng);
             if ((long)wpg > (long)T * spg_max) wpg = (int)((long)T * spg_max);
             if (wpg > 0xffff) wpg = 0xffff;
             GramHolder::Deal deal;
