@@ -48,7 +48,10 @@ struct DevGram {
 // ------------------------------------------------------------------------------------------------
 // (256, 5): at most 96 VGPRs (36 spilled), so that a kin wave fits beside the two 173-VGPR Gram waves of a SIMD -- the producer
 // kernels run concurrently with the Gram kernel of the previous chunk; +2.7 % on the fused pass
-__global__ __launch_bounds__(256, 5) void fbr_kin_kernel(DevModel m, long S, const double *__restrict__ q,
+#ifndef FBR_KIN_WAVES
+#define FBR_KIN_WAVES 5  // waves per SIMD the kernel is compiled for (<= 96 VGPRs; experiments: 8 = 64 VGPRs)
+#endif
+__global__ __launch_bounds__(256, FBR_KIN_WAVES) void fbr_kin_kernel(DevModel m, long S, const double *__restrict__ q,
                                                        const double *__restrict__ dq, const double *__restrict__ ddq,
                                                        const double *__restrict__ bv, const double *__restrict__ ba,
                                                        const double *__restrict__ rpy, double *rec)

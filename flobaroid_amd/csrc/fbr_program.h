@@ -20,7 +20,9 @@
 #include <vector>
 
 #define FBR_TILE 16
-#define FBR_WPB 8         // waves per workgroup of the Gram kernel
+#ifndef FBR_WPB
+#define FBR_WPB 8         // waves per workgroup of the Gram kernel (overridable for experiments)
+#endif
 
 // Shape of the streaming Gram kernel.  Two shapes are compiled (fbr_kernels.h) and chosen per model:
 //   two workgroups per CU:  2 row segments x 5 pairs per wave (10 accumulators, ~106 VGPRs, 4 waves / SIMD), LDS images of
