@@ -1,6 +1,7 @@
 // fbr_api.hip -- C-ABI of libfbr (see include/fbr.h).  Host side: device tables, workspace, launches.
 // gfx950 only; there is deliberately no CPU path in this library.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -127,6 +128,7 @@ struct fbr_model {
     FbrHostModel hm;
     DevModel dm;
     int device = 0;
+    pid_t pid = 0;                              // process that created the handle (HIP state does not survive fork())
     int num_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side = nullptr;                 // producer stream: kinematics + tile-image packing of the next chunk
@@ -212,8 +214,32 @@ static void prof_collect(fbr_model *m)
 // ------------------------------------------------------------------------------------------------
 extern "C" int fbr_version(void) { return 100; }
 
+// The HIP runtime does not survive fork(): a child that inherits an initialised runtime hangs or fails in its first call.  The
+// reference's multi-process users build one Model per worker AFTER the fork (analyticalGradient.py:188-210); this records the process
+// that first touched HIP through the library so that the other order is reported instead of deadlocking.
+static pid_t g_hip_pid = 0;
+static bool forked_after_hip_init()
+{
+    const pid_t me = getpid();
+    if (g_hip_pid == 0) g_hip_pid = me;
+    if (g_hip_pid == me) return false;
+    set_err("HIP was initialised in the parent process before fork(): create the model in the worker (after the fork) or start "
+            "workers with the 'spawn' method");
+    return true;
+}
+static int enter(fbr_model *m)
+{
+    if (m->pid != getpid()) {
+        set_err("this fbr_model was created in another process (before fork()): create one per process");
+        return FBR_E_FORK;
+    }
+    HIPCHK(hipSetDevice(m->device));
+    return FBR_OK;
+}
+
 extern "C" int fbr_device_count(void)
 {
+    if (forked_after_hip_init()) return 0;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -228,6 +254,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
         return FBR_E_INVALID;
     }
     *out = nullptr;
+    if (forked_after_hip_init()) return FBR_E_FORK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_err("no HIP device available (libfbr has no CPU fallback)");
@@ -246,6 +273,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
         return FBR_E_INVALID;
     }
     m->device = device;
+    m->pid = getpid();
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -325,6 +353,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
 
 extern "C" void fbr_model_destroy(fbr_model *m)
 {
+    if (m && m->pid != getpid()) return;  // a handle inherited through fork(): its device resources belong to the parent, nothing to free here
     delete m;  // ~fbr_model releases the device memory, streams and events
 }
 
@@ -435,7 +464,7 @@ static int stage_states(fbr_model *m, const fbr_states *st, DevStates *d, bool n
         set_err("friction layout needs the Coulomb sign series (fbr_states.sign)");
         return FBR_E_INVALID;
     }
-    HIPCHK(hipSetDevice(m->device));
+    if (int rc_enter = enter(m)) return rc_enter;
     const size_t S = (size_t)st->num_samples;
     d->S = (long)S;
     int rc;
@@ -785,7 +814,7 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
         return FBR_E_INVALID;
     }
     fbr_model *m = const_cast<fbr_model *>(mc);
-    HIPCHK(hipSetDevice(m->device));
+    if (int rc_enter = enter(m)) return rc_enter;
     GramHolder *h = nullptr;
     int rc = get_gram(m, k, &h);
     if (rc) return rc;
@@ -1413,7 +1442,7 @@ extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const 
         set_err("bad arguments");
         return FBR_E_INVALID;
     }
-    HIPCHK(hipSetDevice(m->device));
+    if (int rc_enter = enter(m)) return rc_enter;
     const size_t cnt = (size_t)n * n;
     int rc;
     const double *da = nullptr, *db = nullptr;
@@ -1465,7 +1494,7 @@ extern "C" int fbr_filtfilt(fbr_model *m, const double *b, const double *a, int3
         set_err("fbr_filtfilt: the signal must be longer than the padding of 3 * ncoef samples");
         return FBR_E_INVALID;
     }
-    HIPCHK(hipSetDevice(m->device));
+    if (int rc_enter = enter(m)) return rc_enter;
     FbrIir f;
     memset(&f, 0, sizeof(f));
     f.nc = ncoef;
@@ -1534,7 +1563,7 @@ extern "C" int fbr_medfilt(fbr_model *m, int32_t k, double *X, int64_t S, int32_
         set_err("fbr_medfilt: bad arguments (k odd, 1 <= k <= 31, ld >= ncols)");
         return FBR_E_INVALID;
     }
-    HIPCHK(hipSetDevice(m->device));
+    if (int rc_enter = enter(m)) return rc_enter;
     int rc;
     double *dX = nullptr;
     const size_t xcount = (size_t)(S - 1) * ld + ncols;
@@ -1553,7 +1582,7 @@ extern "C" int fbr_central_diff(fbr_model *m, const double *A, const double *T, 
         set_err("fbr_central_diff: bad arguments (S >= 5)");
         return FBR_E_INVALID;
     }
-    HIPCHK(hipSetDevice(m->device));
+    if (int rc_enter = enter(m)) return rc_enter;
     int rc;
     double *dA = nullptr, *dT = nullptr, *dD = D;
     if ((rc = sig_stage(m, m->st_aux, A, (size_t)S * ncols, mem, &dA)) || (rc = sig_stage(m, m->st_aux2, T, (size_t)S, mem, &dT))) return rc;

@@ -30,6 +30,7 @@ extern "C" {
 #define FBR_E_NODEVICE (-2)  /* no HIP device / HIP runtime failure at init */
 #define FBR_E_HIP (-3)       /* HIP runtime error during the call */
 #define FBR_E_UNSUPPORTED (-4)
+#define FBR_E_FORK (-5)      /* handle / HIP runtime inherited through fork(): create the model in the process that uses it */
 
 #define FBR_HOST 0
 #define FBR_DEVICE 1
