@@ -71,7 +71,7 @@ def _synthetic(tmp_path, topo, S=2000, noise=0.05, seed=42):
     return path
 
 
-@pytest.mark.parametrize("variant", ["ols", "ols_apriori_friction", "post_friction", "std_direct"])
+@pytest.mark.parametrize("variant", ["ols", "ols_apriori_friction", "post_friction", "post_friction_deadzone_reg", "std_direct"])
 def test_reference_identification_runs_on_the_work_alike(ref_identifier, tmp_path, variant, capsys):
     topo = load_topo("kuka_lwr4")
     urdf = str(tmp_path / "kuka_lwr4.urdf")
@@ -83,6 +83,9 @@ def test_reference_identification_runs_on_the_work_alike(ref_identifier, tmp_pat
         config.update(useAPriori=1, identifyFrictionSimultaneously=1, postIdentifyFriction=0)
     if variant == "post_friction":   # the reference's second step (identifier.py:979-1099) on the work-alike's arrays; the synthetic
         config.update(useAPriori=1, identifyFrictionSimultaneously=1, postIdentifyFriction=1)   # torques carry no friction, its Fv prior costs fit
+    if variant == "post_friction_deadzone_reg":   # + Swevers dead zone and the relative Tikhonov pull of Fv towards the URDF value
+        config.update(useAPriori=1, identifyFrictionSimultaneously=1, postIdentifyFriction=1, frictionVelocityDeadZone=0.05,
+                      frictionFvRegularizationRelative=1.0)
     if variant == "std_direct":
         config["estimateWith"] = "std_direct"
     np.random.seed(1)
@@ -92,7 +95,25 @@ def test_reference_identification_runs_on_the_work_alike(ref_identifier, tmp_pat
     idf.estimateParameters()
     idf.estimateRegressorTorques()
     residual = la.norm(idf.tauEstimated - idf.model.tauMeasured) * 100 / la.norm(idf.model.tauMeasured)
-    assert residual < (3.0 if variant == "post_friction" else 1.0)                   # tests/test_identification.py:164
+    assert residual < (3.0 if variant.startswith("post_friction") else 1.0)          # tests/test_identification.py:164
+    if variant.startswith("post_friction"):
+        # the reference's _postIdentifyFriction (identifier.py:979-1099) just ran on the work-alike's arrays: the repository's own
+        # restatement of that step (estimation.post_identify_friction) must give the same [Fc, Fv, off]
+        from flobaroid_amd import estimation as est, helpers as fh
+
+        m, S = idf.model, idf.data.num_used_samples
+        ni = m.num_model_params
+        resid = (m.torques_stack - np.asarray(m.YStd)[:, :ni].dot(m.xStd[:ni])).reshape(S, m.num_dofs)
+        vel = idf.data.samples["velocities"][:S]
+        fr = topo.friction
+        prior = np.array([fr[name]["f_velocity"] for name in m.jointNames])
+        mine = est.post_identify_friction(resid, vel, fh.getFrictionSignVelocities(idf.data.samples, config)[:S],
+                                          fh.getFrictionSignSeries(idf.data.samples, config)[:S], 0,
+                                          deadzone=float(config.get("frictionVelocityDeadZone", 0.0)),
+                                          lambda_fv=float(config.get("frictionFvRegularization", 0.0)),
+                                          alpha_fv=float(config.get("frictionFvRegularizationRelative", 0.0)), fv_apriori=prior)
+        for key in ("Fc", "Fv", "off"):
+            assert np.abs(mine[key] - idf.postid_friction[key]).max() <= 1e-10 * max(1.0, np.abs(idf.postid_friction[key]).max()), key
     if variant == "ols":   # (the friction variants identify a zero friction against the URDF's non-zero a-priori friction: no ground truth)
         rel = la.norm(idf.model.xBase - idf.model.xBaseModel) / la.norm(idf.model.xBaseModel)
         assert rel < 0.05                                                            # tests/test_identification.py:163
