@@ -2,6 +2,7 @@
 // gfx950 only; there is deliberately no CPU path in this library.
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <numeric>
 
 #include <cstdint>
 #include <cstdio>
@@ -143,6 +144,7 @@ struct fbr_model {
     DevBuf st_chunk[2];       // per-chunk staging of pinned host inputs (fused Gram pass), double buffered with the tile images
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     FbrTsqrWork tsqr;
+    std::vector<FbrTsqrWork> tsqr_groups;  // one factorisation per row group of the tree-structured TSQR (tsqr_group_plan)
     DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
     // profiling
     bool prof = false;
@@ -160,6 +162,7 @@ struct fbr_model {
         fbr_model *m = this;
         (void)hipSetDevice(m->device);
         m->tsqr.release();
+        for (auto &g : m->tsqr_groups) g.release();
         for (auto &e : m->ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -1213,6 +1216,268 @@ static TsqrPlan tsqr_plan(const FbrHostModel &hm, const int32_t *cols, int32_t n
     return p;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tree-structured TSQR.  The row of joint d is non-zero only in the columns of the links below d (and its own friction columns), and
+// R = qr(A) can be assembled from the factors of any partition of the ROWS.  The rows are therefore grouped along the kinematic
+// tree -- the base-wrench rows, and one group per unbranched chain of joints (cut wherever the parent has more than one child joint)
+// -- and every group is factorised over the columns its rows can touch only: WALK-MAN's leg joints fold 6 rows x 61 columns, its arm
+// joints 7 x 81, the head 2 x 31, the waist 3 x 221 and only the 6 base rows all 481 (0.21 of the dense tile updates instead of the
+// 0.44 of one factorisation with depth-ordered columns, and a third of the chunk bytes).  The group factors are embedded into the
+// caller's column order and folded into the final factor like data rows.  Within a group the columns are ordered by link depth, so
+// a joint row still starts at the first column of its own links.
+// ------------------------------------------------------------------------------------------------
+struct TsqrGroup {
+    std::vector<int> rows;  // regressor rows of the group (slot order)
+    std::vector<int> sel;   // factor columns of the group: indices into the caller's selected columns, in the group's order
+    std::vector<int> fc;    // per slot: first supported column (group order)
+    int Pa = 0;             // sel.size() + k
+};
+struct TsqrGroupPlan {
+    std::vector<TsqrGroup> groups;
+    std::vector<int> rowgroup, rowslot;  // per regressor row (-1: the row touches nothing that is factorised)
+    int main = -1;  // group whose rows are dense in every factorised column (base-wrench rows): factorised in the caller's column order
+                    // straight into the final factor, the other groups' factors are folded into it
+};
+static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols, int32_t ncols, int k)
+{
+    TsqrGroupPlan gp;
+    const int Psel = cols ? ncols : hm.cols;
+    // joint tree: parent joint of joint d (-1: hangs off the base), number of child joints of every joint (index 0: the base)
+    std::vector<int> pj(hm.n, -1), depth(hm.n, 0), nchild(hm.n + 1, 0);
+    for (int l = 0; l < hm.L; l++) {
+        const int d = hm.dof[l];
+        if (d < 0) continue;
+        const std::vector<int> &pa = hm.path[l];
+        depth[d] = (int)pa.size();
+        pj[d] = pa.size() >= 2 ? pa[pa.size() - 2] : -1;
+    }
+    for (int d = 0; d < hm.n; d++) nchild[pj[d] + 1]++;
+    std::vector<int> jgroup(hm.n, -1);
+    int ngroups = 0, base_group = -1;
+    if (hm.fb) base_group = ngroups++;
+    std::vector<int> order(hm.n);
+    for (int d = 0; d < hm.n; d++) order[d] = d;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+    for (int d : order) {
+        const int p = pj[d];
+        int pg = p < 0 ? base_group : jgroup[p];
+        if (nchild[p + 1] == 1 && pg < 0) pg = base_group = ngroups++;  // fixed base, single chain from the root
+        jgroup[d] = (nchild[p + 1] == 1) ? pg : ngroups++;
+    }
+    std::vector<std::vector<int>> grows(ngroups);
+    for (int r = 0; r < hm.fb; r++) grows[base_group].push_back(r);
+    for (int d = 0; d < hm.n; d++) grows[jgroup[d]].push_back(hm.fb + d);
+    auto touches = [&](int r, int uc) {
+        const FbrCol &cd = hm.coldesc[uc];
+        if (cd.kind != 0) return cd.joint == r - hm.fb;
+        if (r < hm.fb) return true;
+        const std::vector<int> &pa = hm.path[cd.link];
+        return std::find(pa.begin(), pa.end(), r - hm.fb) != pa.end();
+    };
+    gp.rowgroup.assign(hm.rows, -1);
+    gp.rowslot.assign(hm.rows, -1);
+    for (int g = 0; g < ngroups; g++) {
+        TsqrGroup G;
+        if (grows[g].empty()) continue;
+        std::vector<int> inert, fric;
+        for (int j = 0; j < Psel; j++) {
+            const int uc = cols ? cols[j] : j;
+            bool any = false;
+            for (int r : grows[g]) any = any || touches(r, uc);
+            if (any) (hm.coldesc[uc].kind == 0 ? inert : fric).push_back(j);
+        }
+        auto cdepth = [&](int j) { return (int)hm.path[hm.coldesc[cols ? cols[j] : j].link].size(); };
+        std::stable_sort(inert.begin(), inert.end(), [&](int a, int b) { return cdepth(a) < cdepth(b); });
+        G.sel = inert;
+        G.sel.insert(G.sel.end(), fric.begin(), fric.end());
+        G.Pa = (int)G.sel.size() + k;
+        if (G.Pa == 0) continue;
+        // slots: rows with the widest support first (their blocks start at the left-most panels)
+        G.rows = grows[g];
+        auto first = [&](int r) {
+            for (size_t i = 0; i < G.sel.size(); i++)
+                if (touches(r, cols ? cols[G.sel[i]] : G.sel[i])) return (int)i;
+            return (int)G.sel.size();
+        };
+        std::stable_sort(G.rows.begin(), G.rows.end(), [&](int a, int b) { return first(a) < first(b); });
+        bool dense = (int)G.sel.size() == Psel;
+        for (size_t i = 0; i < G.rows.size(); i++) {
+            G.fc.push_back(first(G.rows[i]));
+            dense = dense && G.fc.back() == 0;
+            gp.rowgroup[G.rows[i]] = (int)gp.groups.size();
+            gp.rowslot[G.rows[i]] = (int)i;
+        }
+        if (dense && gp.main < 0) {
+            gp.main = (int)gp.groups.size();
+            std::sort(G.sel.begin(), G.sel.end());  // = the caller's order
+        }
+        gp.groups.push_back(std::move(G));
+    }
+    return gp;
+}
+// groups pay when the tree branches and there are enough rows to keep every group's workers busy
+static bool tsqr_use_groups(const TsqrGroupPlan &gp, long S, const double *R_in_unused = nullptr)
+{
+    (void)R_in_unused;
+    const char *e = getenv("FBR_TSQR_GROUP_MIN_SAMPLES");  // (tests force the path at small sizes)
+    const long min_s = e ? atol(e) : 4096;
+    return gp.groups.size() > 1 && S >= min_s && !getenv("FBR_TSQR_NO_GROUPS");
+}
+static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp, long S)
+{
+    double per = 0.0;  // chunk bytes per sample over all groups
+    long lcm = 1;
+    for (const TsqrGroup &G : gp.groups) {
+        FbrTsqrShape sh;
+        if (fbr_tsqr_shape(G.Pa, m->num_cus, 1L << 40, &sh)) return -1;
+        per += 8.0 * (double)G.rows.size() * sh.n;
+        lcm = std::lcm(lcm, (long)sh.mb);
+    }
+    long ch = std::max(1L, (long)(4.0 * 1024 * 1024 * 1024 / per));
+    ch = std::min(ch, chunk_size(m, S));
+    if (ch > lcm) ch -= ch % lcm;  // whole blocks per slot in every group
+    return ch;
+}
+
+static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPlan &gp, const int32_t *cols, int Psel, int k, const double *drhs,
+                            const double *dw, const double *Rin_dev, double *R)
+{
+    const FbrHostModel &hm = m->hm;
+    const long S = d.S;
+    const int G = (int)gp.groups.size(), Pa = Psel + k;
+    int rc;
+    auto tsqr_fail = [&](int code, const char *what) {
+        set_err(std::string(what) + ": " + fbr_tsqr_error());
+        return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
+    };
+    if ((int)m->tsqr_groups.size() < G) m->tsqr_groups.resize(G);
+    const long ch = tsqr_group_chunk_samples(m, gp, S);
+    if (ch < 0) return tsqr_fail(-4, "tsqr group shape");
+    // device tables: ints [rowgroup | rowslot | entry ranges (cols + 1) x 2 | per group: slot first columns | per group: embedding (Pa)],
+    // then the entry lists (int4) and the FbrDevGroup records
+    std::vector<int> tab;
+    tab.insert(tab.end(), gp.rowgroup.begin(), gp.rowgroup.end());
+    tab.insert(tab.end(), gp.rowslot.begin(), gp.rowslot.end());
+    // what every model column writes: one entry per row of every group that holds the column (variant 1: without the structural zeros
+    // left of the row's first supported column tile)
+    std::vector<int> gposv((size_t)G * hm.cols, -1);
+    for (int g = 0; g < G; g++)
+        for (size_t i = 0; i < gp.groups[g].sel.size(); i++) {
+            const int j = gp.groups[g].sel[i];
+            gposv[(size_t)g * hm.cols + (cols ? cols[j] : j)] = (int)i;
+        }
+    std::vector<int> ents[2];
+    size_t o_ebeg[2];
+    for (int var = 0; var < 2; var++) {
+        o_ebeg[var] = tab.size();
+        for (int c = 0; c < hm.cols; c++) {
+            tab.push_back((int)ents[var].size());
+            const FbrCol &cd = hm.coldesc[c];
+            for (int r = 0; r < hm.rows; r++) {
+                const int g = gp.rowgroup[r];
+                if (g < 0) continue;
+                const int pos = gposv[(size_t)g * hm.cols + c];
+                if (pos < 0) continue;
+                int kind;
+                if (cd.kind == 0) {
+                    if (r < hm.fb)
+                        kind = 0;
+                    else {
+                        const std::vector<int> &pa = hm.path[cd.link];
+                        kind = std::find(pa.begin(), pa.end(), r - hm.fb) != pa.end() ? 1 : 2;
+                    }
+                } else {
+                    kind = cd.joint == r - hm.fb ? 3 : 2;
+                }
+                const int slot = gp.rowslot[r];
+                if (var == 1 && kind == 2 && pos < (gp.groups[g].fc[slot] & ~15)) continue;
+                ents[var].push_back(r | (kind << 8) | (pos << 10));
+            }
+        }
+        tab.push_back((int)ents[var].size());
+    }
+    std::vector<size_t> o_fc(G), o_emb(G);
+    for (int g = 0; g < G; g++) {
+        o_fc[g] = tab.size();
+        tab.insert(tab.end(), gp.groups[g].fc.begin(), gp.groups[g].fc.end());
+    }
+    for (int g = 0; g < G; g++) {
+        // column j of the final factor (caller's order) <- column emb[j] of the group factor, -1: not in the group
+        o_emb[g] = tab.size();
+        tab.resize(tab.size() + Pa, -1);
+        const TsqrGroup &Gg = gp.groups[g];
+        for (size_t i = 0; i < Gg.sel.size(); i++) tab[o_emb[g] + Gg.sel[i]] = (int)i;
+        for (int i = 0; i < k; i++) tab[o_emb[g] + Psel + i] = (int)Gg.sel.size() + i;
+    }
+    while (tab.size() & 3) tab.push_back(0);
+    const size_t o_ent0 = tab.size() * sizeof(int), o_ent1 = o_ent0 + ents[0].size() * sizeof(int);
+    const size_t o_grp = (o_ent1 + ents[1].size() * sizeof(int) + 15) & ~(size_t)15;
+    // working factors and chunk buffers of the groups
+    std::vector<FbrDevGroup> hg(G);
+    bool skipzeros = false;
+    long mrows = 0;  // rows the final factor folds: the main group's data rows and the other groups' factors
+    for (int g = 0; g < G; g++) mrows += g == gp.main ? S * (long)gp.groups[g].rows.size() : gp.groups[g].Pa;
+    auto work = [&](int g) -> FbrTsqrWork & { return g == gp.main ? m->tsqr : m->tsqr_groups[g]; };
+    for (int g = 0; g < G; g++) {
+        const TsqrGroup &Gg = gp.groups[g];
+        FbrTsqrWork &wk = work(g);
+        if ((rc = fbr_tsqr_begin(wk, m->stream, Gg.Pa, g == gp.main ? Rin_dev : nullptr, m->num_cus, g == gp.main ? mrows : S * (long)Gg.rows.size())))
+            return tsqr_fail(rc, "tsqr group begin");
+        double *A = nullptr;
+        if ((rc = fbr_tsqr_chunk_buffer(wk, std::min(ch, S) * (long)Gg.rows.size(), &A))) return tsqr_fail(rc, "tsqr group chunk");
+        hg[g] = FbrDevGroup{A, wk.n, (int)Gg.sel.size()};
+    }
+    if ((rc = m->st_x.ensure(o_grp + G * sizeof(FbrDevGroup)))) return rc;
+    HIPCHK(hipMemcpyAsync(m->st_x.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (!ents[0].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_ent0, ents[0].data(), ents[0].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (!ents[1].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_ent1, ents[1].data(), ents[1].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_grp, hg.data(), G * sizeof(FbrDevGroup), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));  // tab, hg are locals
+    const int *t = m->st_x.as<int>();
+    const FbrDevGroup *dgrp = (const FbrDevGroup *)((const char *)m->st_x.p + o_grp);
+    const size_t lds = (size_t)((hm.rec_size() + 1) & ~1) * sizeof(double) + (size_t)hm.rows * sizeof(double *);
+    HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (long s0 = 0; s0 < S; s0 += ch) {
+        const long cs = std::min(ch, S - s0);
+        if ((rc = run_kin(m, d, s0, cs))) return rc;
+        // structural zeros left of a row's first supported column tile are skipped when every block holds rows of one slot
+        skipzeros = true;
+        for (int g = 0; g < G; g++) skipzeros = skipzeros && cs % work(g).mb == 0;
+        {
+            ProfScope ps(m, FBR_PROF_REGRESSOR);
+            hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
+                               m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                               drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
+                               t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)));
+        }
+        HIPCHK(hipGetLastError());
+        ProfScope ps(m, FBR_PROF_TSQR);
+        for (int g = 0; g < G; g++) {
+            const TsqrGroup &Gg = gp.groups[g];
+            FbrTsqrRowOrder ro;
+            ro.first_col = t + o_fc[g];
+            ro.rows = (int)Gg.rows.size();
+            ro.group = cs;
+            if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, cs * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
+        }
+    }
+    // the group factors, embedded into the caller's column order, are folded into the final factor (the main group's, or one seeded with
+    // R_in when no group is dense) like data rows
+    ProfScope ps(m, FBR_PROF_TSQR);
+    if (gp.main < 0 && (rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, mrows))) return tsqr_fail(rc, "tsqr begin");
+    size_t rt = 0;
+    for (int g = 0; g < G; g++) rt = std::max(rt, (size_t)gp.groups[g].Pa * gp.groups[g].Pa);
+    if ((rc = m->tsqr_rtmp.ensure(rt * sizeof(double)))) return rc;
+    for (int g = 0; g < G; g++) {
+        if (g == gp.main) continue;
+        const int Pg = gp.groups[g].Pa;
+        if ((rc = fbr_tsqr_finish(m->tsqr_groups[g], m->stream, m->tsqr_rtmp.as<double>()))) return tsqr_fail(rc, "tsqr group finish");
+        if ((rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pg, Pa, m->tsqr_rtmp.as<double>(), 0, nullptr, nullptr, Pg, t + o_emb[g]))) return tsqr_fail(rc, "tsqr group merge");
+    }
+    if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
+    return FBR_OK;
+}
+
 static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
                      const double *w, const double *R_in, double *R_out, int32_t out_mem)
 {
@@ -1282,6 +1547,13 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         set_err(std::string(what) + ": " + fbr_tsqr_error());
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
+    {
+        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k);
+        if (hm.rows <= 255 && tsqr_use_groups(gp, S)) {  // (the writer's entries hold the regressor row in 8 bits)
+            if ((rc = tsqr_groups_impl(m, d, gp, cols, Psel, k, drhs, dw, Rin_dev, R))) return rc;
+            return finish_output(m, R, R_out, rcount, out_mem);
+        }
+    }
     // an existing factor seeds working factor 0 directly when the column order is the caller's; in the internal order its rows are
     // folded in like data rows (column gather)
     if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, plan.reorder ? nullptr : Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
@@ -1393,6 +1665,60 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
     const TsqrPlan plan = tsqr_plan(hm, cols, ncols, k, (long)num_samples);
     const int Psel = plan.Psel, Pa = plan.Pa;
     (void)Psel;
+    {
+        // tree-structured path (tsqr_groups_impl): level 0 of every group over its own chunks, the groups' trees, and the final factor
+        // that folds the embedded group factors (dense rows) and runs its own tree
+        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k);
+        if (hm.rows <= 255 && tsqr_use_groups(gp, (long)num_samples)) {
+            const long ch = tsqr_group_chunk_samples(m, gp, (long)num_samples);
+            long l0 = 0, tr = 0, mrows = 0;
+            FbrTsqrShape sh;
+            auto fold_mfma = [&](int first_col) -> long {
+                const long np_ = sh.n / 16 - first_col / 16;
+                return np_ > 0 ? (8L * sh.sub + 4) * (np_ * (np_ - 1) / 2) : 0;
+            };
+            auto tree = [&]() {
+                long merge = 0, t = 0;
+                for (int i0 = 0; i0 < sh.n; i0 += sh.mb) merge += fold_mfma(i0);
+                for (int stride = 1; stride < sh.NW; stride *= 2)
+                    for (long a = 0; a + stride < sh.NW; a += 2L * stride) t += merge;
+                return t;
+            };
+            for (int g = 0; g < (int)gp.groups.size(); g++) mrows += g == gp.main ? num_samples * (long)gp.groups[g].rows.size() : gp.groups[g].Pa;
+            for (int g = 0; g < (int)gp.groups.size(); g++) {
+                const TsqrGroup &G = gp.groups[g];
+                const long ns = (long)G.rows.size();
+                if (ch < 0 || fbr_tsqr_shape(G.Pa, m->num_cus, g == gp.main ? mrows : num_samples * ns, &sh)) {
+                    set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
+                    return FBR_E_UNSUPPORTED;
+                }
+                for (long s0 = 0; s0 < num_samples; s0 += ch) {
+                    const long cs = std::min(ch, (long)num_samples - s0), M = cs * ns, Mpad = (M + 15) & ~15L;
+                    for (long b = 0; b < (Mpad + sh.mb - 1) / sh.mb; b++) {
+                        const long r0 = b * sh.mb;
+                        int f = sh.n;
+                        if (r0 < M)
+                            for (long r = r0 / cs; r <= (std::min<long>(r0 + sh.mb, M) - 1) / cs; r++) f = std::min(f, G.fc[r]);
+                        l0 += fold_mfma(f);
+                    }
+                }
+                if (g != gp.main) tr += tree();
+            }
+            if (fbr_tsqr_shape(Pa, m->num_cus, mrows, &sh)) {
+                set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
+                return FBR_E_UNSUPPORTED;
+            }
+            for (int g = 0; g < (int)gp.groups.size(); g++)
+                if (g != gp.main)
+                    for (long r0 = 0; r0 < ((gp.groups[g].Pa + 15) & ~15); r0 += sh.mb) tr += fold_mfma(0);
+            tr += tree();
+            if (mfma_level0) *mfma_level0 = l0;
+            if (mfma_tree) *mfma_tree = tr;
+            if (block_rows) *block_rows = sh.mb;
+            if (n_padded) *n_padded = sh.n;
+            return FBR_OK;
+        }
+    }
     FbrTsqrShape sh;
     if (fbr_tsqr_shape(Pa, m->num_cus, num_samples * (long)hm.rows, &sh)) {
         set_err(std::string("tsqr shape: ") + fbr_tsqr_error());

@@ -300,6 +300,73 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2c: the regressor written as the ROW GROUPS of the tree-structured TSQR (fbr_api.hip: tsqr_group_plan).  A regressor row
+// belongs to one group; a group g owns a packed chunk A_g [slot][sample][ld_g] that holds only the columns its rows can touch,
+// followed by the rhs columns at psel_g.  One workgroup per sample (grid-stride), one thread per model column / rhs column.  What a
+// column thread writes is a host-built entry list (ent[ebeg[c] .. ebeg[c+1])): regressor row | kind << 8 | position in the row's
+// group << 10, kind 0 = base-wrench row, 1 = joint row (S_d . w), 2 = explicit zero, 3 = friction value -- rows of groups
+// that do not hold the column have no entry, and the zeros left of a row's first supported column tile are left out of the list
+// when the folds never read them.  Row weights are applied here.
+// Bound: HBM write of the groups' chunks (WALK-MAN: 5.8 k instead of 17.4 k doubles per sample).
+// ------------------------------------------------------------------------------------------------
+struct FbrDevGroup {
+    double *A;
+    int ld, psel;
+};
+__global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, long S, const double *__restrict__ rec, const double *__restrict__ dq,
+                                                                    const double *__restrict__ sign, const double *__restrict__ rhs, int k,
+                                                                    const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,
+                                                                    const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
+                                                                    const int *__restrict__ ebeg, const int *__restrict__ ent)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *rs = smem;                                    // [rec]
+    double **rowptr = (double **)(smem + ((m.rec + 1) & ~1));  // [rows] chunk row of this sample's regressor row r (its group's chunk)
+    const int tid = threadIdx.x;
+    for (long s = blockIdx.x; s < S; s += gridDim.x) {
+        fbr_barrier_lds();
+        fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        if (tid < m.rows) {
+            const int g = rowgroup[tid];
+            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * S + s) * grp[g].ld : nullptr;
+        }
+        fbr_barrier_lds();
+        // rhs columns: one element per thread (a single thread walking all rows would be the critical path of the sample)
+        for (int t = tid; t < m.rows * k; t += blockDim.x) {
+            const int r = t / k, i = t - r * k;
+            const int g = rowgroup[r];
+            if (g < 0) continue;
+            double v = rhs[(s * m.rows + r) * k + i];
+            if (wts) v *= wts[s * m.rows + r];
+            rowptr[r][grp[g].psel + i] = v;
+        }
+        for (int c = tid; c < m.cols; c += blockDim.x) {
+            const int e0 = ebeg[c], e1 = ebeg[c + 1];
+            if (e0 == e1) continue;
+            const int4 cd = m.coldesc[c];
+            double w6[6] = {0, 0, 0, 0, 0, 0}, fv = 0.0;
+            if (cd.x == 0)
+                fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
+            else
+                fv = fbr_friction_value(cd.z, dq[s * m.n + cd.w], sign ? sign[s * m.n + cd.w] : 0.0, m.stribeck);
+            for (int e = e0; e < e1; e++) {
+                const int en = ent[e];  // row | kind << 8 | position << 10
+                const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
+                double v = 0.0;
+                if (kind == 0)
+                    v = w6[r];
+                else if (kind == 1)
+                    v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
+                else if (kind == 3)
+                    v = fv;
+                if (wts) v *= wts[s * m.rows + r];
+                rowptr[r][pos] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: inverse dynamics / prediction, one wavefront per sample.
 //   mode 0: x = full standard vector (10 per link + friction slots), friction model of model.py:299-326
 //   mode 1: x = identified-parameter vector (cols): tau = Y_s x

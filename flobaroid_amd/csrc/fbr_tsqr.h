@@ -59,7 +59,7 @@ __device__ __forceinline__ long fbr_tsqr_in_row(long o, int rows, long group)
 }
 
 // A[r][c] (ld) = w[r] * [Y | rhs][r][c], zero in the padding columns / rows
-// cols (optional, device): gather columns cols[0..P) of a Y with leading dimension ldy
+// cols (optional, device): gather columns cols[0..P) of a Y with leading dimension ldy (cols[c] < 0: zero column)
 __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, int P, int k, int ld,
                                                              const double *__restrict__ Y, int ldy, const int *__restrict__ cols,
                                                              const double *__restrict__ rhs, const double *__restrict__ w,
@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256) void fbr_tsqr_pack_kernel(long M, long Mpad, i
         double v = 0.0;
         if (o < M) {
             const long r = fbr_tsqr_in_row(o, orows, ogroup);
-            if (c < P)
-                v = Y[r * ldy + (cols ? cols[c] : c)];
+            if (c < P) {
+                const int sc = cols ? cols[c] : c;  // (negative: a column the source does not have -- embedded group factors)
+                v = sc >= 0 ? Y[r * ldy + sc] : 0.0;
+            }
             else if (c < P + k)
                 v = rhs[r * k + (c - P)];
             if (w) v *= w[r];

@@ -368,9 +368,11 @@ def test_pinned_host_inputs_are_staged_chunk_by_chunk(monkeypatch):
 
 
 def test_tsqr_column_order_is_internal(monkeypatch):
-    """The wide factorisation orders the inertial columns by link depth internally and returns the factor in the caller's
-    order: with the reordering switched off the same R^T R and, for a full-rank column subset, the same sign-normalised R; an R_in
-    in the caller's order streams through either way; the executed-work counter reports the saving."""
+    """The single wide factorisation (short batches, unbranched robots) orders the inertial columns by link depth internally
+     and returns the factor in the caller's order: with the reordering switched off the same R^T R and, for a full-rank
+    column subset, the same sign-normalised R; an R_in in the caller's order streams through either way; the executed-work
+    counter reports the saving."""
+    monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
     cfg = CONFIGS[7]
     t, eng, om = _engine_oracle(cfg)
     S = 1200   # (35 S rows >= 64 n: below that the final re-triangularisation is not worth it and the caller's order is kept)
@@ -404,6 +406,52 @@ def test_tsqr_column_order_is_internal(monkeypatch):
         assert np.linalg.norm(R.T @ R - Gc) <= 1e-11 * np.linalg.norm(Gc)
         assert np.linalg.norm(norm(R) - norm(Rc0)) <= 1e-9 * np.linalg.norm(Rc0)
     assert wi1["mfma_level0"] < 0.9 * wi0["mfma_level0"] and wi1["mfma_tree"] > wi0["mfma_tree"]
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[8], CONFIGS[4]], ids=cfg_id)
+def test_tsqr_row_groups_along_the_tree(cfg, monkeypatch):
+    """Tree-structured TSQR: the base-wrench rows and every unbranched chain of joints are factorised on their own, over
+    the columns their rows can touch, and the group factors are folded into the final factor.  Same R^T R as the single
+    factorisation, the same sign-normalised R for a full-rank column subset (also with row weights and a streamed R_in), and the
+    work counter shows the saving on the branched robots."""
+    t, eng, om = _engine_oracle(cfg)
+    S = 1500
+    st, rng = _states(t, cfg, S, 31)
+    rhs = rng.standard_normal((S * om.rows, 2))
+    w = 0.5 + rng.random(S * om.rows)
+    A = _aug(om, st, rhs) * w[:, None]
+    Go = A.T @ A
+    import scipy.linalg as sla
+
+    ncol = min(150, int(np.linalg.matrix_rank(Go[: om.P, : om.P])) - 5)
+    cols = np.sort(sla.qr(Go[: om.P, : om.P], pivoting=True, mode="r")[1][:ncol]).astype(np.int32)
+    sel = np.r_[cols, om.P, om.P + 1]
+    h = S // 3
+    first = {k: v[:h] for k, v in st.items()}
+    second = {k: v[h:] for k, v in st.items()}
+
+    def run():
+        R = eng.tsqr(st, rhs=rhs, w=w)
+        Rc = eng.tsqr(st, rhs=rhs, w=w, cols=cols)
+        Rs = eng.tsqr(second, rhs=rhs[h * om.rows:], w=w[h * om.rows:], cols=cols,
+                      R_in=eng.tsqr(first, rhs=rhs[: h * om.rows], w=w[: h * om.rows], cols=cols))
+        return R, Rc, Rs, eng.tsqr_work_info(S, k=2), eng.tsqr_work_info(1000000, k=2)
+
+    monkeypatch.setenv("FBR_TSQR_GROUP_MIN_SAMPLES", "1")
+    R1, Rc1, Rs1, wi1, big1 = run()
+    monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
+    R0, Rc0, Rs0, wi0, big0 = run()
+    for R in (R0, R1):
+        assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
+    norm = lambda R: R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
+    Gc = Go[np.ix_(sel, sel)]
+    for R in (Rc0, Rc1, Rs0, Rs1):
+        assert np.linalg.norm(R.T @ R - Gc) <= 1e-11 * np.linalg.norm(Gc)
+        assert np.linalg.norm(norm(R) - norm(Rc0)) <= 1e-9 * np.linalg.norm(Rc0)
+    if cfg[0] == "walkman_apriori":   # branched tree: legs / arms / head / waist / base rows are separate factorisations
+        assert big1["flop"] < 0.6 * big0["flop"]
+    else:                             # one chain: one group, the single factorisation
+        assert big1["flop"] == big0["flop"]
 
 
 @pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[7]], ids=cfg_id)
