@@ -510,8 +510,9 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
         "executed_TFLOP_per_s": executed_flop / dt / 1e12,
         "executed_frac_of_fp64_mfma_peak": executed_flop / dt / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world),
         "dense_model_TFLOP_per_s": dense_flop / dt / 1e12,
-        "flop_models": "executed: 2048 flop x MFMAs the folds run (fbr_tsqr_work_info: row-sorted chunks fold from their first supported "
-                       "column); dense: 2*rows*(P+k)^2 per sample (SURVEY 8d)",
+        "flop_models": "executed: 2048 flop x MFMAs the folds run (fbr_tsqr_work_info: rows grouped along the kinematic tree, every group "
+                       "factorised over the columns it can touch, blocks folded from their first supported column); dense: 2*rows*(P+k)^2 per "
+                       "sample (SURVEY 8d)",
         "rank_tree_levels": merges, "relerr_RtR_vs_allreduced_gram": err,
         "kernel_ms_per_call_rank0": {k: v[0] / reps for k, v in pr.items() if v[1]},
     }
