@@ -1437,16 +1437,21 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     const FbrDevGroup *dgrp = (const FbrDevGroup *)((const char *)m->st_x.p + o_grp);
     const size_t lds = (size_t)((hm.rec_size() + 1) & ~1) * sizeof(double) + (size_t)hm.rows * sizeof(double *);
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the kinematic records are produced for several chunks at a time: one lane per sample needs tens of thousands of waves in flight
+    // to hide its latencies (1 M samples: 6.4 ms in one launch, 11 ms in twelve)
+    const long kin_span = std::max(ch, std::min(S, (long)((size_t)(6ull << 30) / ((size_t)hm.rec_size() * sizeof(double))) / ch * ch));
     for (long s0 = 0; s0 < S; s0 += ch) {
         const long cs = std::min(ch, S - s0);
-        if ((rc = run_kin(m, d, s0, cs))) return rc;
+        const long k0 = s0 / kin_span * kin_span;
+        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0)))) return rc;
+        const double *recs = m->rec.as<double>() + (size_t)(s0 - k0) * hm.rec_size();
         // structural zeros left of a row's first supported column tile are skipped when every block holds rows of one slot
         skipzeros = true;
         for (int g = 0; g < G; g++) skipzeros = skipzeros && cs % work(g).mb == 0;
         {
             ProfScope ps(m, FBR_PROF_REGRESSOR);
             hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
-                               m->rec.as<double>(), d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                               recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
                                t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)));
         }
