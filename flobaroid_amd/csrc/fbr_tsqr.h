@@ -31,6 +31,15 @@
 #ifndef FBR_TSQR_SUB2
 #define FBR_TSQR_SUB2 6           // 16-row sub-blocks per fold of the two-tiles-per-wave kernels (n <= 256): 96-row blocks
 #endif
+#ifndef FBR_TSQR_SUB3
+#define FBR_TSQR_SUB3 4           // three tiles per wave (n <= 384)
+#endif
+#ifndef FBR_TSQR_SUB4
+#define FBR_TSQR_SUB4 4           // four tiles per wave (n <= 512: WALK-MAN's 481 columns)
+#endif
+#ifndef FBR_TSQR_INPLACE_MAX_TPW
+#define FBR_TSQR_INPLACE_MAX_TPW 2  // panels are factorised in place in the wave's own tile registers up to this many tiles per wave
+#endif
 #define FBR_TSQR_RING_MAX 6        // published panels (V, T) kept in the LDS: how far the waves may drift apart (fewer for tall blocks)
 template <int SUB> __host__ __device__ constexpr int fbr_tsqr_ring() { return SUB > 6 ? 5 : FBR_TSQR_RING_MAX; }  // 128-row blocks: 5 slots fit the 160 KiB
 #define FBR_TSQR_MAXN 768          // widest supported factor (columns incl. rhs, padded to 16)
@@ -540,6 +549,16 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                     chain_on(C[0], p, G, tc0);
                 else
                     chain_on(C[1], p, G, tc0);
+            } else if constexpr (TPW <= FBR_TSQR_INPLACE_MAX_TPW) {
+                // one copy of the unrolled chain per tile of the wave: the price of factorising a tall tile where it lies
+                if (tp == 0)
+                    chain_on(C[0], p, G, tc0);
+                else if (tp == 1)
+                    chain_on(C[1], p, G, tc0);
+                else if (tp == 2)
+                    chain_on(C[2], p, G, tc0);
+                else
+                    chain_on(C[TPW - 1], p, G, tc0);
             } else {
                 fbr_td4 v[SUB];
 #pragma unroll
@@ -866,12 +885,12 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
     switch (TPWV) {                                    \
     case 1: { constexpr int TPW = 1, SUB = 4; CALL; } break; \
     case 2: { constexpr int TPW = 2, SUB = FBR_TSQR_SUB2; CALL; } break; \
-    case 3: { constexpr int TPW = 3, SUB = 4; CALL; } break; \
-    case 4: { constexpr int TPW = 4, SUB = 4; CALL; } break; \
+    case 3: { constexpr int TPW = 3, SUB = FBR_TSQR_SUB3; CALL; } break; \
+    case 4: { constexpr int TPW = 4, SUB = FBR_TSQR_SUB4; CALL; } break; \
     case 5: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
     default: { constexpr int TPW = 6, SUB = 2; CALL; } break; \
     }
-static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : (tpw <= 4 ? 4 : (tpw == 5 ? 3 : 2)); }
+static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : (tpw == 3 ? FBR_TSQR_SUB3 : (tpw == 4 ? FBR_TSQR_SUB4 : (tpw <= 1 ? 4 : (tpw == 5 ? 3 : 2)))); }
 
 // narrow (wave-private) kernels: column tiles 1..8, 32-row blocks
 #define FBR_TSQR_NARROW_MAX_TILES 8
