@@ -159,7 +159,8 @@ int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W, double ep
 
 /*
  * R_out [(cols+k)][(cols+k)] upper triangular with R^T R = [Y|rhs]^T [Y|rhs], by blocked Householder
- * TSQR over sample blocks (no Gram squaring of the condition number).  If R_in != NULL it is an
+ * TSQR over sample blocks (no Gram squaring of the condition number; on branched robots the rows are grouped along
+ * the kinematic tree and every group is factorised over the columns it can touch -- same R).  If R_in != NULL it is an
  * existing triangular factor (same shape, out_mem space) that is folded in first (streaming / tree
  * reduction across calls and ranks).  Serves la.qr(YBase) (sdp.py:470), sla.qr(YStd, pivoting) column
  * norms / pivots (model.py:841) and lstsq (identifier.py:712) through the small host problems.
@@ -213,8 +214,8 @@ int fbr_profile_get(fbr_model *m, double *ms_out /*[FBR_PROF_COUNT]*/, int64_t *
 /* ---- introspection (tests, tooling) ------------------------------------------------------------ */
 /*
  * MFMA instructions (v_mfma_f64_16x16x4_f64, 2 * 16 * 16 * 4 = 2048 flop each) that fbr_tsqr / fbr_tsqr_cols executes for num_samples
- * samples and k rhs columns: the level-0 folds of the row-sorted chunks (a block is folded from the first column its rows
- * can touch) and the merge tree over the per-workgroup factors -- counted on the host from the same chunking and fold
+ * samples and k rhs columns: the level-0 folds of the row-sorted chunks of every row group (a block is folded from the first
+ * column its rows can touch) and the merge trees over the per-workgroup factors -- counted on the host from the same chunking and fold
  * rules the kernels use, so bench.py can report executed (not dense-model) flops.  cols == NULL: every identified column.
  * block_rows / n_padded (optional): rows per fold and padded factor width.
  */
