@@ -145,6 +145,8 @@ struct fbr_model {
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     FbrTsqrWork tsqr;
     std::vector<FbrTsqrWork> tsqr_groups;  // one factorisation per row group of the tree-structured TSQR (tsqr_group_plan)
+    hipStream_t tsqr_streams[2] = {nullptr, nullptr};  // the groups' merge trees run beside the final factor's (created on first use)
+    hipEvent_t tsqr_ev[3] = {nullptr, nullptr, nullptr};
     DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
     // profiling
     bool prof = false;
@@ -163,6 +165,10 @@ struct fbr_model {
         (void)hipSetDevice(m->device);
         m->tsqr.release();
         for (auto &g : m->tsqr_groups) g.release();
+        for (auto &st : m->tsqr_streams)
+            if (st) (void)hipStreamDestroy(st);
+        for (auto &e : m->tsqr_ev)
+            if (e) (void)hipEventDestroy(e);
         for (auto &e : m->ev_pool) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -1320,7 +1326,7 @@ static bool tsqr_use_groups(const TsqrGroupPlan &gp, long S, const double *R_in_
 {
     (void)R_in_unused;
     const char *e = getenv("FBR_TSQR_GROUP_MIN_SAMPLES");  // (tests force the path at small sizes)
-    const long min_s = e ? atol(e) : 4096;
+    const long min_s = e ? atol(e) : 24000;  // measured on WALK-MAN, groups vs one factorisation: 16 k samples 16 vs 15.8 ms, 32 k 18.5 vs 21.4, 64 k 24 vs 32, 125 k 34 vs 52
     return gp.groups.size() > 1 && S >= min_s && !getenv("FBR_TSQR_NO_GROUPS");
 }
 static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp, long S)
@@ -1466,19 +1472,44 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, cs * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
         }
     }
-    // the group factors, embedded into the caller's column order, are folded into the final factor (the main group's, or one seeded with
-    // R_in when no group is dense) like data rows
+    // Merge trees are latency bound (a level of the full-width tree is 0.96 ms on a handful of workgroups): the groups' trees run on two
+    // side streams beside the main group's tree, then ONE workgroup folds the embedded group factors (a dozen blocks) into the result --
+    // no second full-width tree.  Without a dense group the final factor starts from R_in.
     ProfScope ps(m, FBR_PROF_TSQR);
-    if (gp.main < 0 && (rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, Rin_dev, m->num_cus, mrows))) return tsqr_fail(rc, "tsqr begin");
+    for (auto &st : m->tsqr_streams)
+        if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &e : m->tsqr_ev)
+        if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     size_t rt = 0;
-    for (int g = 0; g < G; g++) rt = std::max(rt, (size_t)gp.groups[g].Pa * gp.groups[g].Pa);
+    std::vector<size_t> o_r(G, 0);
+    for (int g = 0; g < G; g++) {
+        o_r[g] = rt;
+        rt += (size_t)gp.groups[g].Pa * gp.groups[g].Pa;
+    }
     if ((rc = m->tsqr_rtmp.ensure(rt * sizeof(double)))) return rc;
+    double *rtmp = m->tsqr_rtmp.as<double>();
+    HIPCHK(hipEventRecord(m->tsqr_ev[2], m->stream));
+    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(m->tsqr_streams[i], m->tsqr_ev[2], 0));
+    int nside = 0;
+    for (int g = 0; g < G; g++) {
+        if (g == gp.main) continue;
+        if ((rc = fbr_tsqr_finish_async(m->tsqr_groups[g], m->tsqr_streams[nside++ & 1], rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+    }
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventRecord(m->tsqr_ev[i], m->tsqr_streams[i]));
+    const double *seed = Rin_dev;
+    if (gp.main >= 0) {
+        if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, rtmp + o_r[gp.main])) || (rc = fbr_tsqr_check(m->tsqr, m->stream))) return tsqr_fail(rc, "tsqr finish");
+        seed = rtmp + o_r[gp.main];
+    }
+    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, seed, m->num_cus, 1))) return tsqr_fail(rc, "tsqr begin");
     for (int g = 0; g < G; g++) {
         if (g == gp.main) continue;
         const int Pg = gp.groups[g].Pa;
-        if ((rc = fbr_tsqr_finish(m->tsqr_groups[g], m->stream, m->tsqr_rtmp.as<double>()))) return tsqr_fail(rc, "tsqr group finish");
-        if ((rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pg, Pa, m->tsqr_rtmp.as<double>(), 0, nullptr, nullptr, Pg, t + o_emb[g]))) return tsqr_fail(rc, "tsqr group merge");
+        if ((rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pg, Pa, rtmp + o_r[g], 0, nullptr, nullptr, Pg, t + o_emb[g]))) return tsqr_fail(rc, "tsqr group merge");
     }
+    for (int g = 0; g < G; g++)
+        if (g != gp.main && (rc = fbr_tsqr_check(m->tsqr_groups[g], m->stream))) return tsqr_fail(rc, "tsqr group check");
     if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
     return FBR_OK;
 }
@@ -1713,10 +1744,10 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
                 set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
                 return FBR_E_UNSUPPORTED;
             }
+            if (gp.main >= 0) tr += tree();  // the dense group's own tree; the embedded group factors are folded by one workgroup afterwards
             for (int g = 0; g < (int)gp.groups.size(); g++)
                 if (g != gp.main)
                     for (long r0 = 0; r0 < ((gp.groups[g].Pa + 15) & ~15); r0 += sh.mb) tr += fold_mfma(0);
-            tr += tree();
             if (mfma_level0) *mfma_level0 = l0;
             if (mfma_tree) *mfma_tree = tr;
             if (block_rows) *block_rows = sh.mb;

@@ -1064,8 +1064,9 @@ static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, i
     return fbr_tsqr_fold_packed(wk, st, M, ro);
 }
 
-// Binary tree over the working factors, result (Pa x Pa, upper triangular) to R_out (device).
-static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out)
+// Binary tree over the working factors, result (Pa x Pa, upper triangular) to R_out (device): enqueued on st, not waited for
+// (several factorisations can run their latency-bound trees on different streams; fbr_tsqr_check() collects the error word).
+static inline int fbr_tsqr_finish_async(FbrTsqrWork &wk, hipStream_t st, double *R_out)
 {
     if (!wk.active) {
         g_tsqr_err = "tsqr finish without begin";
@@ -1094,6 +1095,12 @@ static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out
     hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, wk.Pa, wk.Rw, wk.ld, R_out, wk.Pa, wk.Pa, wk.Pa);
     TSQR_HIP(hipGetLastError());
     wk.active = false;
+    return 0;
+}
+
+// Wait for the stream and report a pipeline time-out of the factorisation's kernels (the device error word).
+static inline int fbr_tsqr_check(FbrTsqrWork &wk, hipStream_t st)
+{
     unsigned herr = 0;
     TSQR_HIP(hipMemcpyAsync(&herr, wk.err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     TSQR_HIP(hipStreamSynchronize(st));
@@ -1102,4 +1109,11 @@ static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out
         return -5;
     }
     return 0;
+}
+
+// tree + wait + error check
+static inline int fbr_tsqr_finish(FbrTsqrWork &wk, hipStream_t st, double *R_out)
+{
+    if (int rc = fbr_tsqr_finish_async(wk, st, R_out)) return rc;
+    return fbr_tsqr_check(wk, st);
 }
