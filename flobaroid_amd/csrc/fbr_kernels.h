@@ -51,6 +51,10 @@ struct DevGram {
 #ifndef FBR_KIN_WAVES
 #define FBR_KIN_WAVES 5  // waves per SIMD the kernel is compiled for (<= 96 VGPRs; experiments: 8 = 64 VGPRs)
 #endif
+// A link whose parent is the link processed just before it (DFS order: every link of a chain but the first) takes the parent's record
+// from registers; only the first link after a branch point re-reads it from memory (47 -> 5 dependent 168-byte reads per sample on
+// WALK-MAN: fused pass 77.4 -> 75.3 ms, TSQR call -5 ms).  Writing the records through an LDS transposition (coalesced runs of 21
+// doubles instead of 8-byte stores at a 9.5 KB stride) was measured on top of that: no difference.
 __global__ __launch_bounds__(256, FBR_KIN_WAVES) void fbr_kin_kernel(DevModel m, long S, const double *__restrict__ q,
                                                        const double *__restrict__ dq, const double *__restrict__ ddq,
                                                        const double *__restrict__ bv, const double *__restrict__ ba,
@@ -60,10 +64,13 @@ __global__ __launch_bounds__(256, FBR_KIN_WAVES) void fbr_kin_kernel(DevModel m,
     if (s >= S) return;
     double *r = rec + s * (long)m.rec;
     const double *qs = q + s * m.n, *dqs = dq + s * m.n, *ddqs = ddq + s * m.n;
+    double P[FBR_LINK_REC];
+    int prev_l = -2;
     for (int k = 0; k < m.L; k++) {
         const int l = m.order[k];
         const int par = m.parent[l];
-        double out[FBR_LINK_REC];
+        double out[FBR_LINK_REC], Sv[6] = {0, 0, 0, 0, 0, 0};
+        int d = -1;
         if (par < 0) {
             double v6[6] = {0, 0, 0, 0, 0, 0}, a6[6] = {0, 0, 0, 0, 0, 0}, e3[3] = {0, 0, 0};
             if (m.floating) {
@@ -75,9 +82,9 @@ __global__ __launch_bounds__(256, FBR_KIN_WAVES) void fbr_kin_kernel(DevModel m,
             }
             fbr_kin_base(m.floating, m.g, v6, a6, e3, out);
         } else {
-            double P[FBR_LINK_REC], Sv[6];
-            for (int i = 0; i < FBR_LINK_REC; i++) P[i] = r[FBR_LINK_REC * par + i];
-            const int d = m.dof[l];
+            if (par != prev_l)
+                for (int i = 0; i < FBR_LINK_REC; i++) P[i] = r[FBR_LINK_REC * par + i];
+            d = m.dof[l];
             double rR[9], rp[3], ax[3];
             for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
             for (int i = 0; i < 3; i++) {
@@ -91,10 +98,12 @@ __global__ __launch_bounds__(256, FBR_KIN_WAVES) void fbr_kin_kernel(DevModel m,
                 ddqv = ddqs[d];
             }
             fbr_kin_child(P, rR, rp, ax, d >= 0, qv, dqv, ddqv, out, Sv);
-            if (d >= 0)
-                for (int i = 0; i < 6; i++) r[FBR_LINK_REC * m.L + FBR_DOF_REC * d + i] = Sv[i];
         }
+        if (d >= 0)
+            for (int i = 0; i < 6; i++) r[FBR_LINK_REC * m.L + FBR_DOF_REC * d + i] = Sv[i];
         for (int i = 0; i < FBR_LINK_REC; i++) r[FBR_LINK_REC * l + i] = out[i];
+        for (int i = 0; i < FBR_LINK_REC; i++) P[i] = out[i];
+        prev_l = l;
     }
 }
 
