@@ -332,9 +332,25 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
     double *rs = smem;                                    // [rec]
     double **rowptr = (double **)(smem + ((m.rec + 1) & ~1));  // [rows] chunk row of this sample's regressor row r (its group's chunk)
     const int tid = threadIdx.x;
+    // the record of the NEXT sample is fetched into registers while this one is written out (<= 6 doubles per thread)
+    constexpr int PU = 6;
+    const bool pre = m.rec <= 256 * PU;
+    double pv[PU];
+    if (pre && (long)blockIdx.x < S)
+#pragma unroll
+        for (int u = 0; u < PU; u++) pv[u] = rec[blockIdx.x * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
     for (long s = blockIdx.x; s < S; s += gridDim.x) {
         fbr_barrier_lds();
-        fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < PU; u++)
+                if (tid + 256 * u < m.rec) rs[tid + 256 * u] = pv[u];
+            if (s + gridDim.x < S)
+#pragma unroll
+                for (int u = 0; u < PU; u++) pv[u] = rec[(s + gridDim.x) * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+        } else {
+            fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        }
         if (tid < m.rows) {
             const int g = rowgroup[tid];
             rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * S + s) * grp[g].ld : nullptr;
