@@ -573,7 +573,7 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
         out["h2d"] = {"ms_per_step": dth * 1e3, "bytes_per_step": nbytes, "copy_ms_per_step": prh["h2d"][0] / k2,
                       "copy_GB_per_s": nbytes / (prh["h2d"][0] / k2 * 1e-3) / 1e9 if prh["h2d"][0] > 0 else None,
                       "relerr_vs_resident": float(np.linalg.norm(Gh - G_sharded.cpu().numpy()) / np.linalg.norm(Gh)),
-                      "how": "pinned host states + tau, hipMemcpyAsync per chunk on the producer stream (overlaps the Gram kernel of the previous chunk), host Gram out"}
+                      "how": "pinned host states + tau, hipMemcpyAsync per chunk on a copy stream (overlaps the kernels of the previous chunks), host Gram out"}
         del hst, hrhs
 
         # materialising regressor kernel against the HBM roofline
