@@ -46,7 +46,7 @@ struct DevGram {
 // ------------------------------------------------------------------------------------------------
 // K1: link kinematics, one lane per sample, AoS records  rec[s][21*L + 6*n]
 // ------------------------------------------------------------------------------------------------
-// (256, 5): at most 96 VGPRs (36 spilled), so that a kin wave fits beside the two 173-VGPR Gram waves of a SIMD -- the producer
+// (256, 5): at most 96 VGPRs (41 spilled), so that a kin wave fits beside the two 173-VGPR Gram waves of a SIMD -- the producer
 // kernels run concurrently with the Gram kernel of the previous chunk; +2.7 % on the fused pass
 #ifndef FBR_KIN_WAVES
 #define FBR_KIN_WAVES 5  // waves per SIMD the kernel is compiled for (<= 96 VGPRs; experiments: 8 = 64 VGPRs)
