@@ -207,6 +207,36 @@ int emul_row_stats(const EmulTopo *t, int k, long *out)
     return 0;
 }
 
+// histogram of n = MFMAs per k-step instance (row segment, k-step) of one even sample: out[n] for n = 1..8, out[0] = row segments
+int emul_nstats(const EmulTopo *t, int k, long *out)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrGramProgram gp;
+    build_program(gp, hm, k);
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    const int SEGW = gp.cfg.segw, NSEG = gp.cfg.nseg, NPW = gp.cfg.npw();
+    for (int tw = 0; tw < gp.T * FBR_WPB; tw++)
+        for (int sg = 0; sg < NSEG; sg++) {
+            int kb = -1, kmax = 0, ends[16], cnt = 0;
+            for (int j = 0; j < SEGW; j++) {
+                const FbrSlot &sl = gp.slots[(size_t)tw * NPW + sg * SEGW + j];
+                if (sl.pair < 0) continue;
+                kb = sl.kb;
+                ends[cnt++] = gp.pairs[sl.pair].nkend();
+                kmax = std::max(kmax, ends[cnt - 1]);
+            }
+            if (!cnt) continue;
+            out[0]++;
+            for (int ks = kb; ks < kmax; ks++) {
+                int n = 0;
+                for (int j = 0; j < cnt; j++) n += ends[j] > ks;
+                out[std::min(n, 8)]++;
+            }
+        }
+    return 0;
+}
+
 // per part: [load of the most loaded wave, MFMAs, image doubles]; out holds 3 * T ints
 int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
 {
