@@ -143,6 +143,8 @@ struct fbr_model {
     DevBuf rec, partial, out_tmp, g_tmp;
     DevBuf st_chunk[2];       // per-chunk staging of pinned host inputs (fused Gram pass), double buffered with the tile images
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
+    DevBuf fd_tab, fd_part;   // sub-tree column lists of every joint [n + 1 | entries] (built on first use), baseline partial sums [S][n]
+    int fd_tab_entries = -1;
     FbrTsqrWork tsqr;
     std::vector<FbrTsqrWork> tsqr_groups;  // one factorisation per row group of the tree-structured TSQR (tsqr_group_plan)
     hipStream_t tsqr_streams[2] = {nullptr, nullptr};  // the groups' merge trees run beside the final factor's (created on first use)
@@ -1102,9 +1104,29 @@ extern "C" int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W
         dout = m->g_tmp.as<double>();
     }
     if (S > 0) {
+        // columns that a perturbation of joint d can change: the inertial columns of the links below d and d's own friction columns
+        if (m->fd_tab_entries < 0) {
+            std::vector<int> tab(n + 1, 0), ent;
+            for (int dj = 0; dj < n; dj++) {
+                tab[dj] = (int)ent.size();
+                for (int c = 0; c < hm.cols; c++) {
+                    const FbrCol &cd = hm.coldesc[c];
+                    const bool on = cd.kind == 0 ? std::find(hm.path[cd.link].begin(), hm.path[cd.link].end(), dj) != hm.path[cd.link].end() : cd.joint == dj;
+                    if (on) ent.push_back(c);
+                }
+            }
+            tab[n] = (int)ent.size();
+            tab.insert(tab.end(), ent.begin(), ent.end());
+            if ((rc = m->fd_tab.ensure(tab.size() * sizeof(int)))) return rc;
+            HIPCHK(hipMemcpyAsync(m->fd_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipStreamSynchronize(m->stream));  // tab is a local
+            m->fd_tab_entries = (int)ent.size();
+        }
+        const int *jbeg = m->fd_tab.as<int>(), *jcols = jbeg + n + 1;
         // chunks of original samples such that the expanded kinematic records stay within the usual chunk
         long ch = std::max(1L, chunk_size(m, S * nper) / nper);
-        const size_t lds = ((size_t)hm.rec_size() + 4) * sizeof(double);
+        if ((rc = m->fd_part.ensure((size_t)std::min(ch, S) * std::max(n, 1) * sizeof(double)))) return rc;
+        const size_t lds = ((size_t)hm.rec_size() + 4 + hm.cols) * sizeof(double);
         HIPCHK(hipFuncSetAttribute((const void *)fbr_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const size_t cnt[7] = {(size_t)n, (size_t)n, (size_t)n, 6, 6, 3, (size_t)n};
         for (long s0 = 0; s0 < S; s0 += ch) {
@@ -1131,8 +1153,10 @@ extern "C" int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W
             if ((rc = run_kin(m, de, 0, ce))) return rc;
             {
                 ProfScope ps(m, FBR_PROF_REGRESSOR);
-                hipLaunchKernelGGL(fbr_score_kernel, dim3((unsigned)std::min<long>(ce, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, ce,
-                                   nper, m->rec.as<double>(), de.dq, de.sign, dW + (size_t)s0 * hm.rows * hm.cols, dout + (size_t)s0 * nper);
+                for (int phase = 0; phase < (n > 0 ? 2 : 1); phase++)
+                    hipLaunchKernelGGL(fbr_score_kernel, dim3((unsigned)std::min<long>(phase ? cs * (nper - 1) : cs, (long)m->num_cus * 8)), dim3(256), lds,
+                                       m->stream, m->dm, cs, nper, phase, m->rec.as<double>(), de.dq, de.sign, dW + (size_t)s0 * hm.rows * hm.cols,
+                                       dout + (size_t)s0 * nper, m->fd_part.as<double>(), jbeg, jcols);
             }
             HIPCHK(hipGetLastError());
         }
