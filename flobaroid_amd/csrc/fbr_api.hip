@@ -143,6 +143,7 @@ struct fbr_model {
     DevBuf rec, partial, out_tmp, g_tmp;
     DevBuf st_chunk[2];       // per-chunk staging of pinned host inputs (fused Gram pass), double buffered with the tile images
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
+    DevBuf row_flags;         // active_rows(): per regressor row, does any sample weight it
     DevBuf fd_tab, fd_part;   // sub-tree column lists of every joint [n + 1 | entries] (built on first use), baseline partial sums [S][n]
     int fd_tab_entries = -1;
     FbrTsqrWork tsqr;
@@ -837,6 +838,24 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
 }
 
 // ngroups > 1: the samples form ngroups consecutive groups of equal size, one Gram per group (G_out [ngroups][Pa][Pa])
+// Which regressor rows carry a non-zero weight for at least one sample (device scan of w; all rows when there are no weights).
+static int active_rows(fbr_model *m, const double *dw, long S, std::vector<char> *act)
+{
+    const int rows = m->hm.rows;
+    act->assign(rows, 1);
+    if (!dw || S <= 0) return FBR_OK;
+    int rc;
+    if ((rc = m->row_flags.ensure((size_t)rows * sizeof(int)))) return rc;
+    HIPCHK(hipMemsetAsync(m->row_flags.p, 0, (size_t)rows * sizeof(int), m->stream));
+    hipLaunchKernelGGL(fbr_row_active_kernel, dim3(1024), dim3(256), 0, m->stream, dw, S, rows, m->row_flags.as<int>());
+    HIPCHK(hipGetLastError());
+    std::vector<int> h(rows);
+    HIPCHK(hipMemcpyAsync(h.data(), m->row_flags.p, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    for (int r = 0; r < rows; r++) (*act)[r] = h[r] != 0;
+    return FBR_OK;
+}
+
 static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
                      int32_t out_mem, int32_t accumulate, int32_t ngroups)
 {
@@ -870,6 +889,14 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     } else {
         if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
         if ((rc = stage_one(m, m->st_aux2, w, (size_t)S * hm.rows, st->mem, &dw))) return rc;
+    }
+    // row masks that switch every joint row off (base-wrench-only identification, identifier.py:629-636): only the base k-steps run
+    bool base_only = false;
+    if (dw && !h2d_chunked && hm.fb > 0 && !getenv("FBR_GRAM_NO_MASK_SKIP")) {
+        std::vector<char> act;
+        if ((rc = active_rows(m, dw, S, &act))) return rc;
+        base_only = true;
+        for (int r = hm.fb; r < hm.rows; r++) base_only = base_only && !act[r];
     }
     double *G = G_out;
     if (out_mem == FBR_HOST) {
@@ -990,7 +1017,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                 hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs, cs / items[ci].ng,
                                    m->rec2.as<double>(), dc.dq + o * hm.n, dc.sign ? dc.sign + o * hm.n : nullptr,
                                    crhs ? crhs + (size_t)o * hm.rows * k : nullptr, cw ? cw + (size_t)o * hm.rows : nullptr,
-                                   h->pimg[b].as<double>());
+                                   h->pimg[b].as<double>(), base_only ? 1 : 0);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(m->ev_pack[b], side));
@@ -1019,6 +1046,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             if ((rc = get_deal(h, wpg, &deal))) return rc;
             DevGram dg = h->dev;
             dg.wpg = wpg;
+            dg.ks_limit = base_only ? hm.fbp / 4 : (1 << 20);
             dg.wg_tab = deal.tab;
             dg.wg_begin = deal.begin;
             const int NW = wpg * ng;  // workgroups of this launch
@@ -1265,10 +1293,11 @@ struct TsqrGroup {
 struct TsqrGroupPlan {
     std::vector<TsqrGroup> groups;
     std::vector<int> rowgroup, rowslot;  // per regressor row (-1: the row touches nothing that is factorised)
+    bool masked = false;  // some regressor row has weight 0 for every sample and is left out
     int main = -1;  // group whose rows are dense in every factorised column (base-wrench rows): factorised in the caller's column order
                     // straight into the final factor, the other groups' factors are folded into it
 };
-static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols, int32_t ncols, int k)
+static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols, int32_t ncols, int k, const std::vector<char> *active = nullptr)
 {
     TsqrGroupPlan gp;
     const int Psel = cols ? ncols : hm.cols;
@@ -1295,8 +1324,12 @@ static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols
         jgroup[d] = (nchild[p + 1] == 1) ? pg : ngroups++;
     }
     std::vector<std::vector<int>> grows(ngroups);
-    for (int r = 0; r < hm.fb; r++) grows[base_group].push_back(r);
-    for (int d = 0; d < hm.n; d++) grows[jgroup[d]].push_back(hm.fb + d);
+    auto on = [&](int r) { return !active || (*active)[r]; };  // rows switched off by the weights belong to no group
+    for (int r = 0; r < hm.fb; r++)
+        if (on(r)) grows[base_group].push_back(r);
+    for (int d = 0; d < hm.n; d++)
+        if (on(hm.fb + d)) grows[jgroup[d]].push_back(hm.fb + d);
+    for (int r = 0; r < hm.rows; r++) gp.masked = gp.masked || !on(r);
     auto touches = [&](int r, int uc) {
         const FbrCol &cd = hm.coldesc[uc];
         if (cd.kind != 0) return cd.joint == r - hm.fb;
@@ -1351,7 +1384,7 @@ static bool tsqr_use_groups(const TsqrGroupPlan &gp, long S, const double *R_in_
     (void)R_in_unused;
     const char *e = getenv("FBR_TSQR_GROUP_MIN_SAMPLES");  // (tests force the path at small sizes)
     const long min_s = e ? atol(e) : 24000;  // measured on WALK-MAN, groups vs one factorisation: 16 k samples 16 vs 15.8 ms, 32 k 18.5 vs 21.4, 64 k 24 vs 32, 125 k 34 vs 52
-    return gp.groups.size() > 1 && S >= min_s && !getenv("FBR_TSQR_NO_GROUPS");
+    return (gp.groups.size() > 1 || (gp.masked && !gp.groups.empty())) && S >= min_s && !getenv("FBR_TSQR_NO_GROUPS");
 }
 static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp, long S)
 {
@@ -1608,7 +1641,9 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
     {
-        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k);
+        std::vector<char> act;
+        if ((rc = active_rows(m, dw, S, &act))) return rc;
+        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k, &act);
         if (hm.rows <= 255 && tsqr_use_groups(gp, S)) {  // (the writer's entries hold the regressor row in 8 bits)
             if ((rc = tsqr_groups_impl(m, d, gp, cols, Psel, k, drhs, dw, Rin_dev, R))) return rc;
             return finish_output(m, R, R_out, rcount, out_mem);

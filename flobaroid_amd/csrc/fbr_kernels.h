@@ -27,6 +27,7 @@ struct DevModel {
 struct DevGram {
     int T, NT, k, Pa, image_doubles, part_image_max, nitems;
     int npw;                  // accumulators per wave of the kernel shape the program was built for (segw * nseg)
+    int ks_limit;             // k-steps beyond this one are skipped (base-wrench-only row masks: the joint rows carry weight 0); else large
     int base_ks;              // k-steps of the paired base rows (3 with a floating base, else 0): skipped by the odd sample of a pair
     const int4 *items;        // every real column: image offset, kind, a, b
     const int *slotmeta;      // [T*WPB*NSEG*8] per row segment: [0] = offA/64 | cnt<<10 | kbegin<<18 | (tile I is a chain tile)<<23 ;
@@ -345,6 +346,15 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
     }
 }
 
+// active[r] = 1 iff some sample gives regressor row r a non-zero weight (row masks such as the base-wrench-only identification,
+// identifier.py:629-636, switch whole rows off: their groups / k-steps are skipped)
+__global__ __launch_bounds__(256) void fbr_row_active_kernel(const double *__restrict__ w, long S, int rows, int *__restrict__ active)
+{
+    const long total = S * rows;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        if (w[i] != 0.0) active[i % rows] = 1;  // (benign race: every writer stores 1)
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2c: the regressor written as the ROW GROUPS of the tree-structured TSQR (fbr_api.hip: tsqr_group_plan).  A regressor row
 // belongs to one group; a group g owns a packed chunk A_g [slot][sample][ld_g] that holds only the columns its rows can touch,
@@ -565,8 +575,10 @@ __device__ __forceinline__ double fbr_stage_load(const FbrStage &sg, int i, long
 __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m, long S, long Sg, const double *__restrict__ rec,
                                                         const double *__restrict__ dq, const double *__restrict__ sign,
                                                         const double *__restrict__ rhs, const double *__restrict__ wts,
-                                                        double *__restrict__ pimg)
+                                                        double *__restrict__ pimg, int base_only)
 {
+    // base_only: the row weights switch every joint row off (base-wrench-only identification): their image rows are neither computed nor
+    // written, the Gram kernel does not run their k-steps (DevGram::ks_limit)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     FbrStage sg;
     sg.o_rhs = m.rec;
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m,
                 fbr_unit_wrench(rs + FBR_LINK_REC * d.z, d.w, w6);
                 for (int r = 0; r < m.fb; r++) bimg(r)[d.x + bpos(r) * FBR_TILE] = ws ? w6[r] * ws[r] : w6[r];
                 if (m.fb && !odd && !partner) img[d.x + 6 * FBR_TILE] = img[d.x + 7 * FBR_TILE] = 0.0;  // no partner: clear stale ghost rows
-                const int len = plen[d.z];
+                const int len = base_only ? 0 : plen[d.z];
                 for (int j = 0; j < len; j++) {
                     const int dd = ptab[d.z * m.maxd + j];
                     double v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd, w6);
@@ -613,12 +625,13 @@ __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m,
                     img[d.x + ppos[d.z * m.maxd + j] * FBR_TILE] = v;
                 }
             } else if (d.y == 1) {
+                if (base_only) continue;
                 const int r = m.fb + d.z;
                 double v = fbr_friction_value(d.w, rs[sg.o_dq + d.z], sign ? rs[sg.o_sign + d.z] : 0.0, m.stribeck);
                 if (ws) v *= ws[r];
                 img[d.x] = v;  // d.x points at the packed row of the joint
             } else {
-                for (int r = 0; r < m.rows; r++) {
+                for (int r = 0; r < (base_only ? m.fb : m.rows); r++) {
                     double v = rs[sg.o_rhs + r * g.k + d.z];
                     if (ws) v *= ws[r];
                     if (r < m.fb)
@@ -780,7 +793,7 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
                 };
 #define FBR_RUN_PREFIX(N)                                                              \
     if (N <= FBR_SEGW) {                                                               \
-        const int kend = nksteps(mj[(N) - 1 < FBR_SEGW ? (N) - 1 : 0]);                    \
+        const int kend = min(nksteps(mj[(N) - 1 < FBR_SEGW ? (N) - 1 : 0]), g.ks_limit);    \
         for (; ks < kend; ks++) kstep(std::integral_constant<int, (N) <= FBR_SEGW ? (N) : 1>{}, ks); \
     }
                 FBR_RUN_PREFIX(8)

@@ -454,6 +454,39 @@ def test_tsqr_row_groups_along_the_tree(cfg, monkeypatch):
         assert big1["flop"] == big0["flop"]
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[6]], ids=cfg_id)
+def test_tsqr_row_mask_skips_masked_rows(cfg, monkeypatch):
+    """Base-wrench-only identification (identifier.py:629-636: only the 6 base rows of every sample enter the fit) is a 0/1 row
+    weight: rows that no sample weights are left out of the factorisation altogether (their groups are not formed).  Same R^T R as
+    the weighted Gram, also for a mask that keeps single joint rows, and the same sign-normalised R as the unskipped path."""
+    monkeypatch.setenv("FBR_TSQR_GROUP_MIN_SAMPLES", "1")
+    t, eng, om = _engine_oracle(cfg)
+    S = 700
+    st, rng = _states(t, cfg, S, 41)
+    rhs = rng.standard_normal((S * om.rows, 1))
+    A0 = _aug(om, st, rhs)
+    import scipy.linalg as sla
+
+    for keep in (list(range(6)), list(range(6)) + [6 + 2, om.rows - 1]):
+        w = np.zeros((S, om.rows))
+        w[:, keep] = 1.0 + rng.random((S, len(keep)))
+        w = w.reshape(-1)
+        A = A0 * w[:, None]
+        Go = A.T @ A
+        R = eng.tsqr(st, rhs=rhs, w=w)
+        assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
+        G = eng.gram(st, rhs=rhs, w=w)
+        assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go)
+        ncol = min(60, int(np.linalg.matrix_rank(Go[: om.P, : om.P])) - 3)
+        cols = np.sort(sla.qr(Go[: om.P, : om.P], pivoting=True, mode="r")[1][:ncol]).astype(np.int32)
+        Rc = eng.tsqr(st, rhs=rhs, w=w, cols=cols)
+        monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
+        Rc0 = eng.tsqr(st, rhs=rhs, w=w, cols=cols)
+        monkeypatch.delenv("FBR_TSQR_NO_GROUPS")
+        norm = lambda R: R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
+        assert np.linalg.norm(norm(Rc) - norm(Rc0)) <= 1e-9 * np.linalg.norm(Rc0)
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[7]], ids=cfg_id)
 def test_fd_sweep_scores_match_oracle_regressors(cfg):
     """fbr_fd_scores == sum(W_t * Y(state_t + eps e_d)) with the oracle's regressor on every perturbed state
