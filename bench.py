@@ -717,6 +717,30 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
         "rho2_norm_sqr": float(Rb[nbp, nbp] ** 2), "rho2_expected_from_noise": 0.05 ** 2 * (M - nbp),
         "lstsq_default_rcond_kept_singular_values": int(np.count_nonzero(sv > np.finfo(float).eps * M * sv[0])),
         "note": "R1 = R[:nb,:nb], rho1 = R[:nb,nb] are the SDP inputs of sdp.py:470-487 (estimation.sdp_inputs)"}
+    # WALK-MAN's shipped identification mode (walkman_full.yaml:265 useBaseWrenchForBaseParams: only the 6 base-wrench rows of every
+    # sample enter the fit, identifier.py:629-636): a 0/1 row mask; masked rows are detected on the device and skipped
+    wmask = torch.zeros((S1, eng4.rows), dtype=torch.float64, device=dev)
+    wmask[:, :6] = 1.0
+    wmask = wmask.reshape(-1)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    Gm = eng4.gram(st4, rhs=rhs4, w=wmask)
+    Rm = eng4.tsqr(st4, rhs=rhs4, w=wmask, cols=ic)
+    Gmn = Gm.cpu().numpy()[np.ix_(sel, sel)]
+    t_gm = timed(lambda: eng4.gram(st4, rhs=rhs4, w=wmask, out=G5))
+    t_qm = timed(lambda: eng4.tsqr(st4, rhs=rhs4, w=wmask, cols=ic))
+    res["walkman_full_1M_base_wrench_rows_only"] = {
+        "samples": S1, "rows_per_sample_in_the_fit": 6, "fused_gram_ms": t_gm * 1e3, "fused_gram_samples_per_s": S1 / t_gm,
+        "tsqr_base_columns": nbp + 1, "tsqr_ms": t_qm * 1e3, "tsqr_samples_per_s": S1 / t_qm,
+        "relerr_RtR_vs_gram": float(np.linalg.norm(Rm.cpu().numpy().T @ Rm.cpu().numpy() - Gmn) / np.linalg.norm(Gmn))}
     return res
 
 
