@@ -100,14 +100,15 @@ struct GramHolder {
 };
 
 // Device tables of the deal of `wpg` workgroups to the parts (cached per holder).
-static int get_deal(GramHolder *h, int wpg, GramHolder::Deal *out)
+static int get_deal(GramHolder *h, int wpg, GramHolder::Deal *out, bool base_only = false)
 {
-    auto it = h->deals.find(wpg);
+    const int key = wpg | (base_only ? 1 << 24 : 0);
+    auto it = h->deals.find(key);
     if (it != h->deals.end()) {
         *out = it->second;
         return FBR_OK;
     }
-    const std::vector<int> n = fbr_gram_deal(h->prog, wpg);
+    const std::vector<int> n = fbr_gram_deal(h->prog, wpg, base_only);
     // dispatch order: round robin over the parts.  The SIMD arbiter favours the older waves, so the workgroups dispatched first
     // run ~20 % faster than the ones that arrive second on a CU; every part gets the same mix of both.
     std::vector<int2> tab;
@@ -120,7 +121,7 @@ static int get_deal(GramHolder *h, int wpg, GramHolder::Deal *out)
     int rc;
     if ((rc = upload(h->pool, tab, &d.tab))) return rc;
     if ((rc = upload(h->pool, begin, &d.begin))) return rc;
-    h->deals[wpg] = d;
+    h->deals[key] = d;
     *out = d;
     return FBR_OK;
 }
@@ -752,6 +753,14 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     }
     piece_begin[gp.T] = (int)pieces.size();
     rid_begin[gp.T] = (int)ridl.size();
+    // base-wrench-only launches read the first 8 packed rows (one 1 KiB DMA) of every tile only
+    std::vector<int2> pieces_b;
+    std::vector<int> piece_begin_b(gp.T + 1, 0);
+    for (int t = 0; t < gp.T; t++) {
+        piece_begin_b[t] = (int)pieces_b.size();
+        for (int ti : gp.part_tiles[t]) pieces_b.push_back(make_int2(gp.tiles[ti].off, gp.part_tile_off[t][ti]));
+    }
+    piece_begin_b[gp.T] = (int)pieces_b.size();
     const int FBR_SEGW = gp.cfg.segw, FBR_NSEG = gp.cfg.nseg, FBR_NPW = gp.cfg.npw();
     dg.npw = FBR_NPW;
     dg.base_ks = gp.base_ks;
@@ -796,6 +805,8 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     if ((rc = upload(h->pool, meta, &dg.slotmeta))) return rc;
     if ((rc = upload(h->pool, piece_begin, &dg.piece_begin))) return rc;
     if ((rc = upload(h->pool, pieces, &dg.pieces))) return rc;
+    if ((rc = upload(h->pool, piece_begin_b, &dg.piece_begin_b))) return rc;
+    if ((rc = upload(h->pool, pieces_b, &dg.pieces_b))) return rc;
     if ((rc = upload(h->pool, rid_begin, &dg.rid_begin))) return rc;
     if ((rc = upload(h->pool, ridl, &dg.ridl))) return rc;
     if ((rc = upload(h->pool, slot_tiles, &dg.slot_tiles))) return rc;
@@ -1043,10 +1054,14 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             if ((long)wpg > (long)T * spg_max) wpg = (int)((long)T * spg_max);
             if (wpg > 0xffff) wpg = 0xffff;
             GramHolder::Deal deal;
-            if ((rc = get_deal(h, wpg, &deal))) return rc;
+            if ((rc = get_deal(h, wpg, &deal, base_only))) return rc;
             DevGram dg = h->dev;
             dg.wpg = wpg;
             dg.ks_limit = base_only ? hm.fbp / 4 : (1 << 20);
+            if (base_only && hm.fbp == 8) {  // (8 base positions x 16 columns = one full DMA piece per tile)
+                dg.pieces = dg.pieces_b;
+                dg.piece_begin = dg.piece_begin_b;
+            }
             dg.wg_tab = deal.tab;
             dg.wg_begin = deal.begin;
             const int NW = wpg * ng;  // workgroups of this launch

@@ -34,6 +34,8 @@ struct DevGram {
                               //   [1+j] = offB_j/64 | lookup_j<<10 | kend_j<<11   (part-local offsets; the pair runs k-steps [kbegin, kend_j))
     const int *piece_begin;   // [T+1]
     const int2 *pieces;       // x = offset in the global image, y = offset in the part image | half<<30  (doubles)
+    const int *piece_begin_b; // the same for launches that stop after the base k-steps (ks_limit): one piece per tile, its 8 base rows
+    const int2 *pieces_b;
     const int *rid_begin;     // [T+1]
     const int *ridl;          // per part: part-image row -> regressor row (chain tiles)
     const int *slot_tiles;    // [T*WPB*NPW*2] tile I, tile J (or -1)

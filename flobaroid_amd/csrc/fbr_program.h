@@ -637,13 +637,30 @@ struct FbrGramProgram {
 
 // Deal `slots` workgroups (>= T) to the parts so that the slowest workgroup is as fast as possible: every part gets one, each
 // further one goes to the part with the largest cost per workgroup.  Returns n[part]; deterministic.
-static inline std::vector<int> fbr_gram_deal(const FbrGramProgram &gp, int slots)
+// base_only: the launch stops every pair after the base k-steps (row masks that switch the joint rows off): a part then costs its fixed
+// overhead, its image and base-k-step MFMAs in proportion to its pairs
+static inline std::vector<int> fbr_gram_deal(const FbrGramProgram &gp, int slots, bool base_only = false)
 {
+    std::vector<double> cost = gp.part_cost;
+    if (base_only) {
+        const int npw = gp.cfg.npw();
+        for (int p = 0; p < gp.T; p++) {
+            int pairs = 0, wmax = 0;
+            for (int w = 0; w < FBR_WPB; w++) {
+                int pw = 0;
+                for (int i = 0; i < npw; i++) pw += gp.slots[((size_t)p * FBR_WPB + w) * npw + i].pair >= 0;
+                pairs += pw;
+                wmax = std::max(wmax, pw);
+            }
+            const double ks = 1.5;  // base k-steps per pair and sample (pairs of samples share three)
+            cost[p] = gp.cfg.c0 + gp.cfg.cload * (2.0 * ks * wmax) + gp.cfg.cmfma * (ks * pairs) + gp.cfg.cimg * gp.part_image[p];
+        }
+    }
     std::vector<int> n(gp.T, 1);
     for (int left = slots - gp.T; left > 0; left--) {
         int best = 0;
         for (int p = 1; p < gp.T; p++)
-            if (gp.part_cost[p] * n[best] > gp.part_cost[best] * n[p]) best = p;
+            if (cost[p] * n[best] > cost[best] * n[p]) best = p;
         n[best]++;
     }
     return n;
