@@ -6,8 +6,10 @@ calls and the Python sample loop are replaced by batched HIP kernels reached thr
 reference makes.  Reference line numbers are cited at each step.
 
 Deviations that a maintainer should know about (all documented in DESIGN.md §7):
-* the DOF serialisation is URDF document order unless a regressor XML is given (iDynTree's own order is
-  not recoverable offline; it only permutes rows inside a sample block);
+* links and DOFs are serialised in iDynTree's traversal order (``topology.py``: depth-first, LIFO over the joints in
+  document order), which reproduces every joint list the reference holds (``model/*_regressor.xml``); a regressor XML,
+  ``opt['jointNames']`` / ``opt['linkNames']`` (explicit lists) or ``opt['dofOrder']`` / ``opt['linkOrder']``
+  (``"traversal"`` | ``"document"``) override it;
 * errors raise instead of ``sys.exit()`` / printed warnings;
 * ``YStd`` is materialised on request; for very large runs it is a lazy object backed by the kernels.
 """
@@ -23,7 +25,7 @@ from . import helpers
 from .topology import Topology, parse_urdf
 
 
-def pivoted_qr(A: np.ndarray, tie_eps: float = 1e-9):
+def pivoted_qr(A: np.ndarray, tie_eps: float = 1e-7):
     """``scipy.linalg.qr(A, pivoting=True, mode="economic")`` (model.py:809,841) with a DETERMINISTIC rule for ties.
 
     The structural regressor has columns whose pivoting norms are equal in exact arithmetic (e.g. inertia columns of a link that
@@ -33,11 +35,22 @@ def pivoted_qr(A: np.ndarray, tie_eps: float = 1e-9):
     imposed without leaving LAPACK: the pivots are taken from dgeqp3 on A with column j scaled by 1 + tie_eps * (P - j) / P
     (column scaling multiplies the trailing column norms of every step by exactly that factor, so it only reorders ties), then the
     factor is recomputed from the UNSCALED matrix with that column order.  Outside ties the pivots, and to rounding R, are what
-    the reference's call returns."""
+    the reference's call returns.  The default 1e-7 sits above the accuracy of dgeqp3's down-dated partial column norms
+    (~sqrt(eps) = 1.5e-8 before LAPACK recomputes them), so a structural tie is always resolved by the rule, never by rounding;
+    the WALK-MAN pivots are the same for every tolerance from 1e-9 to 1e-6.
+
+    A tall A (the data regressor of useStructuralRegressor = 0, model.py:841) is first reduced by one unpivoted QR: pivots and R
+    of a column-pivoted QR depend on A only through its triangular factor, so the pivoting runs on the small n x n matrix
+    (one tall dgeqrf + one tall GEMM instead of two tall factorisations, one of them the slow dgeqp3)."""
     A = np.asarray(A)
     Pn = A.shape[1]
     if tie_eps and Pn > 0:
         d = 1.0 + float(tie_eps) * (Pn - np.arange(Pn)) / Pn
+        if A.shape[0] > 2 * Pn:
+            Q0, R0 = sla.qr(A, mode="economic")
+            piv = sla.qr(R0 * d[None, :], pivoting=True, mode="r")[1]
+            Qs, R = sla.qr(R0[:, piv], mode="economic")
+            return Q0 @ Qs, R, piv
         piv = sla.qr(A * d[None, :], pivoting=True, mode="r")[1]
         Q, R = sla.qr(A[:, piv], mode="economic")
         return Q, R, piv
@@ -110,7 +123,14 @@ class Model:
             opt.setdefault(k, v)
 
         # load the robot description (model.py:60-68; raises instead of sys.exit())
-        topo = Topology.load(urdf_file)
+        # serialisation (model.py:73-98,121-127: jointNames / linkNames as iDynTree reports them): traversal order by default,
+        # opt['linkOrder'] / opt['dofOrder'] = "traversal" | "document", explicit opt['linkNames'] / opt['jointNames'] lists,
+        # and the joint list of a regressor XML (model.py:74-85) win in that order
+        topo = Topology.load(urdf_file, link_order=opt.get("linkOrder"), dof_order=opt.get("dofOrder"))
+        if opt.get("linkNames"):
+            topo = topo.reordered_links([str(n) for n in opt["linkNames"]])
+        if opt.get("jointNames"):
+            topo = topo.reordered_dofs([str(n) for n in opt["jointNames"]])
         if regressor_file:
             import xml.etree.ElementTree as ET
 
@@ -403,11 +423,11 @@ class Model:
             st["sign"] = np.tanh(dq / float(self.opt.get("frictionSignThreshold", 0.02)))  # model.py:757-758
         return st
 
-    CACHE_PRODUCER = "flobaroid_amd/2"  # /2: pivots follow the lowest-index tie rule
+    CACHE_PRODUCER = "flobaroid_amd/3"  # /2: pivots follow the lowest-index tie rule; /3: traversal serialisation, tie tolerance 1e-7
 
     def _tie_eps(self) -> float:
-        """opt['pivotTieTolerance'] (default 1e-9; 0 = LAPACK's own last-bit tie breaking, as the reference)."""
-        return float(self.opt.get("pivotTieTolerance", 1e-9))
+        """opt['pivotTieTolerance'] (default 1e-7; 0 = LAPACK's own last-bit tie breaking, as the reference)."""
+        return float(self.opt.get("pivotTieTolerance", 1e-7))
 
     def _dof_hash(self) -> str:
         import hashlib
@@ -421,24 +441,31 @@ class Model:
         suffix = ".gravity_regressor.npz" if opt["identifyGravityParamsOnly"] else ".regressor.npz"
         regr_filename = self.urdf_file + suffix
         fb = opt["floatingBase"]
-        generate_new = False
         # The file name and the reference's keys are kept (model.py:811-822) so the tools around it find the cache, but a cache
-        # is only trusted when it was written by this implementation for the same DOF serialisation and friction layout:
-        # iDynTree's DOF order can differ from ours (URDF document order), which permutes the friction columns, and the
-        # reference's own validity check ignores both that and stribeckVelocity.
+        # is only trusted when it was written by this implementation for the same link / DOF serialisation and friction layout
+        # (the reference's own validity check ignores the serialisation and stribeckVelocity).  A cache somebody else wrote is
+        # never overwritten: ours then goes to <name>.fbr.npz beside it.
         dof_hash = self._dof_hash()
         stribeck = float(opt.get("stribeckVelocity", 0) or 0.0)
-        try:
-            f = np.load(regr_filename)
-            R, Q, RQ, PQ = f["R"], f["Q"], f["RQ"], f["PQ"]
-            if (f["n"] != n_samples or f["fb"] != fb or R.shape[0] != self.num_identified_params
-                    or opt["identifyGravityParamsOnly"] != f["grav_only"] or f["fric"] != opt["identifyFrictionSimultaneously"]
-                    or f["fric_sym"] != opt["identifySymmetricVelFriction"]
-                    or "producer" not in f or str(f["producer"]) != self.CACHE_PRODUCER or str(f["dof_hash"]) != dof_hash
-                    or float(f["stribeck"]) != stribeck):
-                generate_new = True
-        except (OSError, KeyError, ValueError):
-            generate_new = True
+        own_filename = regr_filename[:-4] + ".fbr.npz"
+        generate_new = True
+        foreign = False
+        for fn in (regr_filename, own_filename):
+            try:
+                f = np.load(fn)
+                if "producer" not in f:
+                    foreign = foreign or fn == regr_filename
+                    continue
+                R, Q, RQ, PQ = f["R"], f["Q"], f["RQ"], f["PQ"]
+                if not (f["n"] != n_samples or f["fb"] != fb or R.shape[0] != self.num_identified_params
+                        or opt["identifyGravityParamsOnly"] != f["grav_only"] or f["fric"] != opt["identifyFrictionSimultaneously"]
+                        or f["fric_sym"] != opt["identifySymmetricVelFriction"]
+                        or str(f["producer"]) != self.CACHE_PRODUCER or str(f["dof_hash"]) != dof_hash
+                        or float(f["stribeck"]) != stribeck):
+                    generate_new = False
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
         if generate_new:
             if not n_samples:
                 n_samples = self.num_dofs * 1000
@@ -446,10 +473,10 @@ class Model:
             R = self.engine.gram(st)
             Q, RQ, PQ = pivoted_qr(R, self._tie_eps())  # model.py:809
             try:
-                np.savez(regr_filename, R=R, Q=Q, RQ=RQ, PQ=PQ, n=n_samples, fb=opt["floatingBase"],
+                np.savez(own_filename if foreign else regr_filename, R=R, Q=Q, RQ=RQ, PQ=PQ, n=n_samples, fb=opt["floatingBase"],
                          grav_only=opt["identifyGravityParamsOnly"], fric=opt["identifyFrictionSimultaneously"],
                          fric_sym=opt["identifySymmetricVelFriction"], producer=self.CACHE_PRODUCER, dof_hash=dof_hash,
-                         stribeck=stribeck)
+                         stribeck=stribeck, jointNames=np.array(self.jointNames), linkNames=np.array(self.linkNames))
             except OSError:
                 pass  # read-only model directory: skip the cache
         return R, Q, RQ, PQ

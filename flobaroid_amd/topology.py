@@ -9,11 +9,20 @@ documented known answers (KUKA a-priori table, link counts 3/8/9/48, ...).
 
 Conventions
 -----------
-* Links are kept in URDF document order after removing *fake links* (massless links
-  with exactly one neighbour that is attached by a fixed joint).  Removed fake links
-  survive as named frames rigidly attached to their neighbour.
+* *Fake links* (massless links with exactly one neighbour that is attached by a fixed
+  joint) are removed and survive as named frames rigidly attached to their neighbour.
 * The base link is the URDF root, or its only child when the root itself is fake.
-* DOF order = URDF document order of the non-fixed joints (override: ``joint_names``).
+* **Serialisation** (which link owns column block ``10 l``, which joint owns DOF ``d``):
+  ``order="traversal"`` (default) is the order in which a depth-first walk from the root
+  visits the tree when the neighbours of a link are pushed on a LIFO stack in the document
+  order of their joints and a link is numbered when it is popped -- the walk iDynTree's
+  ``Model::computeFullTreeTraversal`` performs and from which its loader renumbers links
+  and joints.  It reproduces every joint list the reference holds
+  (``model/*_regressor.xml``, ``configs/walkman_static.yaml:60-64``: left leg, right leg,
+  waist, left arm, right arm for WALK-MAN); ``tests/golden/reference_joint_orders.json``.
+  ``order="document"`` keeps URDF document order of links / movable joints (rounds 1-2).
+  Explicit name lists (``joint_names``, ``link_names``) override either -- the way to
+  adopt whatever ``Model.jointNames`` / ``Model.linkNames`` an iDynTree build prints.
 * Per-link standard parameters ``[m, m*cx, m*cy, m*cz, Ixx, Ixy, Ixz, Iyy, Iyz, Izz]``
   with the inertia expressed about the link-frame origin in link axes
   (``identification/model.py:220-231``).
@@ -88,6 +97,9 @@ class Topology:
     limits: dict[str, dict[str, float]] = field(default_factory=dict)
     friction: dict[str, dict[str, float]] = field(default_factory=dict)
     frames: dict[str, dict[str, Any]] = field(default_factory=dict)  # name -> {link, R(3x3), p(3)}
+    # URDF document ranks, kept so that either serialisation can be rebuilt from a stored topology:
+    doc_link_rank: list[int] = field(default_factory=list)  # rank of the <link> element among the kept links
+    doc_joint_rank: list[int] = field(default_factory=list)  # rank of the link's parent <joint> element (-1: base)
 
     # ------------------------------------------------------------------ sizes
     @property
@@ -137,6 +149,89 @@ class Topology:
         """Flat a-priori standard parameter vector (10 per link, link-major)."""
         return np.ascontiguousarray(self.params, dtype=np.float64).reshape(-1).copy()
 
+    # ------------------------------------------------------------- serialisation
+    def _ranks(self) -> tuple[list[int], list[int]]:
+        L = self.num_links
+        lr = list(self.doc_link_rank) if len(self.doc_link_rank) == L else list(range(L))
+        jr = list(self.doc_joint_rank) if len(self.doc_joint_rank) == L else [-1 if p < 0 else l for l, p in enumerate(self.parent)]
+        return lr, jr
+
+    def visit_order(self) -> list[int]:
+        """Link indices in iDynTree's visiting order: depth-first from the base, the children of a link pushed on a
+        LIFO stack in the document order of their joints, a link numbered when popped (so the child whose joint
+        comes LAST in the URDF is walked first)."""
+        _, jr = self._ranks()
+        children: list[list[int]] = [[] for _ in range(self.num_links)]
+        for l, p in enumerate(self.parent):
+            if p >= 0:
+                children[p].append(l)
+        order: list[int] = []
+        stack = [self.base_index]
+        while stack:
+            l = stack.pop()
+            order.append(l)
+            stack.extend(sorted(children[l], key=lambda c: jr[c]))
+        if len(order) != self.num_links:
+            raise ValueError("kinematic structure is not a single tree")
+        return order
+
+    def link_order(self, mode: str) -> list[int]:
+        """Current link indices in the order of serialisation ``mode`` ("traversal" | "document")."""
+        if mode == "traversal":
+            return self.visit_order()
+        if mode == "document":
+            lr, _ = self._ranks()
+            return sorted(range(self.num_links), key=lambda l: lr[l])
+        raise ValueError(f"unknown link order '{mode}' (traversal | document)")
+
+    def dof_order(self, mode: str) -> list[str]:
+        """Names of the movable joints in the order of serialisation ``mode``."""
+        if mode == "traversal":
+            return [self.joint_names[l] for l in self.visit_order() if self.dof_index[l] >= 0]
+        if mode == "document":
+            _, jr = self._ranks()
+            return [self.joint_names[l] for l in sorted(range(self.num_links), key=lambda l: jr[l]) if self.dof_index[l] >= 0]
+        raise ValueError(f"unknown DOF order '{mode}' (traversal | document)")
+
+    def reordered_links(self, link_names: list[str]) -> "Topology":
+        """Same tree with the links (= the 10-column parameter blocks) serialised as ``link_names``."""
+        if sorted(link_names) != sorted(self.link_names) or len(set(link_names)) != len(link_names):
+            raise ValueError("link_names must be a permutation of the model's links")
+        old = [self.link_names.index(n) for n in link_names]  # new index -> old index
+        new_of = {o: i for i, o in enumerate(old)}
+        lr, jr = self._ranks()
+        return Topology(
+            name=self.name,
+            link_names=list(link_names),
+            parent=[new_of[self.parent[o]] if self.parent[o] >= 0 else -1 for o in old],
+            joint_names=[self.joint_names[o] for o in old],
+            joint_type=[self.joint_type[o] for o in old],
+            dof_index=[self.dof_index[o] for o in old],
+            rest_R=np.asarray(self.rest_R)[old].copy(),
+            rest_p=np.asarray(self.rest_p)[old].copy(),
+            axis=np.asarray(self.axis)[old].copy(),
+            params=np.asarray(self.params)[old].copy(),
+            dof_names=list(self.dof_names),
+            limits={k: dict(v) for k, v in self.limits.items()},
+            friction={k: dict(v) for k, v in self.friction.items()},
+            frames={k: {"link": new_of[v["link"]], "R": np.array(v["R"], dtype=float), "p": np.array(v["p"], dtype=float)}
+                    for k, v in self.frames.items()},
+            doc_link_rank=[lr[o] for o in old],
+            doc_joint_rank=[jr[o] for o in old],
+        )
+
+    def serialized(self, link_order: str | None = "traversal", dof_order: str | None = "traversal",
+                   joint_names: list[str] | None = None, link_names: list[str] | None = None) -> "Topology":
+        """The same robot in the requested serialisation (``None`` keeps what this object has); explicit name lists win."""
+        t = self
+        names = link_names if link_names is not None else (None if link_order is None else [t.link_names[l] for l in t.link_order(link_order)])
+        if names is not None and list(names) != t.link_names:
+            t = t.reordered_links(list(names))
+        dofs = joint_names if joint_names is not None else (None if dof_order is None else t.dof_order(dof_order))
+        if dofs is not None and list(dofs) != t.dof_names:
+            t = t.reordered_dofs(list(dofs))
+        return t
+
     def reordered_dofs(self, joint_names: list[str]) -> "Topology":
         """Same tree with the DOF serialisation given by ``joint_names``
         (the reference takes it from the regressor XML, ``model.py:74-85``)."""
@@ -168,6 +263,8 @@ class Topology:
                 k: {"link": v["link"], "R": np.asarray(v["R"]).tolist(), "p": np.asarray(v["p"]).tolist()}
                 for k, v in self.frames.items()
             },
+            "doc_link_rank": list(self._ranks()[0]),
+            "doc_joint_rank": list(self._ranks()[1]),
         }
 
     @staticmethod
@@ -190,6 +287,8 @@ class Topology:
                 k: {"link": int(v["link"]), "R": np.array(v["R"], dtype=float), "p": np.array(v["p"], dtype=float)}
                 for k, v in d.get("frames", {}).items()
             },
+            doc_link_rank=[int(v) for v in d.get("doc_link_rank", [])],
+            doc_joint_rank=[int(v) for v in d.get("doc_joint_rank", [])],
         )
 
     def save_json(self, path: str) -> None:
@@ -202,14 +301,17 @@ class Topology:
             return Topology.from_dict(json.load(f))
 
     @staticmethod
-    def load(path: str) -> "Topology":
-        """Load from a URDF (``.urdf``/xml) or from a topology JSON written by ``save_json``."""
+    def load(path: str, link_order: str | None = None, dof_order: str | None = None) -> "Topology":
+        """Load from a URDF (``.urdf``/xml; default serialisation "traversal") or from a topology JSON written by
+        ``save_json`` (keeps the stored serialisation unless an order is asked for)."""
         if path.endswith(".json"):
-            return Topology.load_json(path)
-        return parse_urdf(path)
+            t = Topology.load_json(path)
+            return t.serialized(link_order, dof_order) if (link_order or dof_order) else t
+        return parse_urdf(path, link_order=link_order or "traversal", dof_order=dof_order or "traversal")
 
 
-def parse_urdf(path: str, joint_names: list[str] | None = None) -> Topology:
+def parse_urdf(path: str, joint_names: list[str] | None = None, link_order: str = "traversal",
+               dof_order: str = "traversal", link_names: list[str] | None = None) -> Topology:
     """Extract the topology from a URDF file (rules in the module docstring)."""
     root = ET.parse(path).getroot()
 
@@ -326,9 +428,9 @@ def parse_urdf(path: str, joint_names: list[str] | None = None) -> Topology:
     if any(p == -2 for p in parent):
         raise ValueError("disconnected links in URDF")
 
-    dof_names = list(movable) if joint_names is None else list(joint_names)
-    if sorted(dof_names) != sorted(movable):
+    if joint_names is not None and sorted(joint_names) != sorted(movable):
         raise ValueError("joint_names must list exactly the movable joints of the URDF")
+    dof_names = list(movable)  # document order here; serialised below
     dof_of = {n: i for i, n in enumerate(dof_names)}
     dof_index = [dof_of[joint_name[l]] if joint_type[l] != JOINT_FIXED else -1 for l in range(L)]
 
@@ -356,7 +458,8 @@ def parse_urdf(path: str, joint_names: list[str] | None = None) -> Topology:
             fv = float(de.attrib.get("damping", 0.0))
         friction[j["name"]] = {"f_constant": fc, "f_velocity": fv}
 
-    return Topology(
+    jrank = {j["name"]: r for r, j in enumerate(raw_joints)}
+    doc = Topology(
         name=root.attrib.get("name", ""),
         link_names=kept,
         parent=parent,
@@ -371,7 +474,10 @@ def parse_urdf(path: str, joint_names: list[str] | None = None) -> Topology:
         limits=limits,
         friction=friction,
         frames=frames,
+        doc_link_rank=list(range(L)),
+        doc_joint_rank=[jrank[joint_name[l]] if parent[l] >= 0 else -1 for l in range(L)],
     )
+    return doc.serialized(link_order, dof_order, joint_names=joint_names, link_names=link_names)
 
 
 # ---------------------------------------------------------------------------------------------------------

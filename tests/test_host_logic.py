@@ -112,6 +112,44 @@ def test_model_layout_and_apriori_vector():
     assert (w.num_links, w.num_model_params, w.N_OUT) == (48, 480, 35)
 
 
+def test_serialisation_options_and_regressor_file(tmp_path):
+    """jointNames / linkNames as iDynTree reports them (model.py:73-98,121-127).  Default = the traversal order that reproduces the
+    reference-held lists; a regressor XML (model.py:74-85), opt['jointNames'] / opt['linkNames'] and opt['dofOrder'] / opt['linkOrder']
+    re-serialise, and everything indexed by DOF (a-priori friction entries, limits) follows."""
+    g = json.load(open(os.path.join(GOLDEN, "reference_joint_orders.json")))
+    wpath = os.path.join(ROBOTS, "walkman_apriori.topology.json")
+    w = Model(_opt(floatingBase=1, identifyFrictionSimultaneously=1), wpath, regressor_init=False)
+    assert w.jointNames == g["walkman_apriori"] and w.linkNames[0] == "Waist" and w.linkNames[3] == "LHipMot"
+    # the reference's own regressor XML content (joint list from the golden data; commented-out joints are skipped like ET does)
+    xml = tmp_path / "walkman_regressor.xml"
+    xml.write_text("<regressor><baseLinkDynamics/><jointTorqueDynamics><joints>\n<!-- <joint>NeckYawj</joint> -->\n"
+                   + "".join("<joint>%s</joint>\n" % j for j in g["walkman_apriori"]) + "</joints></jointTorqueDynamics></regressor>")
+    wx = Model(_opt(floatingBase=1, identifyFrictionSimultaneously=1), wpath, regressor_file=str(xml), regressor_init=False)
+    assert wx.jointNames == w.jointNames and wx.topology.dof_index == w.topology.dof_index and np.array_equal(wx.xStdModel, w.xStdModel)
+    # document order (rounds 1-2) on request: a permutation of the same robot
+    d = Model(_opt(floatingBase=1, identifyFrictionSimultaneously=1, linkOrder="document", dofOrder="document"), wpath, regressor_init=False)
+    assert d.jointNames[:3] == ["WaistLat", "WaistSag", "WaistYaw"] and d.linkNames[:4] == ["Waist", "DWL", "DWS", "DWYTorso"]
+    lp = [d.linkNames.index(n) for n in w.linkNames]
+    jp = [d.jointNames.index(n) for n in w.jointNames]
+    assert np.array_equal(w.xStdModel[:480].reshape(48, 10), d.xStdModel[:480].reshape(48, 10)[lp])
+    for k in range(3):  # Coulomb | viscous | offset blocks follow the DOF order (model.py:459-503)
+        assert np.array_equal(w.xStdModel[480 + 29 * k: 480 + 29 * (k + 1)], d.xStdModel[480 + 29 * k: 480 + 29 * (k + 1)][jp])
+    # a reversed XML on KUKA really re-serialises (friction a-priori entries move with their joint)
+    kpath = os.path.join(ROBOTS, "kuka_lwr4.topology.json")
+    k0 = Model(_opt(identifyFrictionSimultaneously=1), kpath, regressor_init=False)
+    rev = tmp_path / "rev.xml"
+    rev.write_text("<regressor><joints>" + "".join("<joint>%s</joint>" % j for j in reversed(k0.jointNames)) + "</joints></regressor>")
+    k1 = Model(_opt(identifyFrictionSimultaneously=1), kpath, regressor_file=str(rev), regressor_init=False)
+    assert k1.jointNames == k0.jointNames[::-1] and k1.topology.dof_index[1:] == [6, 5, 4, 3, 2, 1, 0]
+    assert np.array_equal(k1.xStdModel[80:87], k0.xStdModel[80:87][::-1]) and np.array_equal(k1.xStdModel[:80], k0.xStdModel[:80])
+    k2 = Model(_opt(identifyFrictionSimultaneously=1, jointNames=k0.jointNames[::-1], linkNames=k0.linkNames[::-1]), kpath, regressor_init=False)
+    assert k2.jointNames == k1.jointNames and k2.linkNames == k0.linkNames[::-1]
+    assert np.array_equal(k2.xStdModel[:80].reshape(8, 10), k0.xStdModel[:80].reshape(8, 10)[::-1])
+    with pytest.raises(ValueError):
+        Model(_opt(jointNames=k0.jointNames[:-1]), kpath, regressor_init=False)
+    assert k0._dof_hash() != k1._dof_hash() != k2._dof_hash()
+
+
 def test_lin_deps_qr_on_given_regressor_matches_reference_algorithm():
     """computeRegressorLinDepsQR(regressor) = model.py:841-894 on the oracle's data regressor: bit-exact index set."""
     path = os.path.join(ROBOTS, "kuka_lwr4.topology.json")

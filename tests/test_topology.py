@@ -29,7 +29,20 @@ _URDF = """<robot name="t">
 def test_parse_rules(tmp_path):
     p = tmp_path / "t.urdf"
     p.write_text(_URDF)
-    t = parse_urdf(str(p))
+    # default serialisation = iDynTree's walk: the child whose joint comes LAST in the document is visited first
+    tt = parse_urdf(str(p))
+    assert tt.link_names == ["a", "c", "b"] and tt.parent == [-1, 0, 0]
+    assert tt.dof_names == ["j1", "j2"] and tt.dof_index == [-1, 0, 1]
+    assert tt.frames["sensor"]["link"] == 2 and tt.frames["world_box"]["link"] == 0
+    assert np.array_equal(tt.params[1], parse_urdf(str(p), link_order="document").params[2])
+    # explicit lists win; JSON round trip keeps the document ranks, so either order can be rebuilt from a stored topology
+    t4 = parse_urdf(str(p), link_names=["b", "a", "c"], joint_names=["j2", "j1"])
+    assert t4.link_names == ["b", "a", "c"] and t4.parent == [1, -1, 1] and t4.dof_index == [0, -1, 1] and t4.frames["sensor"]["link"] == 0
+    back = Topology.from_dict(json.loads(json.dumps(t4.to_dict()))).serialized("traversal", "traversal")
+    assert back.link_names == tt.link_names and back.dof_names == tt.dof_names and back.dof_index == tt.dof_index
+    with pytest.raises(ValueError):
+        parse_urdf(str(p), link_names=["a", "b"])
+    t = parse_urdf(str(p), link_order="document", dof_order="document")
     # fake root and fake leaf removed, document order kept, DOFs in document order of the movable joints
     assert t.link_names == ["a", "b", "c"]
     assert t.parent == [-1, 0, 0]
@@ -65,6 +78,36 @@ def test_kuka_apriori_vector_matches_tutorial_table():
     assert t.link_names == ["lwr_base_link"] + [f"lwr_{i}_link" for i in range(1, 8)]
     assert t.dof_names == [f"lwr_{i}_joint" for i in range(7)]
     assert abs(t.params[:, 0].sum() - g["apriori_mass"]) < 1e-12
+
+
+def test_default_serialisation_reproduces_the_reference_held_joint_lists():
+    """model/*_regressor.xml list the joints 'in the same order as reported when running without supplying a regressor file'
+    (walkman_regressor.xml:1), i.e. iDynTree's DOF serialisation (model.py:86-94); configs/walkman_static.yaml:60-64 repeats
+    the WALK-MAN list.  The default topology must reproduce them; URDF document order does not (WALK-MAN)."""
+    g = json.load(open(os.path.join(GOLDEN, "reference_joint_orders.json")))
+    for name in ("threeLinks", "kuka_lwr4", "walkman_left_arm", "walkman_apriori"):
+        t = load_topo(name)
+        assert t.dof_names == g[name], name
+        assert t.dof_order("traversal") == g[name]
+        # links follow the same walk: every link is numbered after its parent, DOFs ascend along the link order
+        assert all(t.parent[l] < l for l in range(t.num_links))
+        d = [x for x in t.dof_index if x >= 0]
+        assert d == sorted(d)
+        if os.path.isdir(REF_MODEL):
+            u = parse_urdf(os.path.join(REF_MODEL, name + ".urdf"))
+            assert u.link_names == t.link_names and u.dof_names == t.dof_names and u.parent == t.parent
+    w = load_topo("walkman_apriori")
+    assert w.dof_names == g["walkman_static_yaml"]
+    assert w.dof_order("document") != g["walkman_apriori"] and w.dof_order("document")[:3] == ["WaistLat", "WaistSag", "WaistYaw"]
+    assert w.link_names[:4] == ["Waist", "imu_link2", "imu_link", "LHipMot"] and w.link_names[-1] == "crane_ft"
+    doc = w.serialized("document", "document")
+    assert doc.link_names[:4] == ["Waist", "DWL", "DWS", "DWYTorso"]  # SURVEY.md Appendix A list
+    assert sorted(doc.link_names) == sorted(w.link_names)
+    # same physical robot: per-link parameters and frames follow their link
+    for n in w.link_names:
+        assert np.array_equal(w.params[w.link_names.index(n)], doc.params[doc.link_names.index(n)])
+    for f in w.frames:
+        assert w.link_names[w.frames[f]["link"]] == doc.link_names[doc.frames[f]["link"]]
 
 
 def test_structure_counts():

@@ -12,6 +12,9 @@ npz) and writes small derived fixtures; no reference source code is copied.
                                               model/kuka_lwr4.urdf.trajectory_opt_1.npz and its recorded
                                               n_observable_base_params (= 64)            (known answer F5)
   tests/golden/structure.json                 documented structure counts (links/DOF/base ranks)
+  tests/golden/reference_joint_orders.json    the DOF serialisations the reference holds: the <joint> lists of model/*_regressor.xml
+                                              ("same order as reported when running without supplying a regressor file",
+                                              model/walkman_regressor.xml:1) and the list in configs/walkman_static.yaml:60-64
   tests/golden/ref_host_functions.npz         seeded inputs and the OUTPUTS OF THE REFERENCE'S OWN pure NumPy/SciPy host
                                               functions run here: Data.preprocess (identification/data.py:369-619),
                                               helpers.getFrictionSignVelocities / getFrictionSignSeries
@@ -103,6 +106,21 @@ def main():
         n_observable_base_params=z["n_observable_base_params"],
     )
 
+    # --- reference-held DOF serialisations -----------------------------------------------
+    import xml.etree.ElementTree as ET
+
+    orders = {"source": "model/<robot>_regressor.xml <joint> lists (comments skipped); configs/walkman_static.yaml:60-64"}
+    for robot, xml in [("threeLinks", "threeLinks_regressor.xml"), ("kuka_lwr4", "kuka_lwr4_regressor.xml"),
+                       ("walkman_left_arm", "walkman_left_arm_regressor.xml"), ("walkman_apriori", "walkman_regressor.xml")]:
+        tree = ET.parse(os.path.join(REF, "model", xml)).getroot()
+        orders[robot] = [(e.text or "").strip() for e in tree.iter() if e.tag == "joint"]
+    with open(os.path.join(REF, "configs", "walkman_static.yaml")) as f:
+        lines = f.read().split("\n")[59:64]
+    orders["walkman_static_yaml"] = re.findall(r"'([A-Za-z0-9_]+)'", " ".join(lines))
+    assert orders["walkman_static_yaml"] == orders["walkman_apriori"] and len(orders["walkman_apriori"]) == 29
+    with open(os.path.join(golden, "reference_joint_orders.json"), "w") as f:
+        json.dump(orders, f, indent=1)
+
     # --- documented structure counts ----------------------------------------------------
     with open(os.path.join(golden, "structure.json"), "w") as f:
         json.dump(
@@ -130,7 +148,7 @@ def reference_host_functions(golden):
         def __getattr__(self, k):
             return ""
 
-    for name in ["idyntree", "idyntree.bindings", "colorama", "trimesh", "cvxpy"]:
+    for name in ["idyntree", "idyntree.bindings", "colorama", "trimesh"]:
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     sys.modules["colorama"].Fore = sys.modules["colorama"].Back = sys.modules["colorama"].Style = _Blank()
