@@ -280,8 +280,21 @@ def cpu_phases_bc_and_parity(eng, topo, Sc=4000):
     R_aug = np_(eng.tsqr(st, rhs=tau.reshape(-1, 1)))
     xb_gpu, _, _ = est.identify_base_parameters(R_aug, ic, P, M, add_contacts=False)
     xstd_gpu = est.find_std_from_base(K, xb_gpu)
+    # index-set audit (model.py:871-884): pivots of the product's rule (ties -> lowest column index, model.pivoted_qr) against
+    # LAPACK's own order on the same Gram bits -- how many of the reference's pivots are coin flips between exactly tied columns,
+    # and how many columns of the independent SET that moves (a tie between a link and a link welded to it straddles the rank)
+    from flobaroid_amd.model import pivoted_qr
+
+    Rr, Pr = pivoted_qr(R_struct)[1:]
+    dr, dl = np.abs(np.diag(Rr)), np.abs(np.diag(RQ))
+    differ = np.flatnonzero(Pr[:r] != PQ[:r])
     out["parity"] = {"samples": Sc, "xstd_rel_fro_err_gpu_vs_cpu": float(la.norm(xstd_gpu - xstd_cpu) / la.norm(xstd_cpu)),
-                     "xbase_rel_err": float(la.norm(xb_gpu - xb_cpu) / la.norm(xb_cpu)), "bar": 1e-6, "num_base_params": r}
+                     "xbase_rel_err": float(la.norm(xb_gpu - xb_cpu) / la.norm(xb_cpu)), "bar": 1e-6, "num_base_params": r,
+                     "pivot_rule_vs_lapack": {"rank_rule": int(np.count_nonzero(dr > 0.005)), "positions_differing": int(len(differ)),
+                                              "largest_rel_gap_at_those": float(max([abs(dr[i] - dl[i]) / dl[i] for i in differ], default=0.0)),
+                                              "index_set_columns_differing": int(len(set(Pr[:r].tolist()) - set(PQ[:r].tolist()))),
+                                              "note": "every differing position is an exact tie (gap at rounding level); "
+                                                      "tests/test_gpu_model.py rrW audits the same against the reference run's own order"}}
     return out, ic, K
 
 
@@ -421,7 +434,14 @@ def run_rank(args) -> int:
             "rhs_columns": 1,
             "parallelism": f"samples sharded over {world} GPU(s), one all-reduce of the (P+1)^2 fp64 Gram per step",
             "backend": args.backend,
+            # which engine ran the steps: the HIP library unless a test injected a stand-in with --engine (then this names it)
+            "engine": f"{type(eng).__module__}.{type(eng).__qualname__}" + (f" (injected with --engine {args.engine})" if args.engine else ""),
+            "serialisation": "links / DOFs in iDynTree traversal order (tests/golden/reference_joint_orders.json)",
         },
+        # `value` is the rate with the inputs resident in HBM (the bench contract: timed steps bracketed by barriers; ms_per_step is
+        # that region).  SURVEY 8(d) words the metric "incl. H2D of states": that rate is `value_incl_h2d` below (N = 1), measured on
+        # the same workload with pinned host inputs staged chunk by chunk on a copy stream.
+        "value_resident": value,
         # all world sizes reduce the same 1 M samples: these must agree (to rounding) between the N = 1, 2, 4, 8 lines
         "gram_checksum": {"trace": float(torch.trace(G_sharded).item()), "fro": float(torch.linalg.norm(G_sharded).item())},
         "roofline": {
@@ -439,6 +459,10 @@ def run_rank(args) -> int:
             "algorithmic_flop_per_sample": alg_flop_per_sample,
             # SURVEY 8(d)'s dense-symmetric flop count over the same launch time (exceeds what the hardware ran: not a fraction)
             "effective_dense_TFLOP_per_s": alg_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
+            # SURVEY 8(d) contract figure: dense-symmetric algorithmic flop / launch time / peak.  > 1 is possible and expected: the
+            # kernel skips the structurally zero k-steps, so this is NOT a hardware utilisation (`frac` is)
+            "contract_frac_dense": (alg_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 / PEAK_FP64_MFMA_TFLOPS) if avg_launch_s > 0 else 0.0,
+            "contract_frac_dense_note": ">1: structural zeros skipped; executed fraction is `frac`",
             "avg_launch_ms": avg_launch_s * 1e3,
             "launches": gram_n,
             "samples_per_launch": samples_per_launch,
