@@ -3,7 +3,9 @@
 The container part that feeds the hot path (loading, startOffset, concatenation, file_boundaries, skipSamples
 accounting) and the step before the path, ``preprocess`` (data.py:369-619): zero-phase
 Butterworth low-passes, median filters and 4th-order central differences that turn raw logs into q, dq, ddq, tau.
-Block selection (data.py:148-345) is out of scope."""
+Block selection (data.py:148-345: iterate the measurement blocks, keep the ones whose base regressor is best conditioned,
+drop near-duplicates, re-assemble) works from the path's small reductions: the condition numbers come from the triangular
+factor / the per-block Grams of the GPU pass (``getBlockStats``, ``getAllBlockStats``), never from a materialised YBase."""
 from __future__ import annotations
 
 from typing import Any
@@ -118,6 +120,146 @@ class Data:
     def updateNumSamples(self) -> None:
         self.num_selected_samples = self.samples["positions"].shape[0]
         self.num_used_samples = self.num_selected_samples // (self.opt["skipSamples"] + 1)
+
+    # ------------------------------------------------------------------ block selection (data.py:160-345)
+    def _slice_block(self, pos: int, size: int) -> dict[str, np.ndarray]:
+        return {k: (v if v.ndim == 0 else v[pos:pos + size]) for k, v in self.measurements.items()}
+
+    def removeLastSampleBlock(self) -> None:
+        """Drop the last ``blockSize`` selected samples again (data.py:160-177)."""
+        bs = self.opt["blockSize"]
+        n = self.num_selected_samples
+        for k in self.measurements.keys():
+            if self.samples[k].ndim:
+                self.samples[k] = self.samples[k][: n - bs]
+        self.updateNumSamples()
+
+    def getNextSampleBlock(self) -> None:
+        """Replace the working samples by the next measurement block (data.py:179-203); the last block may be shorter, and like
+        the reference ``opt['blockSize']`` is shrunk to it."""
+        self.block_pos += self.opt["blockSize"]
+        if self.block_pos + self.opt["blockSize"] > self.num_loaded_samples:
+            self.opt["blockSize"] = self.num_loaded_samples - self.block_pos
+        self.samples = self._slice_block(self.block_pos, self.opt["blockSize"])
+        self.updateNumSamples()
+
+    def block_positions(self) -> list[tuple[int, int]]:
+        """(start, size) of every block the reference's loop visits (identifier.py:1564-1583 with hasMoreSamples /
+        getNextSampleBlock): all multiples of blockSize below the number of loaded samples, the last one possibly short."""
+        bs, N = int(self.opt["blockSize"]), int(self.num_loaded_samples)
+        out, pos = [], 0
+        while True:
+            out.append((pos, min(bs, N - pos)))
+            if pos + bs >= N:
+                return out
+            pos += bs
+
+    def getBlockStats(self, model) -> None:
+        """Record (start, size, cond(YBase), per-link sub-regressor condition numbers) of the block the model was just evaluated
+        on (data.py:205-252).  cond(YBase) is the condition number of the triangular factor R with R^T R = YBase^T YBase
+        (``Model.base_factor``: the TSQR of the path, or a host QR of a materialised YBase) -- the same singular values as the
+        tall matrix the reference hands to ``numpy.linalg.cond``."""
+        self.model = model
+        R = model.base_factor()
+        self.seenBlocks.append((self.block_pos, self.opt["blockSize"], float(np.linalg.cond(R)), model.getSubregressorsConditionNumbers(R)))
+
+    def getAllBlockStats(self, model) -> None:
+        """The whole loop of identifier.py:1564-1583 in one pass over the measurements: the blocks do not depend on each other
+        (``getNextSampleBlock`` replaces the samples), so ``fbr_gram_grouped`` reduces every full block to its own Gram at once
+        (+ one plain Gram for a short last block) and the condition numbers are eigenvalues of nb x nb matrices:
+        cond(YBase_b) = sqrt(lmax / lmin) of G_b[ic, ic].  A block whose Gram is too ill conditioned for that (ratio > 1e13:
+        the smallest eigenvalue would carry < 3 digits) is re-done through its triangular factor (``fbr_tsqr_cols``)."""
+        self.model = model
+        skip = int(self.opt["skipSamples"]) + 1
+        blocks = self.block_positions()
+        ic = np.asarray(model.independent_cols)
+        cols_of_link = model.base_columns_of_links()
+
+        def stats_from_gram(G):
+            Gb = G[np.ix_(ic, ic)]
+            ev = np.linalg.eigvalsh(Gb)
+            if not ev[0] > 1e-13 * ev[-1]:
+                return None
+            conds = []
+            for cols in cols_of_link:
+                if not cols:
+                    conds.append(1e16)
+                    continue
+                e = np.linalg.eigvalsh(Gb[np.ix_(cols, cols)])
+                if not e[0] > 1e-13 * e[-1]:
+                    return None
+                conds.append(float(np.sqrt(e[-1] / e[0])))
+            return float(np.sqrt(ev[-1] / ev[0])), conds
+
+        def states_of(pos, size):
+            return model._states_from_samples(self.measurements, pos + np.arange(size // skip) * skip)
+
+        def stats_from_factor(pos, size):
+            R = np.asarray(model.engine.tsqr(states_of(pos, size), cols=ic.astype(np.int32)))
+            return float(np.linalg.cond(R)), model.getSubregressorsConditionNumbers(R)
+
+        full = [b for b in blocks if b[1] == blocks[0][1]]
+        rest = [b for b in blocks if b[1] != blocks[0][1]]
+        results = {}
+        if full and full[0][1] // skip > 0:
+            used = full[0][1] // skip
+            idx = np.concatenate([pos + np.arange(used) * skip for pos, _ in full])
+            Gs = np.asarray(model.engine.gram_grouped(model._states_from_samples(self.measurements, idx), len(full)))
+            for (pos, size), G in zip(full, Gs):
+                results[pos] = stats_from_gram(G)
+        for pos, size in rest:
+            results[pos] = stats_from_gram(np.asarray(model.engine.gram(states_of(pos, size)))) if size // skip > 0 else None
+        for pos, size in blocks:
+            st = results.get(pos)
+            if st is None:
+                st = stats_from_factor(pos, size)
+            self.seenBlocks.append((pos, size, st[0], st[1]))
+
+    def selectBlocks(self) -> None:
+        """Keep the blocks whose condition number is within the best ``selectBestPerenctage`` percent, then thin out blocks
+        whose per-link condition patterns are near-duplicates (variance of the link condition numbers within 15 % of a
+        neighbour in sorted order: of two close ones the first goes, of three the middle one) -- data.py:254-312."""
+        conds = np.array([b[2] for b in self.seenBlocks], dtype=float)
+        limit = np.percentile(conds, self.opt["selectBestPerenctage"])
+        for blk in self.seenBlocks:
+            (self.unusedBlocks if blk[2] > limit else self.usedBlocks).append(blk)
+        c = len(self.usedBlocks)
+        if c == 0:
+            return
+        var = np.var(np.array([blk[3] for blk in self.usedBlocks], dtype=float).reshape(c, -1), axis=1)
+        order = np.argsort(var)
+        sv = var[order]
+        drop, rel, i = [], 0.15, 1
+        while i < c:
+            if i < c - 1 and abs(sv[i - 1] - sv[i + 1]) < abs(sv[i + 1]) * rel:
+                drop.append(order[i])
+                i += 1
+            elif abs(sv[i - 1] - sv[i]) < abs(sv[i]) * rel:
+                drop.append(order[i - 1])
+            i += 1
+        for d in np.sort(drop)[::-1]:
+            del self.usedBlocks[d]
+
+    def assembleSelectedBlocks(self) -> None:
+        """Concatenate the selected blocks into the working samples (data.py:314-345): 2-D channels stacked, every 1-D channel
+        continued like a clock (re-based to start one step after the previous block's last value), scalars / the contact
+        dictionary kept whole, as the reference does."""
+        if self.usedBlocks:
+            out = {}
+            for k, m in self.measurements.items():
+                if m.ndim == 0:
+                    out[k] = m
+                    continue
+                b0, s0 = self.usedBlocks[0][0], self.usedBlocks[0][1]
+                acc = m[b0:b0 + s0]
+                for b, bs, _, _ in self.usedBlocks[1:]:
+                    mv = m[b:b + bs]
+                    if m.ndim == 1:
+                        mv = mv - mv[0] + (mv[1] - mv[0]) + acc[-1]
+                    acc = np.concatenate((acc, mv), axis=0)
+                out[k] = acc
+            self.samples = out
+        self.updateNumSamples()
 
     # ------------------------------------------------------------------ step before the path (N2)
     @staticmethod

@@ -212,6 +212,56 @@ def wls_row_weights(p_sigma_x: np.ndarray, num_used_samples: int, rows_total: in
     return d[:rows_total].copy()
 
 
+def wls_reference_weights(p_sigma_x: np.ndarray, num_used_samples: int, rows_total: int) -> np.ndarray:
+    """The diagonal the reference's WLS pass really builds (identifier.py:769-774): ``scipy.sparse.spdiags`` of
+    ``np.repeat([1 / p_sigma_x], num_used_samples)`` on an r x r matrix -- entries beyond r are ignored, and when the repeated
+    vector is SHORTER than r the rest of the diagonal is zero (those rows drop out of the fit)."""
+    d = np.repeat(1.0 / np.asarray(p_sigma_x, dtype=float), int(num_used_samples))[:rows_total]
+    return np.concatenate((d, np.zeros(rows_total - d.shape[0])))
+
+
+def wls_reference_compat_rhs(w: np.ndarray, tau: np.ndarray, contact_forces: np.ndarray | None = None) -> np.ndarray:
+    """Right-hand sides that make the weighted reductions reproduce the reference's WLS numbers (``opt['wlsReferenceCompat']``).
+
+    identifier.py:777-789 weights YBase (and model.tau) with G = diag(w) but then solves with the function's LOCAL, unweighted
+    ``tau``: xBase = lstsq(G YBase, tau) - pinv(G YBase) contactForcesSum.  ``fbr_gram_accumulate`` / ``fbr_tsqr`` apply the
+    row weight to Y and to the rhs columns alike, so the same numbers come out of rhs columns divided by w beforehand
+    (rows of weight zero contribute nothing on either side: 0)."""
+    w = np.asarray(w, dtype=float)
+    cols = [np.asarray(tau, dtype=float).reshape(-1)]
+    cols.append(np.zeros_like(cols[0]) if contact_forces is None else np.asarray(contact_forces, dtype=float).reshape(-1))
+    out = np.zeros((w.shape[0], 2))
+    nz = w != 0
+    for c, v in enumerate(cols):
+        out[nz, c] = v[nz] / w[nz]
+    return out
+
+
+def identify_base_parameters_wls(engine, states: dict, tau: np.ndarray, contact_forces, independent_cols, p_sigma_x: np.ndarray,
+                                 reference_compat: bool = False):
+    """The IDIM-WLS pass (identifier.py:739-790) as ONE weighted TSQR of [YBase | tau | contactForcesSum] on the device.
+
+    ``reference_compat=False``: the textbook form -- the row weights apply to Y, tau and the contact forces alike
+    (``wls_row_weights``).  ``reference_compat=True`` (``opt['wlsReferenceCompat']``): the reference's numbers --
+    ``wls_reference_weights`` on Y only (``wls_reference_compat_rhs``).  Returns (xBase, R_aug_base, w)."""
+    S = np.asarray(states["q"]).shape[0]
+    rows = S * engine.rows
+    ic = np.asarray(independent_cols, dtype=np.int32)
+    tau = np.asarray(tau, dtype=float).reshape(-1)
+    if reference_compat:
+        w = wls_reference_weights(p_sigma_x, S, rows)
+        rhs = wls_reference_compat_rhs(w, tau, contact_forces)
+    else:
+        w = wls_row_weights(p_sigma_x, S, rows)
+        rhs = np.column_stack((tau, np.zeros(rows) if contact_forces is None else np.asarray(contact_forces, dtype=float).reshape(-1)))
+    Rb = np.asarray(engine.tsqr(states, rhs=np.ascontiguousarray(rhs), w=w, cols=ic))
+    nb = ic.size
+    xBase, _ = lstsq_from_R(Rb, nb, 0, rows)
+    if contact_forces is not None:
+        xBase = xBase - pinv_apply_from_R(Rb, nb, 1)
+    return xBase, Rb, w
+
+
 def _regularized_neg_log_det(ev: np.ndarray, dopt_regularization: float) -> np.ndarray:
     """-sum(log(max(ev + delta, 1e-300))) along the last axis with the reference's per-trajectory
     delta = doptRegularization * max(lambda_max, 1e-30) (trajectoryOptimizer.py:267-272; eigvalsh returns ascending values)."""

@@ -626,16 +626,30 @@ class Model:
             self._build_symbols()
         return self._base_deps
 
-    def getSubregressorsConditionNumbers(self):  # model.py:1054-1086
+    def base_columns_of_links(self) -> list[list[int]]:
+        """Per link the base-regressor columns that depend on one of its standard parameters: row j of K has a non-zero in the
+        link's columns (the reference asks sympy whether a parameter symbol is free in base_deps[j], model.py:1069-1076)."""
+        idp = {k: i for i, k in enumerate(self.identified_params)}
+        out = []
+        for i in range(self.num_links):
+            cols = [idp[k] for k in range(i * 10, i * 10 + 10) if k in idp]
+            out.append([j for j in range(self.num_base_params) if np.any(self.K[j, cols] != 0)])
+        return out
+
+    def base_factor(self) -> np.ndarray:
+        """Upper-triangular R with R^T R = YBase^T YBase (same singular values as YBase): the TSQR of the path when YBase is
+        the plain column gather of the regressor, a host QR when it was post-processed on the host (filterRegressor,
+        useBasisProjection) or no states are attached."""
+        plain = not (self.opt.get("filterRegressor") or self.opt.get("useBasisProjection"))
+        if plain and getattr(self, "_states", None) is not None:
+            return np.asarray(self.engine.tsqr(self._states, cols=np.asarray(self.independent_cols, dtype=np.int32)))
+        return np.linalg.qr(np.asarray(self.YBase), mode="r")
+
+    def getSubregressorsConditionNumbers(self, R=None):  # model.py:1054-1086
+        """Condition number of the base sub-regressor of every link.  cond(YBase[:, cols]) = cond(R[:, cols]) for the
+        triangular factor R of YBase, so nothing tall is touched (R: ``base_factor()``, computed when not given)."""
         import numpy.linalg as la
 
-        conds = []
-        idp = list(self.identified_params)
-        for i in range(self.num_links):
-            cols = [idp.index(k) for k in range(i * 10, i * 10 + 10) if k in idp]
-            base_columns = [j for j in range(self.num_base_params) if np.any(self.K[j, cols] != 0)]
-            if not base_columns:
-                conds.append(1e16)
-            else:
-                conds.append(la.cond(np.asarray(self.YBase)[:, base_columns]))
-        return conds
+        if R is None:
+            R = self.base_factor()
+        return [1e16 if not cols else float(la.cond(R[:, cols])) for cols in self.base_columns_of_links()]

@@ -378,3 +378,86 @@ def test_walkman_measurements_in_the_reference_joint_order_need_no_regressor_fil
     sign = helpers.getFrictionSignSeries({"velocities": std["dq"]}, c.opt)
     Yo = om.regressor(std, sign).reshape(S, 35, -1)[:, rows][:, :, colmap]
     assert np.abs(Ya - Yo).max() <= 1e-11 * np.abs(Yo).max()
+
+
+def test_block_statistics_from_the_gpu_reductions_match_the_reference(tmp_path):
+    """Data.getBlockStats / getAllBlockStats (data.py:205-252) on the GPU against the reference's own numbers
+    (tests/golden/ref_blocks_wls.npz: numpy.linalg.cond of every block's tall YBase and of its per-link sub-regressors,
+    Model.getSubregressorsConditionNumbers, model.py:1054-1086): (a) the reference's loop with our classes -- computeRegressors on
+    the block, then the condition numbers from the TSQR factor of the block; (b) all blocks in ONE grouped Gram pass
+    (fbr_gram_grouped + eigvalsh); then the same selection and re-assembly."""
+    import json
+
+    from common import GOLDEN
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model
+
+    z = np.load(os.path.join(GOLDEN, "ref_blocks_wls.npz"), allow_pickle=True)
+    opt0 = json.loads(str(z["bl_opt"]))
+    meas = {k[len("bl_in_"):]: z[k] for k in z.files if k.startswith("bl_in_")}
+    fn = str(tmp_path / "blocks.npz")
+    np.savez(fn, **meas)
+    path = str(tmp_path / "kuka_lwr4.topology.json")
+    load_topo("kuka_lwr4").save_json(path)
+
+    def fresh():
+        opt = _opt(**opt0)
+        m = Model(opt, path, regressor_init=False)
+        ic = z["bl_independent_cols"]
+        nb = int(z["bl_num_base_params"])
+        m.independent_cols, m.K, m.num_base_params, m.num_base_inertial_params = ic, z["bl_K"], nb, nb
+        m.Pb = np.eye(m.num_identified_params)[:, ic]
+        m.identified_params = list(range(m.num_identified_params))
+        d = Data(opt)
+        d.init_from_files([[fn]])
+        return m, d
+
+    # (a) block by block, as identifier.py:1564-1583 drives it
+    m, d = fresh()
+    while True:
+        m.computeRegressors(d)
+        d.getBlockStats(m)
+        if d.hasMoreSamples():
+            d.getNextSampleBlock()
+        else:
+            break
+    # (b) one pass
+    m2, d2 = fresh()
+    d2.getAllBlockStats(m2)
+    for dd, tol in ((d, 1e-9), (d2, 1e-7)):   # (b) squares the condition number: ~1e3^2 * eps
+        assert [b[0] for b in dd.seenBlocks] == z["bl_seen_pos"].tolist() and [b[1] for b in dd.seenBlocks] == z["bl_seen_size"].tolist()
+        got = np.array([b[2] for b in dd.seenBlocks])
+        assert np.abs(got / z["bl_seen_cond"] - 1).max() <= tol
+        lc = np.array([b[3] for b in dd.seenBlocks])
+        ref = z["bl_seen_linkconds"]
+        fin = ref < 1e15
+        assert np.array_equal(lc >= 1e15, ~fin)
+        assert np.abs(lc[fin] / ref[fin] - 1).max() <= tol
+        dd.selectBlocks()
+        assert [b[0] for b in dd.usedBlocks] == z["bl_used_pos"].tolist() and [b[0] for b in dd.unusedBlocks] == z["bl_unused_pos"].tolist()
+        dd.assembleSelectedBlocks()
+        for k in meas:
+            assert np.allclose(dd.samples[k], z["bl_out_" + k], rtol=0, atol=1e-14), k
+    # the re-assembled samples feed the next estimation like any other data
+    m.computeRegressors(d)
+    assert np.asarray(m.YStd).shape[0] == d.num_used_samples * m.N_OUT
+
+
+@pytest.mark.parametrize("tag", ["wlsA", "wlsB"])
+def test_wls_pass_on_the_gpu_matches_the_reference(tag):
+    """estimation.identify_base_parameters_wls(reference_compat=True): xBase of the reference's own useWLS = 1 run
+    (identifier.py:739-790; tests/golden/ref_blocks_wls.npz) from ONE weighted fbr_tsqr_cols call; the textbook form differs."""
+    from common import GOLDEN
+    from flobaroid_amd import estimation as est
+    from flobaroid_amd._lib import Engine
+
+    z = np.load(os.path.join(GOLDEN, "ref_blocks_wls.npz"), allow_pickle=True)
+    t = load_topo("threeLinks")
+    st = {k: z["%s_st_%s" % (tag, k)] for k in ("q", "dq", "ddq", "base_vel", "base_acc", "rpy")}
+    eng = Engine(t, floating=True)
+    xB, Rb, w = est.identify_base_parameters_wls(eng, st, z[tag + "_tau"], z[tag + "_cf"], z[tag + "_independent_cols"], z[tag + "_p_sigma_x"],
+                                                 reference_compat=True)
+    assert la.norm(xB - z[tag + "_xBase"]) <= 1e-9 * la.norm(z[tag + "_xBase"])
+    xT, _, _ = est.identify_base_parameters_wls(eng, st, z[tag + "_tau"], z[tag + "_cf"], z[tag + "_independent_cols"], z[tag + "_p_sigma_x"])
+    assert la.norm(xT - xB) > 1e-6 * la.norm(xB)   # (the reference's form is NOT the textbook WLS)
+    eng.close()

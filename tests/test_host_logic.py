@@ -652,3 +652,71 @@ def test_basis_projection_matches_the_reference_code_outputs(tag):
     for e in deps:
         syms |= getattr(e, "free_symbols", set())
     assert [p for p in range(m.num_all_params) if m.param_syms[p] not in syms] == list(m.non_id)
+
+
+def _blocks_fixture():
+    z = np.load(os.path.join(GOLDEN, "ref_blocks_wls.npz"), allow_pickle=True)
+    opt = json.loads(str(z["bl_opt"]))
+    meas = {k[len("bl_in_"):]: z[k] for k in z.files if k.startswith("bl_in_")}
+    return z, opt, meas
+
+
+def test_block_selection_logic_matches_the_reference(tmp_path):
+    """Data.hasMoreSamples / getNextSampleBlock / selectBlocks / assembleSelectedBlocks (data.py:148-345) against the outputs of the
+    reference's own methods run as the loop of identifier.py:1564-1586 (tests/golden/ref_blocks_wls.npz): same blocks visited, same
+    blocks kept after the percentile cut and the near-duplicate thinning (block 3 repeats block 1), same re-assembled channels
+    (2-D stacked, 1-D continued like a clock)."""
+    z, opt, meas = _blocks_fixture()
+    fn = str(tmp_path / "blocks.npz")
+    np.savez(fn, **meas)
+    d = Data(dict(opt, verbose=0, showTiming=0))
+    d.init_from_files([[fn]])
+    assert d.block_positions() == list(zip(z["bl_seen_pos"].tolist(), z["bl_seen_size"].tolist()))
+    visited = []
+    i = 0
+    while True:  # the caller's loop, the condition numbers taken from the fixture
+        assert d.samples["positions"].shape[0] == int(z["bl_seen_size"][i])
+        assert np.array_equal(d.samples["positions"], meas["positions"][d.block_pos:d.block_pos + d.opt["blockSize"]])
+        d.seenBlocks.append((d.block_pos, d.opt["blockSize"], float(z["bl_seen_cond"][i]), list(z["bl_seen_linkconds"][i])))
+        visited.append(d.block_pos)
+        i += 1
+        if d.hasMoreSamples():
+            d.getNextSampleBlock()
+        else:
+            break
+    assert visited == z["bl_seen_pos"].tolist() and d.opt["blockSize"] == 40  # (the reference shrinks opt['blockSize'] on the last block)
+    d.model = type("M", (), {"getSubregressorsConditionNumbers": lambda self: None})()
+    d.selectBlocks()
+    assert [b[0] for b in d.usedBlocks] == z["bl_used_pos"].tolist() and [b[0] for b in d.unusedBlocks] == z["bl_unused_pos"].tolist()
+    d.assembleSelectedBlocks()
+    assert d.num_selected_samples == int(z["bl_num_selected"]) and d.num_used_samples == int(z["bl_num_used"])
+    for k in meas:
+        want = z["bl_out_" + k]
+        assert d.samples[k].shape == want.shape and np.allclose(d.samples[k], want, rtol=0, atol=1e-14), k
+    d.removeLastSampleBlock()
+    assert d.num_selected_samples == int(z["bl_num_selected"]) - 40
+
+
+@pytest.mark.parametrize("tag", ["wlsA", "wlsB"])
+def test_wls_reference_compat_matches_the_reference(tag):
+    """opt['wlsReferenceCompat']: the numbers of the reference's own IDIM-WLS pass (identifier.py:739-790, useWLS = 1, without and
+    with a-priori torques) from weighted reductions: Y weighted with the zero-padded spdiags diagonal, tau and the contact forces NOT
+    (the reference recurses with its local, unweighted tau)."""
+    z = np.load(os.path.join(GOLDEN, "ref_blocks_wls.npz"), allow_pickle=True)
+    t = load_topo("threeLinks")
+    st = {k: z["%s_st_%s" % (tag, k)] for k in ("q", "dq", "ddq", "base_vel", "base_acc", "rpy")}
+    Y = OracleModel(t, floating=True).regressor(st)
+    S = st["q"].shape[0]
+    ic = z[tag + "_independent_cols"]
+    w = est.wls_reference_weights(z[tag + "_p_sigma_x"], S, Y.shape[0])
+    assert w.shape == (Y.shape[0],) and np.array_equal(w[:S], np.full(S, 1.0 / z[tag + "_p_sigma_x"][0]))
+    rhs = est.wls_reference_compat_rhs(w, z[tag + "_tau"], z[tag + "_cf"])
+    A = np.column_stack([Y, rhs]) * w[:, None]
+    R_aug = la.qr(A, mode="r")
+    xB, _, _ = est.identify_base_parameters(R_aug, ic, Y.shape[1], Y.shape[0])
+    assert la.norm(xB - z[tag + "_xBase"]) <= 1e-9 * la.norm(z[tag + "_xBase"])
+    # zero padding when the repeated vector is shorter than the row count (spdiags leaves the rest of the diagonal at 0)
+    w2 = est.wls_reference_weights(np.array([2.0, 4.0]), 3, 8)
+    assert np.array_equal(w2, [0.5, 0.5, 0.5, 0.25, 0.25, 0.25, 0.0, 0.0])
+    r2 = est.wls_reference_compat_rhs(w2, np.arange(8.0), None)
+    assert np.array_equal(r2[:, 0] * w2, [0, 1, 2, 3, 4, 5, 0, 0]) and not r2[:, 1].any()

@@ -35,6 +35,11 @@ npz) and writes small derived fixtures; no reference source code is copied.
                                               contacts on both feet + friction + a-priori torques, getRandomRegressor (10000 random states),
                                               computeRegressorLinDepsQR (minTol 0.005: P, rank, independent columns, K, non_id) and
                                               SDP._observabilityWeights (identification/sdp.py:295-315)
+  tests/golden/ref_blocks_wls.npz             (round 3) the reference's own block selection -- Data.getBlockStats / hasMoreSamples / getNextSampleBlock /
+                                              selectBlocks / assembleSelectedBlocks (identification/data.py:148-345) with
+                                              Model.getSubregressorsConditionNumbers (model.py:1054-1086), run as the loop of identifier.py:1564-1586
+                                              on a seeded KUKA file -- and its IDIM-WLS pass, Identification.identifyBaseParameters with useWLS = 1
+                                              (identifier.py:739-790), with and without a-priori torques
   tests/golden/ref_compute_regressors.npz     the reference's own Model.computeRegressors + simulateDynamicsIDynTree
                                               (identification/model.py:239-632) executed on small sample sets with the
                                               iDynTree calls answered by this repository's CPU oracle (a minimal object shim:
@@ -571,8 +576,120 @@ def reference_compute_regressors(golden):
     print("ref_walkman.npz:", len(outW), "arrays, rank", fm.num_base_params)
 
 
+def reference_blocks_and_wls(golden):
+    """Golden vectors of the reference's block selection and WLS pass (see the module docstring)."""
+    import tempfile
+    import types
+    from types import SimpleNamespace as NS
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from common import load_topo, random_states
+    from oracle.oracle import OracleModel
+
+    rmodel = _import_reference("identification.model")
+    rdata = _import_reference("identification.data")
+    rident = _import_reference("identifier")
+    out = {}
+
+    # ---- block selection on KUKA (fixed base): 640 samples = 6 blocks of 100 + one of 40; block 3 repeats block 1
+    t = load_topo("kuka_lwr4")
+    n, L = t.num_dofs, t.num_links
+    om = OracleModel(t)
+    rng = np.random.default_rng(61)
+    Ys = om.regressor(random_states(t, 300, rng, 0, use_limits=True))
+    fm = NS(opt={"minTol": 1e-4, "useBasisProjection": 0, "orthogonalizeBasis": 1, "identifyGravityParamsOnly": 0, "identifyFrictionSimultaneously": 0,
+                 "identifySymmetricVelFriction": 1, "stribeckVelocity": 0, "randomSamples": 0, "verbose": 0},
+            num_dofs=n, num_links=L, num_model_params=10 * L, num_all_params=10 * L, num_identified_params=10 * L)
+    rmodel.Model.computeRegressorLinDepsQR(fm, regressor=Ys)
+    fm.getSubregressorsConditionNumbers = types.MethodType(rmodel.Model.getSubregressorsConditionNumbers, fm)
+    S, bs, skip = 640, 100, 1
+    st = random_states(t, S, rng, 0, use_limits=True)
+    scale = np.ones(S)
+    for b, f in enumerate((1.0, 0.5, 0.12, 0.5, 1.0, 0.3, 0.08)):  # differently exciting blocks -> a spread of condition numbers
+        scale[b * bs:(b + 1) * bs] = f
+    for k in ("dq", "ddq"):
+        st[k] = st[k] * scale[:, None]
+    for k in ("q", "dq", "ddq"):
+        st[k][3 * bs:4 * bs] = st[k][1 * bs:2 * bs]
+    meas = {"positions": st["q"], "velocities": st["dq"], "accelerations": st["ddq"], "torques": rng.standard_normal((S, n)),
+            "times": 0.005 * np.arange(S), "frequency": np.array(200.0), "aux1d": rng.standard_normal(S)}
+    tmp = tempfile.mkdtemp()
+    fn = os.path.join(tmp, "blocks.npz")
+    np.savez(fn, **meas)
+    opt = {"startOffset": 0, "skipSamples": skip, "verbose": 0, "showTiming": 0, "selectBlocksFromMeasurements": 1, "blockSize": bs,
+           "selectBestPerenctage": 70}
+    d = rdata.Data(opt)
+    d.init_from_files([[fn]])
+    ic = np.asarray(fm.independent_cols)
+    while True:
+        used = d.num_used_samples
+        idx = np.arange(used) * (skip + 1)
+        sb = {"q": d.samples["positions"][idx], "dq": d.samples["velocities"][idx], "ddq": d.samples["accelerations"][idx]}
+        fm.YBase = om.regressor(sb)[:, ic]
+        d.getBlockStats(fm)
+        if d.hasMoreSamples():
+            d.getNextSampleBlock()
+        else:
+            break
+    seen = list(d.seenBlocks)
+    d.selectBlocks()
+    d.assembleSelectedBlocks()
+    for k, v in meas.items():
+        out["bl_in_" + k] = v
+    out.update(bl_opt=json.dumps({"startOffset": 0, "skipSamples": skip, "selectBlocksFromMeasurements": 1, "blockSize": bs, "selectBestPerenctage": 70}),
+               bl_independent_cols=ic, bl_K=fm.K, bl_num_base_params=fm.num_base_params,
+               bl_seen_pos=np.array([b[0] for b in seen]), bl_seen_size=np.array([b[1] for b in seen]), bl_seen_cond=np.array([b[2] for b in seen]),
+               bl_seen_linkconds=np.array([b[3] for b in seen]), bl_used_pos=np.array([b[0] for b in d.usedBlocks]),
+               bl_unused_pos=np.array([b[0] for b in d.unusedBlocks]), bl_num_selected=d.num_selected_samples, bl_num_used=d.num_used_samples)
+    for k, v in d.samples.items():
+        out["bl_out_" + k] = np.asarray(v)
+    print("blocks: seen", [(b[0], b[1], round(b[2], 1)) for b in seen], "used", [b[0] for b in d.usedBlocks], "unused", [b[0] for b in d.unusedBlocks])
+
+    # ---- IDIM-WLS (identifier.py:739-790) on the threeLinks floating problem, without and with a-priori torques
+    t = load_topo("threeLinks")
+    S = 50
+    for tag, useAP, seed in (("wlsA", 0, 71), ("wlsB", 1, 72)):
+        rng = np.random.default_rng(seed)
+        st = random_states(t, S, rng, 1, use_limits=True)
+        Y = OracleModel(t, floating=True).regressor(st)
+        rows = Y.shape[0] // S
+        fmw = NS(opt={"minTol": 1e-8, "useBasisProjection": 0, "orthogonalizeBasis": 1, "identifyGravityParamsOnly": 0, "identifyFrictionSimultaneously": 0,
+                      "identifySymmetricVelFriction": 1, "stribeckVelocity": 0, "randomSamples": 0}, num_dofs=t.num_dofs, num_links=t.num_links,
+                 num_model_params=30, num_all_params=30, num_identified_params=30)
+        rmodel.Model.computeRegressorLinDepsQR(fmw, regressor=Y)
+        x_true = t.x_std() * (1.0 + 0.1 * rng.standard_normal(30))
+        cf = 0.05 * rng.standard_normal(Y.shape[0])
+        torques = Y @ x_true + cf + 0.01 * rng.standard_normal(Y.shape[0])
+        torquesAP = Y @ t.x_std()
+        fmw.YStd, fmw.YBase, fmw.xStdModel = Y, Y @ fmw.Pb, t.x_std()
+        fmw.torques_stack, fmw.torquesAP_stack = torques, torquesAP
+        fmw.tau = torques - torquesAP if useAP else torques.copy()
+        fmw.tauMeasured = torques.reshape(S, rows)
+        fmw.contactForcesSum = cf
+        o = {"useBasisProjection": 0, "addContacts": 1, "showBaseParams": 0, "verbose": 0, "useRegressorRegularization": 0, "useWLS": 1,
+             "useAPriori": useAP, "floatingBase": 1, "skipSamples": 0, "showTiming": 0, "estimateWith": "base", "identifyFrictionSimultaneously": 1,
+             "showErrorHistogram": 0}
+        idf = NS(opt=o, model=fmw, data=NS(num_used_samples=S), urdf_file_real=None)
+        idf.estimateRegressorTorques = types.MethodType(rident.Identification.estimateRegressorTorques, idf)
+        idf.getStdDevForParams = types.MethodType(rident.Identification.getStdDevForParams, idf)
+        idf.identifyBaseParameters = types.MethodType(rident.Identification.identifyBaseParameters, idf)
+        tau_in = fmw.tau.copy()
+        idf.identifyBaseParameters()
+        for k in ("q", "dq", "ddq", "base_vel", "base_acc", "rpy"):
+            out["%s_st_%s" % (tag, k)] = st[k]
+        out.update({tag + "_meta": json.dumps({"robot": "threeLinks", "S": S, "useAPriori": useAP}), tag + "_independent_cols": np.asarray(fmw.independent_cols),
+                    tag + "_tau": tau_in, tag + "_cf": cf, tag + "_torques": torques, tag + "_torquesAP": torquesAP, tag + "_p_sigma_x": idf.p_sigma_x,
+                    tag + "_xBase": fmw.xBase.copy(), tag + "_model_tau_after": np.asarray(fmw.tau).reshape(-1)})
+    np.savez_compressed(os.path.join(golden, "ref_blocks_wls.npz"), **out)
+    print("ref_blocks_wls.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "blocks_wls":
+        reference_blocks_and_wls(os.path.join(REPO, "tests", "golden"))
+        sys.exit(0)
     main()
     reference_host_functions(os.path.join(REPO, "tests", "golden"))
     reference_estimators(os.path.join(REPO, "tests", "golden"))
     reference_compute_regressors(os.path.join(REPO, "tests", "golden"))
+    reference_blocks_and_wls(os.path.join(REPO, "tests", "golden"))
