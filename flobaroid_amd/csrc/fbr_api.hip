@@ -922,7 +922,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         const int blocks_per_cu = (two_per_cu && h->lds_bytes <= 79 * 1024) ? 2 : 1;
         const int FBR_NPW = h->prog.cfg.npw();
         const bool timing = getenv("FBR_GRAM_TIMING") != nullptr;
-        typedef void (*gram_fn)(DevGram, long, int, const double *, double *, unsigned long long *);
+        typedef void (*gram_fn)(DevGram, long, int, const double *, double *, unsigned long long *, int);
         const gram_fn gram_kernel = two_per_cu ? (timing ? fbr_gram_kernel<true, 5, 2> : fbr_gram_kernel<false, 5, 2>)
                                                : (timing ? fbr_gram_kernel<true, FBR_ONE_SEGW, FBR_ONE_NSEG> : fbr_gram_kernel<false, FBR_ONE_SEGW, FBR_ONE_NSEG>);
         HIPCHK(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -963,6 +963,20 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             }
         }
         const long nchunks = (long)items.size();
+        // workgroups per group of a launch: every resident workgroup slot is used (see the launch below)
+        auto wpg_of = [&](long cs, int ng) {
+            static const int oversub_env = getenv("FBR_GROUP_OVERSUB") ? std::max(1, atoi(getenv("FBR_GROUP_OVERSUB"))) : 0;
+            const long spg_max = std::max(1L, cs / ng);
+            const int rounds = ng > 1 ? (oversub_env ? oversub_env : (T > 1 ? 4 : 2)) : 1;
+            int wpg = std::max(T, (rounds * m->num_cus * blocks_per_cu) / ng);
+            if ((long)wpg > (long)T * spg_max) wpg = (int)((long)T * spg_max);
+            return std::min(wpg, 0xffff);
+        };
+        // One reduction per call: when every chunk of a single-group call has the same launch shape, a workgroup carries its partial
+        // sums from chunk to chunk (the accumulators start from the partial-sum buffer) and fbr_gram_reduce_kernel runs once, after
+        // the last chunk -- 15 of the 16 reductions of a 1 M-sample WALK-MAN pass (72 us each, between two Gram launches) go away.
+        bool carry_ok = ngroups == 1 && nchunks > 1 && !timing && !getenv("FBR_GRAM_NO_CARRY");
+        for (long ci = 1; ci < nchunks && carry_ok; ci++) carry_ok = wpg_of(items[ci].cs, 1) == wpg_of(items[0].cs, 1);
         for (int b = 0; b < (nchunks > 1 ? 2 : 1); b++)
             if ((size_t)ch * img_bytes > h->pimg[b].bytes) {
                 if ((rc = h->pimg[b].ensure((size_t)ch * img_bytes))) return rc;
@@ -1043,16 +1057,11 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             HIPCHK(hipStreamWaitEvent(m->stream, m->ev_pack[b], 0));
             // every resident workgroup slot is used: the slots of a sample group are dealt to the parts by cost (fbr_gram_deal),
             // a part's workgroups split the group's samples evenly.  Tiny batches: no more workgroups than samples per part.
-            const long spg_max = std::max(1L, cs / ng);
             // Grouped launches (many short candidates) are oversubscribed: with one round of resident workgroups a group gets too few
             // of them to follow the parts' costs (WALK-MAN, 64 groups x 2000 samples: 5 per group, 15.4 ms; 4 rounds: 11.8 ms; KUKA
             // 0.92 -> 0.90 ms with 2 rounds) and the hardware dispatcher evens out the rest.  Bulk launches lose 17 % when
             // oversubscribed (late workgroups run beside the producer kernels of the next chunk): one round, dealt by cost.
-            static const int oversub_env = getenv("FBR_GROUP_OVERSUB") ? std::max(1, atoi(getenv("FBR_GROUP_OVERSUB"))) : 0;
-            const int rounds = ng > 1 ? (oversub_env ? oversub_env : (T > 1 ? 4 : 2)) : 1;
-            int wpg = std::max(T, (rounds * m->num_cus * blocks_per_cu) / ng);
-            if ((long)wpg > (long)T * spg_max) wpg = (int)((long)T * spg_max);
-            if (wpg > 0xffff) wpg = 0xffff;
+            const int wpg = wpg_of(cs, ng);
             GramHolder::Deal deal;
             if ((rc = get_deal(h, wpg, &deal, base_only))) return rc;
             DevGram dg = h->dev;
@@ -1075,7 +1084,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             {
                 ProfScope ps(m, FBR_PROF_GRAM);
                 hipLaunchKernelGGL(gram_kernel, dim3(NW), dim3(FBR_WPB * 64), h->lds_bytes, m->stream, dg, cs, ng,
-                                   h->pimg[b].as<double>(), m->partial.as<double>(), dbg);
+                                   h->pimg[b].as<double>(), m->partial.as<double>(), dbg, (carry_ok && ci > 0) ? 1 : 0);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(m->ev_gram[b], m->stream));
@@ -1102,7 +1111,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                     fprintf(stderr, "\n");
                 }
             }
-            {
+            if (!carry_ok || ci + 1 == nchunks) {
                 ProfScope ps(m, FBR_PROF_REDUCE);
                 hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW, ng), dim3(256), 0, m->stream, dg,
                                    m->partial.as<double>(), G + (size_t)items[ci].g0 * Pa * Pa);

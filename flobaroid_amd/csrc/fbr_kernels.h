@@ -664,8 +664,10 @@ typedef const __attribute__((address_space(1))) void *fbr_glb_ptr;
 // FBR_SEGW x FBR_NSEG: the wave's accumulator shape (FbrGramConfig, fbr_program.h); (5,2) must fit 128 VGPRs (two workgroups per CU).
 template <bool TIMING, int FBR_SEGW, int FBR_NSEG>
 __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) void fbr_gram_kernel(DevGram g, long S, int NG, const double *__restrict__ pimg,
-                                                           double *__restrict__ partial, unsigned long long *__restrict__ dbg)
+                                                           double *__restrict__ partial, unsigned long long *__restrict__ dbg, int carry)
 {
+    // carry: the accumulators start from this workgroup's partial sums of the previous chunk of the same call (same launch shape),
+    // so that a call reduces its partial sums ONCE, after its last chunk, instead of once per chunk (fixed order: still deterministic)
     constexpr int FBR_NPW = FBR_SEGW * FBR_NSEG;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *buf0 = smem, *buf1 = smem + g.part_image_max;
@@ -694,8 +696,14 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
     }
 
     fbr_d4 acc[FBR_NPW];
+    double *pp = partial + ((((long)group * g.wpg + g.wg_begin[part] + widx) * FBR_WPB + wave) * FBR_NPW) * 256;
+    if (carry) {
 #pragma unroll
-    for (int p = 0; p < FBR_NPW; p++) acc[p] = (fbr_d4){0.0, 0.0, 0.0, 0.0};
+        for (int p = 0; p < FBR_NPW; p++) acc[p] = (fbr_d4){pp[p * 256 + lane], pp[p * 256 + 64 + lane], pp[p * 256 + 128 + lane], pp[p * 256 + 192 + lane]};
+    } else {
+#pragma unroll
+        for (int p = 0; p < FBR_NPW; p++) acc[p] = (fbr_d4){0.0, 0.0, 0.0, 0.0};
+    }
     const int *wmeta = mslot + wave * FBR_NSEG * 8;
     const int li = lane & 15, kk = lane >> 4;
     unsigned long long tacc[3] = {0, 0, 0}, t0 = 0;
@@ -742,7 +750,12 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
     if (TIMING) t0 = __builtin_readcyclecounter();
     for (long s = s0; s < s1; s++) {
         double *img = ((s - s0) & 1) ? buf1 : buf0;
-        __syncthreads();  // this sample's image has landed (vmcnt(0) of every wave) and the other buffer is free
+        // this sample's image has landed and the other buffer is free.  The wave's LDS-DMA pieces are VMEM operations: every wave must
+        // have drained ITS pieces (vmcnt(0)) BEFORE the barrier, or a wave could read rows another wave's DMA has not delivered yet.
+        // The wait is explicit: the compiler's own s_waitcnt insertion puts it in front of the wave's first LDS read of the image
+        // (enough for the wave's own pieces only) whenever nothing else forces it in front of the barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
         if (s + 1 < s1) dma(s + 1, ((s - s0) & 1) ? buf0 : buf1);
         if (TIMING) { const unsigned long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
@@ -818,7 +831,6 @@ __global__ __launch_bounds__(FBR_WPB * 64, (FBR_SEGW * FBR_NSEG <= 10) ? 4 : 2) 
         d[7] = (unsigned long long)(s1 - s0);
     }
     // ---- write this workgroup's accumulators: partial[workgroup][wave][slot][reg][lane]
-    double *pp = partial + ((((long)group * g.wpg + g.wg_begin[part] + widx) * FBR_WPB + wave) * FBR_NPW) * 256;
 #pragma unroll
     for (int p = 0; p < FBR_NPW; p++) {
         pp[p * 256 + 0 * 64 + lane] = acc[p][0];
