@@ -372,10 +372,45 @@ def run_rank(args) -> int:
     st, rhs = with_tau(eng, topo, synth_range(topo, S_total, a, b, dev))
     G = torch.zeros((Pa, Pa), dtype=torch.float64, device=dev)
 
-    def step():
-        eng.gram(st, rhs=rhs, out=G)
+    # Steps are SUBMITTED asynchronously where the engine offers it (fbr_gram_submit, device-resident data): two steps in flight, so
+    # that the kinematics / packing of step i+1's first chunk run beside the last Gram launches of step i, and the all-reduce of step i
+    # (async_op) beside the kernels of step i+1.  Every step still produces its own complete, all-reduced Gram inside the timed region.
+    pipelined = on_gpu and hasattr(eng, "gram_submit") and not os.environ.get("FBR_BENCH_BLOCKING")
+    Gs = [G, torch.zeros_like(G)]
+    state = {"pending": None, "works": [None, None], "i": 0}
+
+    def finish(p):
+        tkt, b = p
+        eng.wait(tkt)
         if use_dist:
-            dist.all_reduce(G)  # (P+1)^2 fp64 = 1.86 MB: the only exchange step of the pass
+            state["works"][b] = dist.all_reduce(Gs[b], async_op=True)  # (P+1)^2 fp64 = 1.86 MB: the only exchange step of the pass
+
+    def step():
+        if not pipelined:
+            eng.gram(st, rhs=rhs, out=Gs[0])
+            if use_dist:
+                dist.all_reduce(Gs[0])
+            state["last"] = 0
+            return
+        b = state["i"] & 1
+        state["i"] += 1
+        if state["works"][b] is not None:  # the all-reduce that last used this buffer
+            state["works"][b].wait()
+            state["works"][b] = None
+        tkt = eng.gram_submit(st, Gs[b], rhs=rhs)
+        if state["pending"] is not None:
+            finish(state["pending"])
+        state["pending"] = (tkt, b)
+        state["last"] = b
+
+    def drain():
+        if state["pending"] is not None:
+            finish(state["pending"])
+            state["pending"] = None
+        for b in (0, 1):
+            if state["works"][b] is not None:
+                state["works"][b].wait()
+                state["works"][b] = None
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -390,17 +425,19 @@ def run_rank(args) -> int:
     # ---- the timed steps of the contract
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     eng.profile_enable(True)
     eng.profile_get()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     prof = eng.profile_get()
     eng.profile_enable(False)
-    G_sharded = G.clone()
+    G_sharded = Gs[state.get("last", 0)].clone()
 
     ms_per_step = dt / args.steps * 1e3
     value = S_total / (dt / args.steps)
@@ -433,6 +470,7 @@ def run_rank(args) -> int:
             "samples_per_gpu": S,
             "rhs_columns": 1,
             "parallelism": f"samples sharded over {world} GPU(s), one all-reduce of the (P+1)^2 fp64 Gram per step",
+            "submission": "asynchronous, two steps in flight (fbr_gram_submit / fbr_wait)" if pipelined else "blocking calls",
             "backend": args.backend,
             # which engine ran the steps: the HIP library unless a test injected a stand-in with --engine (then this names it)
             "engine": f"{type(eng).__module__}.{type(eng).__qualname__}" + (f" (injected with --engine {args.engine})" if args.engine else ""),

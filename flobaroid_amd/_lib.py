@@ -84,6 +84,12 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
          ctypes.c_int32, ctypes.c_int32],
     ),
+    "fbr_gram_submit": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)],
+    ),
+    "fbr_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "fbr_gram_grouped": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -400,6 +406,24 @@ class Engine:
             "fbr_gram_accumulate",
         )
         return ret
+
+    def gram_submit(self, st: dict, out, rhs=None, w=None, accumulate: bool = False) -> int:
+        """``gram`` without waiting (``fbr_gram_submit``): CUDA tensors only, result in ``out`` after ``wait(ticket)``.  The caller
+        keeps ``st`` / ``rhs`` / ``w`` / ``out`` alive and untouched until then; at most two submissions are in flight."""
+        s, keep, S, mem = self._states(st)
+        rr, wr, k = self._rhs(rhs, w, S, mem)
+        Pa = self.cols + k
+        r, _ = self._out(out, (Pa, Pa), mem)
+        if mem != FBR_DEVICE or r.mem != FBR_DEVICE:
+            raise ValueError("gram_submit takes CUDA tensors (states, rhs, w, out)")
+        t = ctypes.c_int64(-1)
+        _check(self._lib.fbr_gram_submit(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, r.ptr, int(bool(accumulate)), ctypes.byref(t)),
+               "fbr_gram_submit")
+        return int(t.value)
+
+    def wait(self, ticket: int = -1) -> None:
+        """Block until the submission ``ticket`` (default: everything submitted) is complete."""
+        _check(self._lib.fbr_wait(self._h, int(ticket)), "fbr_wait")
 
     def gram_grouped(self, st: dict, ngroups: int, rhs=None, w=None, out=None):
         """One raw Gram per group of S / ngroups consecutive samples, shape (ngroups, cols+k, cols+k), in one pass."""

@@ -136,6 +136,12 @@ struct fbr_model {
     hipStream_t side = nullptr;                 // producer stream: kinematics + tile-image packing of the next chunk
     hipStream_t copy = nullptr;                 // staging stream: host -> device copies of the chunk after next (pinned host inputs)
     hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_gram[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_h2d[2] = {nullptr, nullptr};
+    // asynchronous submissions (fbr_gram_submit / fbr_wait): completion event of the submission with ticket t is ev_done[t & 1]
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    int64_t next_ticket = 0;       // ticket of the next submission
+    int64_t waited_ticket = -1;    // every ticket <= this one is known complete
+    bool submitting = false;       // inside fbr_gram_submit
+    bool ev_gram_rec[2] = {false, false};  // ev_gram[b] has been recorded at least once (a later producer may have to wait for it)
     DevBuf rec2;
     std::vector<DevBuf> tables;
     std::map<int, std::unique_ptr<GramHolder>> gram;
@@ -180,6 +186,7 @@ struct fbr_model {
         if (m->side) (void)hipStreamDestroy(m->side);
         if (m->copy) (void)hipStreamDestroy(m->copy);
         for (int i = 0; i < 2; i++) {
+            if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
             if (m->ev_h2d[i]) (void)hipEventDestroy(m->ev_h2d[i]);
             if (m->ev_pack[i]) (void)hipEventDestroy(m->ev_pack[i]);
             if (m->ev_gram[i]) (void)hipEventDestroy(m->ev_gram[i]);
@@ -306,6 +313,7 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
             HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, (pe && pe[0] == 'h') ? greatest : least));
     }
     for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_h2d[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_pack[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_gram[i], hipEventDisableTiming));
@@ -419,6 +427,8 @@ extern "C" int fbr_profile_get(fbr_model *m, double *ms_out, int64_t *launches_o
 // ------------------------------------------------------------------------------------------------
 // state staging
 // ------------------------------------------------------------------------------------------------
+static int wait_ticket(fbr_model *m, int64_t ticket);
+
 struct DevStates {
     long S = 0;
     const double *q = nullptr, *dq = nullptr, *ddq = nullptr, *bv = nullptr, *ba = nullptr, *rpy = nullptr, *sign = nullptr;
@@ -478,6 +488,9 @@ static int stage_states(fbr_model *m, const fbr_states *st, DevStates *d, bool n
         return FBR_E_INVALID;
     }
     if (int rc_enter = enter(m)) return rc_enter;
+    if (!m->submitting) {  // blocking entry points run after every asynchronous submission before them
+        if (int rc_w = wait_ticket(m, m->next_ticket - 1)) return rc_w;
+    }
     const size_t S = (size_t)st->num_samples;
     d->S = (long)S;
     int rc;
@@ -867,9 +880,17 @@ static int active_rows(fbr_model *m, const double *dw, long S, std::vector<char>
     return FBR_OK;
 }
 
+// async_ticket != nullptr: the pass is enqueued and NOT waited for (fbr_gram_submit): device-resident inputs and output only.
 static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
-                     int32_t out_mem, int32_t accumulate, int32_t ngroups)
+                     int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
 {
+    const bool async = async_ticket != nullptr;
+    if (async && (!st || st->mem != FBR_DEVICE || out_mem != FBR_DEVICE)) {
+        set_err("fbr_gram_submit takes device-resident states, rhs, weights and output");
+        return FBR_E_INVALID;
+    }
+    // a submission whose predecessor is still in flight lets its producer start beside the predecessor's last Gram launches
+    bool overlap_prev = false;
     // Pinned host inputs are staged chunk by chunk on the producer stream, overlapped with the Gram kernel of the previous chunk
     // (the PCIe-inclusive rate of the pass); pageable ones up front (an asynchronous copy from pageable memory blocks
     // the host thread and was measured slower when interleaved with the launches).
@@ -877,8 +898,15 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                              is_pinned_host(st->ddq) && is_pinned_host(st->base_vel) && is_pinned_host(st->base_acc) &&
                              is_pinned_host(st->base_rpy) && is_pinned_host(st->sign) && is_pinned_host(rhs) && is_pinned_host(w);
     DevStates d;
+    if (m) m->submitting = async;  // (a blocking call first waits for every submission in flight: stage_states)
     int rc = stage_states(m, st, &d, true, h2d_chunked);
+    if (m) m->submitting = false;
     if (rc) return rc;
+    if (async) {
+        // at most two submissions in flight (two tile-image buffers, two completion events): the one before the last must be done
+        if ((rc = wait_ticket(m, m->next_ticket - 2))) return rc;
+        overlap_prev = m->waited_ticket < m->next_ticket - 1;
+    }
     if (!G_out || k < 0 || k > FBR_MAX_RHS || (k > 0 && !rhs)) {
         set_err("bad rhs / G_out arguments");
         return FBR_E_INVALID;
@@ -963,6 +991,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             }
         }
         const long nchunks = (long)items.size();
+        bool fresh_images = false;  // a tile-image buffer was (re)allocated and zeroed on the main stream in this call
         // workgroups per group of a launch: every resident workgroup slot is used (see the launch below)
         auto wpg_of = [&](long cs, int ng) {
             static const int oversub_env = getenv("FBR_GROUP_OVERSUB") ? std::max(1, atoi(getenv("FBR_GROUP_OVERSUB"))) : 0;
@@ -981,13 +1010,19 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             if ((size_t)ch * img_bytes > h->pimg[b].bytes) {
                 if ((rc = h->pimg[b].ensure((size_t)ch * img_bytes))) return rc;
                 HIPCHK(hipMemsetAsync(h->pimg[b].p, 0, h->pimg[b].bytes, m->stream));  // structural zeros are never rewritten
+                fresh_images = true;
             }
         // producer (kinematics + tile-image packing of chunk i+1) runs on a second stream and shares the CUs with the
         // MFMA-bound Gram kernel of chunk i; the images are double buffered
         HIPCHK(hipEventRecord(m->ev_fork, m->stream));
         // FBR_GRAM_SERIAL (diagnostic): producer on the main stream, i.e. no overlap with the Gram kernel
         hipStream_t side = getenv("FBR_GRAM_SERIAL") ? m->stream : m->side;
-        HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
+        // The producer normally starts after everything enqueued on the main stream so far.  A submission that follows another one
+        // (fbr_gram_submit) skips that: its inputs are device resident, and what its first producer launches must wait for is only
+        // the tile-image buffer they write (ev_gram below) -- kinematics and packing of its first chunk then run beside the last
+        // Gram launches of the submission before, the one piece of producer work nothing else hides.
+        const bool cross = overlap_prev && !fresh_images && side != m->stream;
+        if (!cross) HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
         // per-sample doubles of one staged chunk (pinned host inputs): q dq ddq [bv ba rpy] [sign] [rhs] [w]
         const size_t stage_per = (size_t)3 * hm.n + (hm.floating ? 15 : 0) + (d.sign ? hm.n : 0) + (size_t)hm.rows * k + (dw ? hm.rows : 0);
         if (h2d_chunked)
@@ -996,7 +1031,8 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
         auto produce = [&](long ci) -> int {
             const long s0 = items[ci].s0, cs = items[ci].cs;
             const int b = (int)(ci & 1);
-            if (ci >= 2) HIPCHK(hipStreamWaitEvent(side, m->ev_gram[b], 0));  // Gram of chunk ci-2 is done with this buffer
+            // Gram of chunk ci-2 (or, across submissions, the last Gram launch that read this buffer) is done with it
+            if (ci >= 2 || (cross && m->ev_gram_rec[b])) HIPCHK(hipStreamWaitEvent(side, m->ev_gram[b], 0));
             DevStates dc = d;     // what the kernels of this chunk read, and the sample offset into it
             long o = s0;
             const double *crhs = drhs, *cw = dw;
@@ -1088,6 +1124,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(m->ev_gram[b], m->stream));
+            m->ev_gram_rec[b] = true;
             if (timing) {
                 std::vector<unsigned long long> hb((size_t)NW * FBR_WPB * 8);
                 HIPCHK(hipMemcpyAsync(hb.data(), dbg, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
@@ -1118,16 +1155,58 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             }
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipStreamSynchronize(side));
-        if (h2d_chunked && m->copy) HIPCHK(hipStreamSynchronize(m->copy));
+        if (!async) {
+            HIPCHK(hipStreamSynchronize(side));
+            if (h2d_chunked && m->copy) HIPCHK(hipStreamSynchronize(m->copy));
+        }
+    }
+    if (async) {
+        const int64_t t = m->next_ticket++;
+        HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
+        *async_ticket = t;
+        return FBR_OK;
     }
     return finish_output(m, G, G_out, gcount, out_mem);
+}
+
+// Block until the submission with this ticket (and every earlier one) is complete; ticket < 0 or beyond the last one: everything.
+static int wait_ticket(fbr_model *m, int64_t ticket)
+{
+    const int64_t last = m->next_ticket - 1;
+    if (ticket > last) ticket = last;
+    if (ticket <= m->waited_ticket) return FBR_OK;
+    if (ticket == last) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        HIPCHK(hipStreamSynchronize(m->side));
+        prof_collect(m);
+    } else {
+        HIPCHK(hipEventSynchronize(m->ev_done[ticket & 1]));
+    }
+    m->waited_ticket = ticket;
+    return FBR_OK;
 }
 
 extern "C" int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
                                    double *G_out, int32_t out_mem, int32_t accumulate)
 {
     return gram_impl(m, st, rhs, k, w, G_out, out_mem, accumulate, 1);
+}
+
+extern "C" int fbr_gram_submit(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
+                               int32_t accumulate, int64_t *ticket)
+{
+    if (!ticket) {
+        set_err("ticket is NULL");
+        return FBR_E_INVALID;
+    }
+    return gram_impl(m, st, rhs, k, w, G_out, FBR_DEVICE, accumulate, 1, ticket);
+}
+
+extern "C" int fbr_wait(fbr_model *m, int64_t ticket)
+{
+    int rc = enter(m);
+    if (rc) return rc;
+    return wait_ticket(m, ticket < 0 ? m->next_ticket - 1 : ticket);
 }
 
 extern "C" int fbr_gram_grouped(fbr_model *m, const fbr_states *st, int32_t ngroups, const double *rhs, int32_t k, const double *w,

@@ -137,6 +137,18 @@ int fbr_gram_accumulate(fbr_model *m, const fbr_states *st, const double *rhs, i
                         double *G_out, int32_t out_mem, int32_t accumulate);
 
 /*
+ * Asynchronous form of fbr_gram_accumulate for callers that keep everything in HBM (states, rhs, w and G_out device resident): the
+ * pass is enqueued and the call returns; *ticket identifies it.  Up to TWO submissions are in flight (a third one first waits for
+ * the oldest); the kinematics / packing of a submission's first chunk then run beside the last Gram launches of the one before --
+ * the only producer work of a pass that nothing else hides (a sample loop split over several calls, model.py:370, or one rank's short
+ * shard per step).  G_out must not be read, and the inputs not rewritten, before fbr_wait(m, ticket) has returned.  Every blocking
+ * entry point of the same model first waits for all submissions.  fbr_wait: ticket < 0 waits for everything submitted so far.
+ */
+int fbr_gram_submit(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
+                    int32_t accumulate, int64_t *ticket);
+int fbr_wait(fbr_model *m, int64_t ticket);
+
+/*
  * The same reduction for ngroups consecutive, equally sized groups of samples in ONE pass: G_out [ngroups][(cols+k)][(cols+k)],
  * group g = samples [g*S/ngroups, (g+1)*S/ngroups) (num_samples must be a multiple of ngroups).  Serves the
  * trajectory optimiser's inner loop (excitation/trajectoryOptimizer.py:248-272: YBase^T YBase of every candidate

@@ -714,3 +714,47 @@ def test_baseline_sizes_through_size_independent_properties(name, fl, fric, S):
     assert np.all(np.tril(R, -1) == 0.0) and np.all(np.isfinite(R))
     assert np.linalg.norm(R.T @ R - G) <= 1e-11 * np.linalg.norm(G)
     eng.close()
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[3], CONFIGS[7]], ids=cfg_id)
+def test_gram_submit_pipelines_calls_and_matches_the_blocking_path(cfg):
+    """fbr_gram_submit / fbr_wait: passes enqueued back to back (two in flight, the producer of one beside the last Gram launches of
+    the one before) give bit for bit the Grams of the blocking calls; a blocking entry point in between waits for them; waiting for
+    an old ticket or twice is harmless; host inputs are refused."""
+    import torch
+
+    from flobaroid_amd._lib import FbrError
+
+    t, eng, om = _engine_oracle(cfg)
+    S = 9000 if t.num_links < 10 else 2600   # several chunks each
+    sets = []
+    for i in range(5):
+        st, rng = _states(t, cfg, S + 17 * i, 100 + i)
+        rhs = rng.standard_normal((st["q"].shape[0] * om.rows, 1))
+        sets.append(({k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in st.items()}, torch.from_numpy(rhs).cuda()))
+    want = [eng.gram(st, rhs=rhs).clone() for st, rhs in sets]
+    Pa = om.P + 1
+    outs = [torch.full((Pa, Pa), float("nan"), dtype=torch.float64, device="cuda") for _ in sets]
+    tickets = [eng.gram_submit(st, outs[i], rhs=rhs) for i, (st, rhs) in enumerate(sets[:3])]
+    assert tickets == sorted(tickets) and len(set(tickets)) == 3
+    eng.wait(tickets[0])
+    assert torch.equal(outs[0], want[0])
+    Y = eng.regressor({k: v[:5] for k, v in sets[0][0].items()})  # blocking call: runs after every submission
+    assert torch.equal(outs[1], want[1]) and torch.equal(outs[2], want[2]) and Y.shape == (5 * om.rows, om.P)
+    t3 = eng.gram_submit(sets[3][0], outs[3], rhs=sets[3][1])
+    t4 = eng.gram_submit(sets[4][0], outs[4], rhs=sets[4][1])
+    eng.wait()
+    eng.wait(t3)
+    eng.wait(t4)
+    assert torch.equal(outs[3], want[3]) and torch.equal(outs[4], want[4])
+    # accumulate across submissions: the sum of two passes
+    acc = torch.zeros((Pa, Pa), dtype=torch.float64, device="cuda")
+    eng.gram_submit(sets[0][0], acc, rhs=sets[0][1])
+    eng.gram_submit(sets[1][0], acc, rhs=sets[1][1], accumulate=True)
+    eng.wait()
+    ref = (want[0] + want[1]).cpu().numpy()
+    assert np.linalg.norm(acc.cpu().numpy() - ref) <= 1e-13 * np.linalg.norm(ref)
+    with pytest.raises((FbrError, ValueError)):
+        eng.gram_submit({k: v.cpu().numpy() for k, v in sets[0][0].items()}, outs[0], rhs=sets[0][1])
+    A = np.hstack([om.regressor({k: v.cpu().numpy() for k, v in sets[2][0].items()}, sets[2][0]["sign"].cpu().numpy()), sets[2][1].cpu().numpy()])
+    assert np.linalg.norm(outs[2].cpu().numpy() - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
