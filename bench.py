@@ -314,7 +314,7 @@ def run_rank(args) -> int:
     import torch
     import torch.distributed as dist
 
-    from flobaroid_amd.dist import shard_range, tsqr_tree
+    from flobaroid_amd.dist import shard_range, tsqr_tree, warm_p2p
     from flobaroid_amd.topology import Topology
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,6 +342,7 @@ def run_rank(args) -> int:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise RuntimeError("process group came up with the wrong size")
+        warm_p2p(dev)  # communicators of the all-reduce and of every edge of the TSQR rank tree exist before anything is timed
 
     def sync():
         if on_gpu:

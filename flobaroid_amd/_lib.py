@@ -257,6 +257,7 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     def set_stream(self, stream_ptr: int | None) -> None:
         _check(self._lib.fbr_model_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), "fbr_model_set_stream")
+        self._stream_handle = int(stream_ptr or 0)  # 0: the model's own stream
 
     def use_torch_stream(self) -> None:
         """Run on torch's current stream when that is a real stream object.  torch's DEFAULT stream is the null stream (handle 0),
@@ -264,17 +265,17 @@ class Engine:
         CUDA tensors first waits for torch's stream (``_sync_torch``), so inputs produced by torch kernels are complete."""
         import torch
 
-        h = torch.cuda.current_stream(self.device).cuda_stream
-        self.set_stream(h)
-        self._shares_torch_stream = bool(h)
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _sync_torch(self) -> None:
         # calls are blocking and the library synchronises its own stream on return; what is missing is the other direction:
-        # torch kernels still writing the inputs on a stream the library does not run on
-        if not getattr(self, "_shares_torch_stream", False):
-            import torch
+        # torch kernels still writing the inputs on a stream the library does not run on.  Checked at EVERY call: the caller may have
+        # switched torch streams (or called set_stream) since use_torch_stream().
+        import torch
 
-            torch.cuda.current_stream(self.device).synchronize()
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == 0 or cur.cuda_stream != getattr(self, "_stream_handle", 0):
+            cur.synchronize()
 
     def _states(self, st: dict, need_vel: bool = True):
         q = _Ref(st["q"], name="q")

@@ -931,11 +931,24 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     }
     // row masks that switch every joint row off (base-wrench-only identification, identifier.py:629-636): only the base k-steps run
     bool base_only = false;
-    if (dw && !h2d_chunked && hm.fb > 0 && !getenv("FBR_GRAM_NO_MASK_SKIP")) {
-        std::vector<char> act;
-        if ((rc = active_rows(m, dw, S, &act))) return rc;
-        base_only = true;
-        for (int r = hm.fb; r < hm.rows; r++) base_only = base_only && !act[r];
+    if (w && S > 0 && hm.fb > 0 && hm.rows > hm.fb && !getenv("FBR_GRAM_NO_MASK_SKIP")) {
+        // Host weights are looked at on the host, so that pinned and pageable inputs take the same path: ordinary WLS weights show a
+        // non-zero joint-row weight in the very first sample and cost nothing; only a vector that starts like a base-wrench mask is
+        // scanned to the end.  Device weights: one small scan kernel + a 4-byte-per-row copy.
+        if (st->mem == FBR_HOST) {
+            base_only = true;
+            for (long s = 0; s < S && base_only; s++)
+                for (int r = hm.fb; r < hm.rows; r++)
+                    if (w[s * hm.rows + r] != 0.0) {
+                        base_only = false;
+                        break;
+                    }
+        } else {
+            std::vector<char> act;
+            if ((rc = active_rows(m, dw, S, &act))) return rc;
+            base_only = true;
+            for (int r = hm.fb; r < hm.rows; r++) base_only = base_only && !act[r];
+        }
     }
     double *G = G_out;
     if (out_mem == FBR_HOST) {

@@ -305,9 +305,15 @@ class Data:
             filtfilt = lambda b, a, X: sig.filtfilt(b, a, X, axis=0)
             cdiff = self._central_diff
         else:
-            med = lambda X: engine.medfilt(k, np.ascontiguousarray(X, dtype=np.float64).copy())
-            filtfilt = lambda b, a, X: engine.filtfilt(b, a, np.ascontiguousarray(X, dtype=np.float64).copy())
-            cdiff = lambda A, times: engine.central_diff(np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(times, dtype=np.float64))
+            # the device kernels cover what the shipped configurations use (median windows <= 31, filter orders <= 11, >= 5 samples);
+            # anything beyond runs through the host implementation for that array, like the reference
+            host_med = lambda X: sig.medfilt(X, (k, 1))
+            host_ff = lambda b, a, X: sig.filtfilt(b, a, X, axis=0)
+            med = (lambda X: engine.medfilt(k, np.ascontiguousarray(X, dtype=np.float64).copy())) if k <= 31 else host_med
+            filtfilt = lambda b, a, X: (engine.filtfilt(b, a, np.ascontiguousarray(X, dtype=np.float64).copy())
+                                        if max(len(a), len(b)) - 1 <= 11 and X.shape[0] > 3 * max(len(a), len(b)) else host_ff(b, a, X))
+            cdiff = lambda A, times: (engine.central_diff(np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(times, dtype=np.float64))
+                                      if A.shape[0] >= 5 else self._central_diff(A, times))
         if self.opt["useDeg"]:
             np.copyto(Q, np.deg2rad(Q))
             np.copyto(V, np.deg2rad(V))

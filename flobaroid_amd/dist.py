@@ -29,6 +29,33 @@ def allreduce_gram(G: torch.Tensor, group=None) -> torch.Tensor:
     return G
 
 
+def _tree_edges(world: int) -> list[tuple[int, int]]:
+    """(receiver, sender) pairs of the binary tree, level by level (group-local ranks)."""
+    edges, step = [], 1
+    while step < world:
+        edges += [(r, r + step) for r in range(0, world, 2 * step) if r + step < world]
+        step *= 2
+    return edges
+
+
+def warm_p2p(device=None, group=None) -> None:
+    """Set up the communicators the exchange steps use BEFORE anything is timed: RCCL creates a point-to-point communicator per
+    peer pair lazily on the first send / recv (tens of milliseconds each), and the collective one on the first all-reduce.  One
+    8-byte message over every edge of the rank tree, one all-reduce and one broadcast."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    x = torch.zeros(1, dtype=torch.float64, device=device)
+    for recv, send in _tree_edges(world):
+        if rank == recv:
+            dist.recv(x, src=g(send), group=group)
+        elif rank == send:
+            dist.send(x, dst=g(recv), group=group)
+    dist.all_reduce(x, group=group)
+    dist.broadcast(x, src=g(0), group=group)
+
+
 def tsqr_tree(R: torch.Tensor, merge: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], group=None) -> torch.Tensor:
     """Binary-tree reduction of per-rank triangular factors; every rank returns the global factor.
 
