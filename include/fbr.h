@@ -40,8 +40,9 @@ typedef struct fbr_model fbr_model; /* opaque */
 /*
  * Kinematic tree + identified-column layout.  Replaces what the reference pulls out of
  * iDynTree::ModelLoader / Model (identification/model.py:60-68,112-131) and the layout logic of
- * Model.__init__ (model.py:134-168).  Links are indexed in URDF document order after fake-link
- * removal; columns of the regressor are link-major, 10 per link
+ * Model.__init__ (model.py:134-168).  Links and DOFs are indexed as the caller serialises them (any order: parents
+ * need not precede children); flobaroid_amd/topology.py hands over iDynTree's traversal order, the one the reference's
+ * linkNames / jointNames follow (model.py:86-94,121-127).  Columns of the regressor are link-major, 10 per link
  * [m, m*cx, m*cy, m*cz, Ixx, Ixy, Ixz, Iyy, Iyz, Izz] (model.py:220-231), followed by the friction
  * blocks Fc | Fv (or Fv+,Fv-) | off | Fs (model.py:459-503).
  */
