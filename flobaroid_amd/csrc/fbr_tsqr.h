@@ -41,7 +41,8 @@
 #define FBR_TSQR_INPLACE_MAX_TPW 2  // panels are factorised in place in the wave's own tile registers up to this many tiles per wave
 #endif
 #define FBR_TSQR_RING_MAX 6        // published panels (V, T) kept in the LDS: how far the waves may drift apart (fewer for tall blocks)
-template <int SUB> __host__ __device__ constexpr int fbr_tsqr_ring() { return SUB > 6 ? 5 : FBR_TSQR_RING_MAX; }  // 128-row blocks: 5 slots fit the 160 KiB
+// (128-row blocks: 5 slots fit the 160 KiB; four-wave workgroups, two per CU, have 80 KiB each: 3 slots -- enough for 4 waves)
+template <int SUB, int W = FBR_TSQR_WAVES> __host__ __device__ constexpr int fbr_tsqr_ring() { return W < FBR_TSQR_WAVES ? 3 : (SUB > 6 ? 5 : FBR_TSQR_RING_MAX); }
 #define FBR_TSQR_MAXN 768          // widest supported factor (columns incl. rhs, padded to 16)
 #define FBR_TSQR_SPIN_LIMIT (1 << 20)  // ~50 ms of polling: far beyond any legitimate wait (a fold tail is ~0.1 ms)
 
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, i
 #define FBR_TSQR_TSZ (16 * FBR_TSQR_LDT)
 
 // LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vr[RING][MB*17] | Tr[RING][256] | Rp[WAVES][256] | flags[16]
-template <int TPW, int SUB> static inline size_t fbr_tsqr_lds_doubles()
+template <int TPW, int SUB, int W = FBR_TSQR_WAVES> static inline size_t fbr_tsqr_lds_doubles()
 {
-    return (size_t)FBR_TSQR_WAVES * TPW * 256 + (size_t)fbr_tsqr_ring<SUB>() * (16 * SUB * FBR_TSQR_LDV + FBR_TSQR_TSZ) + (size_t)FBR_TSQR_WAVES * 256 + 16 + FBR_TSQR_RING_MAX;
+    return (size_t)W * TPW * 256 + (size_t)fbr_tsqr_ring<SUB, W>() * (16 * SUB * FBR_TSQR_LDV + FBR_TSQR_TSZ) + (size_t)W * 256 + 16 + FBR_TSQR_RING_MAX;
 }
 typedef __attribute__((address_space(3))) void *fbr_tsqr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_tsqr_glb_ptr;
@@ -297,13 +298,13 @@ __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const do
 // and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
 // Tiles are updated one at a time (a paired form ran dead / padding tiles through the MFMAs: +34 % MFMA work, slower;
 // splitting V^T C over two accumulators to shorten the dependent chain was 3 % slower as well).
-template <int TPW, int SUB, int T>
+template <int TPW, int SUB, int T, int W>
 __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], const double *Rl, double *__restrict__ R, unsigned ld, int q, int wave,
                                                      int lane, const double *Vl, const double *Tm)
 {
     const int li = lane & 15, kk = lane >> 4;
     const unsigned j0 = 16u * (unsigned)q;
-    const double *Rt = Rl + (wave + FBR_TSQR_WAVES * T) * 256;
+    const double *Rt = Rl + (wave + W * T) * 256;
     fbr_td4 acc, w2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) acc[reg] = Rt[(4 * reg + kk) * 16 + li];
@@ -317,7 +318,7 @@ __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], con
     for (int ks = 0; ks < 4; ks++) w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(4 * ks + kk) * FBR_TSQR_LDT + li], acc[ks], w2, 0, 0, 0);
     {
         // uniform (scalar) base + one per-lane offset shared by every store of the kernel
-        const unsigned c0 = 16u * (unsigned)(wave + FBR_TSQR_WAVES * T);
+        const unsigned c0 = 16u * (unsigned)(wave + W * T);
         const unsigned voff = (unsigned)kk * ld + (unsigned)li;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) (R + ((j0 + 4 * reg) * ld + c0))[voff] = Rt[(4 * reg + kk) * 16 + li] - w2[reg];
@@ -341,7 +342,7 @@ __device__ __forceinline__ void fbr_dma_wait() { asm volatile("s_waitcnt vmcnt(0
 
 // LDS-DMA of the R rows of panel q under the wave's tiles t >= t0 into their LDS slots (lane l -> row 8 h + l / 8,
 // columns 2 (l % 8), +1: 16 bytes per lane).  Issued once per panel after the wave's whole update.
-template <int TPW>
+template <int TPW, int W>
 __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, int t1, double *Rl, const double *__restrict__ R, unsigned ld, int q, int wave, int lane)
 {
     const unsigned voff = ((unsigned)(lane >> 3) * ld + 2u * (unsigned)(lane & 7)) * 8u;
@@ -349,7 +350,7 @@ __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, int t1, double *Rl, 
 #pragma unroll
     for (int t = 0; t < TPW; t++)
         if (t >= t0 && t < t1) {
-            const int ct = wave + FBR_TSQR_WAVES * t;
+            const int ct = wave + W * t;
 #pragma unroll
             for (int h = 0; h < 2; h++)
                 fbr_dma16(R + ((unsigned)(16 * q + 8 * h) * ld + 16u * (unsigned)ct), voff, lds0 + (unsigned)(ct * 256 + h * 128) * 8u);
@@ -358,25 +359,25 @@ __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, int t1, double *Rl, 
 
 // the wave's tiles t0 <= t < t1, one at a time (static register indexing, a uniform branch per tile; dead and padding
 // tiles cost nothing)
-template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateFrom {
+template <int TPW, int SUB, int W, int T = 0> struct FbrTsqrUpdateFrom {
     static __device__ __forceinline__ void run(int t0, int t1, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
                                                int wave, int lane, const double *Vl, const double *Tm)
     {
         if constexpr (T < TPW) {
-            if (T >= t0 && T < t1) fbr_tsqr_update_tile<TPW, SUB, T>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
-            FbrTsqrUpdateFrom<TPW, SUB, T + 1>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            if (T >= t0 && T < t1) fbr_tsqr_update_tile<TPW, SUB, T, W>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
+            FbrTsqrUpdateFrom<TPW, SUB, W, T + 1>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
         }
     }
 };
 
 // the single tile tp (uniform, selected by a static switch)
-template <int TPW, int SUB, int T = 0> struct FbrTsqrUpdateOne {
+template <int TPW, int SUB, int W, int T = 0> struct FbrTsqrUpdateOne {
     static __device__ __forceinline__ void run(int tp, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
                                                int wave, int lane, const double *Vl, const double *Tm)
     {
         if constexpr (T < TPW) {
-            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
-            FbrTsqrUpdateOne<TPW, SUB, T + 1>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T, W>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
+            FbrTsqrUpdateOne<TPW, SUB, W, T + 1>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
         }
     }
 };
@@ -410,7 +411,7 @@ struct FbrTsqrFoldDesc {
 };
 
 // TIMING: diagnostic instantiation (s_memtime cycles per phase into tacc[16]); the production kernels carry none of it
-template <int TPW, int SUB, bool TIMING, class FoldFn>
+template <int TPW, int SUB, bool TIMING, int W, class FoldFn>
 __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, int ldr, int nfolds, FoldFn fold_of, double *smem, unsigned *errflag,
                                                 unsigned long long *tacc = nullptr)
 {
@@ -422,8 +423,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         tk = t1;                                                          \
     }
     constexpr int MB = 16 * SUB;
-    constexpr int W = FBR_TSQR_WAVES;
-    constexpr int FBR_TSQR_RING = fbr_tsqr_ring<SUB>();
+    constexpr int FBR_TSQR_RING = fbr_tsqr_ring<SUB, W>();
     double *Rl = smem;  // 16-byte aligned tiles for the LDS-DMA
     double *Vr = Rl + W * TPW * 256;
     double *Tr = Vr + FBR_TSQR_RING * MB * FBR_TSQR_LDV;
@@ -482,7 +482,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         fetch_rpp(q0 + ((wave - q0) % W + W) % W);
         // R rows of the first panel under this wave's tiles right of it (the wave is done with its tiles of the
         // previous fold, so their LDS slots are free)
-        fbr_tsqr_fetch_rows<TPW>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, t1, Rl, R, ld, q0, wave, lane);
+        fbr_tsqr_fetch_rows<TPW, W>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, t1, Rl, R, ld, q0, wave, lane);
         FBR_TT(0)
 
         // factorise panel p = tile p of this wave (global index G): Householder QR of [R_pp ; tile] in registers,
@@ -560,10 +560,13 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 else
                     chain_on(C[TPW - 1], p, G, tc0);
             } else {
+                // copy of the panel's tile: a uniform BRANCH per tile (the empty asm keeps the compiler from turning the four cheap
+                // blocks into 32 x 4 selects: 128 v_cndmask per panel on the fold's critical path)
                 fbr_td4 v[SUB];
 #pragma unroll
                 for (int t = 0; t < TPW; t++)
                     if (t == tp) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int sb = 0; sb < SUB; sb++) v[sb] = C[t][sb];
                     }
@@ -588,7 +591,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 // next panel's owner: its tile first, then its factorisation, then the rest of panel q.  This is the
                 // serial dependency chain of the fold: raise the wave's issue priority over the waves that only update
                 __builtin_amdgcn_s_setprio(3);
-                if (apply) FbrTsqrUpdateOne<TPW, SUB>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                if (apply) FbrTsqrUpdateOne<TPW, SUB, W>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
                 FBR_TT(3)
                 chain(q + 1, G + 1);
                 __builtin_amdgcn_s_setprio(0);
@@ -596,11 +599,11 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 t0 = (q + 1) / W + 1;
             }
             if (apply) {
-                FbrTsqrUpdateFrom<TPW, SUB>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                FbrTsqrUpdateFrom<TPW, SUB, W>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
                 fbr_lds_release();
                 if (lane == 0) __atomic_store_n(done + wave, G + 1, __ATOMIC_RELAXED);
                 // R rows of the next panel under the tiles right of it
-                if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, t1, Rl, R, ld, q + 1, wave, lane);
+                if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW, W>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, t1, Rl, R, ld, q + 1, wave, lane);
             }
             FBR_TT(3)
         }
@@ -611,8 +614,9 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
 }
 
 // level 0: workgroup w folds blocks w, w+NW, ... of A into Rw[w]
-template <int TPW, int SUB, bool TIMING>
-__global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
+// W = waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU, n <= 320: two independent folds in flight per CU)
+template <int TPW, int SUB, bool TIMING, int W = FBR_TSQR_WAVES>
+__global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
                                                                                double *__restrict__ Rw, long nblocks, unsigned *errflag,
                                                                                unsigned long long *dbg, const int *__restrict__ rowfc, int orows,
                                                                                long ogroup, long M)
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
-    constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;  // leading dimension of the working factors (>= n)
+    constexpr int LD = 16 * W * TPW;  // leading dimension of the working factors (>= n)
     double *R = Rw + (long)blockIdx.x * n * LD;
     const int nfolds = (int)((nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
     auto fold_of = [&](int f) {
@@ -637,20 +641,20 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_level0_kernel(co
         }
         return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc};
     };
-    fbr_tsqr_stream<TPW, SUB, TIMING>(R, n, LD, nfolds, fold_of, smem, errflag, tacc);
+    fbr_tsqr_stream<TPW, SUB, TIMING, W>(R, n, LD, nfolds, fold_of, smem, errflag, tacc);
     if (TIMING && (threadIdx.x & 63) == 0) {
-        unsigned long long *d = dbg + ((long)blockIdx.x * FBR_TSQR_WAVES + (threadIdx.x >> 6)) * 16;
+        unsigned long long *d = dbg + ((long)blockIdx.x * W + (threadIdx.x >> 6)) * 16;
         for (int i = 0; i < 16; i++) d[i] = tacc[i];
     }
 }
 
 // tree level: workgroup i folds Rw[(2i+1)*stride] (upper triangular, MB rows at a time) into Rw[2i*stride]
-template <int TPW, int SUB>
-__global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_tree_kernel(double *__restrict__ Rw, int n, int stride, int count, unsigned *errflag)
+template <int TPW, int SUB, int W = FBR_TSQR_WAVES>
+__global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_tree_kernel(double *__restrict__ Rw, int n, int stride, int count, unsigned *errflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
-    constexpr int LD = 16 * FBR_TSQR_WAVES * TPW;
+    constexpr int LD = 16 * W * TPW;
     const long a = (long)2 * blockIdx.x * stride, b = a + stride;
     if (b >= count) return;
     const double *Rb = Rw + b * n * LD;
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(FBR_TSQR_THREADS, 1) void fbr_tsqr_tree_kernel(doub
         const int i0 = f * MB;
         return FbrTsqrFoldDesc{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), i0};
     };
-    fbr_tsqr_stream<TPW, SUB, false>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
+    fbr_tsqr_stream<TPW, SUB, false, W>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -846,7 +850,7 @@ struct FbrTsqrWork {
     double *A = nullptr;    // packed chunk [Mpad][n]
     unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
     size_t rw_bytes = 0, a_bytes = 0;
-    int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0;
+    int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0, waves = FBR_TSQR_WAVES;
     bool active = false, narrow = false;
     void release()
     {
@@ -890,6 +894,17 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
     case 5: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
     default: { constexpr int TPW = 6, SUB = 2; CALL; } break; \
     }
+// four-wave workgroups, two per CU (9..20 column tiles: the base regressor of WALK-MAN, the waist chain's group): the fold of a wide
+// factor is the serial sum of its panel chains with the MFMA pipes two thirds idle, so for the widths whose
+// block fits HALF the register file at the same height two independent folds per CU run side by side
+#define FBR_TSQR_HALF_WAVES 4
+#define FBR_TSQR_HALF_MAX_TILES 20
+#define FBR_TSQR_DISPATCH_HALF(TPWV, CALL)             \
+    switch (TPWV) {                                    \
+    case 3: { constexpr int TPW = 3, SUB = FBR_TSQR_SUB3; CALL; } break; \
+    case 4: { constexpr int TPW = 4, SUB = FBR_TSQR_SUB4; CALL; } break; \
+    default: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
+    }
 static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : (tpw == 3 ? FBR_TSQR_SUB3 : (tpw == 4 ? FBR_TSQR_SUB4 : (tpw <= 1 ? 4 : (tpw == 5 ? 3 : 2)))); }
 
 // narrow (wave-private) kernels: column tiles 1..8, 32-row blocks
@@ -914,6 +929,7 @@ static inline int fbr_tsqr_narrow_sub_for(int npt) { return npt <= 6 ? FBR_TSQR_
 struct FbrTsqrShape {
     int n, tpw, sub, mb, NW, ld;
     bool narrow;
+    int waves;  // waves per workgroup of the wide kernels (8, or 4 with two workgroups per CU)
 };
 static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrShape *out)
 {
@@ -923,15 +939,18 @@ static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrSha
         return -4;
     }
     const bool narrow = n / 16 <= FBR_TSQR_NARROW_MAX_TILES && !getenv("FBR_TSQR_NO_NARROW");
-    const int tpw = narrow ? n / 16 : (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
+    const bool half = !narrow && n / 16 > FBR_TSQR_NARROW_MAX_TILES && n / 16 <= FBR_TSQR_HALF_MAX_TILES && !getenv("FBR_TSQR_NO_HALF") &&
+                      !getenv("FBR_TSQR_TIMING");
+    const int waves = half ? FBR_TSQR_HALF_WAVES : FBR_TSQR_WAVES;
+    const int tpw = narrow ? n / 16 : (n / 16 + waves - 1) / waves;
     const int sub = narrow ? fbr_tsqr_narrow_sub_for(tpw) : fbr_tsqr_sub_for(tpw);
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
     const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
-    const long per_cu = envw ? std::max(1, atoi(envw)) : (narrow ? 2 * FBR_TSQR_NARROW_WAVES : 1);  // narrow: private R per WAVE
+    const long per_cu = envw ? std::max(1, atoi(envw)) : (narrow ? 2 * FBR_TSQR_NARROW_WAVES : (half ? 2 : 1));  // narrow: private R per WAVE
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
-    const int ld = narrow ? n : 16 * FBR_TSQR_WAVES * tpw;
-    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow};
+    const int ld = narrow ? n : 16 * waves * tpw;
+    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow, waves};
     return 0;
 }
 
@@ -950,7 +969,7 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         TSQR_HIP(hipMalloc((void **)&wk.Rw, need));
         wk.rw_bytes = need;
     }
-    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub; wk.narrow = narrow;
+    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub; wk.narrow = narrow; wk.waves = sh.waves;
     if (!wk.err) TSQR_HIP(hipMalloc((void **)&wk.err, sizeof(unsigned)));
     TSQR_HIP(hipMemsetAsync(wk.err, 0, sizeof(unsigned), st));
     TSQR_HIP(hipMemsetAsync(wk.Rw, 0, need, st));
@@ -999,6 +1018,15 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
     }
     const int grid = (int)std::min<long>(wk.NW, nblocks);
     unsigned long long *dbg = nullptr;
+    if (wk.waves == FBR_TSQR_HALF_WAVES) {
+        constexpr int HW = FBR_TSQR_HALF_WAVES;
+        FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, false, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double))));
+        FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, false, HW>), dim3(grid), dim3(64 * HW),
+                                                          (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+        TSQR_HIP(hipGetLastError());
+        return 0;
+    }
     if (getenv("FBR_TSQR_TIMING")) {
         TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 16 * 8));
         TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 16 * 8, st));
@@ -1080,6 +1108,16 @@ static inline int fbr_tsqr_finish_async(FbrTsqrWork &wk, hipStream_t st, double 
             FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_tree_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
                                                                 (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, wk.Rw,
                                                                 stride, wk.NW));
+            TSQR_HIP(hipGetLastError());
+        }
+    } else if (wk.waves == FBR_TSQR_HALF_WAVES) {
+        constexpr int HW = FBR_TSQR_HALF_WAVES;
+        FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double))));
+        for (int stride = 1; stride < wk.NW; stride *= 2) {
+            const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
+            FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB, HW>), dim3(pairs), dim3(64 * HW),
+                                                              (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, wk.err));
             TSQR_HIP(hipGetLastError());
         }
     } else {
