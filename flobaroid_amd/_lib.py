@@ -409,14 +409,15 @@ class Engine:
         return ret
 
     def gram_submit(self, st: dict, out, rhs=None, w=None, accumulate: bool = False) -> int:
-        """``gram`` without waiting (``fbr_gram_submit``): CUDA tensors only, result in ``out`` after ``wait(ticket)``.  The caller
-        keeps ``st`` / ``rhs`` / ``w`` / ``out`` alive and untouched until then; at most two submissions are in flight."""
+        """``gram`` without waiting (``fbr_gram_submit``): ``out`` is a CUDA tensor, the inputs CUDA tensors or PINNED host tensors
+        (staged chunk by chunk on a copy stream); result in ``out`` after ``wait(ticket)``.  The caller keeps ``st`` / ``rhs`` / ``w`` /
+        ``out`` alive and untouched until then; at most two submissions are in flight."""
         s, keep, S, mem = self._states(st)
         rr, wr, k = self._rhs(rhs, w, S, mem)
         Pa = self.cols + k
         r, _ = self._out(out, (Pa, Pa), mem)
-        if mem != FBR_DEVICE or r.mem != FBR_DEVICE:
-            raise ValueError("gram_submit takes CUDA tensors (states, rhs, w, out)")
+        if r.mem != FBR_DEVICE:
+            raise ValueError("gram_submit needs a CUDA tensor for the output")
         t = ctypes.c_int64(-1)
         _check(self._lib.fbr_gram_submit(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, r.ptr, int(bool(accumulate)), ctypes.byref(t)),
                "fbr_gram_submit")

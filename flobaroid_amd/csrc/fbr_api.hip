@@ -141,7 +141,8 @@ struct fbr_model {
     int64_t next_ticket = 0;       // ticket of the next submission
     int64_t waited_ticket = -1;    // every ticket <= this one is known complete
     bool submitting = false;       // inside fbr_gram_submit
-    bool ev_gram_rec[2] = {false, false};  // ev_gram[b] has been recorded at least once (a later producer may have to wait for it)
+    bool ev_gram_rec[2] = {false, false};
+    bool ev_pack_rec[2] = {false, false};  // ev_gram[b] has been recorded at least once (a later producer may have to wait for it)
     DevBuf rec2;
     std::vector<DevBuf> tables;
     std::map<int, std::unique_ptr<GramHolder>> gram;
@@ -885,10 +886,6 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                      int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
 {
     const bool async = async_ticket != nullptr;
-    if (async && (!st || st->mem != FBR_DEVICE || out_mem != FBR_DEVICE)) {
-        set_err("fbr_gram_submit takes device-resident states, rhs, weights and output");
-        return FBR_E_INVALID;
-    }
     // a submission whose predecessor is still in flight lets its producer start beside the predecessor's last Gram launches
     bool overlap_prev = false;
     // Pinned host inputs are staged chunk by chunk on the producer stream, overlapped with the Gram kernel of the previous chunk
@@ -897,6 +894,10 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     const bool h2d_chunked = st && st->mem == FBR_HOST && !getenv("FBR_NO_CHUNKED_H2D") && is_pinned_host(st->q) && is_pinned_host(st->dq) &&
                              is_pinned_host(st->ddq) && is_pinned_host(st->base_vel) && is_pinned_host(st->base_acc) &&
                              is_pinned_host(st->base_rpy) && is_pinned_host(st->sign) && is_pinned_host(rhs) && is_pinned_host(w);
+    if (async && (!st || out_mem != FBR_DEVICE || (st->mem != FBR_DEVICE && !h2d_chunked))) {
+        set_err("fbr_gram_submit takes a device-resident output and device-resident or PINNED host states / rhs / weights");
+        return FBR_E_INVALID;
+    }
     DevStates d;
     if (m) m->submitting = async;  // (a blocking call first waits for every submission in flight: stage_states)
     int rc = stage_states(m, st, &d, true, h2d_chunked);
@@ -1057,7 +1058,9 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                 if (!m->copy && !getenv("FBR_H2D_ON_SIDE")) HIPCHK(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
                 hipStream_t cps = m->copy ? m->copy : side;
                 if (cps != side) {
-                    if (ci >= 2)
+                    // the staging buffer's last reader is the pack kernel of the chunk two before (or, across submissions, the last
+                    // pack launch that used this buffer)
+                    if (ci >= 2 || (cross && m->ev_pack_rec[b]))
                         HIPCHK(hipStreamWaitEvent(cps, m->ev_pack[b], 0));
                     else
                         HIPCHK(hipStreamWaitEvent(cps, m->ev_fork, 0));
@@ -1095,6 +1098,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(m->ev_pack[b], side));
+            m->ev_pack_rec[b] = true;
             return FBR_OK;
         };
         if ((rc = produce(0))) return rc;
@@ -1191,6 +1195,7 @@ static int wait_ticket(fbr_model *m, int64_t ticket)
     if (ticket == last) {
         HIPCHK(hipStreamSynchronize(m->stream));
         HIPCHK(hipStreamSynchronize(m->side));
+        if (m->copy) HIPCHK(hipStreamSynchronize(m->copy));
         prof_collect(m);
     } else {
         HIPCHK(hipEventSynchronize(m->ev_done[ticket & 1]));

@@ -754,7 +754,15 @@ def test_gram_submit_pipelines_calls_and_matches_the_blocking_path(cfg):
     eng.wait()
     ref = (want[0] + want[1]).cpu().numpy()
     assert np.linalg.norm(acc.cpu().numpy() - ref) <= 1e-13 * np.linalg.norm(ref)
-    with pytest.raises((FbrError, ValueError)):
-        eng.gram_submit({k: v.cpu().numpy() for k, v in sets[0][0].items()}, outs[0], rhs=sets[0][1])
+    with pytest.raises((FbrError, ValueError)):   # pageable host inputs are refused
+        eng.gram_submit({k: v.cpu().numpy() for k, v in sets[0][0].items()}, outs[0], rhs=sets[0][1].cpu().numpy())
+    # pinned host inputs: staged chunk by chunk on the copy stream, also across the two submissions in flight
+    pinned = [({k: v.cpu().pin_memory() for k, v in st.items()}, rhs.cpu().pin_memory()) for st, rhs in sets[:3]]
+    outs_h = [torch.full((Pa, Pa), float("nan"), dtype=torch.float64, device="cuda") for _ in pinned]
+    for i, (st, rhs) in enumerate(pinned):
+        eng.gram_submit(st, outs_h[i], rhs=rhs)
+    eng.wait()
+    for i in range(3):
+        assert torch.equal(outs_h[i], want[i])
     A = np.hstack([om.regressor({k: v.cpu().numpy() for k, v in sets[2][0].items()}, sets[2][0]["sign"].cpu().numpy()), sets[2][1].cpu().numpy()])
     assert np.linalg.norm(outs[2].cpu().numpy() - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
