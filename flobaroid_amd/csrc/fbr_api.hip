@@ -174,6 +174,10 @@ struct fbr_model {
     {
         fbr_model *m = this;
         (void)hipSetDevice(m->device);
+        // submissions still in flight (fbr_gram_submit without fbr_wait) read the workspaces freed below
+        if (m->stream) (void)hipStreamSynchronize(m->stream);
+        if (m->side) (void)hipStreamSynchronize(m->side);
+        if (m->copy) (void)hipStreamSynchronize(m->copy);
         m->tsqr.release();
         for (auto &g : m->tsqr_groups) g.release();
         for (auto &st : m->tsqr_streams)

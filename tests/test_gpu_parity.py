@@ -766,3 +766,40 @@ def test_gram_submit_pipelines_calls_and_matches_the_blocking_path(cfg):
         assert torch.equal(outs_h[i], want[i])
     A = np.hstack([om.regressor({k: v.cpu().numpy() for k, v in sets[2][0].items()}, sets[2][0]["sign"].cpu().numpy()), sets[2][1].cpu().numpy()])
     assert np.linalg.norm(outs[2].cpu().numpy() - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
+
+
+@pytest.mark.parametrize("name,fl", [("kuka_lwr4", 0), ("walkman_apriori", 1)])
+def test_any_link_and_dof_serialisation(name, fl):
+    """include/fbr.h: links and DOFs may be serialised in ANY order (parents need not precede children).  A shuffled serialisation of
+    the same robot gives the same regressor / Gram / TSQR factor under the row and column permutation, and matches the oracle run on
+    the shuffled topology itself."""
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    t = load_topo(name)
+    rng = np.random.default_rng(17)
+    lperm = rng.permutation(t.num_links)
+    dperm = rng.permutation(t.num_dofs)
+    t2 = t.reordered_links([t.link_names[i] for i in lperm]).reordered_dofs([t.dof_names[i] for i in dperm])
+    assert any(p > l for l, p in enumerate(t2.parent))  # some child is numbered before its parent
+    S = 300
+    st = random_states(t, S, rng, fl, use_limits=True)
+    st2 = {k: (v[:, dperm] if v.shape[1] == t.num_dofs else v) for k, v in st.items()}
+    e1, e2 = Engine(t, floating=bool(fl), friction=True), Engine(t2, floating=bool(fl), friction=True)
+    sg, sg2 = np.tanh(st["dq"] / 0.02), np.tanh(st2["dq"] / 0.02)
+    st["sign"], st2["sign"] = sg, sg2
+    fb = 6 * fl
+    n, L = t.num_dofs, t.num_links
+    rows = np.concatenate([np.arange(fb), fb + dperm])                       # row i of the shuffled model = row rows[i] of the original
+    cols = np.concatenate([np.concatenate([10 * l + np.arange(10) for l in lperm])] + [10 * L + n * k + dperm for k in range(3)])
+    Y1 = e1.regressor(st).reshape(S, fb + n, -1)
+    Y2 = e2.regressor(st2).reshape(S, fb + n, -1)
+    assert np.abs(Y2 - Y1[:, rows][:, :, cols]).max() <= 1e-11 * np.abs(Y1).max()
+    Yo = OracleModel(t2, floating=bool(fl), fric=True, fric_sym=True).regressor(st2, sg2).reshape(S, fb + n, -1)
+    assert np.abs(Y2 - Yo).max() <= 1e-11 * np.abs(Yo).max()
+    G1, G2 = e1.gram(st), e2.gram(st2)
+    assert np.linalg.norm(G2 - G1[np.ix_(cols, cols)]) <= 1e-11 * np.linalg.norm(G1)
+    R2 = e2.tsqr(st2)
+    assert np.linalg.norm(R2.T @ R2 - G2) <= 1e-11 * np.linalg.norm(G2)
+    e1.close()
+    e2.close()
