@@ -238,12 +238,15 @@ def wls_reference_compat_rhs(w: np.ndarray, tau: np.ndarray, contact_forces: np.
 
 
 def identify_base_parameters_wls(engine, states: dict, tau: np.ndarray, contact_forces, independent_cols, p_sigma_x: np.ndarray,
-                                 reference_compat: bool = False):
+                                 reference_compat: bool | None = None, opt: dict | None = None):
     """The IDIM-WLS pass (identifier.py:739-790) as ONE weighted TSQR of [YBase | tau | contactForcesSum] on the device.
 
     ``reference_compat=False``: the textbook form -- the row weights apply to Y, tau and the contact forces alike
     (``wls_row_weights``).  ``reference_compat=True`` (``opt['wlsReferenceCompat']``): the reference's numbers --
-    ``wls_reference_weights`` on Y only (``wls_reference_compat_rhs``).  Returns (xBase, R_aug_base, w)."""
+    ``wls_reference_weights`` on Y only (``wls_reference_compat_rhs``).  ``reference_compat=None`` reads the option dictionary.
+    Returns (xBase, R_aug_base, w)."""
+    if reference_compat is None:
+        reference_compat = bool((opt or {}).get("wlsReferenceCompat", 0))
     S = np.asarray(states["q"]).shape[0]
     rows = S * engine.rows
     ic = np.asarray(independent_cols, dtype=np.int32)
