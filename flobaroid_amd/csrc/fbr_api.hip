@@ -1059,7 +1059,15 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                 // they wait for the pack kernel of chunk ci-2 (the last reader of this staging buffer), the producer waits for them
                 // (created on first use: HIP maps streams to hardware queues in creation order, and the producer stream's queue must
                 // stay what it is for device-resident inputs)
-                if (!m->copy && !getenv("FBR_H2D_ON_SIDE")) HIPCHK(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
+                if (!m->copy && !getenv("FBR_H2D_ON_SIDE")) {
+                    // a priority level of its own (main stream: normal, producer: lowest, copies: highest), so that the copy stream
+                    // never lands on the hardware queue of the Gram stream whatever streams the process created before (seen in
+                    // bench.py after the TSQR leg had created two more streams: copies and Gram launches serialised, 78.6 instead
+                    // of 74.1 ms per step)
+                    int least = 0, greatest = 0;
+                    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    HIPCHK(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, greatest));
+                }
                 hipStream_t cps = m->copy ? m->copy : side;
                 if (cps != side) {
                     // the staging buffer's last reader is the pack kernel of the chunk two before (or, across submissions, the last
