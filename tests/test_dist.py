@@ -25,11 +25,13 @@ _WORKER = """
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
-from flobaroid_amd.dist import shard_range, allreduce_gram, tsqr_tree
+from flobaroid_amd.dist import shard_range, allreduce_gram, tsqr_tree, warm_p2p, _tree_edges
 from common import load_topo, random_states
 from oracle.oracle import OracleModel
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
+warm_p2p()   # one message over every edge of the rank tree + all-reduce + broadcast: must neither hang nor mismatch
+assert len(_tree_edges(world)) == world - 1 and sorted(s for _, s in _tree_edges(world)) == list(range(1, world))
 t = load_topo("kuka_lwr4")
 om = OracleModel(t)
 S = 301
@@ -55,6 +57,7 @@ assert all(torch.equal(Rs[0], r) for r in Rs)
 if world == 3:
     sub = dist.new_group([1, 2])
     if rank in (1, 2):
+        warm_p2p(group=sub)
         Ab = A[om.rows * (0 if rank == 1 else 150):om.rows * (150 if rank == 1 else S)]
         Rg = tsqr_tree(torch.from_numpy(np.linalg.qr(Ab, mode="r")), merge, group=sub)
         assert np.linalg.norm(Rg.numpy().T @ Rg.numpy() - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
