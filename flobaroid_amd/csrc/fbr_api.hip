@@ -156,9 +156,10 @@ struct fbr_model {
     int fd_tab_entries = -1;
     FbrTsqrWork tsqr;
     std::vector<FbrTsqrWork> tsqr_groups;  // one factorisation per row group of the tree-structured TSQR (tsqr_group_plan)
-    hipStream_t tsqr_streams[2] = {nullptr, nullptr};  // the groups' merge trees run beside the final factor's (created on first use)
-    hipEvent_t tsqr_ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t tsqr_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // the groups' merge trees run beside the final factor's (created on first use)
+    hipEvent_t tsqr_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [i]: side stream i is done; [4]: fork point on the main stream
     DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
+    DevBuf tsqr_embed;        // stacked rows of the embedded group factors (tree-structured TSQR)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -260,6 +261,14 @@ static int enter(fbr_model *m)
     }
     HIPCHK(hipSetDevice(m->device));
     return FBR_OK;
+}
+
+static int wait_ticket(fbr_model *m, int64_t ticket);
+// entry of a blocking call that does not go through stage_states: every asynchronous submission before it has completed
+static int enter_blocking(fbr_model *m)
+{
+    if (int rc = enter(m)) return rc;
+    return wait_ticket(m, m->next_ticket - 1);
 }
 
 extern "C" int fbr_device_count(void)
@@ -400,7 +409,13 @@ extern "C" int fbr_model_set_stream(fbr_model *m, void *s)
         set_err("null model");
         return FBR_E_INVALID;
     }
-    m->stream = s ? (hipStream_t)s : m->own_stream;
+    // submissions in flight were enqueued on the stream used so far (their completion events and Gram launches live there): they
+    // are waited for before the switch, so that fbr_wait / the destructor never look at a stream that does not carry them
+    const hipStream_t next = s ? (hipStream_t)s : m->own_stream;
+    if (next != m->stream) {
+        if (int rc = enter_blocking(m)) return rc;
+    }
+    m->stream = next;
     return FBR_OK;
 }
 
@@ -1204,13 +1219,13 @@ static int wait_ticket(fbr_model *m, int64_t ticket)
     const int64_t last = m->next_ticket - 1;
     if (ticket > last) ticket = last;
     if (ticket <= m->waited_ticket) return FBR_OK;
+    // the completion event is what carries the submission (recorded on the stream it ran on, whatever m->stream is by now)
+    HIPCHK(hipEventSynchronize(m->ev_done[ticket & 1]));
     if (ticket == last) {
         HIPCHK(hipStreamSynchronize(m->stream));
         HIPCHK(hipStreamSynchronize(m->side));
         if (m->copy) HIPCHK(hipStreamSynchronize(m->copy));
         prof_collect(m);
-    } else {
-        HIPCHK(hipEventSynchronize(m->ev_done[ticket & 1]));
     }
     m->waited_ticket = ticket;
     return FBR_OK;
@@ -1592,6 +1607,27 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         }
         tab.push_back((int)ents[var].size());
     }
+    // the same lists per PAIR of adjacent inertial columns (16-byte stores, fbr_regressor_groups2_kernel): possible when both columns
+    // of every pair sit side by side at an even position in every group that holds them
+    const int npairs = (hm.cpl % 2 == 0) ? hm.cpl * hm.L / 2 : 0;
+    bool pairable = npairs > 0 && !getenv("FBR_TSQR_WRITER8");
+    std::vector<int> pents[2];
+    size_t o_pbeg[2] = {0, 0};
+    for (int var = 0; var < 2 && pairable; var++) {
+        o_pbeg[var] = tab.size();
+        for (int pr = 0; pr < npairs && pairable; pr++) {
+            tab.push_back((int)pents[var].size());
+            const int c = 2 * pr;
+            const int ea = tab[o_ebeg[var] + c], eb = tab[o_ebeg[var] + c + 1], ec = tab[o_ebeg[var] + c + 2];
+            pairable = hm.coldesc[c].kind == 0 && hm.coldesc[c + 1].kind == 0 && hm.coldesc[c].link == hm.coldesc[c + 1].link && eb - ea == ec - eb;
+            for (int i = 0; i < eb - ea && pairable; i++) {
+                const int x = ents[var][ea + i], y = ents[var][eb + i];
+                pairable = (x & 0x3ff) == (y & 0x3ff) && (y >> 10) == (x >> 10) + 1 && ((x >> 10) & 1) == 0;
+                pents[var].push_back(x);
+            }
+        }
+        tab.push_back((int)pents[var].size());
+    }
     std::vector<size_t> o_fc(G), o_emb(G);
     for (int g = 0; g < G; g++) {
         o_fc[g] = tab.size();
@@ -1607,7 +1643,8 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     }
     while (tab.size() & 3) tab.push_back(0);
     const size_t o_ent0 = tab.size() * sizeof(int), o_ent1 = o_ent0 + ents[0].size() * sizeof(int);
-    const size_t o_grp = (o_ent1 + ents[1].size() * sizeof(int) + 15) & ~(size_t)15;
+    const size_t o_pent0 = o_ent1 + ents[1].size() * sizeof(int), o_pent1 = o_pent0 + (pairable ? pents[0].size() : 0) * sizeof(int);
+    const size_t o_grp = (o_pent1 + (pairable ? pents[1].size() : 0) * sizeof(int) + 15) & ~(size_t)15;
     // working factors and chunk buffers of the groups
     std::vector<FbrDevGroup> hg(G);
     bool skipzeros = false;
@@ -1620,19 +1657,23 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         if ((rc = fbr_tsqr_begin(wk, m->stream, Gg.Pa, g == gp.main ? Rin_dev : nullptr, m->num_cus, g == gp.main ? mrows : S * (long)Gg.rows.size())))
             return tsqr_fail(rc, "tsqr group begin");
         double *A = nullptr;
-        if ((rc = fbr_tsqr_chunk_buffer(wk, std::min(ch, S) * (long)Gg.rows.size(), &A))) return tsqr_fail(rc, "tsqr group chunk");
+        if ((rc = fbr_tsqr_chunk_buffer(wk, std::min(ch, S) * (long)Gg.rows.size(), &A)) || (rc = fbr_tsqr_chunk_clean(wk, m->stream)))
+            return tsqr_fail(rc, "tsqr group chunk");
         hg[g] = FbrDevGroup{A, wk.n, (int)Gg.sel.size()};
     }
     if ((rc = m->st_x.ensure(o_grp + G * sizeof(FbrDevGroup)))) return rc;
     HIPCHK(hipMemcpyAsync(m->st_x.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
     if (!ents[0].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_ent0, ents[0].data(), ents[0].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
     if (!ents[1].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_ent1, ents[1].data(), ents[1].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (pairable && !pents[0].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_pent0, pents[0].data(), pents[0].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (pairable && !pents[1].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_pent1, pents[1].data(), pents[1].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_grp, hg.data(), G * sizeof(FbrDevGroup), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));  // tab, hg are locals
     const int *t = m->st_x.as<int>();
     const FbrDevGroup *dgrp = (const FbrDevGroup *)((const char *)m->st_x.p + o_grp);
     const size_t lds = (size_t)((hm.rec_size() + 1) & ~1) * sizeof(double) + (size_t)hm.rows * sizeof(double *);
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // the kinematic records are produced for several chunks at a time: one lane per sample needs tens of thousands of waves in flight
     // to hide its latencies (1 M samples: 6.4 ms in one launch, 11 ms in twelve)
     const long kin_span = std::max(ch, std::min(S, (long)((size_t)(6ull << 30) / ((size_t)hm.rec_size() * sizeof(double))) / ch * ch));
@@ -1646,10 +1687,17 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         for (int g = 0; g < G; g++) skipzeros = skipzeros && cs % work(g).mb == 0;
         {
             ProfScope ps(m, FBR_PROF_REGRESSOR);
-            hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
-                               recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
-                               drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
-                               t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)));
+            if (pairable)
+                hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
+                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
+                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)),
+                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_pent1 : o_pent0)), npairs);
+            else
+                hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
+                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
+                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)));
         }
         HIPCHK(hipGetLastError());
         ProfScope ps(m, FBR_PROF_TSQR);
@@ -1662,14 +1710,17 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, cs * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
         }
     }
-    // Merge trees are latency bound (a level of the full-width tree is 0.96 ms on a handful of workgroups): the groups' trees run on two
-    // side streams beside the main group's tree, then ONE workgroup folds the embedded group factors (a dozen blocks) into the result --
-    // no second full-width tree.  Without a dense group the final factor starts from R_in.
+    // Merge trees are latency bound (a level of the full-width tree is 0.93 ms on a handful of workgroups, 8 levels over 256 private
+    // factors).  The groups' trees run on side streams beside the main group's.  Their factors, embedded into the caller's column
+    // order, are dense rows of the final factorisation: they are folded INSIDE the main tree -- once at most 8 of its factors are
+    // alive, one launch deals the embedded rows to those factors (a block or two per workgroup) -- instead of by one workgroup, group
+    // after group, behind the tree (round 3: 3.3 ms per call).  Without a dense group the final factor starts from R_in.
     ProfScope ps(m, FBR_PROF_TSQR);
     for (auto &st : m->tsqr_streams)
         if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto &e : m->tsqr_ev)
         if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    constexpr int NSIDE = (int)(sizeof(m->tsqr_streams) / sizeof(m->tsqr_streams[0]));
     size_t rt = 0;
     std::vector<size_t> o_r(G, 0);
     for (int g = 0; g < G; g++) {
@@ -1678,20 +1729,60 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     }
     if ((rc = m->tsqr_rtmp.ensure(rt * sizeof(double)))) return rc;
     double *rtmp = m->tsqr_rtmp.as<double>();
-    HIPCHK(hipEventRecord(m->tsqr_ev[2], m->stream));
-    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(m->tsqr_streams[i], m->tsqr_ev[2], 0));
+    HIPCHK(hipEventRecord(m->tsqr_ev[NSIDE], m->stream));
+    for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->tsqr_streams[i], m->tsqr_ev[NSIDE], 0));
+    // the longest trees first, one stream each as far as they go (a short tree queued behind the waist chain's tree was the last to finish)
+    std::vector<int> side_order;
+    for (int g = 0; g < G; g++)
+        if (g != gp.main) side_order.push_back(g);
+    std::stable_sort(side_order.begin(), side_order.end(), [&](int a, int b) { return gp.groups[a].Pa > gp.groups[b].Pa; });
     int nside = 0;
-    for (int g = 0; g < G; g++) {
-        if (g == gp.main) continue;
-        if ((rc = fbr_tsqr_finish_async(m->tsqr_groups[g], m->tsqr_streams[nside++ & 1], rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+    for (int g : side_order)
+        if ((rc = fbr_tsqr_finish_async(m->tsqr_groups[g], m->tsqr_streams[nside++ % NSIDE], rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+    for (int i = 0; i < NSIDE; i++) HIPCHK(hipEventRecord(m->tsqr_ev[i], m->tsqr_streams[i]));
+    // rows of the embedded group factors, stacked: [sum of the groups' Pa][n] in the final factor's column order
+    long erows = 0;
+    for (int g : side_order) erows += gp.groups[g].Pa;
+    const bool inside = gp.main >= 0 && !m->tsqr.narrow && erows > 0 && !getenv("FBR_TSQR_EMBED_AFTER");
+    auto pack_embedded = [&](FbrTsqrWork &wk, double *dst) -> int {
+        long off = 0;
+        const long epad = (erows + 15) & ~15L;
+        for (size_t i = 0; i < side_order.size(); i++) {
+            const int g = side_order[i], Pg = gp.groups[g].Pa;
+            const long mp = i + 1 == side_order.size() ? epad - off : Pg;  // (the last one also clears the rows up to the padded count)
+            hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(256), dim3(256), 0, m->stream, (long)Pg, mp, Pa, 0, wk.n, rtmp + o_r[g], Pg, t + o_emb[g],
+                               (const double *)nullptr, (const double *)nullptr, dst + off * wk.n, 0, 0L);
+            HIPCHK(hipGetLastError());
+            off += Pg;
+        }
+        return FBR_OK;
+    };
+    if (inside) {
+        FbrTsqrWork &wk = m->tsqr;
+        int alive_stride = 1;  // levels with stride < alive_stride have run
+        while ((wk.NW + alive_stride - 1) / alive_stride > 8) alive_stride *= 2;
+        if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, alive_stride))) return tsqr_fail(rc, "tsqr tree");
+        for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
+        if ((rc = m->tsqr_embed.ensure((size_t)((erows + 15) & ~15L) * wk.n * sizeof(double)))) return rc;
+        if ((rc = pack_embedded(wk, m->tsqr_embed.as<double>()))) return rc;
+        const int alive = (wk.NW + alive_stride - 1) / alive_stride;
+        if ((rc = fbr_tsqr_fold_packed(wk, m->stream, erows, FbrTsqrRowOrder(), m->tsqr_embed.as<double>(), alive_stride, alive)))
+            return tsqr_fail(rc, "tsqr embedded group factors");
+        if ((rc = fbr_tsqr_tree_levels(wk, m->stream, alive_stride, 1 << 30)) || (rc = fbr_tsqr_copy_out(wk, m->stream, R)))
+            return tsqr_fail(rc, "tsqr tree");
+        for (int g = 0; g < G; g++)
+            if (g != gp.main && (rc = fbr_tsqr_check(m->tsqr_groups[g], m->stream))) return tsqr_fail(rc, "tsqr group check");
+        if ((rc = fbr_tsqr_check(wk, m->stream))) return tsqr_fail(rc, "tsqr finish");
+        return FBR_OK;
     }
-    for (int i = 0; i < 2; i++) HIPCHK(hipEventRecord(m->tsqr_ev[i], m->tsqr_streams[i]));
+    // no dense group (fixed base behind a branching first link, masked base rows) or wave-private main kernels: the group factors are
+    // folded by one workgroup into a factor seeded with the main group's result / R_in
     const double *seed = Rin_dev;
     if (gp.main >= 0) {
         if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, rtmp + o_r[gp.main])) || (rc = fbr_tsqr_check(m->tsqr, m->stream))) return tsqr_fail(rc, "tsqr finish");
         seed = rtmp + o_r[gp.main];
     }
-    for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
+    for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
     if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, seed, m->num_cus, 1))) return tsqr_fail(rc, "tsqr begin");
     for (int g = 0; g < G; g++) {
         if (g == gp.main) continue;
@@ -1819,7 +1910,8 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
             ro.group = cs;
             long rs_s = hm.rows, rs_r = 1;
             if (direct) {
-                if ((rc = fbr_tsqr_chunk_buffer(m->tsqr, cs * hm.rows, &dst))) return tsqr_fail(rc, "tsqr chunk");
+                if ((rc = fbr_tsqr_chunk_buffer(m->tsqr, cs * hm.rows, &dst)) || (k == 0 && (rc = fbr_tsqr_chunk_clean(m->tsqr, m->stream))))
+                    return tsqr_fail(rc, "tsqr chunk");
                 ldy = m->tsqr.n;
                 if (ro.rows) {
                     rs_s = 1;
@@ -1907,7 +1999,10 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
             };
             auto tree = [&]() {
                 long merge = 0, t = 0;
-                for (int i0 = 0; i0 < sh.n; i0 += sh.mb) merge += fold_mfma(i0);
+                for (int i0 = 0; i0 < sh.n; i0 += sh.tmb) {
+                    const long np_ = sh.n / 16 - i0 / 16;
+                    merge += np_ > 0 ? (8L * sh.tsub + 4) * (np_ * (np_ - 1) / 2) : 0;
+                }
                 for (int stride = 1; stride < sh.NW; stride *= 2)
                     for (long a = 0; a + stride < sh.NW; a += 2L * stride) t += merge;
                 return t;
@@ -1936,13 +2031,26 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
                 set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
                 return FBR_E_UNSUPPORTED;
             }
-            if (gp.main >= 0) tr += tree();  // the dense group's own tree; the embedded group factors are folded by one workgroup afterwards
+            if (gp.main >= 0) tr += tree();  // the dense group's own tree
+            const int main_mb = sh.mb;
+            long erows = 0;
             for (int g = 0; g < (int)gp.groups.size(); g++)
-                if (g != gp.main)
-                    for (long r0 = 0; r0 < ((gp.groups[g].Pa + 15) & ~15); r0 += sh.mb) tr += fold_mfma(0);
+                if (g != gp.main) erows += gp.groups[g].Pa;
+            if (gp.main >= 0 && !sh.narrow && erows > 0 && !getenv("FBR_TSQR_EMBED_AFTER")) {
+                // the stacked embedded group factors are folded into the factors alive inside the main tree (tsqr_groups_impl)
+                for (long r0 = 0; r0 < ((erows + 15) & ~15L); r0 += sh.mb) tr += fold_mfma(0);
+            } else {
+                if (fbr_tsqr_shape(Pa, m->num_cus, 1, &sh)) {  // (that factorisation is begun for a handful of rows: fbr_tsqr_begin(.., 1))
+                    set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
+                    return FBR_E_UNSUPPORTED;
+                }
+                for (int g = 0; g < (int)gp.groups.size(); g++)
+                    if (g != gp.main)
+                        for (long r0 = 0; r0 < ((gp.groups[g].Pa + 15) & ~15); r0 += sh.mb) tr += fold_mfma(0);
+            }
             if (mfma_level0) *mfma_level0 = l0;
             if (mfma_tree) *mfma_tree = tr;
-            if (block_rows) *block_rows = sh.mb;
+            if (block_rows) *block_rows = main_mb;
             if (n_padded) *n_padded = sh.n;
             return FBR_OK;
         }
@@ -1978,11 +2086,17 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
         }
     }
     long merge = 0;  // one node of the tree: the partner's triangular factor folded in block_rows-row pieces
-    for (int i0 = 0; i0 < sh.n; i0 += sh.mb) merge += fold_mfma(i0);
+    for (int i0 = 0; i0 < sh.n; i0 += sh.tmb) {
+        const long np_ = NP - i0 / 16;
+        merge += np_ > 0 ? (8L * sh.tsub + 4) * (np_ * (np_ - 1) / 2) : 0;
+    }
     for (int stride = 1; stride < sh.NW; stride *= 2)
         for (long a = 0; a + stride < sh.NW; a += 2L * stride) tr += merge;
-    if (plan.reorder)  // the factor is brought back to the caller's column order: Pa dense rows folded by one workgroup
-        for (long r0 = 0; r0 < ((Pa + 15) & ~15); r0 += sh.mb) tr += fold_mfma(0);
+    if (plan.reorder) {  // the factor is brought back to the caller's column order: Pa dense rows folded by one workgroup
+        FbrTsqrShape s1;
+        if (fbr_tsqr_shape(Pa, m->num_cus, 1, &s1)) return FBR_E_UNSUPPORTED;
+        for (long r0 = 0; r0 < ((Pa + 15) & ~15); r0 += s1.mb) tr += (8L * s1.sub + 4) * ((long)NP * (NP - 1) / 2);
+    }
     if (mfma_level0) *mfma_level0 = l0;
     if (mfma_tree) *mfma_tree = tr;
     if (block_rows) *block_rows = sh.mb;
@@ -1996,7 +2110,7 @@ extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const 
         set_err("bad arguments");
         return FBR_E_INVALID;
     }
-    if (int rc_enter = enter(m)) return rc_enter;
+    if (int rc_enter = enter_blocking(m)) return rc_enter;
     const size_t cnt = (size_t)n * n;
     int rc;
     const double *da = nullptr, *db = nullptr;
@@ -2048,7 +2162,7 @@ extern "C" int fbr_filtfilt(fbr_model *m, const double *b, const double *a, int3
         set_err("fbr_filtfilt: the signal must be longer than the padding of 3 * ncoef samples");
         return FBR_E_INVALID;
     }
-    if (int rc_enter = enter(m)) return rc_enter;
+    if (int rc_enter = enter_blocking(m)) return rc_enter;
     FbrIir f;
     memset(&f, 0, sizeof(f));
     f.nc = ncoef;
@@ -2117,7 +2231,7 @@ extern "C" int fbr_medfilt(fbr_model *m, int32_t k, double *X, int64_t S, int32_
         set_err("fbr_medfilt: bad arguments (k odd, 1 <= k <= 31, ld >= ncols)");
         return FBR_E_INVALID;
     }
-    if (int rc_enter = enter(m)) return rc_enter;
+    if (int rc_enter = enter_blocking(m)) return rc_enter;
     int rc;
     double *dX = nullptr;
     const size_t xcount = (size_t)(S - 1) * ld + ncols;
@@ -2136,7 +2250,7 @@ extern "C" int fbr_central_diff(fbr_model *m, const double *A, const double *T, 
         set_err("fbr_central_diff: bad arguments (S >= 5)");
         return FBR_E_INVALID;
     }
-    if (int rc_enter = enter(m)) return rc_enter;
+    if (int rc_enter = enter_blocking(m)) return rc_enter;
     int rc;
     double *dA = nullptr, *dT = nullptr, *dD = D;
     if ((rc = sig_stage(m, m->st_aux, A, (size_t)S * ncols, mem, &dA)) || (rc = sig_stage(m, m->st_aux2, T, (size_t)S, mem, &dT))) return rc;

@@ -442,6 +442,94 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
     }
 }
 
+// K2d: the same writer with one thread per PAIR of adjacent inertial columns and 16-byte stores (a wave instruction covers 1 KiB of a
+// chunk row instead of 512 B; the 8-byte form is bound by its store instructions at 2.5 TB/s).  The two columns of a pair belong to one
+// link, so they share their entry list: pent[pbeg[pr] .. pbeg[pr+1]) = regressor row | kind << 8 | (even) position of the first column
+// in the row's group << 10.  Used when every group keeps the two columns of every pair side by side at an even position (always for the
+// whole regressor; a column subset falls back to K2c).  Friction columns take the single-column entries (ebeg / ent) as in K2c.
+__global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, long S, const double *__restrict__ rec, const double *__restrict__ dq,
+                                                                     const double *__restrict__ sign, const double *__restrict__ rhs, int k,
+                                                                     const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,
+                                                                     const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
+                                                                     const int *__restrict__ ebeg, const int *__restrict__ ent,
+                                                                     const int *__restrict__ pbeg, const int *__restrict__ pent, int npairs)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *rs = smem;                                    // [rec]
+    double **rowptr = (double **)(smem + ((m.rec + 1) & ~1));  // [rows] chunk row of this sample's regressor row r (its group's chunk)
+    const int tid = threadIdx.x;
+    constexpr int PU = 6;
+    const bool pre = m.rec <= 256 * PU;
+    double pv[PU];
+    if (pre && (long)blockIdx.x < S)
+#pragma unroll
+        for (int u = 0; u < PU; u++) pv[u] = rec[blockIdx.x * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+    for (long s = blockIdx.x; s < S; s += gridDim.x) {
+        fbr_barrier_lds();
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < PU; u++)
+                if (tid + 256 * u < m.rec) rs[tid + 256 * u] = pv[u];
+            if (s + gridDim.x < S)
+#pragma unroll
+                for (int u = 0; u < PU; u++) pv[u] = rec[(s + gridDim.x) * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+        } else {
+            fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        }
+        if (tid < m.rows) {
+            const int g = rowgroup[tid];
+            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * S + s) * grp[g].ld : nullptr;
+        }
+        fbr_barrier_lds();
+        for (int t = tid; t < m.rows * k; t += blockDim.x) {
+            const int r = t / k, i = t - r * k;
+            const int g = rowgroup[r];
+            if (g < 0) continue;
+            double v = rhs[(s * m.rows + r) * k + i];
+            if (wts) v *= wts[s * m.rows + r];
+            rowptr[r][grp[g].psel + i] = v;
+        }
+        for (int pr = tid; pr < npairs; pr += blockDim.x) {
+            const int e0 = pbeg[pr], e1 = pbeg[pr + 1];
+            if (e0 == e1) continue;
+            const int4 ca = m.coldesc[2 * pr], cb = m.coldesc[2 * pr + 1];
+            double wa[6], wb[6];
+            fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, ca.z, wa);
+            fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, cb.z, wb);
+            int en_next = pent[e0];
+            for (int e = e0; e < e1; e++) {
+                const int en = en_next;
+                en_next = pent[e + 1 < e1 ? e + 1 : e];
+                const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
+                fbr_d2 v = {0.0, 0.0};
+                if (kind == 0) {
+                    v[0] = wa[r];
+                    v[1] = wb[r];
+                } else if (kind == 1) {
+                    const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb);
+                    v[0] = fbr_dot6(Sd, wa);
+                    v[1] = fbr_dot6(Sd, wb);
+                }
+                if (wts) v *= wts[s * m.rows + r];
+                __builtin_nontemporal_store(v, (fbr_d2 *)(rowptr[r] + pos));
+            }
+        }
+        for (int c = 2 * npairs + tid; c < m.cols; c += blockDim.x) {  // friction columns
+            const int e0 = ebeg[c], e1 = ebeg[c + 1];
+            if (e0 == e1) continue;
+            const int4 cd = m.coldesc[c];
+            const double fv = fbr_friction_value(cd.z, dq[s * m.n + cd.w], sign ? sign[s * m.n + cd.w] : 0.0, m.stribeck);
+            for (int e = e0; e < e1; e++) {
+                const int en = ent[e];
+                const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
+                double v = kind == 3 ? fv : 0.0;
+                if (wts) v *= wts[s * m.rows + r];
+                __builtin_nontemporal_store(v, rowptr[r] + pos);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: inverse dynamics / prediction, one wavefront per sample.
 //   mode 0: x = full standard vector (10 per link + friction slots), friction model of model.py:299-326

@@ -42,7 +42,13 @@
 #endif
 #define FBR_TSQR_RING_MAX 6        // published panels (V, T) kept in the LDS: how far the waves may drift apart (fewer for tall blocks)
 // (128-row blocks: 5 slots fit the 160 KiB; four-wave workgroups, two per CU, have 80 KiB each: 3 slots -- enough for 4 waves)
-template <int SUB, int W = FBR_TSQR_WAVES> __host__ __device__ constexpr int fbr_tsqr_ring() { return W < FBR_TSQR_WAVES ? 3 : (SUB > 6 ? 5 : FBR_TSQR_RING_MAX); }
+// R rows through REGISTERS instead of LDS tiles (fbr_tsqr_stream, RREG): the four-wave workgroups that cover more than 20 column tiles
+// (two 32-row folds per CU for WALK-MAN's 31 tiles) have no room for one LDS tile per column tile in their 80 KiB
+template <int TPW, int W> __host__ __device__ constexpr bool fbr_tsqr_rreg() { return W < FBR_TSQR_WAVES && TPW > 5; }
+template <int SUB, int W = FBR_TSQR_WAVES, bool RREG = false> __host__ __device__ constexpr int fbr_tsqr_ring()
+{
+    return RREG ? FBR_TSQR_RING_MAX : (W < FBR_TSQR_WAVES ? 3 : (SUB > 6 ? 5 : FBR_TSQR_RING_MAX));
+}
 #define FBR_TSQR_MAXN 768          // widest supported factor (columns incl. rhs, padded to 16)
 #define FBR_TSQR_SPIN_LIMIT (1 << 20)  // ~50 ms of polling: far beyond any legitimate wait (a fold tail is ~0.1 ms)
 
@@ -131,7 +137,9 @@ __global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, i
 // LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vr[RING][MB*17] | Tr[RING][256] | Rp[WAVES][256] | flags[16]
 template <int TPW, int SUB, int W = FBR_TSQR_WAVES> static inline size_t fbr_tsqr_lds_doubles()
 {
-    return (size_t)W * TPW * 256 + (size_t)fbr_tsqr_ring<SUB, W>() * (16 * SUB * FBR_TSQR_LDV + FBR_TSQR_TSZ) + (size_t)W * 256 + 16 + FBR_TSQR_RING_MAX;
+    constexpr bool RREG = fbr_tsqr_rreg<TPW, W>();
+    return (RREG ? 0 : (size_t)W * TPW * 256) + (size_t)fbr_tsqr_ring<SUB, W, RREG>() * (16 * SUB * FBR_TSQR_LDV + FBR_TSQR_TSZ) + (size_t)W * 256 + 16 +
+           FBR_TSQR_RING_MAX;
 }
 typedef __attribute__((address_space(3))) void *fbr_tsqr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_tsqr_glb_ptr;
@@ -298,16 +306,26 @@ __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const do
 // and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
 // Tiles are updated one at a time (a paired form ran dead / padding tiles through the MFMAs: +34 % MFMA work, slower;
 // splitting V^T C over two accumulators to shorten the dependent chain was 3 % slower as well).
-template <int TPW, int SUB, int T, int W>
+// R rows of panel q under column tile ct, straight from global memory in the C/D layout (RREG: prefetched one tile ahead)
+__device__ __forceinline__ fbr_td4 fbr_tsqr_load_rrows(const double *__restrict__ R, unsigned ld, int q, int ct, int lane)
+{
+    const unsigned voff = (unsigned)(lane >> 4) * ld + (unsigned)(lane & 15);
+    fbr_td4 r;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) r[reg] = (R + ((unsigned)(16 * q + 4 * reg) * ld + 16u * (unsigned)ct))[voff];
+    return r;
+}
+
+template <int TPW, int SUB, int T, int W, bool RREG = false>
 __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], const double *Rl, double *__restrict__ R, unsigned ld, int q, int wave,
-                                                     int lane, const double *Vl, const double *Tm)
+                                                     int lane, const double *Vl, const double *Tm, const fbr_td4 r0 = fbr_td4{0.0, 0.0, 0.0, 0.0})
 {
     const int li = lane & 15, kk = lane >> 4;
     const unsigned j0 = 16u * (unsigned)q;
     const double *Rt = Rl + (wave + W * T) * 256;
     fbr_td4 acc, w2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) acc[reg] = Rt[(4 * reg + kk) * 16 + li];
+    for (int reg = 0; reg < 4; reg++) acc[reg] = RREG ? r0[reg] : Rt[(4 * reg + kk) * 16 + li];
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
 #pragma unroll
@@ -321,7 +339,7 @@ __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], con
         const unsigned c0 = 16u * (unsigned)(wave + W * T);
         const unsigned voff = (unsigned)kk * ld + (unsigned)li;
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) (R + ((j0 + 4 * reg) * ld + c0))[voff] = Rt[(4 * reg + kk) * 16 + li] - w2[reg];
+        for (int reg = 0; reg < 4; reg++) (R + ((j0 + 4 * reg) * ld + c0))[voff] = (RREG ? r0[reg] : Rt[(4 * reg + kk) * 16 + li]) - w2[reg];
     }
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
@@ -359,25 +377,34 @@ __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, int t1, double *Rl, 
 
 // the wave's tiles t0 <= t < t1, one at a time (static register indexing, a uniform branch per tile; dead and padding
 // tiles cost nothing)
-template <int TPW, int SUB, int W, int T = 0> struct FbrTsqrUpdateFrom {
+// (RREG: rn holds the R rows of tile t0 on entry; the rows of the next tile are requested before the current one is updated)
+template <int TPW, int SUB, int W, int T = 0, bool RREG = false> struct FbrTsqrUpdateFrom {
     static __device__ __forceinline__ void run(int t0, int t1, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
-                                               int wave, int lane, const double *Vl, const double *Tm)
+                                               int wave, int lane, const double *Vl, const double *Tm, fbr_td4 &rn)
     {
         if constexpr (T < TPW) {
-            if (T >= t0 && T < t1) fbr_tsqr_update_tile<TPW, SUB, T, W>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
-            FbrTsqrUpdateFrom<TPW, SUB, W, T + 1>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            if (T >= t0 && T < t1) {
+                if constexpr (RREG) {
+                    const fbr_td4 r0 = rn;
+                    if (T + 1 < t1) rn = fbr_tsqr_load_rrows(R, ld, q, wave + W * (T + 1), lane);
+                    fbr_tsqr_update_tile<TPW, SUB, T, W, true>(C, Rl, R, ld, q, wave, lane, Vl, Tm, r0);
+                } else {
+                    fbr_tsqr_update_tile<TPW, SUB, T, W>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
+                }
+            }
+            FbrTsqrUpdateFrom<TPW, SUB, W, T + 1, RREG>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
         }
     }
 };
 
 // the single tile tp (uniform, selected by a static switch)
-template <int TPW, int SUB, int W, int T = 0> struct FbrTsqrUpdateOne {
+template <int TPW, int SUB, int W, int T = 0, bool RREG = false> struct FbrTsqrUpdateOne {
     static __device__ __forceinline__ void run(int tp, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
-                                               int wave, int lane, const double *Vl, const double *Tm)
+                                               int wave, int lane, const double *Vl, const double *Tm, const fbr_td4 &r0)
     {
         if constexpr (T < TPW) {
-            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T, W>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
-            FbrTsqrUpdateOne<TPW, SUB, W, T + 1>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T, W, RREG>(C, Rl, R, ld, q, wave, lane, Vl, Tm, r0);
+            FbrTsqrUpdateOne<TPW, SUB, W, T + 1, RREG>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, r0);
         }
     }
 };
@@ -423,9 +450,10 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         tk = t1;                                                          \
     }
     constexpr int MB = 16 * SUB;
-    constexpr int FBR_TSQR_RING = fbr_tsqr_ring<SUB, W>();
+    constexpr bool RREG = fbr_tsqr_rreg<TPW, W>();
+    constexpr int FBR_TSQR_RING = fbr_tsqr_ring<SUB, W, RREG>();
     double *Rl = smem;  // 16-byte aligned tiles for the LDS-DMA
-    double *Vr = Rl + W * TPW * 256;
+    double *Vr = Rl + (RREG ? 0 : W * TPW * 256);
     double *Tr = Vr + FBR_TSQR_RING * MB * FBR_TSQR_LDV;
     double *Rps = Tr + FBR_TSQR_RING * FBR_TSQR_TSZ;
     int *done = (int *)(Rps + W * 256);  // done[w]: wave w needs no panel < done[w] any more
@@ -482,7 +510,11 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         fetch_rpp(q0 + ((wave - q0) % W + W) % W);
         // R rows of the first panel under this wave's tiles right of it (the wave is done with its tiles of the
         // previous fold, so their LDS slots are free)
-        fbr_tsqr_fetch_rows<TPW, W>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, t1, Rl, R, ld, q0, wave, lane);
+        // RREG: the rows of the FIRST tile the wave will update with a panel travel in rn, requested an iteration ahead: the tile of the
+        // next panel when the wave owns it (updated first, in front of the chain), else its first tile right of the panel
+        fbr_td4 rn = {0.0, 0.0, 0.0, 0.0};
+        auto first_tile = [&](int q) { return (q + 1 < NP && wave == (q + 1) % W) ? (q + 1) / W : ((q >= wave) ? (q - wave) / W + 1 : 0); };
+        if constexpr (!RREG) fbr_tsqr_fetch_rows<TPW, W>((q0 >= wave) ? (q0 - wave) / W + 1 : 0, t1, Rl, R, ld, q0, wave, lane);
         FBR_TT(0)
 
         // factorise panel p = tile p of this wave (global index G): Householder QR of [R_pp ; tile] in registers,
@@ -591,19 +623,29 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 // next panel's owner: its tile first, then its factorisation, then the rest of panel q.  This is the
                 // serial dependency chain of the fold: raise the wave's issue priority over the waves that only update
                 __builtin_amdgcn_s_setprio(3);
-                if (apply) FbrTsqrUpdateOne<TPW, SUB, W>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                if (apply) FbrTsqrUpdateOne<TPW, SUB, W, 0, RREG>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
                 FBR_TT(3)
+                t0 = (q + 1) / W + 1;
+                // (RREG: the rows under the wave's next tile travel during the chain)
+                if constexpr (RREG)
+                    if (apply && t0 < t1) rn = fbr_tsqr_load_rrows(R, ld, q, wave + W * t0, lane);
                 chain(q + 1, G + 1);
                 __builtin_amdgcn_s_setprio(0);
                 FBR_TT(1)
-                t0 = (q + 1) / W + 1;
             }
             if (apply) {
-                FbrTsqrUpdateFrom<TPW, SUB, W>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm);
+                FbrTsqrUpdateFrom<TPW, SUB, W, 0, RREG>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
                 fbr_lds_release();
                 if (lane == 0) __atomic_store_n(done + wave, G + 1, __ATOMIC_RELAXED);
                 // R rows of the next panel under the tiles right of it
-                if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW, W>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, t1, Rl, R, ld, q + 1, wave, lane);
+                if constexpr (!RREG)
+                    if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW, W>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, t1, Rl, R, ld, q + 1, wave, lane);
+            }
+            if constexpr (RREG) {
+                if (q + 1 < NP) {
+                    const int tf = first_tile(q + 1);
+                    if (tf < t1) rn = fbr_tsqr_load_rrows(R, ld, q + 1, wave + W * tf, lane);
+                }
             }
             FBR_TT(3)
         }
@@ -619,13 +661,15 @@ template <int TPW, int SUB, bool TIMING, int W = FBR_TSQR_WAVES>
 __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
                                                                                double *__restrict__ Rw, long nblocks, unsigned *errflag,
                                                                                unsigned long long *dbg, const int *__restrict__ rowfc, int orows,
-                                                                               long ogroup, long M)
+                                                                               long ogroup, long M, int slot_stride)
 {
+    // slot_stride: workgroup w folds into working factor w * slot_stride (1 for data chunks; 2^l when rows are folded into the factors
+    // that are still alive after l levels of the merge tree: the embedded group factors of the tree-structured TSQR)
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
     constexpr int LD = 16 * W * TPW;  // leading dimension of the working factors (>= n)
-    double *R = Rw + (long)blockIdx.x * n * LD;
+    double *R = Rw + (long)blockIdx.x * slot_stride * n * LD;
     const int nfolds = (int)((nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x);
     auto fold_of = [&](int f) {
         const long r0 = ((long)blockIdx.x + (long)f * gridDim.x) * MB;
@@ -850,7 +894,9 @@ struct FbrTsqrWork {
     double *A = nullptr;    // packed chunk [Mpad][n]
     unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
     size_t rw_bytes = 0, a_bytes = 0;
-    int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0, waves = FBR_TSQR_WAVES;
+    long clean_key = -1;  // (Pa, n) for which the padding columns [Pa, n) of the whole chunk buffer are zero and stay zero (writers that
+                          // fill the chunk in place never touch them): the per-chunk tail pass then only clears the rows M..Mpad
+    int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0, waves = FBR_TSQR_WAVES, ttpw = 0;
     bool active = false, narrow = false;
     void release()
     {
@@ -899,11 +945,22 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
 // block fits HALF the register file at the same height two independent folds per CU run side by side
 #define FBR_TSQR_HALF_WAVES 4
 #define FBR_TSQR_HALF_MAX_TILES 20
+// Wider than 20 tiles the four-wave workgroups keep the R rows in registers instead of LDS tiles (RREG) and fold 48- / 32-row blocks:
+// two independent folds per CU for WALK-MAN's 31 tiles (6 tiles per wave: 21..24 column tiles, 8 per wave: 25..32)
+#ifndef FBR_TSQR_SUB6H
+#define FBR_TSQR_SUB6H 3
+#endif
+#ifndef FBR_TSQR_SUB8H
+#define FBR_TSQR_SUB8H 2
+#endif
+#define FBR_TSQR_DUAL_MAX_TILES 32
 #define FBR_TSQR_DISPATCH_HALF(TPWV, CALL)             \
     switch (TPWV) {                                    \
     case 3: { constexpr int TPW = 3, SUB = FBR_TSQR_SUB3; CALL; } break; \
     case 4: { constexpr int TPW = 4, SUB = FBR_TSQR_SUB4; CALL; } break; \
-    default: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
+    case 5: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
+    case 6: { constexpr int TPW = 6, SUB = FBR_TSQR_SUB6H; CALL; } break; \
+    default: { constexpr int TPW = 8, SUB = FBR_TSQR_SUB8H; CALL; } break; \
     }
 static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : (tpw == 3 ? FBR_TSQR_SUB3 : (tpw == 4 ? FBR_TSQR_SUB4 : (tpw <= 1 ? 4 : (tpw == 5 ? 3 : 2)))); }
 
@@ -930,6 +987,7 @@ struct FbrTsqrShape {
     int n, tpw, sub, mb, NW, ld;
     bool narrow;
     int waves;  // waves per workgroup of the wide kernels (8, or 4 with two workgroups per CU)
+    int ttpw, tsub, tmb;  // tiles per wave / block rows of the kernel that runs the merge tree (the eight-wave one for the RREG shapes)
 };
 static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrShape *out)
 {
@@ -939,18 +997,25 @@ static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrSha
         return -4;
     }
     const bool narrow = n / 16 <= FBR_TSQR_NARROW_MAX_TILES && !getenv("FBR_TSQR_NO_NARROW");
-    const bool half = !narrow && n / 16 > FBR_TSQR_NARROW_MAX_TILES && n / 16 <= FBR_TSQR_HALF_MAX_TILES && !getenv("FBR_TSQR_NO_HALF") &&
-                      !getenv("FBR_TSQR_TIMING");
+    // two 32- / 48-row folds per CU (RREG) instead of one 64-row fold.  MEASURED SLOWER (round 4: WALK-MAN 1 M samples 196 vs 175 ms per
+    // call -- 1.5 x the panel-chain work per row, 11 % more MFMAs, and twice the R traffic per row: 512 private factors of 2 MB are
+    // streamed per 32 rows) and therefore OFF unless FBR_TSQR_DUAL is set; kept so that the measurement can be repeated
+    const bool dual = !narrow && n / 16 > FBR_TSQR_HALF_MAX_TILES && n / 16 <= FBR_TSQR_DUAL_MAX_TILES && rows_hint >= 64L * 8 * num_cus &&
+                      getenv("FBR_TSQR_DUAL") && !getenv("FBR_TSQR_TIMING");
+    const bool half = dual || (!narrow && n / 16 > FBR_TSQR_NARROW_MAX_TILES && n / 16 <= FBR_TSQR_HALF_MAX_TILES && !getenv("FBR_TSQR_NO_HALF") &&
+                               !getenv("FBR_TSQR_TIMING"));
     const int waves = half ? FBR_TSQR_HALF_WAVES : FBR_TSQR_WAVES;
-    const int tpw = narrow ? n / 16 : (n / 16 + waves - 1) / waves;
-    const int sub = narrow ? fbr_tsqr_narrow_sub_for(tpw) : fbr_tsqr_sub_for(tpw);
+    const int tpw8 = (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
+    const int tpw = narrow ? n / 16 : (dual ? (n / 16 <= 24 ? 6 : 8) : (n / 16 + waves - 1) / waves);
+    const int sub = narrow ? fbr_tsqr_narrow_sub_for(tpw) : (dual ? (tpw == 6 ? FBR_TSQR_SUB6H : FBR_TSQR_SUB8H) : fbr_tsqr_sub_for(tpw));
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
     const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
     const long per_cu = envw ? std::max(1, atoi(envw)) : (narrow ? 2 * FBR_TSQR_NARROW_WAVES : (half ? 2 : 1));  // narrow: private R per WAVE
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
     const int ld = narrow ? n : 16 * waves * tpw;
-    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow, waves};
+    // (the RREG shapes share their leading dimension with the eight-wave kernel of the same width: 16 x 4 x 6 = 16 x 8 x 3, 16 x 4 x 8 = 16 x 8 x 4)
+    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow, waves, dual ? tpw8 : tpw, dual ? fbr_tsqr_sub_for(tpw8) : sub, dual ? 16 * fbr_tsqr_sub_for(tpw8) : mb};
     return 0;
 }
 
@@ -969,7 +1034,7 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         TSQR_HIP(hipMalloc((void **)&wk.Rw, need));
         wk.rw_bytes = need;
     }
-    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub; wk.narrow = narrow; wk.waves = sh.waves;
+    wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub; wk.narrow = narrow; wk.waves = sh.waves; wk.ttpw = sh.ttpw;
     if (!wk.err) TSQR_HIP(hipMalloc((void **)&wk.err, sizeof(unsigned)));
     TSQR_HIP(hipMemsetAsync(wk.err, 0, sizeof(unsigned), st));
     TSQR_HIP(hipMemsetAsync(wk.Rw, 0, need, st));
@@ -996,34 +1061,53 @@ static inline int fbr_tsqr_chunk_buffer(FbrTsqrWork &wk, long M, double **A)
         wk.a_bytes = 0;
         TSQR_HIP(hipMalloc((void **)&wk.A, need));
         wk.a_bytes = need;
+        wk.clean_key = -1;
     }
     *A = wk.A;
     return 0;
 }
 
+// Before a writer fills the chunk in place for fbr_tsqr_fold_chunk(k = 0): make the padding columns zero once per (buffer, width).
+static inline int fbr_tsqr_chunk_clean(FbrTsqrWork &wk, hipStream_t st)
+{
+    const long key = (long)wk.Pa * 4096 + wk.n;
+    if (wk.clean_key == key || !wk.A) return 0;
+    TSQR_HIP(hipMemsetAsync(wk.A, 0, wk.a_bytes, st));
+    wk.clean_key = key;
+    return 0;
+}
+
 // level 0 over the packed chunk wk.A (M rows)
-static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, const FbrTsqrRowOrder &ro = FbrTsqrRowOrder())
+// Asrc (optional): another packed chunk than wk.A.  slot_stride / max_wgs: the blocks are dealt to at most max_wgs workgroups and
+// workgroup w folds into working factor w * slot_stride (wide kernels only: rows folded into the factors still alive inside the tree).
+static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, const FbrTsqrRowOrder &ro = FbrTsqrRowOrder(),
+                                       const double *Asrc = nullptr, int slot_stride = 1, int max_wgs = 0)
 {
     const int n = wk.n;
     const long Mpad = (M + 15) & ~15L;
     const long nblocks = (Mpad + wk.mb - 1) / wk.mb;
+    const double *A = Asrc ? Asrc : wk.A;
     if (wk.narrow) {
+        if (slot_stride != 1 || max_wgs) {
+            g_tsqr_err = "slot stride is not supported by the wave-private kernels";
+            return -1;
+        }
         const int nwaves = (int)std::min<long>(wk.NW, nblocks);
         const int grid = (nwaves + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
         FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
-                                                            (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, wk.A, Mpad,
+                                                            (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, A, Mpad,
                                                             wk.Rw, nblocks, nwaves, ro.first_col, ro.rows, ro.group, M));
         TSQR_HIP(hipGetLastError());
         return 0;
     }
-    const int grid = (int)std::min<long>(wk.NW, nblocks);
+    const int grid = (int)std::min<long>(max_wgs > 0 ? std::min(max_wgs, wk.NW) : wk.NW, nblocks);
     unsigned long long *dbg = nullptr;
     if (wk.waves == FBR_TSQR_HALF_WAVES) {
         constexpr int HW = FBR_TSQR_HALF_WAVES;
         FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, false, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                  (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double))));
         FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, false, HW>), dim3(grid), dim3(64 * HW),
-                                                          (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+                                                          (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride));
         TSQR_HIP(hipGetLastError());
         return 0;
     }
@@ -1035,12 +1119,12 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, true>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride));
     } else {
         FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, false>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M));
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride));
     }
     TSQR_HIP(hipGetLastError());
     if (dbg) {
@@ -1073,7 +1157,7 @@ static inline int fbr_tsqr_fold_rows(FbrTsqrWork &wk, hipStream_t st, long M, in
     const long Mpad = (M + 15) & ~15L;
     hipLaunchKernelGGL(fbr_tsqr_pack_kernel, dim3(2048), dim3(256), 0, st, M, Mpad, P, k, wk.n, Y, ldy, cols, rhs, w, A, ro.rows, ro.group);
     TSQR_HIP(hipGetLastError());
-    return fbr_tsqr_fold_packed(wk, st, M, ro);
+    return fbr_tsqr_fold_packed(wk, st, M, ro);  // (the pack kernel writes zeros into the padding columns: a clean buffer of this width stays clean)
 }
 
 // Fold the chunk whose first P columns were already written into fbr_tsqr_chunk_buffer() (leading dimension wk.n):
@@ -1087,22 +1171,38 @@ static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, i
     }
     if (M <= 0) return 0;
     const long Mpad = (M + 15) & ~15L;
-    hipLaunchKernelGGL(fbr_tsqr_tail_kernel, dim3(1024), dim3(256), 0, st, M, Mpad, P, k, wk.n, rhs, wk.A, ro.rows, ro.group);
-    TSQR_HIP(hipGetLastError());
+    if (k == 0 && !getenv("FBR_TSQR_NO_CLEAN_PAD")) {
+        // the writer has stored every column < Pa (rhs columns included): what is left are the zero padding columns -- written once per
+        // buffer instead of once per chunk (WALK-MAN: 15 columns x 6 M base-wrench rows per 1 M samples) -- and the rows M..Mpad
+        const long key = (long)wk.Pa * 4096 + wk.n;
+        if (wk.clean_key != key) {
+            TSQR_HIP(hipMemsetAsync(wk.A, 0, wk.a_bytes, st));
+            g_tsqr_err = "chunk buffer cleared after it was filled";  // (callers clear BEFORE the writer runs: fbr_tsqr_chunk_clean)
+            return -1;
+        }
+        if (Mpad > M) TSQR_HIP(hipMemsetAsync(wk.A + M * wk.n, 0, (size_t)(Mpad - M) * wk.n * sizeof(double), st));
+    } else {
+        hipLaunchKernelGGL(fbr_tsqr_tail_kernel, dim3(1024), dim3(256), 0, st, M, Mpad, P, k, wk.n, rhs, wk.A, ro.rows, ro.group);
+        TSQR_HIP(hipGetLastError());
+        wk.clean_key = -1;
+    }
     return fbr_tsqr_fold_packed(wk, st, M, ro);
 }
 
 // Binary tree over the working factors, result (Pa x Pa, upper triangular) to R_out (device): enqueued on st, not waited for
 // (several factorisations can run their latency-bound trees on different streams; fbr_tsqr_check() collects the error word).
-static inline int fbr_tsqr_finish_async(FbrTsqrWork &wk, hipStream_t st, double *R_out)
+// Levels of the binary tree with stride_from <= stride < stride_to (strides are powers of two; the factors alive after the level of
+// stride s are the slots that are multiples of 2 s).
+static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stride_from, int stride_to)
 {
     if (!wk.active) {
         g_tsqr_err = "tsqr finish without begin";
         return -1;
     }
     const int n = wk.n;
+    stride_to = std::min(stride_to, wk.NW);
     if (wk.narrow) {
-        for (int stride = 1; stride < wk.NW; stride *= 2) {
+        for (int stride = stride_from; stride < stride_to; stride *= 2) {
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
             const int grid = (pairs + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
             FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_tree_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
@@ -1110,30 +1210,44 @@ static inline int fbr_tsqr_finish_async(FbrTsqrWork &wk, hipStream_t st, double 
                                                                 stride, wk.NW));
             TSQR_HIP(hipGetLastError());
         }
-    } else if (wk.waves == FBR_TSQR_HALF_WAVES) {
+    } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw) {
         constexpr int HW = FBR_TSQR_HALF_WAVES;
         FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                  (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double))));
-        for (int stride = 1; stride < wk.NW; stride *= 2) {
+        for (int stride = stride_from; stride < stride_to; stride *= 2) {
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
             FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB, HW>), dim3(pairs), dim3(64 * HW),
                                                               (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, wk.err));
             TSQR_HIP(hipGetLastError());
         }
     } else {
-    FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // (wk.ttpw: the RREG shapes run their merge tree on the eight-wave kernel of the same leading dimension: taller blocks, half the
+    // serial panel steps per merge)
+    FBR_TSQR_DISPATCH(wk.ttpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
-    for (int stride = 1; stride < wk.NW; stride *= 2) {
+    for (int stride = stride_from; stride < stride_to; stride *= 2) {
         const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
-        FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB>), dim3(pairs), dim3(FBR_TSQR_THREADS),
+        FBR_TSQR_DISPATCH(wk.ttpw, hipLaunchKernelGGL((fbr_tsqr_tree_kernel<TPW, SUB>), dim3(pairs), dim3(FBR_TSQR_THREADS),
                                                      (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, wk.err));
         TSQR_HIP(hipGetLastError());
     }
     }
+    return 0;
+}
+
+// Working factor 0 (the root of the tree) to R_out (device, Pa x Pa): ends the factorisation.
+static inline int fbr_tsqr_copy_out(FbrTsqrWork &wk, hipStream_t st, double *R_out)
+{
     hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, wk.Pa, wk.Rw, wk.ld, R_out, wk.Pa, wk.Pa, wk.Pa);
     TSQR_HIP(hipGetLastError());
     wk.active = false;
     return 0;
+}
+
+static inline int fbr_tsqr_finish_async(FbrTsqrWork &wk, hipStream_t st, double *R_out)
+{
+    if (int rc = fbr_tsqr_tree_levels(wk, st, 1, 1 << 30)) return rc;
+    return fbr_tsqr_copy_out(wk, st, R_out);
 }
 
 // Wait for the stream and report a pipeline time-out of the factorisation's kernels (the device error word).
