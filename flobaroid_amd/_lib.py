@@ -109,6 +109,11 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), _ip, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32],
     ),
+    "fbr_tsqr_submit": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.POINTER(fbr_states), _ip, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+    ),
     "fbr_tsqr_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "fbr_tsqr_work_info": (
         ctypes.c_int,
@@ -421,11 +426,43 @@ class Engine:
         t = ctypes.c_int64(-1)
         _check(self._lib.fbr_gram_submit(self._h, ctypes.byref(s), rr.ptr, k, wr.ptr, r.ptr, int(bool(accumulate)), ctypes.byref(t)),
                "fbr_gram_submit")
+        # the GPU reads the arrays handed to the library until wait(): contiguous copies / reshapes made on the way (``_Ref``, ``_rhs``)
+        # would otherwise go back to torch's allocator on return and could be reused while still being read
+        self._keep_inflight(int(t.value), (keep, rr, wr, r))
         return int(t.value)
+
+    def _keep_inflight(self, ticket: int, refs) -> None:
+        infl = self.__dict__.setdefault("_inflight", {})
+        infl[ticket] = refs
+        for old in [k_ for k_ in infl if k_ < ticket - 1]:  # (a third submission has waited for the oldest inside the library)
+            del infl[old]
 
     def wait(self, ticket: int = -1) -> None:
         """Block until the submission ``ticket`` (default: everything submitted) is complete."""
-        _check(self._lib.fbr_wait(self._h, int(ticket)), "fbr_wait")
+        try:
+            _check(self._lib.fbr_wait(self._h, int(ticket)), "fbr_wait")
+        finally:
+            infl = self.__dict__.get("_inflight", {})
+            for k_ in [k_ for k_ in infl if ticket < 0 or k_ <= ticket]:
+                del infl[k_]
+
+    def tsqr_submit(self, st: dict, out, rhs=None, w=None, R_in=None, cols=None) -> int:
+        """``tsqr`` without waiting (``fbr_tsqr_submit``): CUDA tensors only; result in ``out`` after ``wait(ticket)``.  At most two
+        submissions (of either kind) are in flight; consecutive TSQR submissions overlap the next one's kinematics / first regressor
+        chunk with the merge trees of the one before."""
+        s, keep, S, mem = self._states(st)
+        rr, wr, k = self._rhs(rhs, w, S, mem)
+        ca = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+        Pa = (self.cols if ca is None else int(ca.size)) + k
+        r, _ = self._out(out, (Pa, Pa), mem)
+        rin = _Ref(R_in, (Pa, Pa), "R_in") if R_in is not None else _Ref(None)
+        if mem != FBR_DEVICE or r.mem != FBR_DEVICE or (rin.mem is not None and rin.mem != FBR_DEVICE):
+            raise ValueError("tsqr_submit needs CUDA tensors for the states, rhs, weights, R_in and the output")
+        t = ctypes.c_int64(-1)
+        _check(self._lib.fbr_tsqr_submit(self._h, ctypes.byref(s), None if ca is None else ca.ctypes.data_as(_ip), 0 if ca is None else int(ca.size),
+                                         rr.ptr, k, wr.ptr, rin.ptr, r.ptr, ctypes.byref(t)), "fbr_tsqr_submit")
+        self._keep_inflight(int(t.value), (keep, rr, wr, rin, r, ca))
+        return int(t.value)
 
     def gram_grouped(self, st: dict, ngroups: int, rhs=None, w=None, out=None):
         """One raw Gram per group of S / ngroups consecutive samples, shape (ngroups, cols+k, cols+k), in one pass."""

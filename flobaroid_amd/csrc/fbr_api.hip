@@ -160,6 +160,19 @@ struct fbr_model {
     hipEvent_t tsqr_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [i]: side stream i is done; [4]: fork point on the main stream
     DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
     DevBuf tsqr_embed;        // stacked rows of the embedded group factors (tree-structured TSQR)
+    // per-call state of the TSQR entry points, double buffered by the parity of the call's ticket so that a submission (fbr_tsqr_submit)
+    // can be enqueued while the one before is still running
+    DevBuf tsqr_tab[2];                        // device tables (index lists, entry lists, group records)
+    void *tsqr_tab_host[2] = {nullptr, nullptr};  // their pinned host staging (the copy is asynchronous: the source must outlive it)
+    size_t tsqr_tab_host_bytes[2] = {0, 0};
+    unsigned *tsqr_err = nullptr;              // device word every factorisation of a call reports into (pipeline flag time-out)
+    unsigned *tsqr_err_host = nullptr;         // pinned [2]: its value at the end of the call with that ticket parity
+    int ticket_kind[2] = {0, 0};               // what the submission with that parity was: 0 = Gram pass, 1 = TSQR
+    int last_submit_kind = 0;
+    hipEvent_t ev_tsqr_l0 = nullptr;           // the last level-0 fold of the latest TSQR call has been enqueued behind this event
+    hipEvent_t ev_tsqr_pro = nullptr;          // prologue (kinematics + first chunk's writer on the producer stream) of a submission
+    hipStream_t tsqr_pro_stream = nullptr;     // the stream it runs on (created on first use, confined to part of the CUs)
+    bool tsqr_l0_rec = false;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -181,6 +194,16 @@ struct fbr_model {
         if (m->copy) (void)hipStreamSynchronize(m->copy);
         m->tsqr.release();
         for (auto &g : m->tsqr_groups) g.release();
+        for (auto &h : m->tsqr_tab_host)
+            if (h) (void)hipHostFree(h);
+        if (m->tsqr_err) (void)hipFree(m->tsqr_err);
+        if (m->tsqr_err_host) (void)hipHostFree(m->tsqr_err_host);
+        if (m->ev_tsqr_l0) (void)hipEventDestroy(m->ev_tsqr_l0);
+        if (m->ev_tsqr_pro) (void)hipEventDestroy(m->ev_tsqr_pro);
+        if (m->tsqr_pro_stream) {
+            (void)hipStreamSynchronize(m->tsqr_pro_stream);
+            (void)hipStreamDestroy(m->tsqr_pro_stream);
+        }
         for (auto &st : m->tsqr_streams)
             if (st) (void)hipStreamDestroy(st);
         for (auto &e : m->tsqr_ev)
@@ -333,6 +356,12 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
         HIPCHK(hipEventCreateWithFlags(&m->ev_gram[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_tsqr_l0, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_tsqr_pro, hipEventDisableTiming));
+    HIPCHK(hipMalloc((void **)&m->tsqr_err, sizeof(unsigned)));
+    HIPCHK(hipMemset(m->tsqr_err, 0, sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&m->tsqr_err_host, 2 * sizeof(unsigned), hipHostMallocDefault));
+    m->tsqr_err_host[0] = m->tsqr_err_host[1] = 0;
 
     const FbrHostModel &hm = m->hm;
     DevModel &dm = m->dm;
@@ -547,7 +576,8 @@ static long chunk_size(const fbr_model *m, long S)
     return std::min(S, ch);
 }
 
-static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, hipStream_t st = nullptr, DevBuf *recbuf = nullptr)
+// beside_gram: the launch shares the CUs with the Gram kernel (producer stream of the fused pass): the register-capped instance
+static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, hipStream_t st = nullptr, DevBuf *recbuf = nullptr, bool beside_gram = false)
 {
     const FbrHostModel &hm = m->hm;
     if (!st) st = m->stream;
@@ -557,9 +587,19 @@ static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, hipStream
     const int threads = 256;
     const int blocks = (int)((cs + threads - 1) / threads);
     ProfScope ps(m, FBR_PROF_KIN, st);
-    hipLaunchKernelGGL(fbr_kin_kernel, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n,
-                       d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
-                       d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
+    // (the instance that fits beside the Gram kernel's waves on the producer stream of the fused pass; the uncapped one everywhere else)
+    if (beside_gram && !getenv("FBR_KIN_UNCAPPED"))
+        hipLaunchKernelGGL(fbr_kin_kernel<FBR_KIN_WAVES>, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n,
+                           d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
+                           d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
+    else if (getenv("FBR_KIN_CAPPED"))
+        hipLaunchKernelGGL(fbr_kin_kernel<FBR_KIN_WAVES>, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n,
+                           d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
+                           d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
+    else
+        hipLaunchKernelGGL(fbr_kin_kernel<2>, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n,
+                           d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
+                           d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
     HIPCHK(hipGetLastError());
     return FBR_OK;
 }
@@ -900,9 +940,11 @@ static int active_rows(fbr_model *m, const double *dw, long S, std::vector<char>
     return FBR_OK;
 }
 
+static int drain_after_failed_submit(fbr_model *m);
+
 // async_ticket != nullptr: the pass is enqueued and NOT waited for (fbr_gram_submit): device-resident inputs and output only.
-static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
-                     int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
+static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
+                           int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket)
 {
     const bool async = async_ticket != nullptr;
     // a submission whose predecessor is still in flight lets its producer start beside the predecessor's last Gram launches
@@ -1113,7 +1155,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                     HIPCHK(hipStreamWaitEvent(side, m->ev_h2d[b], 0));
                 }
             }
-            int rc2 = run_kin(m, dc, o, cs, side, &m->rec2);
+            int rc2 = run_kin(m, dc, o, cs, side, &m->rec2, true);
             if (rc2) return rc2;
             {
                 ProfScope ps(m, FBR_PROF_PACK, side);
@@ -1206,11 +1248,25 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
     }
     if (async) {
         const int64_t t = m->next_ticket++;
+        m->ticket_kind[t & 1] = 0;
+        m->last_submit_kind = 0;
         HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
         *async_ticket = t;
         return FBR_OK;
     }
     return finish_output(m, G, G_out, gcount, out_mem);
+}
+
+static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
+                     int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
+{
+    int rc = gram_impl_inner(m, st, rhs, k, w, G_out, out_mem, accumulate, ngroups, async_ticket);
+    if (rc && async_ticket && m && m->pid == getpid()) {  // a failed submission issues no ticket: nothing of it may stay in flight
+        const std::string msg = g_err;
+        drain_after_failed_submit(m);
+        set_err(msg);
+    }
+    return rc;
 }
 
 // Block until the submission with this ticket (and every earlier one) is complete; ticket < 0 or beyond the last one: everything.
@@ -1227,7 +1283,14 @@ static int wait_ticket(fbr_model *m, int64_t ticket)
         if (m->copy) HIPCHK(hipStreamSynchronize(m->copy));
         prof_collect(m);
     }
+    const int64_t first = m->waited_ticket + 1;
     m->waited_ticket = ticket;
+    for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)  // (at most two submissions were in flight)
+        if (m->ticket_kind[t & 1] == 1 && m->tsqr_err_host && m->tsqr_err_host[t & 1]) {
+            m->tsqr_err_host[t & 1] = 0;
+            set_err("TSQR pipeline flag wait timed out (internal error) in submission " + std::to_string(t));
+            return FBR_E_HIP;
+        }
     return FBR_OK;
 }
 
@@ -1550,8 +1613,33 @@ static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp
     return ch;
 }
 
+// Device tables of a TSQR call: assembled in pinned host memory that belongs to the call's ticket parity and copied asynchronously on
+// `st` -- no host wait, and the tables of the submission before (other parity) stay intact while it is still running.
+static int tsqr_upload_tables(fbr_model *m, int par, const std::vector<std::pair<const void *, size_t>> &pieces, const std::vector<size_t> &offs,
+                              size_t total, hipStream_t st, const char **dev)
+{
+    total = std::max<size_t>(total, 16);
+    if (m->tsqr_tab_host_bytes[par] < total) {
+        if (m->tsqr_tab_host[par]) (void)hipHostFree(m->tsqr_tab_host[par]);
+        m->tsqr_tab_host[par] = nullptr;
+        m->tsqr_tab_host_bytes[par] = 0;
+        HIPCHK(hipHostMalloc(&m->tsqr_tab_host[par], total + total / 2, hipHostMallocDefault));
+        m->tsqr_tab_host_bytes[par] = total + total / 2;
+    }
+    int rc = m->tsqr_tab[par].ensure(total);
+    if (rc) return rc;
+    for (size_t i = 0; i < pieces.size(); i++)
+        if (pieces[i].second) memcpy((char *)m->tsqr_tab_host[par] + offs[i], pieces[i].first, pieces[i].second);
+    HIPCHK(hipMemcpyAsync(m->tsqr_tab[par].p, m->tsqr_tab_host[par], total, hipMemcpyHostToDevice, st));
+    *dev = (const char *)m->tsqr_tab[par].p;
+    return FBR_OK;
+}
+
+// overlap: the call follows a TSQR submission that is still running: its prologue (tables, kinematics and the writer of the first chunk)
+// goes to the producer stream and waits only for the LAST LEVEL-0 FOLD of that submission -- it runs beside the submission's merge trees,
+// which occupy a handful of CUs (7.7 of WALK-MAN's 8.2 ms of trees hide 5.5 + 1.2 ms of kinematics and first writer).
 static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPlan &gp, const int32_t *cols, int Psel, int k, const double *drhs,
-                            const double *dw, const double *Rin_dev, double *R)
+                            const double *dw, const double *Rin_dev, double *R, int par, bool overlap)
 {
     const FbrHostModel &hm = m->hm;
     const long S = d.S;
@@ -1654,23 +1742,41 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     for (int g = 0; g < G; g++) {
         const TsqrGroup &Gg = gp.groups[g];
         FbrTsqrWork &wk = work(g);
-        if ((rc = fbr_tsqr_begin(wk, m->stream, Gg.Pa, g == gp.main ? Rin_dev : nullptr, m->num_cus, g == gp.main ? mrows : S * (long)Gg.rows.size())))
+        if ((rc = fbr_tsqr_begin(wk, m->stream, Gg.Pa, g == gp.main ? Rin_dev : nullptr, m->num_cus, g == gp.main ? mrows : S * (long)Gg.rows.size(),
+                                 m->tsqr_err)))
             return tsqr_fail(rc, "tsqr group begin");
+    }
+    // prologue stream: everything up to the first chunk's writer
+    // (a stream confined to three quarters of the CUs: the prologue's kernels would otherwise fill every CU with their waves, and the
+    // tree's eight-wave workgroups -- a whole CU's registers each -- could not be placed until they drain: measured, the first tree
+    // level then takes 3.6 instead of 1.0 ms and nothing is gained)
+    if (overlap && !m->tsqr_pro_stream) {
+        const int words = (m->num_cus + 31) / 32;
+        std::vector<uint32_t> mask(words, 0x00ffffffu);
+        if (getenv("FBR_TSQR_PROLOGUE_NOMASK") || hipExtStreamCreateWithCUMask(&m->tsqr_pro_stream, (uint32_t)words, mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&m->tsqr_pro_stream, hipStreamNonBlocking));
+        }
+    }
+    hipStream_t pst = overlap ? m->tsqr_pro_stream : m->stream;
+    if (overlap) HIPCHK(hipStreamWaitEvent(pst, m->ev_tsqr_l0, 0));  // the chunk buffers and the kinematic records are free again
+    for (int g = 0; g < G; g++) {
+        const TsqrGroup &Gg = gp.groups[g];
+        FbrTsqrWork &wk = work(g);
         double *A = nullptr;
-        if ((rc = fbr_tsqr_chunk_buffer(wk, std::min(ch, S) * (long)Gg.rows.size(), &A)) || (rc = fbr_tsqr_chunk_clean(wk, m->stream)))
+        if ((rc = fbr_tsqr_chunk_buffer(wk, std::min(ch, S) * (long)Gg.rows.size(), &A)) || (rc = fbr_tsqr_chunk_clean(wk, pst)))
             return tsqr_fail(rc, "tsqr group chunk");
         hg[g] = FbrDevGroup{A, wk.n, (int)Gg.sel.size()};
     }
-    if ((rc = m->st_x.ensure(o_grp + G * sizeof(FbrDevGroup)))) return rc;
-    HIPCHK(hipMemcpyAsync(m->st_x.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    if (!ents[0].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_ent0, ents[0].data(), ents[0].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    if (!ents[1].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_ent1, ents[1].data(), ents[1].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    if (pairable && !pents[0].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_pent0, pents[0].data(), pents[0].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    if (pairable && !pents[1].empty()) HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_pent1, pents[1].data(), pents[1].size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync((char *)m->st_x.p + o_grp, hg.data(), G * sizeof(FbrDevGroup), hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));  // tab, hg are locals
-    const int *t = m->st_x.as<int>();
-    const FbrDevGroup *dgrp = (const FbrDevGroup *)((const char *)m->st_x.p + o_grp);
+    const char *dtab = nullptr;
+    if ((rc = tsqr_upload_tables(m, par,
+                                 {{tab.data(), tab.size() * sizeof(int)}, {ents[0].data(), ents[0].size() * sizeof(int)}, {ents[1].data(), ents[1].size() * sizeof(int)},
+                                  {pents[0].data(), (pairable ? pents[0].size() : 0) * sizeof(int)}, {pents[1].data(), (pairable ? pents[1].size() : 0) * sizeof(int)},
+                                  {hg.data(), G * sizeof(FbrDevGroup)}},
+                                 {0, o_ent0, o_ent1, o_pent0, o_pent1, o_grp}, o_grp + G * sizeof(FbrDevGroup), pst, &dtab)))
+        return rc;
+    const int *t = (const int *)dtab;
+    const FbrDevGroup *dgrp = (const FbrDevGroup *)(dtab + o_grp);
     const size_t lds = (size_t)((hm.rec_size() + 1) & ~1) * sizeof(double) + (size_t)hm.rows * sizeof(double *);
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1680,26 +1786,31 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     for (long s0 = 0; s0 < S; s0 += ch) {
         const long cs = std::min(ch, S - s0);
         const long k0 = s0 / kin_span * kin_span;
-        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0)))) return rc;
+        hipStream_t cst = s0 == 0 ? pst : m->stream;  // the first chunk's kinematics and writer belong to the prologue
+        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0), cst))) return rc;
         const double *recs = m->rec.as<double>() + (size_t)(s0 - k0) * hm.rec_size();
         // structural zeros left of a row's first supported column tile are skipped when every block holds rows of one slot
         skipzeros = true;
         for (int g = 0; g < G; g++) skipzeros = skipzeros && cs % work(g).mb == 0;
         {
-            ProfScope ps(m, FBR_PROF_REGRESSOR);
+            ProfScope ps(m, FBR_PROF_REGRESSOR, cst);
             if (pairable)
-                hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
+                hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
-                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)),
-                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_pent1 : o_pent0)), npairs);
+                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)),
+                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_pent1 : o_pent0)), npairs);
             else
-                hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, m->stream, m->dm, cs,
+                hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
-                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)((const char *)m->st_x.p + (skipzeros ? o_ent1 : o_ent0)));
+                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)));
         }
         HIPCHK(hipGetLastError());
+        if (cst != m->stream) {  // the folds (main stream) wait for the prologue
+            HIPCHK(hipEventRecord(m->ev_tsqr_pro, cst));
+            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_tsqr_pro, 0));
+        }
         ProfScope ps(m, FBR_PROF_TSQR);
         for (int g = 0; g < G; g++) {
             const TsqrGroup &Gg = gp.groups[g];
@@ -1710,6 +1821,13 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, cs * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
         }
     }
+    bool l0_recorded = false;
+    auto record_l0 = [&]() -> int {  // what a following submission's prologue waits for
+        if (!l0_recorded) HIPCHK(hipEventRecord(m->ev_tsqr_l0, m->stream));
+        l0_recorded = true;
+        m->tsqr_l0_rec = true;
+        return FBR_OK;
+    };
     // Merge trees are latency bound (a level of the full-width tree is 0.93 ms on a handful of workgroups, 8 levels over 256 private
     // factors).  The groups' trees run on side streams beside the main group's.  Their factors, embedded into the caller's column
     // order, are dense rows of the final factorisation: they are folded INSIDE the main tree -- once at most 8 of its factors are
@@ -1761,7 +1879,10 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         FbrTsqrWork &wk = m->tsqr;
         int alive_stride = 1;  // levels with stride < alive_stride have run
         while ((wk.NW + alive_stride - 1) / alive_stride > 8) alive_stride *= 2;
-        if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, alive_stride))) return tsqr_fail(rc, "tsqr tree");
+        // (a following submission's prologue starts behind the two widest tree levels: 128 and 64 workgroups)
+        const int s_pro = std::min(4, alive_stride);
+        if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, s_pro)) || (rc = record_l0()) || (rc = fbr_tsqr_tree_levels(wk, m->stream, s_pro, alive_stride)))
+            return tsqr_fail(rc, "tsqr tree");
         for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
         if ((rc = m->tsqr_embed.ensure((size_t)((erows + 15) & ~15L) * wk.n * sizeof(double)))) return rc;
         if ((rc = pack_embedded(wk, m->tsqr_embed.as<double>()))) return rc;
@@ -1770,37 +1891,49 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             return tsqr_fail(rc, "tsqr embedded group factors");
         if ((rc = fbr_tsqr_tree_levels(wk, m->stream, alive_stride, 1 << 30)) || (rc = fbr_tsqr_copy_out(wk, m->stream, R)))
             return tsqr_fail(rc, "tsqr tree");
-        for (int g = 0; g < G; g++)
-            if (g != gp.main && (rc = fbr_tsqr_check(m->tsqr_groups[g], m->stream))) return tsqr_fail(rc, "tsqr group check");
-        if ((rc = fbr_tsqr_check(wk, m->stream))) return tsqr_fail(rc, "tsqr finish");
-        return FBR_OK;
+        return FBR_OK;  // (the error word of the call is read once, at its end: tsqr_impl)
     }
     // no dense group (fixed base behind a branching first link, masked base rows) or wave-private main kernels: the group factors are
     // folded by one workgroup into a factor seeded with the main group's result / R_in
+    if ((rc = record_l0())) return rc;
     const double *seed = Rin_dev;
     if (gp.main >= 0) {
-        if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, rtmp + o_r[gp.main])) || (rc = fbr_tsqr_check(m->tsqr, m->stream))) return tsqr_fail(rc, "tsqr finish");
+        if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, rtmp + o_r[gp.main]))) return tsqr_fail(rc, "tsqr finish");
         seed = rtmp + o_r[gp.main];
     }
     for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
-    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, seed, m->num_cus, 1))) return tsqr_fail(rc, "tsqr begin");
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, seed, m->num_cus, 1, m->tsqr_err))) return tsqr_fail(rc, "tsqr begin");
     for (int g = 0; g < G; g++) {
         if (g == gp.main) continue;
         const int Pg = gp.groups[g].Pa;
         if ((rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pg, Pa, rtmp + o_r[g], 0, nullptr, nullptr, Pg, t + o_emb[g]))) return tsqr_fail(rc, "tsqr group merge");
     }
-    for (int g = 0; g < G; g++)
-        if (g != gp.main && (rc = fbr_tsqr_check(m->tsqr_groups[g], m->stream))) return tsqr_fail(rc, "tsqr group check");
-    if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
+    if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
     return FBR_OK;
 }
 
-static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
-                     const double *w, const double *R_in, double *R_out, int32_t out_mem)
+// async_ticket != nullptr: the factorisation is enqueued and NOT waited for (fbr_tsqr_submit): device-resident inputs and output only.
+static int tsqr_impl_inner(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
+                           const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
+    const bool async = async_ticket != nullptr;
+    if (async && (!st || st->mem != FBR_DEVICE || out_mem != FBR_DEVICE)) {
+        set_err("fbr_tsqr_submit takes device-resident states, rhs, weights, R_in and R_out");
+        return FBR_E_INVALID;
+    }
     DevStates d;
+    if (m) m->submitting = async;
     int rc = stage_states(m, st, &d);
+    if (m) m->submitting = false;
     if (rc) return rc;
+    bool overlap = false;
+    if (async) {
+        // at most two submissions in flight (two sets of tables / error slots / completion events)
+        if ((rc = wait_ticket(m, m->next_ticket - 2))) return rc;
+        overlap = m->waited_ticket < m->next_ticket - 1 && m->last_submit_kind == 1 && m->tsqr_l0_rec && !getenv("FBR_TSQR_NO_PROLOGUE_OVERLAP");
+    }
+    const int par = (int)(m->next_ticket & 1);  // (blocking calls: nothing is in flight, either set is free)
+    HIPCHK(hipMemsetAsync(m->tsqr_err, 0, sizeof(unsigned), m->stream));
     if (!R_out || k < 0 || k > FBR_MAX_RHS || (k > 0 && !rhs)) {
         set_err("bad rhs / R_out arguments");
         return FBR_E_INVALID;
@@ -1823,25 +1956,6 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
     const long S = d.S;
     const TsqrPlan plan = tsqr_plan(hm, cols, ncols, k, S);
     const int Psel = plan.Psel, Pa = plan.Pa;
-    // device tables: [fcols (Psel) | perm (Pa) | inv (Pa) | linkpos (L) | row first columns (rows)]
-    const int *dcols = nullptr, *dperm = nullptr, *dinv = nullptr, *dlinkpos = nullptr, *dfc = nullptr;
-    {
-        std::vector<int> tab;
-        tab.insert(tab.end(), plan.fcols.begin(), plan.fcols.end());
-        tab.insert(tab.end(), plan.perm.begin(), plan.perm.end());
-        tab.insert(tab.end(), plan.inv.begin(), plan.inv.end());
-        tab.insert(tab.end(), plan.linkpos.begin(), plan.linkpos.end());
-        tab.insert(tab.end(), plan.fc.begin(), plan.fc.end());
-        if ((rc = m->st_x.ensure(tab.size() * sizeof(int)))) return rc;
-        HIPCHK(hipMemcpyAsync(m->st_x.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));  // tab is a local
-        const int *t = m->st_x.as<int>();
-        if (cols || (plan.reorder)) dcols = t;  // gather list of the materialised path
-        dperm = t + Psel;
-        dinv = dperm + Pa;
-        if (!cols && plan.reorder) dlinkpos = dinv + Pa;
-        dfc = dinv + Pa + plan.linkpos.size();
-    }
     const size_t rcount = (size_t)Pa * Pa;
     const double *drhs = nullptr, *dw = nullptr;
     if ((rc = stage_one(m, m->st_aux, rhs, (size_t)S * hm.rows * k, st->mem, &drhs))) return rc;
@@ -1864,18 +1978,58 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
         set_err(std::string(what) + ": " + fbr_tsqr_error());
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
+    // the end of every path: the call's error word goes to the pinned slot of its parity; a submission returns its ticket, a blocking
+    // call waits and looks at the slot
+    auto done = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(&m->tsqr_err_host[par], m->tsqr_err, sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
+        if (async) {
+            const int64_t t = m->next_ticket++;
+            m->ticket_kind[t & 1] = 1;
+            m->last_submit_kind = 1;
+            HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
+            *async_ticket = t;
+            return FBR_OK;
+        }
+        int rc2 = finish_output(m, R, R_out, rcount, out_mem);
+        if (rc2) return rc2;
+        if (m->tsqr_err_host[par]) {
+            m->tsqr_err_host[par] = 0;
+            set_err("TSQR pipeline flag wait timed out (internal error)");
+            return FBR_E_HIP;
+        }
+        return FBR_OK;
+    };
     {
+        // (row weights on the device are scanned for switched-off rows: that read-back waits for the stream, i.e. for a submission in flight)
         std::vector<char> act;
         if ((rc = active_rows(m, dw, S, &act))) return rc;
         const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k, &act);
         if (hm.rows <= 255 && tsqr_use_groups(gp, S)) {  // (the writer's entries hold the regressor row in 8 bits)
-            if ((rc = tsqr_groups_impl(m, d, gp, cols, Psel, k, drhs, dw, Rin_dev, R))) return rc;
-            return finish_output(m, R, R_out, rcount, out_mem);
+            if ((rc = tsqr_groups_impl(m, d, gp, cols, Psel, k, drhs, dw, Rin_dev, R, par, overlap))) return rc;
+            return done();
         }
+    }
+    // device tables: [fcols (Psel) | perm (Pa) | inv (Pa) | linkpos (L) | row first columns (rows)]
+    const int *dcols = nullptr, *dperm = nullptr, *dinv = nullptr, *dlinkpos = nullptr, *dfc = nullptr;
+    {
+        std::vector<int> tab;
+        tab.insert(tab.end(), plan.fcols.begin(), plan.fcols.end());
+        tab.insert(tab.end(), plan.perm.begin(), plan.perm.end());
+        tab.insert(tab.end(), plan.inv.begin(), plan.inv.end());
+        tab.insert(tab.end(), plan.linkpos.begin(), plan.linkpos.end());
+        tab.insert(tab.end(), plan.fc.begin(), plan.fc.end());
+        const char *dtab = nullptr;
+        if ((rc = tsqr_upload_tables(m, par, {{tab.data(), tab.size() * sizeof(int)}}, {0}, tab.size() * sizeof(int), m->stream, &dtab))) return rc;
+        const int *t = (const int *)dtab;
+        if (cols || (plan.reorder)) dcols = t;  // gather list of the materialised path
+        dperm = t + Psel;
+        dinv = dperm + Pa;
+        if (!cols && plan.reorder) dlinkpos = dinv + Pa;
+        dfc = dinv + Pa + plan.linkpos.size();
     }
     // an existing factor seeds working factor 0 directly when the column order is the caller's; in the internal order its rows are
     // folded in like data rows (column gather)
-    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, plan.reorder ? nullptr : Rin_dev, m->num_cus, S * (long)hm.rows))) return tsqr_fail(rc, "tsqr begin");
+    if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, plan.reorder ? nullptr : Rin_dev, m->num_cus, S * (long)hm.rows, m->tsqr_err))) return tsqr_fail(rc, "tsqr begin");
     if (plan.reorder && Rin_dev) {
         ProfScope ps(m, FBR_PROF_TSQR);
         if ((rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pa, Pa, Rin_dev, 0, nullptr, nullptr, Pa, dperm))) return tsqr_fail(rc, "tsqr fold R_in");
@@ -1944,18 +2098,47 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
     {
         ProfScope ps(m, FBR_PROF_TSQR);
         if (!plan.reorder) {
-            if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
+            if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, R))) return tsqr_fail(rc, "tsqr finish");
         } else {
             // factor in the internal column order -> the caller's: R = qr(R' [:, inv]) (one workgroup, Pa dense rows)
             if ((rc = m->tsqr_rtmp.ensure(rcount * sizeof(double)))) return rc;
-            if ((rc = fbr_tsqr_finish(m->tsqr, m->stream, m->tsqr_rtmp.as<double>()))) return tsqr_fail(rc, "tsqr finish");
-            if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, nullptr, m->num_cus, 1)) ||
+            if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, m->tsqr_rtmp.as<double>()))) return tsqr_fail(rc, "tsqr finish");
+            if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, Pa, nullptr, m->num_cus, 1, m->tsqr_err)) ||
                 (rc = fbr_tsqr_fold_rows(m->tsqr, m->stream, Pa, Pa, m->tsqr_rtmp.as<double>(), 0, nullptr, nullptr, Pa, dinv)) ||
-                (rc = fbr_tsqr_finish(m->tsqr, m->stream, R)))
+                (rc = fbr_tsqr_finish_async(m->tsqr, m->stream, R)))
                 return tsqr_fail(rc, "tsqr column order");
         }
     }
-    return finish_output(m, R, R_out, rcount, out_mem);
+    return done();
+}
+
+// A submission that fails after work was enqueued has no ticket its caller could wait on: everything in flight is drained before the
+// error is returned (the same for the Gram pass, gram_impl below), so that the inputs may be freed and later calls start from a quiet device.
+static int drain_after_failed_submit(fbr_model *m)
+{
+    if (!m) return FBR_OK;
+    (void)hipStreamSynchronize(m->stream);
+    if (m->side) (void)hipStreamSynchronize(m->side);
+    if (m->copy) (void)hipStreamSynchronize(m->copy);
+    if (m->tsqr_pro_stream) (void)hipStreamSynchronize(m->tsqr_pro_stream);
+    for (auto &s2 : m->tsqr_streams)
+        if (s2) (void)hipStreamSynchronize(s2);
+    m->waited_ticket = m->next_ticket - 1;
+    m->ev_gram_rec[0] = m->ev_gram_rec[1] = m->ev_pack_rec[0] = m->ev_pack_rec[1] = false;
+    m->tsqr_l0_rec = false;
+    return FBR_OK;
+}
+
+static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
+                     const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket = nullptr)
+{
+    int rc = tsqr_impl_inner(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem, async_ticket);
+    if (rc && async_ticket && m && m->pid == getpid()) {
+        const std::string msg = g_err;
+        drain_after_failed_submit(m);
+        set_err(msg);
+    }
+    return rc;
 }
 
 extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
@@ -1972,6 +2155,20 @@ extern "C" int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *
         return FBR_E_INVALID;
     }
     return tsqr_impl(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem);
+}
+
+extern "C" int fbr_tsqr_submit(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
+                               const double *w, const double *R_in, double *R_out, int64_t *ticket)
+{
+    if (!ticket) {
+        set_err("ticket is NULL");
+        return FBR_E_INVALID;
+    }
+    if (cols && ncols <= 0) {
+        set_err("bad column subset size");
+        return FBR_E_INVALID;
+    }
+    return tsqr_impl(m, st, cols, cols ? ncols : 0, rhs, k, w, R_in, R_out, FBR_DEVICE, ticket);
 }
 
 extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t ncols, int32_t k, int64_t num_samples, int64_t *mfma_level0,

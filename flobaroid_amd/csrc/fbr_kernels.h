@@ -58,7 +58,10 @@ struct DevGram {
 // from registers; only the first link after a branch point re-reads it from memory (47 -> 5 dependent 168-byte reads per sample on
 // WALK-MAN: fused pass 77.4 -> 75.3 ms, TSQR call -5 ms).  Writing the records through an LDS transposition (coalesced runs of 21
 // doubles instead of 8-byte stores at a 9.5 KB stride) was measured on top of that: no difference.
-__global__ __launch_bounds__(256, FBR_KIN_WAVES) void fbr_kin_kernel(DevModel m, long S, const double *__restrict__ q,
+// WAVES: waves per SIMD the instance is compiled for.  FBR_KIN_WAVES (96 VGPRs, spills) for the producer stream of the fused Gram pass;
+// 2 (no register cap, no spills) where the kernel runs alone (TSQR, materialised regressor, inverse dynamics, ...)
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void fbr_kin_kernel(DevModel m, long S, const double *__restrict__ q,
                                                        const double *__restrict__ dq, const double *__restrict__ ddq,
                                                        const double *__restrict__ bv, const double *__restrict__ ba,
                                                        const double *__restrict__ rpy, double *rec)

@@ -893,6 +893,7 @@ struct FbrTsqrWork {
     double *Rw = nullptr;   // [NW][n][ld]
     double *A = nullptr;    // packed chunk [Mpad][n]
     unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
+    bool own_err = true;      // false: the word belongs to the caller (one per model, cleared once per call and read once at its end)
     size_t rw_bytes = 0, a_bytes = 0;
     long clean_key = -1;  // (Pa, n) for which the padding columns [Pa, n) of the whole chunk buffer are zero and stay zero (writers that
                           // fill the chunk in place never touch them): the per-chunk tail pass then only clears the rows M..Mpad
@@ -902,8 +903,9 @@ struct FbrTsqrWork {
     {
         if (Rw) (void)hipFree(Rw);
         if (A) (void)hipFree(A);
-        if (err) (void)hipFree(err);
+        if (err && own_err) (void)hipFree(err);
         err = nullptr;
+        own_err = true;
         Rw = A = nullptr;
         rw_bytes = a_bytes = 0;
         active = false;
@@ -1020,7 +1022,7 @@ static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrSha
 }
 
 // Start a factorisation of width Pa: working factors zeroed, R_in (device, Pa x Pa, may be null) seeded into slot 0.
-static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint)
+static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint, unsigned *shared_err = nullptr)
 {
     FbrTsqrShape sh;
     if (int rc = fbr_tsqr_shape(Pa, num_cus, rows_hint, &sh)) return rc;
@@ -1035,8 +1037,18 @@ static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const 
         wk.rw_bytes = need;
     }
     wk.n = n; wk.ld = ld; wk.NW = NW; wk.Pa = Pa; wk.mb = mb; wk.tpw = tpw; wk.sub = sub; wk.narrow = narrow; wk.waves = sh.waves; wk.ttpw = sh.ttpw;
-    if (!wk.err) TSQR_HIP(hipMalloc((void **)&wk.err, sizeof(unsigned)));
-    TSQR_HIP(hipMemsetAsync(wk.err, 0, sizeof(unsigned), st));
+    if (shared_err) {
+        if (wk.err && wk.own_err) (void)hipFree(wk.err);
+        wk.err = shared_err;  // (cleared by the caller once per call: several factorisations of one call report into it)
+        wk.own_err = false;
+    } else {
+        if (!wk.err || !wk.own_err) {
+            wk.err = nullptr;
+            wk.own_err = true;
+            TSQR_HIP(hipMalloc((void **)&wk.err, sizeof(unsigned)));
+        }
+        TSQR_HIP(hipMemsetAsync(wk.err, 0, sizeof(unsigned), st));
+    }
     TSQR_HIP(hipMemsetAsync(wk.Rw, 0, need, st));
     if (R_in) {
         hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, st, Pa, R_in, Pa, wk.Rw, ld, n, ld);

@@ -190,6 +190,20 @@ int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, c
 int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
                   const double *w, const double *R_in, double *R_out, int32_t out_mem);
 
+/*
+ * Asynchronous form of fbr_tsqr / fbr_tsqr_cols (cols == NULL: every identified column) for callers that keep everything in HBM: the
+ * factorisation is enqueued and the call returns; *ticket identifies it, fbr_wait(m, ticket) completes it (tickets are shared with
+ * fbr_gram_submit: at most TWO submissions of either kind are in flight, a third one first waits for the oldest).  When the submission
+ * before is a TSQR as well, the kinematics and the first chunk's regressor writer of this one run beside its merge trees -- the part of
+ * a call that executes no MFMA and that the (latency-bound, few-workgroup) trees leave the CUs free for: a streamed sequence of calls
+ * (la.qr of a regressor that arrives in pieces, sdp.py:470-487 over several measurement files; one rank's shard per step) pays the
+ * trees once.  R_out must not be read, and the inputs / R_in not rewritten, before fbr_wait has returned; a pipeline error of the
+ * kernels is reported by fbr_wait.  Row weights w are scanned for switched-off rows on the host: with w != NULL the call first waits
+ * for the stream (correct, not overlapped).
+ */
+int fbr_tsqr_submit(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
+                    const double *w, const double *R_in, double *R_out, int64_t *ticket);
+
 /* R_out = R factor of [R_a; R_b] (both n x n upper triangular, row-major) -- one node of the TSQR tree. */
 int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const double *R_b, double *R_out, int32_t mem);
 

@@ -1,0 +1,181 @@
+"""Run-to-run determinism of the device reductions -- the suite's race detector.
+
+The design promises a fixed evaluation order (fixed block -> workgroup assignment, fixed merge trees, fixed summation order of the Gram
+partials), so the SAME call on the SAME inputs must return the SAME BITS, whatever else shares the device: the producer kernels beside
+the Gram kernel, two submissions in flight, the merge trees of five row groups on four side streams, spin flags, hand-placed waits and
+LDS-DMA double buffers.  A race shows up as a last-bit difference long before it shows up against a tolerance, and the base-parameter
+index set depends on the last bits of the Gram (identification/model.py:871-884).  Every case repeats a call at the bench's size and
+compares with ``torch.equal`` / ``np.array_equal``.  The second half runs the randomised stress of tools/stress_gpu.py (random trees x
+option combinations x both Gram kernel shapes against the oracle) as parametrised cases.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from common import load_topo, random_states
+
+pytestmark = pytest.mark.gpu
+
+REPS = 20
+
+
+def _device_states(topo, S, seed, floating=True):
+    import torch
+
+    rng = np.random.default_rng(seed)
+    st = random_states(topo, S, rng, floating, use_limits=True)
+    dev = torch.device("cuda", 0)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st.items()}, dev
+
+
+@pytest.fixture(scope="module")
+def walkman():
+    import torch
+
+    from flobaroid_amd._lib import Engine
+
+    topo = load_topo("walkman_apriori")
+    S = 1_000_000
+    st, dev = _device_states(topo, S, 5)
+    eng = Engine(topo, floating=True)
+    eng.use_torch_stream()
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    rhs = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev, generator=g)
+    yield topo, eng, st, rhs, dev
+    eng.close()
+
+
+def _all_equal(first, others):
+    import torch
+
+    return all(bool(torch.equal(first, o)) for o in others)
+
+
+def test_gram_blocking_repeats_bitwise(walkman):
+    """1 M WALK-MAN samples, fused Gram, blocking calls: producer (kin + pack) co-resident with the Gram kernel from the second chunk on."""
+    topo, eng, st, rhs, dev = walkman
+    G0 = eng.gram(st, rhs=rhs).clone()
+    assert _all_equal(G0, [eng.gram(st, rhs=rhs) for _ in range(REPS)])
+
+
+def test_gram_two_submissions_in_flight_bitwise(walkman):
+    """fbr_gram_submit, two in flight: the first chunk's producer of a pass runs beside the last Gram launches of the pass before."""
+    import torch
+
+    topo, eng, st, rhs, dev = walkman
+    G0 = eng.gram(st, rhs=rhs).clone()
+    outs = [torch.zeros_like(G0), torch.zeros_like(G0)]
+    pend, bad = None, 0
+    for i in range(REPS):
+        tk = eng.gram_submit(st, outs[i & 1], rhs=rhs)
+        if pend is not None:
+            eng.wait(pend[0])
+            bad += not bool(torch.equal(G0, outs[pend[1]]))
+        pend = (tk, i & 1)
+    eng.wait(pend[0])
+    bad += not bool(torch.equal(G0, outs[pend[1]]))
+    assert bad == 0
+
+
+def test_gram_shape_two_repeats_bitwise():
+    """The two-workgroups-per-CU kernel shape forced on WALK-MAN (FBR_GRAM_SHAPE=two), 300 k samples."""
+    from flobaroid_amd._lib import Engine
+
+    topo = load_topo("walkman_apriori")
+    st, dev = _device_states(topo, 300_000, 6)
+    os.environ["FBR_GRAM_SHAPE"] = "two"
+    try:
+        eng = Engine(topo, floating=True)
+        eng.use_torch_stream()
+        G0 = eng.gram(st).clone()
+        assert _all_equal(G0, [eng.gram(st) for _ in range(REPS)])
+        eng.close()
+    finally:
+        del os.environ["FBR_GRAM_SHAPE"]
+
+
+def test_grouped_gram_repeats_bitwise(walkman):
+    """fbr_gram_grouped: 64 candidate trajectories x 2000 samples in one (oversubscribed) pass."""
+    topo, eng, st, rhs, dev = walkman
+    sub = {k: v[:128000].contiguous() for k, v in st.items()}
+    G0 = eng.gram_grouped(sub, 64).clone()
+    assert _all_equal(G0, [eng.gram_grouped(sub, 64) for _ in range(REPS)])
+
+
+def test_tsqr_all_columns_repeats_bitwise(walkman):
+    """Householder TSQR of 35 M x 481: five row groups, spin-flag panel pipelines, trees on four side streams, group factors folded
+    inside the main tree."""
+    topo, eng, st, rhs, dev = walkman
+    R0 = eng.tsqr(st, rhs=rhs).clone()
+    assert _all_equal(R0, [eng.tsqr(st, rhs=rhs) for _ in range(8)])
+
+
+def test_tsqr_base_columns_and_submissions_bitwise(walkman):
+    """fbr_tsqr_cols on 213 independent columns + tau (config 5's call), blocking and two submissions in flight (the second one's
+    prologue runs beside the first one's merge trees)."""
+    import scipy.linalg as sla
+    import torch
+
+    topo, eng, st, rhs, dev = walkman
+    sub = {k: v[:10000].contiguous() for k, v in st.items()}
+    G = eng.gram(sub).cpu().numpy()
+    _, piv = sla.qr(G, pivoting=True, mode="r")
+    cols = np.sort(piv[:213]).astype(np.int32)
+    R0 = eng.tsqr(st, rhs=rhs, cols=cols).clone()
+    assert _all_equal(R0, [eng.tsqr(st, rhs=rhs, cols=cols) for _ in range(8)])
+    outs = [torch.zeros_like(R0), torch.zeros_like(R0)]
+    pend, bad = None, 0
+    for i in range(8):
+        tk = eng.tsqr_submit(st, outs[i & 1], rhs=rhs, cols=cols)
+        if pend is not None:
+            eng.wait(pend[0])
+            bad += not bool(torch.equal(R0, outs[pend[1]]))
+        pend = (tk, i & 1)
+    eng.wait(pend[0])
+    bad += not bool(torch.equal(R0, outs[pend[1]]))
+    assert bad == 0
+    # mixed kinds in flight: a Gram pass behind a TSQR and the other way round
+    Gf = eng.gram(st, rhs=rhs).clone()
+    Ra = eng.tsqr(st, rhs=rhs).clone()
+    Gb, Rb = torch.zeros_like(Gf), torch.zeros_like(Ra)
+    for _ in range(3):
+        t1 = eng.tsqr_submit(st, Rb, rhs=rhs)
+        t2 = eng.gram_submit(st, Gb, rhs=rhs)
+        eng.wait(t2)
+        assert torch.equal(Gb, Gf) and torch.equal(Rb, Ra)
+        t1 = eng.gram_submit(st, Gb, rhs=rhs)
+        t2 = eng.tsqr_submit(st, Rb, rhs=rhs)
+        eng.wait(t1)
+        eng.wait(t2)
+        assert torch.equal(Gb, Gf) and torch.equal(Rb, Ra)
+
+
+def test_left_arm_gram_and_tsqr_repeat_bitwise():
+    """WALK-MAN left arm, 500 k samples (config 3): two-per-CU Gram shape and the wave-private narrow TSQR kernels."""
+    from flobaroid_amd._lib import Engine
+
+    topo = load_topo("walkman_left_arm")
+    st, dev = _device_states(topo, 500_000, 8)
+    eng = Engine(topo, floating=True)
+    eng.use_torch_stream()
+    G0 = eng.gram(st).clone()
+    assert _all_equal(G0, [eng.gram(st) for _ in range(REPS)])
+    R0 = eng.tsqr(st).clone()
+    assert _all_equal(R0, [eng.tsqr(st) for _ in range(REPS)])
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(50))
+def test_random_trees_against_the_oracle(seed):
+    """tools/stress_gpu.py, one seed per case: a random kinematic tree x options x both Gram kernel shapes, fused Gram and TSQR vs the oracle."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.join(root, "tools") not in sys.path:
+        sys.path.insert(0, os.path.join(root, "tools"))
+    from stress_gpu import run_case
+
+    for desc, e_gram, e_tsqr in run_case(seed):
+        assert e_gram < 1e-11 and e_tsqr < 1e-9, desc

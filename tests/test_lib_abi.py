@@ -74,5 +74,5 @@ def test_register_budget_for_co_residency(tmp_path):
     find = lambda frag: [v for k, v in vgprs.items() if frag in k]
     assert find("fbr_gram_kernelILb0ELi6ELi3E") and max(find("fbr_gram_kernelILb0ELi6ELi3E")) <= 176
     assert find("fbr_gram_kernelILb0ELi5ELi2E") and max(find("fbr_gram_kernelILb0ELi5ELi2E")) <= 128  # two workgroups per CU
-    assert max(find("fbr_kin_kernel")) <= 96
+    assert find("fbr_kin_kernelILi5E") and max(find("fbr_kin_kernelILi5E")) <= 96  # the instance of the producer stream (the uncapped <2> runs alone)
     assert max(find("fbr_pack_kernel")) <= 64

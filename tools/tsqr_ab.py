@@ -33,7 +33,24 @@ for var in variants:
     dt = (time.perf_counter() - t0) / reps
     pr = eng.profile_get(); eng.profile_enable(False)
     same = bool(torch.equal(R, R2))
+    # the same calls submitted two in flight (fbr_tsqr_submit): the next call's kinematics / first writer run beside the trees
+    outs = [torch.zeros_like(R), torch.zeros_like(R)]
+    n2 = 6
+    eng.wait(eng.tsqr_submit(st, outs[0], rhs=rhs))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pend = None
+    for i in range(n2):
+        tk = eng.tsqr_submit(st, outs[i & 1], rhs=rhs)
+        if pend is not None:
+            eng.wait(pend)
+        pend = tk
+    eng.wait(pend)
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t0) / n2
+    same = same and bool(torch.equal(R, outs[0])) and bool(torch.equal(R, outs[1]))
     wi = eng.tsqr_work_info(S, k=1)
+    print(f"pipelined {dtp*1e3:8.2f} ms ({wi['flop']/dtp/1e12/78.6:.3f}) |", end=" ")
     print(f"{var:40s} S={S} {dt*1e3:8.2f} ms  executed {wi['flop']/dt/1e12:6.2f} TF ({wi['flop']/dt/1e12/78.6:.3f})  relerr {err:.2e} repeat-bitwise {same} |",
           {k: round(v[0] / reps, 2) for k, v in pr.items() if v[1]}, flush=True)
     for k, v in sets:
