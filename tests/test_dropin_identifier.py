@@ -120,3 +120,31 @@ def test_reference_identification_runs_on_the_work_alike(ref_identifier, tmp_pat
     assert idf.model.xStd.shape[0] in (idf.model.num_identified_params, idf.model.num_all_params)
     assert os.path.exists(urdf + ".regressor.npz")
     capsys.readouterr()
+
+
+@pytest.mark.parametrize("name", ["threelinks", "walkman"])
+def test_reference_identification_floating_base(ref_identifier, tmp_path, name, capsys):
+    """identifier.py, unchanged, through its FLOATING-BASE branches on the work-alike Model / Data (CPU stand-in engine): threeLinks with
+    configs/threeLinks.yaml (data-driven QR, OLS) and WALK-MAN with the configs/walkman_full.yaml option set -- useBaseWrenchForBaseParams
+    -> _extractBaseWrenchRows (identifier.py:888-892, 617-681) with useTrajectoryWeighting over two files, contact wrenches, and
+    _postIdentifyFriction (:979-1099).  Its outputs ARE the committed fixture tests/golden/ref_identification_fb.npz (regenerated here and
+    compared), and the chain the -m gpu test runs on the HIP engine (tests/fb_chain.py) reproduces them on the stand-in engine."""
+    import fb_chain
+    import make_fixtures as mf
+
+    config, files, outs = mf.run_reference_identification_fb(name, str(tmp_path))
+    z = fb_chain.load_fixture()
+    for k, v in outs.items():
+        ref = z[name + "_out_" + k]
+        assert np.allclose(np.asarray(v, dtype=float), np.asarray(ref, dtype=float), rtol=1e-9, atol=1e-9 * max(1.0, np.abs(ref).max())), k
+    assert int(outs["num_base_params"]) == (24 if name == "threelinks" else 213)
+    # the repository's own chain on the same engine the reference's class just used
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model
+
+    d2 = tmp_path / "chain"
+    d2.mkdir()
+    opt, mfiles, topo, tpath = fb_chain.write_inputs(z, name, d2)
+    out = fb_chain.run_chain(opt, mfiles, topo, tpath, Model, Data)
+    fb_chain.compare(out, z, name, 1e-7)
+    capsys.readouterr()

@@ -684,12 +684,150 @@ def reference_blocks_and_wls(golden):
     print("ref_blocks_wls.npz:", len(out), "arrays")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the reference's OWN Identification class (identifier.py, unchanged) driven through the floating-base estimator chain
+# ---------------------------------------------------------------------------------------------------------------------------------
+FB_SCENARIOS = {
+    # configs/threeLinks.yaml as shipped (floating base, data-driven pivoted QR: useStructuralRegressor 0), OLS variant: the SDP needs
+    # cvxpy, which the image lacks -> constrainToConsistent 0 (identifier.py:944-954)
+    "threelinks": dict(robot="threeLinks", yaml="threeLinks.yaml", files=[(2000, 0.05, 42)], contacts=[],
+                       over=dict(constrainToConsistent=0, createPlots=0, verbose=0, showTiming=0, showBaseParams=0, showStandardParams=0,
+                                 showBaseEqns=0)),
+    # configs/walkman_full.yaml as shipped -- useBaseWrenchForBaseParams 1 (Ayusawa's base-link method, identifier.py:888-892 ->
+    # _extractBaseWrenchRows :617-681), useTrajectoryWeighting 1 on TWO measurement files of different noise levels, contact wrenches on
+    # the two foot FT frames, postIdentifyFriction 1 -- without the SDP (constrainToConsistent 0) and its a-priori feasibility check
+    "walkman": dict(robot="walkman_apriori", yaml="walkman_full.yaml", files=[(520, 0.05, 7), (610, 0.4, 8)], contacts=["l_leg_ft", "r_leg_ft"], with_base=True,
+                    over=dict(constrainToConsistent=0, checkAPrioriFeasibility=0, createPlots=0, verbose=0, showTiming=0, showBaseParams=0,
+                              showStandardParams=0, showBaseEqns=0, randomSamples=3000)),
+}
+
+
+def fb_measurement_files(name, outdir):
+    """Seeded synthetic measurement files of a floating-base scenario (the generator of the reference's tests/test_identification.py:25-93
+    with the base states of model.py:720-725): [(path, arrays)] -- tau = inverse dynamics of the a-priori parameters (CPU oracle) + noise,
+    joint torques only (the base wrench is simulated by the path, model.py:398-413), contact wrenches on the listed frames."""
+    from oracle.oracle import OracleModel
+    from flobaroid_amd.topology import Topology
+
+    sc = FB_SCENARIOS[name]
+    topo = Topology.load(os.path.join(REPO, "flobaroid_amd", "robots", sc["robot"] + ".topology.json"))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from common import random_states
+
+    om = OracleModel(topo, floating=True)
+    out = []
+    for i, (S, noise, seed) in enumerate(sc["files"]):
+        rng = np.random.default_rng(seed)
+        st = random_states(topo, S, rng, 1, use_limits=True)
+        tau = om.inverse_dynamics(st, topo.x_std()) + rng.normal(0, noise, (S, 6 + topo.num_dofs))
+        contacts = {f: 0.02 * rng.standard_normal((S, 6)) for f in sc["contacts"]}  # (small: the weighting pre-pass does not subtract them, identifier.py:661)
+        for f, wr in contacts.items():
+            # the reference's convention (model.py:562-576): measured JOINT torques already contain the contact contribution, the base
+            # rows receive it inside the path
+            tau[:, 6:] += np.asarray(om.contact_torques(st, f, wr)).reshape(S, -1)[:, 6:]
+        # (measured base wrench + joint torques where the scenario says so: the per-file noise then reaches the base rows that the
+        # trajectory weighting looks at; else joint torques only and the path simulates the base wrench, model.py:398-413)
+        arrs = dict(positions=st["q"], velocities=st["dq"], accelerations=st["ddq"], torques=tau if sc.get("with_base") else tau[:, 6:],
+                    times=np.arange(S) / 200.0,
+                    base_velocity=st["base_vel"], base_acceleration=st["base_acc"], base_rpy=st["rpy"], frequency=np.array(200.0))
+        if sc["contacts"]:
+            arrs["contacts"] = np.array(contacts)
+        path = os.path.join(outdir, "%s_meas_%d.npz" % (name, i))
+        np.savez(path, **arrs)
+        out.append((path, arrs))
+    return out
+
+
+def fb_config(name):
+    import yaml
+
+    sc = FB_SCENARIOS[name]
+    with open(os.path.join(REF, "configs", sc["yaml"])) as f:
+        c = yaml.load(f, Loader=yaml.SafeLoader)
+    c.update(sc["over"])
+    return c
+
+
+def run_reference_identification_fb(name, workdir):
+    """identifier.py's Identification, not a line changed, on a floating-base scenario with Model / Data replaced by this repository's
+    work-alikes and the CPU stand-in engine (tests/cpu_engine.py: the oracle) answering the device calls.  Returns (config, files, outputs)."""
+    import shutil
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import cpu_engine
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model
+
+    rident = _import_reference("identifier")
+    saved = (rident.Model, rident.Data, Model.engine)
+
+    def _engine(self):
+        if self._engine is None:
+            o = self.opt
+            self._engine = cpu_engine.NumpyOracleEngine(self.topology, floating=o["floatingBase"], friction=o["identifyFrictionSimultaneously"],
+                                                        friction_symmetric=o["identifySymmetricVelFriction"], gravity_only=o["identifyGravityParamsOnly"],
+                                                        stribeck_velocity=float(o.get("stribeckVelocity", 0) or 0.0))
+        return self._engine
+
+    rident.Model, rident.Data, Model.engine = Model, Data, property(_engine)
+    try:
+        sc = FB_SCENARIOS[name]
+        urdf = os.path.join(workdir, sc["robot"] + ".urdf")
+        shutil.copy(os.path.join(REF, "model", sc["robot"] + ".urdf"), urdf)
+        files = fb_measurement_files(name, workdir)
+        config = fb_config(name)
+        np.random.seed(3)
+        idf = rident.Identification(config, urdf, None, [[p for p, _ in files]], None, None)
+        idf.estimateParameters()
+        idf.estimateRegressorTorques()
+        m = idf.model
+        outs = dict(xBase=np.array(m.xBase), xStd=np.array(m.xStd), tauEstimated=np.array(idf.tauEstimated), base_error=np.array(idf.base_error),
+                    independent_cols=np.array(m.independent_cols), num_base_params=np.array(m.num_base_params), tauMeasured=np.array(m.tauMeasured),
+                    num_used_samples=np.array(idf.data.num_used_samples), file_boundaries=np.array(getattr(idf.data, "file_boundaries", [0])))
+        if hasattr(idf, "postid_friction"):
+            for k in ("Fc", "Fv", "off"):
+                outs["postid_" + k] = np.array(idf.postid_friction[k])
+        return config, files, outs
+    finally:
+        rident.Model, rident.Data, Model.engine = saved
+
+
+def reference_identification_fb(golden):
+    """tests/golden/ref_identification_fb.npz: inputs (measurement arrays, option overrides) and the outputs of the reference's own
+    Identification on threeLinks floating (configs/threeLinks.yaml, OLS) and on WALK-MAN with the configs/walkman_full.yaml option set."""
+    import tempfile
+
+    out = {}
+    for name in FB_SCENARIOS:
+        with tempfile.TemporaryDirectory() as td:
+            config, files, outs = run_reference_identification_fb(name, td)
+        # (the option set as the reference's constructor left it: yaml values + the overrides + what identifier.py:57-69 forces)
+        out[name + "_meta"] = json.dumps({"robot": FB_SCENARIOS[name]["robot"], "yaml": FB_SCENARIOS[name]["yaml"], "over": FB_SCENARIOS[name]["over"],
+                                          "contacts": FB_SCENARIOS[name]["contacts"], "files": len(files),
+                                          "opt": {k: v for k, v in config.items() if isinstance(v, (int, float, str, list, dict, type(None)))}})
+        for i, (_, arrs) in enumerate(files):
+            for k, v in arrs.items():
+                if k == "contacts":
+                    for f, a in v.item().items():
+                        out["%s_in%d_contacts_%s" % (name, i, f)] = a
+                else:
+                    out["%s_in%d_%s" % (name, i, k)] = v
+        for k, v in outs.items():
+            out["%s_out_%s" % (name, k)] = v
+        print("  ", name, "base params", int(outs["num_base_params"]), "base_error", float(outs["base_error"]))
+    np.savez_compressed(os.path.join(golden, "ref_identification_fb.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "blocks_wls":
         reference_blocks_and_wls(os.path.join(REPO, "tests", "golden"))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fb":
+        reference_identification_fb(os.path.join(REPO, "tests", "golden"))
         sys.exit(0)
     main()
     reference_host_functions(os.path.join(REPO, "tests", "golden"))
     reference_estimators(os.path.join(REPO, "tests", "golden"))
     reference_compute_regressors(os.path.join(REPO, "tests", "golden"))
     reference_blocks_and_wls(os.path.join(REPO, "tests", "golden"))
+    reference_identification_fb(os.path.join(REPO, "tests", "golden"))
