@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="only the timed steps (profiling runs)")
     ap.add_argument("--sustain-seconds", type=float, default=10.0, help="N = 1: length of the sustained leg after the timed steps")
+    ap.add_argument("--selfcheck-dist", action="store_true",
+                    help="N > 1: only the self-check of the exchange steps (it also runs at the start of every --gpus N > 1 run)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds a distributed step may take before the watchdog ends the rank with a message")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU tensors; only meaningful with --engine (the test-suite's stand-in), the product has no CPU path")
     ap.add_argument("--engine", default=None,
@@ -314,7 +317,7 @@ def run_rank(args) -> int:
     import torch
     import torch.distributed as dist
 
-    from flobaroid_amd.dist import shard_range, tsqr_tree, warm_p2p
+    from flobaroid_amd.dist import Watchdog, selfcheck, shard_range, tsqr_tree, warm_p2p
     from flobaroid_amd.topology import Topology
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,7 +345,10 @@ def run_rank(args) -> int:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise RuntimeError("process group came up with the wrong size")
-        warm_p2p(dev)  # communicators of the all-reduce and of every edge of the TSQR rank tree exist before anything is timed
+        # communicators of the all-reduce and of every edge of the TSQR rank tree exist before anything is timed; a step that does not
+        # finish ends the rank with a message naming it (flobaroid_amd/dist.py: Watchdog) instead of hanging the job
+        with Watchdog(args.dist_timeout, "warm_p2p (creating the RCCL communicators: one per tree edge + the collective one)", rank):
+            warm_p2p(dev)
 
     def sync():
         if on_gpu:
@@ -365,6 +371,19 @@ def run_rank(args) -> int:
     eng = make_engine(args, topo, True, local)
     if on_gpu:
         eng.use_torch_stream()
+    check = None
+    if use_dist and world > 1:
+        # every exchange step once, on data whose result each rank can compute alone: a wrong transport, a missing peer or a bad merge
+        # is reported here with the step's name, not as a hang or a wrong number ten minutes into the run
+        check = selfcheck(dev, eng.tsqr_merge, timeout=args.dist_timeout)
+        if args.selfcheck_dist:
+            if rank == 0:
+                print(json.dumps({"selfcheck_dist": "ok", **check}))
+            dist.destroy_process_group()
+            return 0
+    elif args.selfcheck_dist:
+        print(json.dumps({"selfcheck_dist": "nothing to check with one rank"}))
+        return 0
     rows, P = eng.rows, eng.cols
     Pa = P + 1
     S_total = args.samples
@@ -378,7 +397,13 @@ def run_rank(args) -> int:
     # (async_op) beside the kernels of step i+1.  Every step still produces its own complete, all-reduced Gram inside the timed region.
     pipelined = on_gpu and hasattr(eng, "gram_submit") and not os.environ.get("FBR_BENCH_BLOCKING")
     Gs = [G, torch.zeros_like(G)]
-    state = {"pending": None, "works": [None, None], "i": 0}
+    state = {"pending": None, "works": [None, None], "i": 0, "ar_wait": 0.0}
+
+    def wait_work(b):  # (the time a rank spends here is the all-reduce it could not hide: reported per rank)
+        t_ = time.perf_counter()
+        state["works"][b].wait()
+        state["ar_wait"] += time.perf_counter() - t_
+        state["works"][b] = None
 
     def finish(p):
         tkt, b = p
@@ -390,14 +415,16 @@ def run_rank(args) -> int:
         if not pipelined:
             eng.gram(st, rhs=rhs, out=Gs[0])
             if use_dist:
+                t_ = time.perf_counter()
                 dist.all_reduce(Gs[0])
+                sync()
+                state["ar_wait"] += time.perf_counter() - t_
             state["last"] = 0
             return
         b = state["i"] & 1
         state["i"] += 1
         if state["works"][b] is not None:  # the all-reduce that last used this buffer
-            state["works"][b].wait()
-            state["works"][b] = None
+            wait_work(b)
         tkt = eng.gram_submit(st, Gs[b], rhs=rhs)
         if state["pending"] is not None:
             finish(state["pending"])
@@ -410,8 +437,7 @@ def run_rank(args) -> int:
             state["pending"] = None
         for b in (0, 1):
             if state["works"][b] is not None:
-                state["works"][b].wait()
-                state["works"][b] = None
+                wait_work(b)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -430,12 +456,21 @@ def run_rank(args) -> int:
     barrier()
     eng.profile_enable(True)
     eng.profile_get()
+    state["ar_wait"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()
+    sync()
+    dt_rank = time.perf_counter() - t0   # this rank's own time up to its last result (before the closing barrier)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    per_rank = [[dt_rank / args.steps * 1e3, state["ar_wait"] / args.steps * 1e3]]
+    if use_dist:
+        tt = torch.tensor(per_rank[0], dtype=torch.float64, device=dev)
+        gl = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gl, tt)
+        per_rank = [g_.cpu().tolist() for g_ in gl]
     prof = eng.profile_get()
     eng.profile_enable(False)
     G_sharded = Gs[state.get("last", 0)].clone()
@@ -507,7 +542,13 @@ def run_rank(args) -> int:
             "samples_per_launch": samples_per_launch,
         },
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+        # every rank's own time per step up to its last result, and the part of it spent waiting for the Gram all-reduce it could not
+        # hide behind the next step's kernels: a slow rank or a slow link shows here
+        "per_rank_ms_per_step": [p_[0] for p_ in per_rank],
+        "per_rank_allreduce_wait_ms_per_step": [p_[1] for p_ in per_rank],
     }
+    if check is not None:
+        out["selfcheck_dist"] = check
     try:  # HBM traffic of the dominant kernel: committed rocprofv3 PMC passes, scaled to this run's samples per launch
         import glob
 

@@ -83,3 +83,148 @@ def tsqr_tree(R: torch.Tensor, merge: Callable[[torch.Tensor, torch.Tensor], tor
         step *= 2
     dist.broadcast(R, src=g(0), group=group)
     return R
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# First contact with hardware: a self-check of every exchange step, with a watchdog instead of a hang
+# ---------------------------------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Names the step a rank is in and, if the step does not finish in ``seconds``, prints WHERE this rank is stuck and what to look at,
+    then ends the process (a blocked RCCL call cannot be interrupted from Python: the launcher sees the exit code and tears the job
+    down instead of waiting for the collective's own time-out).  ``with Watchdog(60, "warm_p2p") as wd: ...; wd.step("next")``."""
+
+    HINT = ("hints: NCCL_DEBUG=INFO (RCCL's own log: transport per peer, the call it is in); HSA_ENABLE_IPC_MODE_LEGACY=0 must be set for "
+            "multi-process GPU work on this image (dmabuf IPC; without it hipIpcGetMemHandle fails); rendezvous on 127.0.0.1 "
+            "(MASTER_ADDR); every rank needs its own device (LOCAL_RANK); `rocm-smi --showtopo` shows the xGMI links")
+
+    def __init__(self, seconds: float, what: str, rank: int | None = None, hard_exit: bool = True):
+        self.seconds, self.cur, self.hard_exit = float(seconds), what, hard_exit
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self._timer = None
+        self.fired = False
+
+    def _arm(self):
+        import threading
+
+        self._disarm()
+        self._timer = threading.Timer(self.seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def _fire(self):
+        import os
+        import sys
+
+        self.fired = True
+        print(f"[rank {self.rank}] distributed step '{self.cur}' did not finish within {self.seconds:.0f} s -- a peer is missing, stuck in another "
+              f"step or its link is down.  {self.HINT}", file=sys.stderr, flush=True)
+        if self.hard_exit:
+            os._exit(3)
+
+    def step(self, what: str) -> None:
+        self.cur = what
+        self._arm()
+
+    def __enter__(self):
+        self._arm()
+        return self
+
+    def __exit__(self, *exc):
+        self._disarm()
+        return False
+
+
+def _edge_payload(recv: int, send: int, n: int = 4096) -> torch.Tensor:
+    """what the sender of a tree edge transmits in the self-check: a vector every rank can rebuild"""
+    g = torch.Generator().manual_seed(1000003 * recv + send + 17)
+    return torch.randn(n, dtype=torch.float64, generator=g)
+
+
+def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] | None = None, timeout: float = 120.0, n: int = 48,
+              group=None) -> dict:
+    """Exercise every exchange step of the N > 1 path once, on data whose result every rank can compute alone, and FAIL WITH A MESSAGE
+    (which step, which peer, what was expected) instead of hanging or producing a wrong reduction:
+      1. all-reduce of a small tensor (rank r contributes r + 1: the sum is known);
+      2. one send / recv over every edge of the TSQR rank tree with a payload the receiver rebuilds and compares bit for bit;
+      3. ``tsqr_tree`` on seeded random triangles against the same merges done locally, and R^T R against the sum of the R_r^T R_r;
+      4. broadcast from rank 0.
+    ``merge``: the R-factor merge the run uses (``Engine.tsqr_merge``); None: NumPy QR.  Returns the seconds every step took."""
+    import time
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {"world": 1}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    if merge is None:
+        import numpy as np
+
+        def merge(Ra, Rb):  # noqa: E306
+            return torch.from_numpy(np.linalg.qr(np.vstack([Ra.cpu().numpy(), Rb.cpu().numpy()]), mode="r")).to(Ra.device)
+
+    out: dict = {"world": world}
+
+    def fail(msg):
+        raise RuntimeError(f"[rank {rank}] distributed self-check failed: {msg}.  {Watchdog.HINT}")
+
+    with Watchdog(timeout, "all-reduce", rank) as wd:
+        t0 = time.perf_counter()
+        x = torch.full((8,), float(rank + 1), dtype=torch.float64, device=device)
+        dist.all_reduce(x, group=group)
+        want = world * (world + 1) / 2.0
+        if not bool((x.cpu() == want).all()):
+            fail(f"all-reduce over {world} ranks gave {x.cpu().tolist()} instead of {want}")
+        out["allreduce_s"] = time.perf_counter() - t0
+
+        t0 = time.perf_counter()
+        for recv, send in _tree_edges(world):
+            wd.step(f"send/recv over tree edge {send} -> {recv}")
+            if rank == send:
+                dist.send(_edge_payload(recv, send).to(device) if device is not None else _edge_payload(recv, send), dst=g(recv), group=group)
+            elif rank == recv:
+                buf = torch.empty(4096, dtype=torch.float64, device=device)
+                dist.recv(buf, src=g(send), group=group)
+                if not torch.equal(buf.cpu(), _edge_payload(recv, send)):
+                    bad = int((buf.cpu() != _edge_payload(recv, send)).sum())
+                    fail(f"payload received over tree edge {send} -> {recv} differs from what rank {send} sends in {bad} of 4096 entries")
+        out["edges_s"] = time.perf_counter() - t0
+
+        wd.step("tsqr_tree on random triangles")
+        t0 = time.perf_counter()
+
+        def tri(r):
+            gg = torch.Generator().manual_seed(7919 * r + 5)
+            return torch.triu(torch.randn((n, n), dtype=torch.float64, generator=gg))
+
+        mine = tri(rank).to(device) if device is not None else tri(rank)
+        R = tsqr_tree(mine, merge, group=group)
+        # the same tree, merged locally
+        loc = {r: (tri(r).to(device) if device is not None else tri(r)) for r in range(world)}
+        step = 1
+        while step < world:
+            for r in range(0, world, 2 * step):
+                if r + step < world:
+                    loc[r] = merge(loc[r], loc[r + step]).contiguous()
+            step *= 2
+        ref = loc[0].cpu()
+        gram = sum(tri(r).T @ tri(r) for r in range(world))
+        Rc = R.cpu()
+        e1 = float(torch.linalg.norm(Rc.T @ Rc - gram) / torch.linalg.norm(gram))
+        e2 = float(torch.linalg.norm(Rc - ref) / torch.linalg.norm(ref))
+        if not (e1 <= 1e-12 and e2 <= 1e-12):
+            fail(f"tsqr_tree over {world} ranks: ||R^T R - sum R_r^T R_r|| / ||.|| = {e1:.2e}, vs the locally merged tree {e2:.2e} (expected <= 1e-12)")
+        out["tsqr_tree_s"] = time.perf_counter() - t0
+        out["tsqr_tree_relerr"] = max(e1, e2)
+
+        wd.step("broadcast from rank 0")
+        t0 = time.perf_counter()
+        y = torch.full((8,), 42.0 if rank == 0 else -1.0, dtype=torch.float64, device=device)
+        dist.broadcast(y, src=g(0), group=group)
+        if not bool((y.cpu() == 42.0).all()):
+            fail("broadcast from rank 0 did not arrive")
+        out["broadcast_s"] = time.perf_counter() - t0
+    return out

@@ -25,12 +25,20 @@ _WORKER = """
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
-from flobaroid_amd.dist import shard_range, allreduce_gram, tsqr_tree, warm_p2p, _tree_edges
+from flobaroid_amd.dist import shard_range, allreduce_gram, tsqr_tree, warm_p2p, _tree_edges, selfcheck, Watchdog
 from common import load_topo, random_states
 from oracle.oracle import OracleModel
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
 warm_p2p()   # one message over every edge of the rank tree + all-reduce + broadcast: must neither hang nor mismatch
+chk = selfcheck()   # every exchange step on data each rank can check alone
+assert chk["world"] == world and chk["tsqr_tree_relerr"] <= 1e-12
+if os.environ.get("FBR_TEST_BAD_MERGE"):   # a merge that returns a wrong factor must be reported by name, not survive
+    try:
+        selfcheck(merge=lambda a, b: a)
+        print("BAD MERGE NOT DETECTED"); sys.exit(5)
+    except RuntimeError as e:
+        assert "tsqr_tree" in str(e) and "self-check failed" in str(e), str(e)
 assert len(_tree_edges(world)) == world - 1 and sorted(s for _, s in _tree_edges(world)) == list(range(1, world))
 t = load_topo("kuka_lwr4")
 om = OracleModel(t)
@@ -81,11 +89,27 @@ def test_two_rank_gloo(tmp_path):
     procs = []
     for world in (2, 3):
         for r in range(world):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world))
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world), FBR_TEST_BAD_MERGE="1")
             procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=240)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
         procs = []
+
+
+def test_watchdog_names_the_step_and_ends_the_process(tmp_path):
+    """A distributed step that never finishes: the watchdog prints the step and the hints and ends the process with code 3 (here a rank
+    waiting for a message nobody sends)."""
+    script = tmp_path / "stuck.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        from flobaroid_amd.dist import Watchdog
+        with Watchdog(1.0, "recv from rank 7 that never sends", rank=0):
+            time.sleep(30)
+        print("not reached")
+    """ % ROOT))
+    r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 3 and b"recv from rank 7 that never sends" in r.stderr and b"NCCL_DEBUG" in r.stderr and b"not reached" not in r.stdout
 
 
 def _run_bench(extra, env_extra=None, timeout=600):
@@ -120,6 +144,10 @@ def test_bench_gpus_2_spawns_two_ranks_end_to_end():
         assert abs(one["gram_checksum"][key] - two["gram_checksum"][key]) <= 1e-11 * abs(one["gram_checksum"][key])
     assert two["tsqr"]["rank_tree_levels"] == 1 and two["tsqr"]["relerr_RtR_vs_allreduced_gram"] <= 1e-11
     assert two["weak_scaling"]["samples_per_gpu"] == 192 and two["weak_scaling"]["relerr_vs_world_x_sharded_gram"] <= 1e-11
+    assert two["selfcheck_dist"]["world"] == 2 and two["selfcheck_dist"]["tsqr_tree_relerr"] <= 1e-12 and "selfcheck_dist" not in one
+    assert len(two["per_rank_ms_per_step"]) == 2 and len(two["per_rank_allreduce_wait_ms_per_step"]) == 2 and len(one["per_rank_ms_per_step"]) == 1
+    r = _run_bench(["--gpus", "2", "--selfcheck-dist"])   # the self-check alone
+    assert r.returncode == 0 and b'"selfcheck_dist": "ok"' in r.stdout, r.stderr.decode()[-2000:]
     assert "weak_scaling" not in one and one["tsqr"]["rank_tree_levels"] == 0
 
 

@@ -21,7 +21,7 @@ _WORKER = """
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
-from flobaroid_amd.dist import shard_range, allreduce_gram, tsqr_tree
+from flobaroid_amd.dist import shard_range, allreduce_gram, tsqr_tree, selfcheck
 from flobaroid_amd._lib import Engine
 from common import load_topo, random_states
 from oracle.oracle import OracleModel
@@ -53,6 +53,9 @@ for name, fl, S in (("walkman_apriori", 1, 700), ("kuka_lwr4", 0, 2001)):   # wi
     Rs = [torch.empty(R.shape, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(Rs, torch.from_numpy(R))
     assert all(torch.equal(Rs[0], r) for r in Rs)
+    # the self-check bench.py runs at the start of every N > 1 run, with fbr_tsqr_merge on the GPU as the merge
+    chk = selfcheck(None, lambda Ra, Rb: torch.from_numpy(eng.tsqr_merge(Ra.numpy(), Rb.numpy())), timeout=120.0)
+    assert chk["world"] == world and chk["tsqr_tree_relerr"] <= 1e-12, chk
     eng.close()
 dist.destroy_process_group()
 print("rank", rank, "ok")
