@@ -618,8 +618,59 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
                        "factorised over the columns it can touch, blocks folded from their first supported column); dense: 2*rows*(P+k)^2 per "
                        "sample (SURVEY 8d)",
         "rank_tree_levels": merges, "relerr_RtR_vs_allreduced_gram": err,
+        # device time per class on the call's own stream: `tree` = merge tree of the main row group (the latency-bound tail of a call:
+        # 8 levels over 256 private factors, a handful of workgroups each), `tsqr` = the level-0 folds + the embedded group factors
         "kernel_ms_per_call_rank0": {k: v[0] / reps for k, v in pr.items() if v[1]},
+        "tree_share_of_call": (pr["tree"][0] / reps) / (dt * 1e3) if pr.get("tree", (0, 0))[1] else None,
     }
+
+    def tsqr_pipelined(stx, rhsx, n_sub):
+        """the same calls submitted two in flight (fbr_tsqr_submit): the next call's kinematics / first writer beside the trees"""
+        Ro = [torch.zeros((P + 1, P + 1), dtype=torch.float64, device=dev) for _ in range(2)]
+        eng.wait(eng.tsqr_submit(stx, Ro[0], rhs=rhsx))
+        sync()
+        t0 = time.perf_counter()
+        pend = None
+        for i in range(n_sub):
+            tk = eng.tsqr_submit(stx, Ro[i & 1], rhs=rhsx)
+            if pend is not None:
+                eng.wait(pend)
+            pend = tk
+        eng.wait(pend)
+        sync()
+        return (time.perf_counter() - t0) / n_sub, Ro[(n_sub - 1) & 1]
+
+    if world == 1 and on_gpu and hasattr(eng, "tsqr_submit"):
+        dtp, Rp = tsqr_pipelined(st, rhs, 4)
+        out["tsqr"]["pipelined_seconds"] = dtp
+        out["tsqr"]["pipelined_executed_frac_of_fp64_mfma_peak"] = executed_flop / dtp / 1e12 / PEAK_FP64_MFMA_TFLOPS
+        out["tsqr"]["pipelined_equals_blocking_bitwise"] = bool(torch.equal(Rp, R))
+        # ---- one rank's share of the 1 M samples at 8 GPUs: does the TSQR call scale down to a shard?  (its fixed costs -- the merge
+        # trees, the first chunk's producer -- do not shrink with the samples: this leg is the ceiling of the 8-GPU TSQR scaling)
+        Ssh = S_total // 8
+        sts = {k_: v[:Ssh].contiguous() for k_, v in st.items()}
+        rhss = rhs[:Ssh * rows].contiguous()
+        eng.tsqr(sts, rhs=rhss)
+        eng.profile_enable(True)
+        eng.profile_get()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.tsqr(sts, rhs=rhss)
+        sync()
+        dsh = (time.perf_counter() - t0) / 5
+        prs = eng.profile_get()
+        eng.profile_enable(False)
+        dshp, _ = tsqr_pipelined(sts, rhss, 8)
+        wsh = eng.tsqr_work_info(Ssh, k=1)
+        out["tsqr_shard"] = {
+            "samples": Ssh, "seconds": dsh, "pipelined_seconds": dshp, "one_eighth_of_the_1M_call_seconds": dt / 8,
+            "ratio_to_one_eighth": dsh / (dt / 8), "pipelined_ratio_to_one_eighth_of_pipelined": dshp / (dtp / 8),
+            "scaling_ceiling_at_8_gpus": dt / dsh, "executed_frac_of_fp64_mfma_peak": wsh["flop"] / dsh / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "kernel_ms_per_call": {k_: v[0] / 5 for k_, v in prs.items() if v[1]},
+            "tree_share_of_call": (prs["tree"][0] / 5) / (dsh * 1e3) if prs.get("tree", (0, 0))[1] else None,
+        }
+        del sts, rhss
 
     # ---- weak scaling: 1 M samples PER GPU (N = 1: identical to the timed steps)
     if world > 1:

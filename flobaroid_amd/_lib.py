@@ -570,7 +570,7 @@ class Engine:
         return {"mfma_level0": l0.value, "mfma_tree": tr.value, "block_rows": mb.value, "n_padded": npad.value,
                 "flop": 2048 * (l0.value + tr.value)}
 
-    PROF_CLASSES = ("kin", "regressor", "gram", "reduce", "id", "tsqr", "pack", "h2d")
+    PROF_CLASSES = ("kin", "regressor", "gram", "reduce", "id", "tsqr", "pack", "h2d", "tree")
 
     def profile_enable(self, on: bool = True) -> None:
         _check(self._lib.fbr_profile_enable(self._h, int(bool(on))), "fbr_profile_enable")

@@ -1833,7 +1833,6 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     // order, are dense rows of the final factorisation: they are folded INSIDE the main tree -- once at most 8 of its factors are
     // alive, one launch deals the embedded rows to those factors (a block or two per workgroup) -- instead of by one workgroup, group
     // after group, behind the tree (round 3: 3.3 ms per call).  Without a dense group the final factor starts from R_in.
-    ProfScope ps(m, FBR_PROF_TSQR);
     for (auto &st : m->tsqr_streams)
         if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto &e : m->tsqr_ev)
@@ -1881,14 +1880,21 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         while ((wk.NW + alive_stride - 1) / alive_stride > 8) alive_stride *= 2;
         // (a following submission's prologue starts behind the two widest tree levels: 128 and 64 workgroups)
         const int s_pro = std::min(4, alive_stride);
-        if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, s_pro)) || (rc = record_l0()) || (rc = fbr_tsqr_tree_levels(wk, m->stream, s_pro, alive_stride)))
-            return tsqr_fail(rc, "tsqr tree");
+        {
+            ProfScope ps(m, FBR_PROF_TREE);
+            if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, s_pro)) || (rc = record_l0()) || (rc = fbr_tsqr_tree_levels(wk, m->stream, s_pro, alive_stride)))
+                return tsqr_fail(rc, "tsqr tree");
+        }
         for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->stream, m->tsqr_ev[i], 0));
         if ((rc = m->tsqr_embed.ensure((size_t)((erows + 15) & ~15L) * wk.n * sizeof(double)))) return rc;
-        if ((rc = pack_embedded(wk, m->tsqr_embed.as<double>()))) return rc;
         const int alive = (wk.NW + alive_stride - 1) / alive_stride;
-        if ((rc = fbr_tsqr_fold_packed(wk, m->stream, erows, FbrTsqrRowOrder(), m->tsqr_embed.as<double>(), alive_stride, alive)))
-            return tsqr_fail(rc, "tsqr embedded group factors");
+        {
+            ProfScope ps(m, FBR_PROF_TSQR);
+            if ((rc = pack_embedded(wk, m->tsqr_embed.as<double>()))) return rc;
+            if ((rc = fbr_tsqr_fold_packed(wk, m->stream, erows, FbrTsqrRowOrder(), m->tsqr_embed.as<double>(), alive_stride, alive)))
+                return tsqr_fail(rc, "tsqr embedded group factors");
+        }
+        ProfScope ps(m, FBR_PROF_TREE);
         if ((rc = fbr_tsqr_tree_levels(wk, m->stream, alive_stride, 1 << 30)) || (rc = fbr_tsqr_copy_out(wk, m->stream, R)))
             return tsqr_fail(rc, "tsqr tree");
         return FBR_OK;  // (the error word of the call is read once, at its end: tsqr_impl)
@@ -1896,6 +1902,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     // no dense group (fixed base behind a branching first link, masked base rows) or wave-private main kernels: the group factors are
     // folded by one workgroup into a factor seeded with the main group's result / R_in
     if ((rc = record_l0())) return rc;
+    ProfScope ps(m, FBR_PROF_TSQR);
     const double *seed = Rin_dev;
     if (gp.main >= 0) {
         if ((rc = fbr_tsqr_finish_async(m->tsqr, m->stream, rtmp + o_r[gp.main]))) return tsqr_fail(rc, "tsqr finish");

@@ -231,7 +231,9 @@ int fbr_central_diff(fbr_model *m, const double *A, const double *T, double *D, 
 #define FBR_PROF_TSQR 5      /* TSQR fold kernels (level 0 per chunk, merge tree) */
 #define FBR_PROF_PACK 6      /* tile-image packing kernel of the fused Gram pass (producer stream) */
 #define FBR_PROF_H2D 7       /* host -> device staging copies of the chunked fused pass (pinned host inputs) */
-#define FBR_PROF_COUNT 8
+#define FBR_PROF_TREE 8      /* TSQR merge tree of the main row group on the call's stream (the latency-bound tail of a call; the other
+                                groups' trees run beside it on side streams and are not counted) */
+#define FBR_PROF_COUNT 9
 /* When enabled, every kernel launch is bracketed by hipEvents on the launch stream; fbr_profile_get
    returns, per kernel class, the summed device time in ms and the launch count since the last reset
    (the counters are reset by the call).  Used by bench.py for the live roofline figures. */

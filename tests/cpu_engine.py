@@ -26,7 +26,7 @@ class OracleEngine:
         self.rows, self.cols = self.om.rows, self.om.P
         self.n = topo.num_dofs
         self.device = device
-        self._prof = {c: [0.0, 0] for c in ("kin", "regressor", "gram", "reduce", "id", "tsqr", "pack", "h2d")}
+        self._prof = {c: [0.0, 0] for c in ("kin", "regressor", "gram", "reduce", "id", "tsqr", "pack", "h2d", "tree")}
 
     def close(self):
         pass
