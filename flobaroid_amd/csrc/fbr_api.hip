@@ -160,6 +160,7 @@ struct fbr_model {
     hipEvent_t tsqr_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [i]: side stream i is done; [4]: fork point on the main stream
     DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
     DevBuf tsqr_embed;        // stacked rows of the embedded group factors (tree-structured TSQR)
+    DevBuf gram_r_tmp;        // factor of gram_via_tsqr (robots beyond the fused Gram's 60 rows per sample)
     // per-call state of the TSQR entry points, double buffered by the parity of the call's ticket so that a submission (fbr_tsqr_submit)
     // can be enqueued while the one before is still running
     DevBuf tsqr_tab[2];                        // device tables (index lists, entry lists, group records)
@@ -941,6 +942,43 @@ static int active_rows(fbr_model *m, const double *dw, long S, std::vector<char>
 }
 
 static int drain_after_failed_submit(fbr_model *m);
+static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k, const double *w,
+                     const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket);
+
+// G (+)= R^T R for an upper-triangular R (Pa x Pa): the Gram of a robot the fused tile program does not cover, from its TSQR factor
+__global__ __launch_bounds__(256) void fbr_rtr_kernel(int Pa, const double *__restrict__ R, double *__restrict__ G, int accumulate)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pa * Pa; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / Pa), j = (int)(e % Pa);
+        double acc = 0.0;
+        for (int r = 0; r <= min(i, j); r++) acc += R[(long)r * Pa + i] * R[(long)r * Pa + j];
+        G[e] = accumulate ? G[e] + acc : acc;
+    }
+}
+
+// Robots with more than 60 regressor rows per sample (54 DOF on a floating base) are outside the fused Gram's tile program (15 MFMA
+// k-steps per tile pair).  Their Gram is formed from the Householder factor of the same rows: G = R^T R with R from fbr_tsqr (up to 255
+// rows per sample and 768 columns) -- slower than the fused pass, numerically at least as good, and it keeps every caller of
+// fbr_gram_accumulate working for any URDF the reference loads (model.py:116-168).
+static int gram_via_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out, int32_t out_mem,
+                         int32_t accumulate)
+{
+    const int Pa = m->hm.cols + k;
+    const size_t cnt = (size_t)Pa * Pa;
+    int rc;
+    if ((rc = m->gram_r_tmp.ensure(cnt * sizeof(double)))) return rc;
+    double *R = m->gram_r_tmp.as<double>();
+    if ((rc = tsqr_impl(m, st, nullptr, 0, rhs, k, w, nullptr, R, FBR_DEVICE, nullptr))) return rc;
+    double *G = G_out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
+        G = m->g_tmp.as<double>();
+        if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, cnt * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    }
+    hipLaunchKernelGGL(fbr_rtr_kernel, dim3(1024), dim3(256), 0, m->stream, Pa, R, G, accumulate ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return finish_output(m, G, G_out, cnt, out_mem);
+}
 
 // async_ticket != nullptr: the pass is enqueued and NOT waited for (fbr_gram_submit): device-resident inputs and output only.
 static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
@@ -978,6 +1016,14 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
         return FBR_E_INVALID;
     }
     const FbrHostModel &hm = m->hm;
+    if ((hm.rows + 3) / 4 * 4 > 60) {  // beyond the tile program's 15 k-steps: the Gram from the TSQR factor
+        if (async || ngroups != 1) {
+            set_err("robots with more than 60 regressor rows per sample (54 DOF on a floating base) are served by the blocking, ungrouped "
+                    "fbr_gram_accumulate only (Gram from the TSQR factor): fbr_gram_submit / fbr_gram_grouped are limited to 60 rows");
+            return FBR_E_UNSUPPORTED;
+        }
+        return gram_via_tsqr(m, st, rhs, k, w, G_out, out_mem, accumulate);
+    }
     GramHolder *h = nullptr;
     if ((rc = get_gram(m, k, &h))) return rc;
     const int Pa = h->prog.Pa;
@@ -2137,7 +2183,7 @@ static int drain_after_failed_submit(fbr_model *m)
 }
 
 static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
-                     const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket = nullptr)
+                     const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
     int rc = tsqr_impl_inner(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem, async_ticket);
     if (rc && async_ticket && m && m->pid == getpid()) {
@@ -2151,7 +2197,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
 extern "C" int fbr_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w,
                         const double *R_in, double *R_out, int32_t out_mem)
 {
-    return tsqr_impl(m, st, nullptr, 0, rhs, k, w, R_in, R_out, out_mem);
+    return tsqr_impl(m, st, nullptr, 0, rhs, k, w, R_in, R_out, out_mem, nullptr);
 }
 
 extern "C" int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs,
@@ -2161,7 +2207,7 @@ extern "C" int fbr_tsqr_cols(fbr_model *m, const fbr_states *st, const int32_t *
         set_err("cols is NULL");
         return FBR_E_INVALID;
     }
-    return tsqr_impl(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem);
+    return tsqr_impl(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem, nullptr);
 }
 
 extern "C" int fbr_tsqr_submit(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,

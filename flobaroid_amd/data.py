@@ -170,6 +170,13 @@ class Data:
         cond(YBase_b) = sqrt(lmax / lmin) of G_b[ic, ic].  A block whose Gram is too ill conditioned for that (ratio > 1e13:
         the smallest eigenvalue would carry < 3 digits) is re-done through its triangular factor (``fbr_tsqr_cols``)."""
         self.model = model
+        # The one-pass form evaluates the raw measurement states against ONE basis.  Where the reference's per-block loop does
+        # something the grouped reduction does not see -- velocities / accelerations zeroed for gravity-only identification
+        # (model.py:382-385), a projected or filtered base regressor (useBasisProjection, filterRegressor), a basis recomputed from
+        # every block's own regressor (useStructuralRegressor 0, model.py:598-601) -- the loop itself is run, block by block.
+        o = self.opt
+        if o.get("identifyGravityParamsOnly") or o.get("useBasisProjection") or o.get("filterRegressor") or not o.get("useStructuralRegressor", 1):
+            return self._block_stats_loop(model)
         skip = int(self.opt["skipSamples"]) + 1
         blocks = self.block_positions()
         ic = np.asarray(model.independent_cols)
@@ -214,6 +221,22 @@ class Data:
             if st is None:
                 st = stats_from_factor(pos, size)
             self.seenBlocks.append((pos, size, st[0], st[1]))
+        # leave the cursor, the block size and the working samples where the reference's loop leaves them: on the last block
+        self.block_pos, self.opt["blockSize"] = blocks[-1]
+        self.samples = self._slice_block(*blocks[-1])
+        self.updateNumSamples()
+
+    def _block_stats_loop(self, model) -> None:
+        """identifier.py:1564-1583 block by block: regressors of the working block, its statistics, next block."""
+        self.block_pos = 0
+        self.samples = self._slice_block(0, min(int(self.opt["blockSize"]), int(self.num_loaded_samples)))
+        self.updateNumSamples()
+        while True:
+            model.computeRegressors(self)
+            self.getBlockStats(model)
+            if not self.hasMoreSamples():
+                break
+            self.getNextSampleBlock()
 
     def selectBlocks(self) -> None:
         """Keep the blocks whose condition number is within the best ``selectBestPerenctage`` percent, then thin out blocks

@@ -421,9 +421,25 @@ def test_block_statistics_from_the_gpu_reductions_match_the_reference(tmp_path):
             d.getNextSampleBlock()
         else:
             break
+    end_state = (d.block_pos, d.opt["blockSize"], d.num_used_samples, d.samples["positions"].shape)
     # (b) one pass
     m2, d2 = fresh()
     d2.getAllBlockStats(m2)
+    assert (d2.block_pos, d2.opt["blockSize"], d2.num_used_samples, d2.samples["positions"].shape) == end_state   # where the reference's loop ends
+    # options the grouped reduction does not see (a basis recomputed from every block's own regressor): the loop itself is run
+    m3, d3 = fresh()
+    m3.opt["useStructuralRegressor"] = d3.opt["useStructuralRegressor"] = 0
+    d3.getAllBlockStats(m3)
+    m4, d4 = fresh()
+    m4.opt["useStructuralRegressor"] = d4.opt["useStructuralRegressor"] = 0
+    while True:
+        m4.computeRegressors(d4)
+        d4.getBlockStats(m4)
+        if d4.hasMoreSamples():
+            d4.getNextSampleBlock()
+        else:
+            break
+    assert [b[:3] for b in d3.seenBlocks] == [b[:3] for b in d4.seenBlocks] and len(d3.seenBlocks) == len(d.seenBlocks)
     for dd, tol in ((d, 1e-9), (d2, 1e-7)):   # (b) squares the condition number: ~1e3^2 * eps
         assert [b[0] for b in dd.seenBlocks] == z["bl_seen_pos"].tolist() and [b[1] for b in dd.seenBlocks] == z["bl_seen_size"].tolist()
         got = np.array([b[2] for b in dd.seenBlocks])

@@ -803,3 +803,38 @@ def test_any_link_and_dof_serialisation(name, fl):
     assert np.linalg.norm(R2.T @ R2 - G2) <= 1e-11 * np.linalg.norm(G2)
     e1.close()
     e2.close()
+
+
+def test_gram_of_a_robot_beyond_60_rows_per_sample_comes_from_the_tsqr_factor():
+    """More than 60 regressor rows per sample (54 DOF on a floating base) is outside the fused Gram's tile program (15 MFMA k-steps):
+    ``fbr_gram_accumulate`` then forms G = R^T R from the Householder factor of the same rows, so every caller keeps working for any URDF
+    the reference loads (model.py:116-168); the asynchronous and the grouped form name the limit instead."""
+    import torch
+
+    from common import random_topology
+    from flobaroid_amd._lib import Engine, FbrError
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(77)
+    t = random_topology(rng, 62, p_fixed=0.0, branchiness=0.4)
+    assert t.num_dofs + 6 > 60
+    eng = Engine(t, floating=True)
+    om = OracleModel(t, floating=True)
+    S = 300
+    st = random_states(t, S, rng, 1)
+    Y = om.regressor(st)
+    tau = rng.standard_normal((Y.shape[0], 2))
+    w = rng.random(Y.shape[0]) + 0.5
+    A = np.hstack([Y, tau]) * w[:, None]
+    Go = A.T @ A
+    G = eng.gram(st, rhs=tau, w=w)
+    assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go)
+    G2 = eng.gram(st, rhs=tau, w=w, out=G.copy(), accumulate=True)
+    assert np.linalg.norm(G2 - 2 * Go) <= 1e-11 * np.linalg.norm(Go)
+    assert np.abs(eng.regressor(st) - Y).max() <= 1e-11 * np.abs(Y).max()
+    dst = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    with pytest.raises(FbrError, match="60 rows"):
+        eng.gram_submit(dst, torch.zeros((eng.cols, eng.cols), dtype=torch.float64, device="cuda"))
+    with pytest.raises(FbrError, match="60 rows"):
+        eng.gram_grouped(st, 3)
+    eng.close()
