@@ -1333,8 +1333,10 @@ static int wait_ticket(fbr_model *m, int64_t ticket)
     m->waited_ticket = ticket;
     for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)  // (at most two submissions were in flight)
         if (m->ticket_kind[t & 1] == 1 && m->tsqr_err_host && m->tsqr_err_host[t & 1]) {
+            char hx[16];
+            snprintf(hx, sizeof hx, "%08x", m->tsqr_err_host[t & 1]);
             m->tsqr_err_host[t & 1] = 0;
-            set_err("TSQR pipeline flag wait timed out (internal error) in submission " + std::to_string(t));
+            set_err("TSQR pipeline flag wait timed out (internal error, code " + std::string(hx) + ") in submission " + std::to_string(t));
             return FBR_E_HIP;
         }
     return FBR_OK;
@@ -2046,8 +2048,10 @@ static int tsqr_impl_inner(fbr_model *m, const fbr_states *st, const int32_t *co
         int rc2 = finish_output(m, R, R_out, rcount, out_mem);
         if (rc2) return rc2;
         if (m->tsqr_err_host[par]) {
+            char hx[16];
+            snprintf(hx, sizeof hx, "%08x", m->tsqr_err_host[par]);
             m->tsqr_err_host[par] = 0;
-            set_err("TSQR pipeline flag wait timed out (internal error)");
+            set_err("TSQR pipeline flag wait timed out (internal error, code " + std::string(hx) + ")");
             return FBR_E_HIP;
         }
         return FBR_OK;

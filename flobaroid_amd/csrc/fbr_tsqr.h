@@ -135,11 +135,11 @@ __global__ __launch_bounds__(256) void fbr_tsqr_tail_kernel(long M, long Mpad, i
 #define FBR_TSQR_TSZ (16 * FBR_TSQR_LDT)
 
 // LDS carve (doubles): Rl[WAVES*TPW tiles][256] | Vr[RING][MB*17] | Tr[RING][256] | Rp[WAVES][256] | flags[16]
-template <int TPW, int SUB, int W = FBR_TSQR_WAVES> static inline size_t fbr_tsqr_lds_doubles()
+template <int TPW, int SUB, int W = FBR_TSQR_WAVES, bool XWG = false> __host__ __device__ static inline constexpr size_t fbr_tsqr_lds_doubles()
 {
-    constexpr bool RREG = fbr_tsqr_rreg<TPW, W>();
+    constexpr bool RREG = fbr_tsqr_rreg<TPW, W>() || XWG;
     return (RREG ? 0 : (size_t)W * TPW * 256) + (size_t)fbr_tsqr_ring<SUB, W, RREG>() * (16 * SUB * FBR_TSQR_LDV + FBR_TSQR_TSZ) + (size_t)W * 256 + 16 +
-           FBR_TSQR_RING_MAX;
+           FBR_TSQR_RING_MAX + (XWG ? 32 : 0);  // (XWG: 64 ints at the very end for the blocks the workgroup has claimed)
 }
 typedef __attribute__((address_space(3))) void *fbr_tsqr_lds_ptr;
 typedef const __attribute__((address_space(1))) void *fbr_tsqr_glb_ptr;
@@ -306,17 +306,37 @@ __device__ __forceinline__ void fbr_tsqr_panel_steps(fbr_td4 (&v)[SUB], const do
 // and W feed the next product straight from the accumulator registers -- no LDS round trip, no barrier.
 // Tiles are updated one at a time (a paired form ran dead / padding tiles through the MFMAs: +34 % MFMA work, slower;
 // splitting V^T C over two accumulators to shorten the dependent chain was 3 % slower as well).
+// Elements of a factor that ANOTHER workgroup reads or has written in the same launch (XWG: the cross-workgroup merge pipeline of the
+// tree, fbr_tsqr_tree_x_kernel): 8-byte agent-scope relaxed atomics on both sides -- `sc1` stores write through, `sc1` loads bypass the
+// reading CU's L1 (MI355X_MICROARCH.md, inter-workgroup visibility: "8-B agent atomics both sides"); ordering comes from the progress
+// flags (fbr_xwg_publish / fbr_xwg_wait).
+template <bool XWG> __device__ __forceinline__ double fbr_tsqr_ld(const double *p)
+{
+    if constexpr (XWG)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        return *p;
+}
+template <bool XWG> __device__ __forceinline__ void fbr_tsqr_st(double *p, double v)
+{
+    if constexpr (XWG)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
 // R rows of panel q under column tile ct, straight from global memory in the C/D layout (RREG: prefetched one tile ahead)
+template <bool XWG = false>
 __device__ __forceinline__ fbr_td4 fbr_tsqr_load_rrows(const double *__restrict__ R, unsigned ld, int q, int ct, int lane)
 {
     const unsigned voff = (unsigned)(lane >> 4) * ld + (unsigned)(lane & 15);
     fbr_td4 r;
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) r[reg] = (R + ((unsigned)(16 * q + 4 * reg) * ld + 16u * (unsigned)ct))[voff];
+    for (int reg = 0; reg < 4; reg++) r[reg] = fbr_tsqr_ld<XWG>(R + ((unsigned)(16 * q + 4 * reg) * ld + 16u * (unsigned)ct) + voff);
     return r;
 }
 
-template <int TPW, int SUB, int T, int W, bool RREG = false>
+template <int TPW, int SUB, int T, int W, bool RREG = false, bool XWG = false>
 __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], const double *Rl, double *__restrict__ R, unsigned ld, int q, int wave,
                                                      int lane, const double *Vl, const double *Tm, const fbr_td4 r0 = fbr_td4{0.0, 0.0, 0.0, 0.0})
 {
@@ -339,7 +359,7 @@ __device__ __forceinline__ void fbr_tsqr_update_tile(fbr_td4 (&C)[TPW][SUB], con
         const unsigned c0 = 16u * (unsigned)(wave + W * T);
         const unsigned voff = (unsigned)kk * ld + (unsigned)li;
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) (R + ((j0 + 4 * reg) * ld + c0))[voff] = (RREG ? r0[reg] : Rt[(4 * reg + kk) * 16 + li]) - w2[reg];
+        for (int reg = 0; reg < 4; reg++) fbr_tsqr_st<XWG>(R + ((j0 + 4 * reg) * ld + c0) + voff, (RREG ? r0[reg] : Rt[(4 * reg + kk) * 16 + li]) - w2[reg]);
     }
 #pragma unroll
     for (int sb = 0; sb < SUB; sb++)
@@ -378,7 +398,7 @@ __device__ __forceinline__ void fbr_tsqr_fetch_rows(int t0, int t1, double *Rl, 
 // the wave's tiles t0 <= t < t1, one at a time (static register indexing, a uniform branch per tile; dead and padding
 // tiles cost nothing)
 // (RREG: rn holds the R rows of tile t0 on entry; the rows of the next tile are requested before the current one is updated)
-template <int TPW, int SUB, int W, int T = 0, bool RREG = false> struct FbrTsqrUpdateFrom {
+template <int TPW, int SUB, int W, int T = 0, bool RREG = false, bool XWG = false> struct FbrTsqrUpdateFrom {
     static __device__ __forceinline__ void run(int t0, int t1, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
                                                int wave, int lane, const double *Vl, const double *Tm, fbr_td4 &rn)
     {
@@ -386,25 +406,25 @@ template <int TPW, int SUB, int W, int T = 0, bool RREG = false> struct FbrTsqrU
             if (T >= t0 && T < t1) {
                 if constexpr (RREG) {
                     const fbr_td4 r0 = rn;
-                    if (T + 1 < t1) rn = fbr_tsqr_load_rrows(R, ld, q, wave + W * (T + 1), lane);
-                    fbr_tsqr_update_tile<TPW, SUB, T, W, true>(C, Rl, R, ld, q, wave, lane, Vl, Tm, r0);
+                    if (T + 1 < t1) rn = fbr_tsqr_load_rrows<XWG>(R, ld, q, wave + W * (T + 1), lane);
+                    fbr_tsqr_update_tile<TPW, SUB, T, W, true, XWG>(C, Rl, R, ld, q, wave, lane, Vl, Tm, r0);
                 } else {
                     fbr_tsqr_update_tile<TPW, SUB, T, W>(C, Rl, R, ld, q, wave, lane, Vl, Tm);
                 }
             }
-            FbrTsqrUpdateFrom<TPW, SUB, W, T + 1, RREG>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
+            FbrTsqrUpdateFrom<TPW, SUB, W, T + 1, RREG, XWG>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
         }
     }
 };
 
 // the single tile tp (uniform, selected by a static switch)
-template <int TPW, int SUB, int W, int T = 0, bool RREG = false> struct FbrTsqrUpdateOne {
+template <int TPW, int SUB, int W, int T = 0, bool RREG = false, bool XWG = false> struct FbrTsqrUpdateOne {
     static __device__ __forceinline__ void run(int tp, fbr_td4 (&C)[TPW][SUB], double *Rl, double *__restrict__ R, unsigned ld, int q, int NP,
                                                int wave, int lane, const double *Vl, const double *Tm, const fbr_td4 &r0)
     {
         if constexpr (T < TPW) {
-            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T, W, RREG>(C, Rl, R, ld, q, wave, lane, Vl, Tm, r0);
-            FbrTsqrUpdateOne<TPW, SUB, W, T + 1, RREG>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, r0);
+            if (tp == T) fbr_tsqr_update_tile<TPW, SUB, T, W, RREG, XWG>(C, Rl, R, ld, q, wave, lane, Vl, Tm, r0);
+            FbrTsqrUpdateOne<TPW, SUB, W, T + 1, RREG, XWG>::run(tp, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, r0);
         }
     }
 };
@@ -435,10 +455,35 @@ __device__ __forceinline__ bool fbr_tsqr_wait_ge(const int *flag, int want)
 struct FbrTsqrFoldDesc {
     const double *B;  // block rows (row-major, leading dimension ldb), rows >= mrows are zero
     int ldb, mrows, first_col;
+    // XWG (cross-workgroup merge pipeline): per-wave progress counters (global memory, [waves]) of the block folded into the same factor
+    // right before this one by ANOTHER workgroup (null: none), and of this block.  Counter of wave w = number of panel iterations wave w
+    // has completed: after iteration q it is q + 1, and the R rows of panel q under the wave's tiles and the R_pp of panel q + 1 (if the
+    // wave owns it) are final for this block and visible.
+    const int *prev = nullptr;
+    int *mine = nullptr;
 };
 
+// progress flags of the cross-workgroup pipeline: relaxed agent-scope atomics (the data travels as agent-scope atomics as well; the
+// publisher first waits for its own stores, the poller is bounded like the LDS waits)
+__device__ __forceinline__ void fbr_xwg_publish(int *flag, int v, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
+    if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool fbr_xwg_wait(const int *flag, int want)
+{
+    for (int it = 0; it < FBR_TSQR_SPIN_LIMIT; it++) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) {
+            asm volatile("" ::: "memory");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
 // TIMING: diagnostic instantiation (s_memtime cycles per phase into tacc[16]); the production kernels carry none of it
-template <int TPW, int SUB, bool TIMING, int W, class FoldFn>
+template <int TPW, int SUB, bool TIMING, int W, bool XWG = false, class FoldFn>
 __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, int ldr, int nfolds, FoldFn fold_of, double *smem, unsigned *errflag,
                                                 unsigned long long *tacc = nullptr)
 {
@@ -450,7 +495,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         tk = t1;                                                          \
     }
     constexpr int MB = 16 * SUB;
-    constexpr bool RREG = fbr_tsqr_rreg<TPW, W>();
+    constexpr bool RREG = fbr_tsqr_rreg<TPW, W>() || XWG;
     constexpr int FBR_TSQR_RING = fbr_tsqr_ring<SUB, W, RREG>();
     double *Rl = smem;  // 16-byte aligned tiles for the LDS-DMA
     double *Vr = Rl + (RREG ? 0 : W * TPW * 256);
@@ -471,6 +516,15 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
     __syncthreads();  // the only workgroup barrier
 
     bool ok = true;
+    unsigned fail_code = 0;
+    int fail_q = 0;
+    auto note = [&](bool good, unsigned code, int q) {
+        if (ok && !good) {
+            fail_code = code;
+            fail_q = q;
+        }
+        ok = ok && good;
+    };
     int gbase = 0;  // global index of panel q0 of the current fold
     for (int f = 0; f < nfolds; f++) {
         const FbrTsqrFoldDesc fd = fold_of(f);
@@ -503,11 +557,24 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     const double *Rs = R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)p);  // uniform
-                    rpp[reg] = Rs[(unsigned)kk * ld + (unsigned)li];  // (entries below the diagonal are masked at use)
+                    rpp[reg] = fbr_tsqr_ld<XWG>(Rs + ((unsigned)kk * ld + (unsigned)li));  // (entries below the diagonal are masked at use)
                 }
             }
         };
-        fetch_rpp(q0 + ((wave - q0) % W + W) % W);
+        // XWG: what this block reads of the shared factor must have been finished by the block before it (another workgroup): the wave
+        // waits on the progress counter of ITS OWN index there (same tile ownership in every block).  Only the owner of the first panel
+        // needs something before the first iteration (R_pp of q0: final once the predecessor has chained it, in its iteration q0 - 1);
+        // everything else is requested at the end of an iteration for the next one (below).
+        const int *wprev = XWG && fd.prev ? fd.prev + wave : nullptr;
+        int *wmine = XWG ? fd.mine + wave : nullptr;
+        if constexpr (XWG) {
+            if (wave == q0 % W) {
+                if (wprev && ok) note(fbr_xwg_wait(wprev, q0), 3u, q0);
+                fetch_rpp(q0);
+            }
+        } else {
+            fetch_rpp(q0 + ((wave - q0) % W + W) % W);
+        }
         // R rows of the first panel under this wave's tiles right of it (the wave is done with its tiles of the
         // previous fold, so their LDS slots are free)
         // RREG: the rows of the FIRST tile the wave will update with a panel travel in rn, requested an iteration ahead: the tile of the
@@ -545,7 +612,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                     if (!free_) __builtin_amdgcn_s_sleep(1);
                 }
                 fbr_lds_acquire();
-                ok = ok && free_;
+                note(free_, 2u, G);
                 if constexpr (TIMING) tacc[5] += __builtin_readcyclecounter() - tq;
             }
             double *Vl = Vr + (G % FBR_TSQR_RING) * (MB * FBR_TSQR_LDV);
@@ -567,9 +634,9 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             for (int reg = 0; reg < 4; reg++) {
                 const int i = 4 * reg + kk;
                 double *Rs = R + ((unsigned)(16 * p + 4 * reg) * ld + 16u * (unsigned)p);  // uniform
-                if (li >= i) Rs[(unsigned)kk * ld + (unsigned)li] = rq[reg];
+                if (li >= i) fbr_tsqr_st<XWG>(Rs + ((unsigned)kk * ld + (unsigned)li), rq[reg]);
             }
-            fetch_rpp(p + W);
+            if constexpr (!XWG) fetch_rpp(p + W);  // (XWG: requested behind the predecessor's progress, at the end of iteration p + W - 2)
         };
         auto chain = [&](int p, int G) __attribute__((always_inline)) {
             const unsigned long long tc0 = TIMING ? __builtin_readcyclecounter() : 0;
@@ -613,7 +680,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             const bool next_owner = q + 1 < NP && wave == (q + 1) % W;
             int t0 = (q >= wave) ? (q - wave) / W + 1 : 0;  // this wave's first tile right of panel q
             const bool need_panel = apply && (next_owner || t0 < t1);
-            if (need_panel) ok = ok && fbr_tsqr_wait_ge(seq + (G + FBR_TSQR_RING) % FBR_TSQR_RING, G + 1);
+            if (need_panel && ok) note(fbr_tsqr_wait_ge(seq + (G + FBR_TSQR_RING) % FBR_TSQR_RING, G + 1), 1u, q);
             if (need_panel || next_owner) fbr_dma_wait();  // vmcnt(0): this wave's R rows (LDS-DMA) / R_pp have landed
             FBR_TT(2)
             const int slot = (G + FBR_TSQR_RING) % FBR_TSQR_RING;
@@ -623,25 +690,35 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                 // next panel's owner: its tile first, then its factorisation, then the rest of panel q.  This is the
                 // serial dependency chain of the fold: raise the wave's issue priority over the waves that only update
                 __builtin_amdgcn_s_setprio(3);
-                if (apply) FbrTsqrUpdateOne<TPW, SUB, W, 0, RREG>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
+                if (apply) FbrTsqrUpdateOne<TPW, SUB, W, 0, RREG, XWG>::run((q + 1) / W, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
                 FBR_TT(3)
                 t0 = (q + 1) / W + 1;
                 // (RREG: the rows under the wave's next tile travel during the chain)
                 if constexpr (RREG)
-                    if (apply && t0 < t1) rn = fbr_tsqr_load_rrows(R, ld, q, wave + W * t0, lane);
+                    if (apply && t0 < t1) rn = fbr_tsqr_load_rrows<XWG>(R, ld, q, wave + W * t0, lane);
                 chain(q + 1, G + 1);
                 __builtin_amdgcn_s_setprio(0);
                 FBR_TT(1)
             }
             if (apply) {
-                FbrTsqrUpdateFrom<TPW, SUB, W, 0, RREG>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
+                FbrTsqrUpdateFrom<TPW, SUB, W, 0, RREG, XWG>::run(t0, t1, C, Rl, R, ld, q, NP, wave, lane, Vl, Tm, rn);
                 fbr_lds_release();
                 if (lane == 0) __atomic_store_n(done + wave, G + 1, __ATOMIC_RELAXED);
                 // R rows of the next panel under the tiles right of it
                 if constexpr (!RREG)
                     if (q + 1 < NP) fbr_tsqr_fetch_rows<TPW, W>((q + 1 >= wave) ? (q + 1 - wave) / W + 1 : 0, t1, Rl, R, ld, q + 1, wave, lane);
             }
-            if constexpr (RREG) {
+            if constexpr (XWG) {
+                // this wave's part of iteration q is final: publish, then -- behind the predecessor's iteration q + 1 -- request what
+                // iteration q + 1 reads: the R rows under the first tile it will update and, for the owner of panel q + 2, its R_pp
+                fbr_xwg_publish(wmine, q + 1, lane);
+                if (q + 1 < NP) {
+                    if (wprev && ok) note(fbr_xwg_wait(wprev, q + 2), 4u, q);
+                    const int tf = first_tile(q + 1);
+                    if (tf < t1) rn = fbr_tsqr_load_rrows<true>(R, ld, q + 1, wave + W * tf, lane);
+                    if (q + 2 < NP && wave == (q + 2) % W) fetch_rpp(q + 2);
+                }
+            } else if constexpr (RREG) {
                 if (q + 1 < NP) {
                     const int tf = first_tile(q + 1);
                     if (tf < t1) rn = fbr_tsqr_load_rrows(R, ld, q + 1, wave + W * tf, lane);
@@ -651,7 +728,8 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         }
         gbase += NP - q0;
     }
-    if (!ok && lane == 0) atomicOr(errflag, 1u);
+    // first failing wave: which wait (1 = panel publish, 2 = ring slot, 3 = predecessor's R_pp, 4 = predecessor's iteration), wave, panel, block
+    if (!ok && lane == 0) atomicCAS(errflag, 0u, fail_code | ((unsigned)wave << 4) | (((unsigned)fail_q & 0xffu) << 8) | ((unsigned)blockIdx.x << 16) | 0x80000000u);
 #undef FBR_TT
 }
 
@@ -685,7 +763,7 @@ __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_
         }
         return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc};
     };
-    fbr_tsqr_stream<TPW, SUB, TIMING, W>(R, n, LD, nfolds, fold_of, smem, errflag, tacc);
+    fbr_tsqr_stream<TPW, SUB, TIMING, W, false>(R, n, LD, nfolds, fold_of, smem, errflag, tacc);
     if (TIMING && (threadIdx.x & 63) == 0) {
         unsigned long long *d = dbg + ((long)blockIdx.x * W + (threadIdx.x >> 6)) * 16;
         for (int i = 0; i < 16; i++) d[i] = tacc[i];
@@ -706,7 +784,66 @@ __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_
         const int i0 = f * MB;
         return FbrTsqrFoldDesc{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), i0};
     };
-    fbr_tsqr_stream<TPW, SUB, false, W>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
+    fbr_tsqr_stream<TPW, SUB, false, W, false>(Rw + a * n * LD, n, LD, (n + MB - 1) / MB, fold_of, smem, errflag);
+}
+
+// Tree level with the merges PIPELINED ACROSS WORKGROUPS.  A merge folds the partner's factor in MB-row blocks, and a block can follow
+// the one before it through the panels as soon as that one is a panel ahead -- but one workgroup holds one block at a time, so in
+// fbr_tsqr_tree_kernel the 8 blocks of a 496-column merge are 136 serial panel steps (0.93 ms per level, 8 levels: the fixed tail of
+// every TSQR call).  Here G workgroups share a merge: workgroup j folds blocks j, j + G, ... and block b runs a panel or two behind
+// block b - 1 of its neighbour, synchronised per wave and panel through progress counters in global memory (FbrTsqrFoldDesc::prev /
+// mine); the factor's rows travel between the CUs as agent-scope atomics.  With G = 8 a merge takes ~40 panel steps instead of 136.
+// The blocks are folded in the same order by the same arithmetic: the result is bit-identical to fbr_tsqr_tree_kernel's.
+// prog: [pairs][blocks of a merge][8] ints, zero before the launch.  The workgroups of a merge are consecutive in the grid, so that
+// in-order dispatch starts a block's predecessor first (a predecessor never waits for its successor: no deadlock even if the grid is
+// not fully resident; the waits are bounded and report through errflag).
+template <int TPW, int SUB, int W = FBR_TSQR_WAVES>
+__global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_tree_x_kernel(double *__restrict__ Rw, int n, int stride, int count, int G,
+                                                                                 int *__restrict__ prog, unsigned *errflag)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int MB = 16 * SUB;
+    constexpr int LD = 16 * W * TPW;
+    const int p = blockIdx.x / G;
+    const long a = (long)2 * p * stride, b = a + stride;
+    if (b >= count) return;
+    const double *Rb = Rw + b * n * LD;
+    const int nblk = (n + MB - 1) / MB;
+    // Blocks are CLAIMED, not assigned: the workgroups of a merge take the next block of their pair from a counter as they come
+    // (the first wave of a workgroup to reach its fold f claims for the workgroup, through the LDS).  A block's predecessor has then
+    // always been claimed by a workgroup that is already running -- the waits below never depend on the order in which the hardware
+    // dispatches the grid (HIP promises none; with blocks assigned by blockIdx a consumer could hold its CU while its producer
+    // waited for one: seen as flag time-outs under mixed asynchronous submissions).  Which workgroup folds which block does not
+    // change the arithmetic: the blocks still enter the factor in order.
+    int *claimed = (int *)(smem + fbr_tsqr_lds_doubles<TPW, SUB, W, true>()) - 64;
+    int *next = prog + (long)gridDim.x / G * nblk * W + p;  // (the pairs' claim counters sit behind the progress flags)
+    if (threadIdx.x < 64) claimed[threadIdx.x] = -1;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    auto fold_of = [&](int f) {
+        int v = 0;
+        if (lane == 0) {
+            v = atomicCAS(&claimed[f], -1, -2);
+            if (v == -1) {
+                v = __hip_atomic_fetch_add(next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_store_n(&claimed[f], v, __ATOMIC_RELAXED);
+            } else {
+                for (int it = 0; v < 0 && it < FBR_TSQR_SPIN_LIMIT; it++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    v = __atomic_load_n(&claimed[f], __ATOMIC_RELAXED);
+                }
+                if (v < 0) v = 1 << 20;  // (gives up: the block is left out and the error word set by the waits that follow)
+            }
+        }
+        const int bi = __builtin_amdgcn_readfirstlane(v);
+        if (bi >= nblk) return FbrTsqrFoldDesc{Rb, LD, 0, n};  // nothing left to claim: an empty fold (first column = n)
+        const int i0 = bi * MB;
+        FbrTsqrFoldDesc fd{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), i0};
+        fd.prev = bi > 0 ? prog + ((long)p * nblk + bi - 1) * W : nullptr;
+        fd.mine = prog + ((long)p * nblk + bi) * W;
+        return fd;
+    };
+    fbr_tsqr_stream<TPW, SUB, false, W, true>(Rw + a * n * LD, n, LD, nblk, fold_of, smem, errflag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -895,6 +1032,8 @@ struct FbrTsqrWork {
     unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
     bool own_err = true;      // false: the word belongs to the caller (one per model, cleared once per call and read once at its end)
     size_t rw_bytes = 0, a_bytes = 0;
+    int *prog = nullptr;      // progress counters of the cross-workgroup merge pipeline (fbr_tsqr_tree_x_kernel)
+    size_t prog_bytes = 0;
     long clean_key = -1;  // (Pa, n) for which the padding columns [Pa, n) of the whole chunk buffer are zero and stay zero (writers that
                           // fill the chunk in place never touch them): the per-chunk tail pass then only clears the rows M..Mpad
     int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0, waves = FBR_TSQR_WAVES, ttpw = 0;
@@ -903,6 +1042,9 @@ struct FbrTsqrWork {
     {
         if (Rw) (void)hipFree(Rw);
         if (A) (void)hipFree(A);
+        if (prog) (void)hipFree(prog);
+        prog = nullptr;
+        prog_bytes = 0;
         if (err && own_err) (void)hipFree(err);
         err = nullptr;
         own_err = true;
@@ -1222,6 +1364,34 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
                                                                 stride, wk.NW));
             TSQR_HIP(hipGetLastError());
         }
+    } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw && !getenv("FBR_TSQR_TREE_ONE_WG")) {
+        // four-wave shapes (two workgroups per CU): the same cross-workgroup merge pipeline (fbr_tsqr_tree_x_kernel)
+        constexpr int HW = FBR_TSQR_HALF_WAVES;
+        const int nblk = (n + wk.mb - 1) / wk.mb;
+        const size_t need = ((size_t)((wk.NW + 1) / 2) * nblk * HW + (wk.NW + 1) / 2) * sizeof(int);  // flags + claim counters
+        if (need > wk.prog_bytes) {
+            if (wk.prog) (void)hipFree(wk.prog);
+            wk.prog = nullptr;
+            wk.prog_bytes = 0;
+            TSQR_HIP(hipMalloc((void **)&wk.prog, need));
+            wk.prog_bytes = need;
+        }
+        int cus = 0, dev = 0;
+        TSQR_HIP(hipGetDevice(&dev));
+        TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_x_kernel<TPW, SUB, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double))));
+        for (int stride = stride_from; stride < stride_to; stride *= 2) {
+            const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
+            int G = 1;
+            while (G < 8 && 2 * G <= nblk && pairs * 2 * G <= 2 * std::max(cus, 1)) G *= 2;
+            if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
+            TSQR_HIP(hipMemsetAsync(wk.prog, 0, ((size_t)pairs * nblk * HW + pairs) * sizeof(int), st));
+            FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB, HW>), dim3(pairs * G), dim3(64 * HW),
+                                                              (fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G, wk.prog,
+                                                              wk.err));
+            TSQR_HIP(hipGetLastError());
+        }
     } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw) {
         constexpr int HW = FBR_TSQR_HALF_WAVES;
         FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1235,6 +1405,36 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
     } else {
     // (wk.ttpw: the RREG shapes run their merge tree on the eight-wave kernel of the same leading dimension: taller blocks, half the
     // serial panel steps per merge)
+    if (!getenv("FBR_TSQR_TREE_ONE_WG") && wk.n / 16 > FBR_TSQR_NARROW_MAX_TILES) {
+        // merges pipelined across workgroups (fbr_tsqr_tree_x_kernel): as many workgroups per merge as keep the level's grid within one
+        // round of CUs (2 at the 128 merges of level 1, 4 at 64, 8 from 32 merges on)
+        const int sub_t = fbr_tsqr_sub_for(wk.ttpw), nblk = (n + 16 * sub_t - 1) / (16 * sub_t);
+        const size_t need = ((size_t)((wk.NW + 1) / 2) * nblk * FBR_TSQR_WAVES + (wk.NW + 1) / 2) * sizeof(int);  // flags + claim counters
+        if (need > wk.prog_bytes) {
+            if (wk.prog) (void)hipFree(wk.prog);
+            wk.prog = nullptr;
+            wk.prog_bytes = 0;
+            TSQR_HIP(hipMalloc((void **)&wk.prog, need));
+            wk.prog_bytes = need;
+        }
+        int cus = 0, dev = 0;
+        TSQR_HIP(hipGetDevice(&dev));
+        TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        FBR_TSQR_DISPATCH(wk.ttpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_x_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            (int)(fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double))));
+        for (int stride = stride_from; stride < stride_to; stride *= 2) {
+            const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
+            int G = 1;
+            while (G < 8 && 2 * G <= nblk && pairs * 2 * G <= std::max(cus, 1)) G *= 2;
+            if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
+            TSQR_HIP(hipMemsetAsync(wk.prog, 0, ((size_t)pairs * nblk * FBR_TSQR_WAVES + pairs) * sizeof(int), st));
+            FBR_TSQR_DISPATCH(wk.ttpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB>), dim3(pairs * G), dim3(FBR_TSQR_THREADS),
+                                                          (fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
+                                                          wk.prog, wk.err));
+            TSQR_HIP(hipGetLastError());
+        }
+        return 0;
+    }
     FBR_TSQR_DISPATCH(wk.ttpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
     for (int stride = stride_from; stride < stride_to; stride *= 2) {

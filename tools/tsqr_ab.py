@@ -17,6 +17,7 @@ st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth_sta
 rhs = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
 G = eng.gram(st, rhs=rhs)
 gn = float(torch.linalg.norm(G))
+Rfirst = None
 for var in variants:
     sets = [] if var == "-" else [kv.split("=") for kv in var.split(",")]
     for k, v in sets:
@@ -33,6 +34,9 @@ for var in variants:
     dt = (time.perf_counter() - t0) / reps
     pr = eng.profile_get(); eng.profile_enable(False)
     same = bool(torch.equal(R, R2))
+    if Rfirst is None:
+        Rfirst = R.clone()
+    same_as_first = bool(torch.equal(R, Rfirst))
     # the same calls submitted two in flight (fbr_tsqr_submit): the next call's kinematics / first writer run beside the trees
     outs = [torch.zeros_like(R), torch.zeros_like(R)]
     n2 = 6
@@ -51,7 +55,7 @@ for var in variants:
     same = same and bool(torch.equal(R, outs[0])) and bool(torch.equal(R, outs[1]))
     wi = eng.tsqr_work_info(S, k=1)
     print(f"pipelined {dtp*1e3:8.2f} ms ({wi['flop']/dtp/1e12/78.6:.3f}) |", end=" ")
-    print(f"{var:40s} S={S} {dt*1e3:8.2f} ms  executed {wi['flop']/dt/1e12:6.2f} TF ({wi['flop']/dt/1e12/78.6:.3f})  relerr {err:.2e} repeat-bitwise {same} |",
+    print(f"{var:40s} S={S} {dt*1e3:8.2f} ms  executed {wi['flop']/dt/1e12:6.2f} TF ({wi['flop']/dt/1e12/78.6:.3f})  relerr {err:.2e} repeat-bitwise {same} bitwise-equal-to-first-variant {same_as_first} |",
           {k: round(v[0] / reps, 2) for k, v in pr.items() if v[1]}, flush=True)
     for k, v in sets:
         del os.environ[k]
