@@ -1881,8 +1881,21 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     // order, are dense rows of the final factorisation: they are folded INSIDE the main tree -- once at most 8 of its factors are
     // alive, one launch deals the embedded rows to those factors (a block or two per workgroup) -- instead of by one workgroup, group
     // after group, behind the tree (round 3: 3.3 ms per call).  Without a dense group the final factor starts from R_in.
-    for (auto &st : m->tsqr_streams)
-        if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    {
+        // the side streams get DIFFERENT priority levels: HIP gives a stream of another level a hardware queue of its own, while streams of
+        // one level share a few queues round robin -- three trees on two queues were the tail of the call (the legs' tree queued behind
+        // the arms')
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prios[4] = {greatest, least, (least + greatest) / 2, (least + greatest) / 2};
+        for (int i = 0; i < (int)(sizeof(m->tsqr_streams) / sizeof(m->tsqr_streams[0])); i++)
+            if (!m->tsqr_streams[i]) {
+                if (getenv("FBR_TSQR_SIDE_SAME_PRIORITY"))
+                    HIPCHK(hipStreamCreateWithFlags(&m->tsqr_streams[i], hipStreamNonBlocking));
+                else
+                    HIPCHK(hipStreamCreateWithPriority(&m->tsqr_streams[i], hipStreamNonBlocking, prios[i]));
+            }
+    }
     for (auto &e : m->tsqr_ev)
         if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     constexpr int NSIDE = (int)(sizeof(m->tsqr_streams) / sizeof(m->tsqr_streams[0]));
@@ -1901,9 +1914,32 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     for (int g = 0; g < G; g++)
         if (g != gp.main) side_order.push_back(g);
     std::stable_sort(side_order.begin(), side_order.end(), [&](int a, int b) { return gp.groups[a].Pa > gp.groups[b].Pa; });
+    // (narrow factors of one shape -- the two arms, the two legs -- share their launches: fbr_tsqr_finish_narrow_batch)
     int nside = 0;
-    for (int g : side_order)
-        if ((rc = fbr_tsqr_finish_async(m->tsqr_groups[g], m->tsqr_streams[nside++ % NSIDE], rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+    std::vector<char> finished(G, 0);
+    for (int g : side_order) {
+        if (finished[g]) continue;
+        FbrTsqrWork &wg = m->tsqr_groups[g];
+        FbrTsqrWork *batch[FBR_TSQR_NARROW_BATCH];
+        double *outs[FBR_TSQR_NARROW_BATCH];
+        int nb = 0;
+        if (wg.narrow && !getenv("FBR_TSQR_NO_NARROW_BATCH"))
+            for (int h : side_order)
+                if (!finished[h] && nb < FBR_TSQR_NARROW_BATCH && m->tsqr_groups[h].narrow && m->tsqr_groups[h].n == wg.n && m->tsqr_groups[h].NW == wg.NW &&
+                    m->tsqr_groups[h].tpw == wg.tpw) {
+                    batch[nb] = &m->tsqr_groups[h];
+                    outs[nb++] = rtmp + o_r[h];
+                    finished[h] = 1;
+                }
+        hipStream_t sst = m->tsqr_streams[nside++ % NSIDE];
+        if (nb >= 2) {
+            if ((rc = fbr_tsqr_finish_narrow_batch(batch, nb, sst, outs))) return tsqr_fail(rc, "tsqr group finish");
+        } else {
+            for (int i = 0; i < nb; i++) finished[(int)(batch[i] - &m->tsqr_groups[0])] = 0;  // (a batch of one: the plain path)
+            finished[g] = 1;
+            if ((rc = fbr_tsqr_finish_async(wg, sst, rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+        }
+    }
     for (int i = 0; i < NSIDE; i++) HIPCHK(hipEventRecord(m->tsqr_ev[i], m->tsqr_streams[i]));
     // rows of the embedded group factors, stacked: [sum of the groups' Pa][n] in the final factor's column order
     long erows = 0;

@@ -1013,6 +1013,28 @@ __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow
     for (int i0 = 0; i0 < n; i0 += MB) fbr_tsqr_wave_fold<NPT, SUB>(Rw + a * n * n, Rb + (long)i0 * n, n, std::min(MB, n - i0), i0, lds, lane);
 }
 
+// the same level for up to FBR_TSQR_NARROW_BATCH factorisations of one shape at once (blockIdx.y): the trees of narrow factors are
+// launch bound (11 levels of 50 - 100 us over 2048 wave-private factors), and the row groups of a symmetric robot come in equal pairs
+// (two arms, two legs) -- one launch sequence serves both
+#define FBR_TSQR_NARROW_BATCH 4
+struct FbrTsqrNarrowBatch {
+    double *Rw[FBR_TSQR_NARROW_BATCH];
+};
+template <int NPT, int SUB>
+__global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow_tree_batch_kernel(FbrTsqrNarrowBatch bt, int stride, int count)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int MB = 16 * SUB, n = 16 * NPT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long i = (long)blockIdx.x * FBR_TSQR_NARROW_WAVES + wave;
+    const long a = 2 * i * stride, b = a + stride;
+    if (b >= count) return;
+    double *Rw = bt.Rw[blockIdx.y];
+    double *lds = smem + wave * fbr_tsqr_narrow_lds_doubles<SUB>();
+    const double *Rb = Rw + b * n * n;
+    for (int i0 = 0; i0 < n; i0 += MB) fbr_tsqr_wave_fold<NPT, SUB>(Rw + a * n * n, Rb + (long)i0 * n, n, std::min(MB, n - i0), i0, lds, lane);
+}
+
 // copy between the caller's Pa x Pa factor and the padded n x n working factor (upper triangle only)
 __global__ void fbr_tsqr_copy_kernel(int Pa, const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd,
                                      int rows_dst, int cols_dst)
@@ -1460,6 +1482,24 @@ static inline int fbr_tsqr_finish_async(FbrTsqrWork &wk, hipStream_t st, double 
 {
     if (int rc = fbr_tsqr_tree_levels(wk, st, 1, 1 << 30)) return rc;
     return fbr_tsqr_copy_out(wk, st, R_out);
+}
+
+// Trees of several narrow factorisations of one shape (same width, same number of private factors) level by level in shared launches.
+static inline int fbr_tsqr_finish_narrow_batch(FbrTsqrWork **wks, int nw, hipStream_t st, double **R_out)
+{
+    FbrTsqrWork &w0 = *wks[0];
+    FbrTsqrNarrowBatch bt;
+    for (int i = 0; i < FBR_TSQR_NARROW_BATCH; i++) bt.Rw[i] = wks[std::min(i, nw - 1)]->Rw;
+    for (int stride = 1; stride < w0.NW; stride *= 2) {
+        const int pairs = (w0.NW + 2 * stride - 1) / (2 * stride);
+        const int grid = (pairs + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
+        FBR_TSQR_NARROW_DISPATCH(w0.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_tree_batch_kernel<NPT, SUB>), dim3(grid, nw), dim3(FBR_TSQR_NARROW_WAVES * 64),
+                                                            (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, bt, stride, w0.NW));
+        TSQR_HIP(hipGetLastError());
+    }
+    for (int i = 0; i < nw; i++)
+        if (int rc = fbr_tsqr_copy_out(*wks[i], st, R_out[i])) return rc;
+    return 0;
 }
 
 // Wait for the stream and report a pipeline time-out of the factorisation's kernels (the device error word).
