@@ -2413,6 +2413,26 @@ extern "C" int fbr_tsqr_merge(fbr_model *m, int32_t n, const double *R_a, const 
     }
     // one workgroup (narrow factors: one wave) folds the partner's factor, 64 (32) rows at a time, into a working factor seeded with
     // R_a; a block of the triangular R_b is folded from its first non-zero column.  (rows_hint = 1: a single working factor, no tree.)
+    // Wide factors: the two triangles become working factors 0 and 1 and ONE level of the merge tree joins them -- pipelined across up to
+    // eight workgroups (fbr_tsqr_tree_x_kernel: 0.33 instead of 0.93 ms for WALK-MAN's 496 columns; the same blocks in the same order,
+    // bit-identical).  This is the step on the critical path of the TSQR rank tree across GPUs (flobaroid_amd/dist.py: one merge per level).
+    FbrTsqrShape sh;
+    if (!fbr_tsqr_shape(n, m->num_cus, 1, &sh) && !sh.narrow && !getenv("FBR_TSQR_TREE_ONE_WG")) {
+        FbrTsqrWork &wk = m->tsqr;
+        if ((rc = fbr_tsqr_begin(wk, m->stream, n, da, m->num_cus, 2L * sh.mb))) {  // rows for two blocks: two working factors
+            set_err(std::string("tsqr merge: ") + fbr_tsqr_error());
+            return rc == -4 ? FBR_E_UNSUPPORTED : (rc == -3 ? FBR_E_HIP : FBR_E_INVALID);
+        }
+        if (wk.NW == 2) {
+            hipLaunchKernelGGL(fbr_tsqr_copy_kernel, dim3(256), dim3(256), 0, m->stream, n, db, n, wk.Rw + (size_t)wk.n * wk.ld, wk.ld, wk.n, wk.ld);
+            HIPCHK(hipGetLastError());
+            if ((rc = fbr_tsqr_finish(wk, m->stream, R))) {
+                set_err(std::string("tsqr merge: ") + fbr_tsqr_error());
+                return rc == -4 ? FBR_E_UNSUPPORTED : (rc == -3 ? FBR_E_HIP : FBR_E_INVALID);
+            }
+            return finish_output(m, R, R_out, cnt, mem);
+        }
+    }
     FbrTsqrRowOrder tri;
     tri.rows = -1;
     if ((rc = fbr_tsqr_begin(m->tsqr, m->stream, n, da, m->num_cus, 1)) ||
