@@ -1390,7 +1390,10 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         // four-wave shapes (two workgroups per CU): the same cross-workgroup merge pipeline (fbr_tsqr_tree_x_kernel)
         constexpr int HW = FBR_TSQR_HALF_WAVES;
         const int nblk = (n + wk.mb - 1) / wk.mb;
-        const size_t need = ((size_t)((wk.NW + 1) / 2) * nblk * HW + (wk.NW + 1) / 2) * sizeof(int);  // flags + claim counters
+        auto level_ints = [&](int stride) { const size_t pr = (wk.NW + 2 * stride - 1) / (2 * stride); return pr * nblk * HW + pr; };  // flags + claim counters
+        size_t all_ints = 0;
+        for (int stride = 1; stride < wk.NW; stride *= 2) all_ints += level_ints(stride);
+        const size_t need = std::max<size_t>(all_ints, 1) * sizeof(int);
         if (need > wk.prog_bytes) {
             if (wk.prog) (void)hipFree(wk.prog);
             wk.prog = nullptr;
@@ -1403,15 +1406,18 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_x_kernel<TPW, SUB, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                  (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double))));
+        if (stride_from == 1) TSQR_HIP(hipMemsetAsync(wk.prog, 0, need, st));
+        size_t off = 0;
+        for (int stride = 1; stride < stride_from; stride *= 2) off += level_ints(stride);
         for (int stride = stride_from; stride < stride_to; stride *= 2) {
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
             int G = 1;
             while (G < 8 && 2 * G <= nblk && pairs * 2 * G <= 2 * std::max(cus, 1)) G *= 2;
             if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
-            TSQR_HIP(hipMemsetAsync(wk.prog, 0, ((size_t)pairs * nblk * HW + pairs) * sizeof(int), st));
             FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB, HW>), dim3(pairs * G), dim3(64 * HW),
-                                                              (fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G, wk.prog,
-                                                              wk.err));
+                                                              (fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
+                                                              wk.prog + off, wk.err));
+            off += level_ints(stride);
             TSQR_HIP(hipGetLastError());
         }
     } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw) {
@@ -1431,7 +1437,12 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         // merges pipelined across workgroups (fbr_tsqr_tree_x_kernel): as many workgroups per merge as keep the level's grid within one
         // round of CUs (2 at the 128 merges of level 1, 4 at 64, 8 from 32 merges on)
         const int sub_t = fbr_tsqr_sub_for(wk.ttpw), nblk = (n + 16 * sub_t - 1) / (16 * sub_t);
-        const size_t need = ((size_t)((wk.NW + 1) / 2) * nblk * FBR_TSQR_WAVES + (wk.NW + 1) / 2) * sizeof(int);  // flags + claim counters
+        // progress flags + claim counters of EVERY level, one region per level, cleared once in front of the first level (a clear per
+        // level was a 20 - 40 us launch on the tree's critical path each time)
+        auto level_ints = [&](int stride) { const size_t pr = (wk.NW + 2 * stride - 1) / (2 * stride); return pr * nblk * FBR_TSQR_WAVES + pr; };
+        size_t all_ints = 0;
+        for (int stride = 1; stride < wk.NW; stride *= 2) all_ints += level_ints(stride);
+        const size_t need = std::max<size_t>(all_ints, 1) * sizeof(int);
         if (need > wk.prog_bytes) {
             if (wk.prog) (void)hipFree(wk.prog);
             wk.prog = nullptr;
@@ -1444,15 +1455,18 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         FBR_TSQR_DISPATCH(wk.ttpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_x_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)(fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double))));
+        if (stride_from == 1) TSQR_HIP(hipMemsetAsync(wk.prog, 0, need, st));
+        size_t off = 0;
+        for (int stride = 1; stride < stride_from; stride *= 2) off += level_ints(stride);
         for (int stride = stride_from; stride < stride_to; stride *= 2) {
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
             int G = 1;
             while (G < 8 && 2 * G <= nblk && pairs * 2 * G <= std::max(cus, 1)) G *= 2;
             if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
-            TSQR_HIP(hipMemsetAsync(wk.prog, 0, ((size_t)pairs * nblk * FBR_TSQR_WAVES + pairs) * sizeof(int), st));
             FBR_TSQR_DISPATCH(wk.ttpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB>), dim3(pairs * G), dim3(FBR_TSQR_THREADS),
                                                           (fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
-                                                          wk.prog, wk.err));
+                                                          wk.prog + off, wk.err));
+            off += level_ints(stride);
             TSQR_HIP(hipGetLastError());
         }
         return 0;

@@ -27,4 +27,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$REPO/$OUT" -o tsqr_pmc_sq -- $T > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$REPO/$OUT" -o tsqr_pmc_fetch -- $T > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT" -o tsqr -- $T > /dev/null 2>&1
+# 6. the whole TSQR call of the bench (1 M samples) and of one rank's shard at 8 GPUs (125 k) under the kernel trace: the per-kernel split
+rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT" -o tsqr_full -- python $REPO/tools/tsqr_probe.py 1000000 3 > "$REPO/$OUT/tsqr_full_stdout.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT" -o tsqr_shard -- python $REPO/tools/tsqr_probe.py 125000 5 > "$REPO/$OUT/tsqr_shard_stdout.txt" 2>&1
 ls -la "$REPO/$OUT"

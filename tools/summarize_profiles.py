@@ -77,3 +77,81 @@ if gk:
     json.dump(out, open(os.path.join(dst, tag + "_gram_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 print("bench:", bench["value"], bench["roofline"]["avg_launch_ms"], bench.get("tsqr", {}).get("executed_TFLOP_per_s"))
+
+# ---- the whole TSQR call (1 M samples) and one rank's shard at 8 GPUs (125 k): kernel split per call
+import re
+import statistics
+
+splits = {}
+for name, reps in (("tsqr_full", 4), ("tsqr_shard", 6)):   # tools/tsqr_probe.py: one warm-up call + the timed ones
+    f = os.path.join(src, name + "_kernel_stats.csv")
+    if not os.path.exists(f):
+        continue
+    shutil.copy(f, os.path.join(dst, tag + "_" + name + "_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    cls = collections.defaultdict(float)
+    for r in rows:
+        n = short(r["Name"])
+        key = ("merge trees" if "tree" in n else "level-0 folds" if "level0" in n else "regressor writer" if "regressor" in n else
+               "kinematics" if "kin" in n else "other")
+        cls[key] += float(r["TotalDurationNs"]) / reps / 1e6
+    splits[name] = {"kernel_ms_per_call": {k: round(v, 3) for k, v in sorted(cls.items(), key=lambda kv: -kv[1])},
+                    "sum_ms_per_call": round(tot / reps / 1e6, 3), "tree_share_of_kernel_time": round(cls["merge trees"] / (tot / reps / 1e6), 4),
+                    "stdout": open(os.path.join(src, name + "_stdout.txt")).read().strip().splitlines()[-1][:400]}
+if splits:
+    json.dump({"command": "rocprofv3 --kernel-trace --stats -- python tools/tsqr_probe.py 1000000 3 | 125000 5 (tools/profile_round.sh); kernel time "
+                          "summed per class and divided by the calls (trees of the row groups overlap on side streams: the sum exceeds the wall time)",
+               "splits": splits}, open(os.path.join(dst, tag + "_tsqr_call_split.json"), "w"), indent=1)
+
+# ---- Gram launches of the bench command: the full-size launches (62 500 samples) apart from the shorter ones of the other legs
+gl = []
+tr = os.path.join(src, "bench_kernel_trace.csv")
+if os.path.exists(tr):
+    for r in csv.DictReader(open(tr)):
+        if "fbr_gram_kernel" in r["Kernel_Name"]:
+            gl.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+full = [x for x in gl if x > 0.8 * statistics.median(gl)] if gl else []
+gram_line = (f"`fbr_gram_kernel`: {len(gl)} launches in the bench command, {len(full)} of them full-size (62 500 samples): median {statistics.median(full):.3f} ms, "
+             f"mean {statistics.mean(full):.3f} ms (the bench's HIP events: {bench['roofline']['avg_launch_ms']:.3f} ms over the timed steps)") if full else ""
+
+# ---- profiles/README.md is GENERATED here (numbers cannot go stale)
+traffic = json.load(open(os.path.join(dst, tag + "_gram_pmc_traffic.json")))["hbm_bytes_per_sample"] if os.path.exists(os.path.join(dst, tag + "_gram_pmc_traffic.json")) else None
+mops = None
+for k, v in pmc.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).items():
+    if k.startswith("fbr_gram_kernel"):
+        mops = v
+lines = [
+    "# profiles/", "",
+    f"Generated by `tools/summarize_profiles.py {tag}` from `gpurun_out/prof_{tag}/` (`tools/profile_round.sh {tag}`, one MI355X, the final code of the round). "
+    f"`{tag}_*` is the current evidence; older tags are the earlier rounds, kept for the history in DESIGN §11.", "",
+    f"* `{tag}_bench_default.json` – the line printed by `python bench.py` (unprofiled run, CPU baselines included): "
+    f"{bench['value'] / 1e6:.2f} M samples/s, {bench['ms_per_step']:.2f} ms/step, Gram kernel {bench['roofline']['frac']:.3f} of the fp64 MFMA peak (executed); "
+    f"TSQR {bench['tsqr']['seconds'] * 1e3:.1f} ms per 1 M samples = {bench['tsqr']['executed_frac_of_fp64_mfma_peak']:.3f} executed"
+    + (f"; 125 k-sample shard {bench['tsqr_shard']['seconds'] * 1e3:.1f} ms = {bench['tsqr_shard']['ratio_to_one_eighth']:.2f} x one eighth of the 1 M call" if "tsqr_shard" in bench else ""),
+    f"* `{tag}_bench_kernel_stats.csv` – `rocprofv3 --kernel-trace --stats` summary of `python bench.py --no-cpu-baseline --sustain-seconds 0` "
+    f"(timed steps + TSQR / shard / H2D / assembly / other-config legs). {gram_line}",
+    f"* `{tag}_pmc.json` – per-kernel PMC sums per launch of the fused pass (FETCH_SIZE, WRITE_SIZE, MFMA, SQ counters; separate passes, "
+    "`bench.py --samples 200000 --steps 1 --warmup 0 --no-secondary`)"
+    + (f": `SQ_INSTS_VALU_MFMA_MOPS_F64` = {mops['per_launch']:.0f} per launch of {S // mops['launches']} samples = "
+       f"{mops['per_launch'] / (S / mops['launches']) / 4:.0f} MFMAs per sample (the program's count: {bench['roofline']['executed_mfma_per_sample']})" if mops else ""),
+    f"* `{tag}_gram_pmc_traffic.json` – HBM-side bytes per sample of the Gram kernel (FETCH_SIZE × 2 on gfx950, MI355X_MICROARCH.md)"
+    + (f": {traffic / 1024:.0f} KB; read by bench.py for `roofline.traffic`" if traffic else ""),
+    f"* `{tag}_tsqr_pmc.json`, `{tag}_tsqr_kernel_stats.csv` – the same counter sets and the kernel trace of `tools/tsqr_pmc_probe.py` "
+    "(WALK-MAN 150 k samples × 481 columns, left arm 500 k × 91)",
+]
+if splits:
+    for name, what in (("tsqr_full", "1 M samples"), ("tsqr_shard", "125 k samples (one rank's share at 8 GPUs)")):
+        if name in splits:
+            sp = splits[name]
+            lines.append(f"* `{tag}_{name}_kernel_stats.csv`, `{tag}_tsqr_call_split.json` – kernel split of the whole `fbr_tsqr` call, {what}: "
+                         + ", ".join(f"{k} {v} ms" for k, v in sp["kernel_ms_per_call"].items())
+                         + f" per call; merge trees = {100 * sp['tree_share_of_kernel_time']:.1f} % of the kernel time")
+lines += [
+    "* `r02_coissue_probe.txt` – `tools/coissue_probe.hip`: fp64 VALU beside fp64 MFMA on one SIMD (they share the DP pipe)",
+    "* `r02_tsqr_timing.txt` – `FBR_TSQR_TIMING=1 tools/tsqr_timing_probe.py`: per-phase cycles of the wide TSQR fold",
+    "* `r03b_*` – round 3; `r02a/b/c_*` – round 2 (before / after the link-depth column order / with the tree-structured TSQR); `r01n_*`, `r01_mfma_f64_peak.txt` – round 1",
+    "",
+]
+open(os.path.join(dst, "README.md"), "w").write("\n".join(lines))
+print(gram_line)
