@@ -1307,7 +1307,9 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                      int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
 {
     int rc = gram_impl_inner(m, st, rhs, k, w, G_out, out_mem, accumulate, ngroups, async_ticket);
-    if (rc && async_ticket && m && m->pid == getpid()) {  // a failed submission issues no ticket: nothing of it may stay in flight
+    // a failed submission issues no ticket, and a blocking call that fails half way may have launched on the producer / copy streams:
+    // nothing of either may stay in flight when the error is returned
+    if (rc && m && m->pid == getpid() && m->stream) {
         const std::string msg = g_err;
         drain_after_failed_submit(m);
         set_err(msg);
@@ -2226,7 +2228,7 @@ static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, in
                      const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
     int rc = tsqr_impl_inner(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem, async_ticket);
-    if (rc && async_ticket && m && m->pid == getpid()) {
+    if (rc && m && m->pid == getpid() && m->stream) {  // (blocking calls too: the groups' trees run on side streams)
         const std::string msg = g_err;
         drain_after_failed_submit(m);
         set_err(msg);
