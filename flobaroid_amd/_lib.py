@@ -129,6 +129,7 @@ _SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int32, _ip, _ip, ctypes.POINTER(ctypes.c_int64), _ip],
     ),
+    "fbr_model_link_merge_info": (ctypes.c_int, [ctypes.c_void_p, _ip, _ip]),
 }
 
 
@@ -582,6 +583,13 @@ class Engine:
         cnt = (ctypes.c_int64 * n)()
         _check(self._lib.fbr_profile_get(self._h, ms, cnt), "fbr_profile_get")
         return {c: (float(ms[i]), int(cnt[i])) for i, c in enumerate(self.PROF_CLASSES)}
+
+    def link_merge_info(self) -> dict:
+        """What the Gram / TSQR reductions run on: the moving bodies (links attached by fixed joints are merged into the body they
+        ride on and the result expanded, fbr.h fbr_model_link_merge_info)."""
+        ml, rc = ctypes.c_int32(), ctypes.c_int32()
+        _check(self._lib.fbr_model_link_merge_info(self._h, ctypes.byref(ml), ctypes.byref(rc)), "fbr_model_link_merge_info")
+        return {"moving_links": ml.value, "reduced_cols": rc.value, "links": self.topo.num_links, "cols": self.cols}
 
     def gram_program_info(self, k: int = 0) -> dict:
         nt, npairs, parts = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()

@@ -161,6 +161,16 @@ struct fbr_model {
     DevBuf tsqr_rtmp;         // factor in the internal column order before it is brought back to the caller's
     DevBuf tsqr_embed;        // stacked rows of the embedded group factors (tree-structured TSQR)
     DevBuf gram_r_tmp;        // factor of gram_via_tsqr (robots beyond the fused Gram's 60 rows per sample)
+    // Link merging (build_reduction): the same robot with every FIXED link merged into the moving body it is attached to.  The
+    // regressor columns of a fixed link are exact linear combinations of its body's columns (Y_c = Y_a T, T the 10 x 10 change of
+    // frame of the inertial parameters), so the reductions run on the moving bodies' columns only and are expanded at the end:
+    // G = E^T G_red E,  R = qr(R_red E).  `red` has its own workspaces and runs on this model's stream.
+    std::unique_ptr<fbr_model> red;
+    const int *E_beg = nullptr, *E_row = nullptr;   // CSC of the augmented E [(cols_red + 16) x (cols + 16)]: column j of the full
+    const double *E_val = nullptr;                  // layout = sum of E_val[e] x (reduced column E_row[e]), e in [E_beg[j], E_beg[j+1])
+    DevBuf red_out[2];        // G_red / R_red of a pass, by ticket parity
+    int64_t red_ticket[2] = {-1, -1};  // the reduced model's ticket behind this model's ticket of that parity
+    int ticket_via_red[2] = {0, 0};
     // per-call state of the TSQR entry points, double buffered by the parity of the call's ticket so that a submission (fbr_tsqr_submit)
     // can be enqueued while the one before is still running
     DevBuf tsqr_tab[2];                        // device tables (index lists, entry lists, group records)
@@ -305,7 +315,9 @@ extern "C" int fbr_device_count(void)
 
 extern "C" const char *fbr_last_error(void) { return g_err.c_str(); }
 
-extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **out)
+static int build_reduction(fbr_model *m, const fbr_topology *t);
+
+static int create_model(const fbr_topology *t, int device, fbr_model **out, bool allow_merge)
 {
     if (!t || !out) {
         set_err("null argument");
@@ -412,14 +424,199 @@ extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **o
     if ((rc = upload(m->tables, sub_begin, &dm.sub_begin))) return rc;
     if ((rc = upload(m->tables, sub_links, &dm.sub_links))) return rc;
     if ((rc = upload(m->tables, dof_link, &dm.dof_link))) return rc;
+    if (allow_merge && !getenv("FBR_NO_LINK_MERGE"))
+        if ((rc = build_reduction(m.get(), t))) return rc;
     *out = m.release();
     return FBR_OK;
+}
+
+extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **out) { return create_model(t, device, out, true); }
+
+// ------------------------------------------------------------------------------------------------
+// Link merging.  A link attached to its parent by a FIXED joint has no kinematics of its own: a rigid body with parameters pi_c given
+// in the link's frame c is the same body with parameters T pi_c in the frame a of the moving body it rides on (x_a = R x_c + r):
+//     m' = m,   h' = R h + m r,   I' = R I R^T + 2 (r . Rh) 1 - (r (Rh)^T + (Rh) r^T) + m (|r|^2 1 - r r^T)
+// (first moment h = m c, inertia about the frame origin -- the reference's parameter convention, model.py:220-231,
+// helpers.py:374-407).  Hence the link's regressor columns are Y_c = Y_a T, for every row and every state: exact column dependencies
+// known from the URDF alone (they are why WALK-MAN's 480 columns have rank 213).  The reductions therefore run on the REDUCED robot --
+// moving bodies only (WALK-MAN: 30 of 48 links, 300 of 480 columns; rest transforms composed across the fixed links) -- and are
+// expanded with the constant E = [T blocks | identity]:  [Y|rhs] = [Y_red|rhs] E^  =>  G = E^T G_red E,  R = qr(R_red E).
+// Same results (to rounding), 0.39 of the column pairs.
+// ------------------------------------------------------------------------------------------------
+static void fbr_param_transform(const double *R, const double *r, double T[10][10])
+{
+    static const int I0[6] = {0, 0, 0, 1, 1, 2}, I1[6] = {0, 1, 2, 1, 2, 2};
+    for (int p = 0; p < 10; p++) {
+        double pi[10] = {0};
+        pi[p] = 1.0;
+        const double mass = pi[0], *h = pi + 1;
+        double I[3][3];
+        for (int e = 0; e < 6; e++) I[I0[e]][I1[e]] = I[I1[e]][I0[e]] = pi[4 + e];
+        double Rh[3], RI[3][3], Ia[3][3];
+        for (int i = 0; i < 3; i++) Rh[i] = R[3 * i] * h[0] + R[3 * i + 1] * h[1] + R[3 * i + 2] * h[2];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) RI[i][j] = R[3 * i] * I[0][j] + R[3 * i + 1] * I[1][j] + R[3 * i + 2] * I[2][j];
+        const double rRh = r[0] * Rh[0] + r[1] * Rh[1] + r[2] * Rh[2], rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                Ia[i][j] = RI[i][0] * R[3 * j] + RI[i][1] * R[3 * j + 1] + RI[i][2] * R[3 * j + 2];
+                Ia[i][j] += (i == j ? 2.0 * rRh : 0.0) - (r[i] * Rh[j] + Rh[i] * r[j]) + mass * ((i == j ? rr : 0.0) - r[i] * r[j]);
+            }
+        T[0][p] = mass;
+        for (int i = 0; i < 3; i++) T[1 + i][p] = Rh[i] + mass * r[i];
+        for (int e = 0; e < 6; e++) T[4 + e][p] = Ia[I0[e]][I1[e]];
+    }
+}
+
+static int build_reduction(fbr_model *m, const fbr_topology *t)
+{
+    const FbrHostModel &hm = m->hm;
+    const int L = hm.L;
+    int nfixed = 0;
+    for (int l = 0; l < L; l++) nfixed += hm.parent[l] >= 0 && hm.dof[l] < 0;
+    if (nfixed == 0) return FBR_OK;
+    // gravity-only models keep 4 of a link's 10 columns (m, h): the frame change feeds m and h into the INERTIA of the body as well, so
+    // the kept columns of a fixed link are not combinations of the kept columns of its body -- nothing is merged there
+    if (hm.grav_only) return FBR_OK;
+    // moving bodies in link order; for every link: its body and the constant transform body <- link
+    std::vector<int> red_of(L, -1), body(L, -1), moving;
+    for (int l = 0; l < L; l++)
+        if (hm.parent[l] < 0 || hm.dof[l] >= 0) {
+            red_of[l] = (int)moving.size();
+            moving.push_back(l);
+        }
+    std::vector<double> bR((size_t)9 * L), bp((size_t)3 * L);  // x_body = bR x_link + bp
+    for (int l : hm.order) {  // parents first
+        double *R = &bR[9 * l], *p = &bp[3 * l];
+        if (red_of[l] >= 0) {
+            body[l] = l;
+            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            p[0] = p[1] = p[2] = 0.0;
+        } else {
+            const int q = hm.parent[l];
+            body[l] = body[q];
+            const double *Rq = &bR[9 * q], *pq = &bp[3 * q], *Rl = &hm.restR[9 * l], *pl = &hm.restp[3 * l];
+            fbr_mm(Rq, Rl, R);
+            double tmp[3];
+            fbr_mv(Rq, pl, tmp);
+            for (int i = 0; i < 3; i++) p[i] = pq[i] + tmp[i];
+        }
+    }
+    // the reduced robot: a moving link hangs off the body of its parent, its rest transform composed across the fixed links between
+    const int Lr = (int)moving.size();
+    std::vector<int32_t> rparent(Lr), rdof(Lr);
+    std::vector<double> rR((size_t)9 * Lr), rp((size_t)3 * Lr), rax((size_t)3 * Lr);
+    for (int i = 0; i < Lr; i++) {
+        const int l = moving[i], q = hm.parent[l];
+        rdof[i] = hm.dof[l];
+        for (int c = 0; c < 3; c++) rax[3 * i + c] = hm.axis[3 * l + c];
+        if (q < 0) {
+            rparent[i] = -1;
+            for (int c = 0; c < 9; c++) rR[9 * i + c] = hm.restR[9 * l + c];
+            for (int c = 0; c < 3; c++) rp[3 * i + c] = hm.restp[3 * l + c];
+        } else {
+            rparent[i] = red_of[body[q]];
+            fbr_mm(&bR[9 * q], &hm.restR[9 * l], &rR[9 * i]);
+            double tmp[3];
+            fbr_mv(&bR[9 * q], &hm.restp[3 * l], tmp);
+            for (int c = 0; c < 3; c++) rp[3 * i + c] = bp[3 * q + c] + tmp[c];
+        }
+    }
+    fbr_topology tr = *t;
+    tr.num_links = Lr;
+    tr.parent = rparent.data();
+    tr.dof_index = rdof.data();
+    tr.rest_R = rR.data();
+    tr.rest_p = rp.data();
+    tr.axis = rax.data();
+    fbr_model *red = nullptr;
+    if (int rc = create_model(&tr, m->device, &red, false)) return rc;
+    m->red.reset(red);
+    // E, augmented with 16 rhs columns, column by column of the FULL layout
+    const int cpl = hm.cpl, Pr = red->hm.cols, Pf = hm.cols;
+    std::vector<int> beg(Pf + FBR_MAX_RHS + 1, 0), row;
+    std::vector<double> val;
+    for (int l = 0; l < L; l++) {
+        double T[10][10];
+        fbr_param_transform(&bR[9 * l], &bp[3 * l], T);
+        const int b = red_of[body[l]];
+        for (int p = 0; p < cpl; p++) {
+            beg[cpl * l + p] = (int)row.size();
+            for (int pr = 0; pr < cpl; pr++)
+                if (T[pr][p] != 0.0) {
+                    row.push_back(cpl * b + pr);
+                    val.push_back(T[pr][p]);
+                }
+        }
+    }
+    for (int j = cpl * L; j < Pf; j++) {  // friction columns: the same joints in the same layout
+        beg[j] = (int)row.size();
+        row.push_back(cpl * Lr + (j - cpl * L));
+        val.push_back(1.0);
+    }
+    for (int r = 0; r < FBR_MAX_RHS; r++) {
+        beg[Pf + r] = (int)row.size();
+        row.push_back(Pr + r);
+        val.push_back(1.0);
+    }
+    beg[Pf + FBR_MAX_RHS] = (int)row.size();
+    int rc;
+    if ((rc = upload(m->tables, beg, &m->E_beg)) || (rc = upload(m->tables, row, &m->E_row)) || (rc = upload(m->tables, val, &m->E_val))) return rc;
+    return FBR_OK;
+}
+
+// G (+)= E^T G_red E on the augmented layouts (Pa = cols + k, Pra = cols_red + k); the k rhs columns of E sit at E_beg[cols + r]
+__global__ __launch_bounds__(256) void fbr_expand_gram_kernel(int cols, int k, int Pra, const int *__restrict__ Eb, const int *__restrict__ Er,
+                                                               const double *__restrict__ Ev, const double *__restrict__ Gred, double *__restrict__ G,
+                                                               int accumulate)
+{
+    const int Pa = cols + k;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pa * Pa; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / Pa), j = (int)(e - (long)i * Pa);
+        if (i > j) continue;  // the upper triangle is computed, the lower one mirrored: G is symmetric to the bit, like the fused Gram's
+        const int a0 = Eb[i], a1 = Eb[i + 1], b0 = Eb[j], b1 = Eb[j + 1];  // (rhs column r of this call: E column cols + r, one unit entry)
+        double acc = 0.0;
+        for (int a = a0; a < a1; a++) {
+            const double *Grow = Gred + (long)Er[a] * Pra;
+            double t = 0.0;
+            for (int b = b0; b < b1; b++) t += Ev[b] * Grow[Er[b]];
+            acc += Ev[a] * t;
+        }
+        G[e] = accumulate ? G[e] + acc : acc;
+        if (i != j) G[(long)j * Pa + i] = accumulate ? G[(long)j * Pa + i] + acc : acc;
+    }
+}
+
+// dst[r][j] (leading dimension ldd) = (R_red E)[r][j] for r < Pra, j < Pa: the rows the final factor of a TSQR folds
+__global__ __launch_bounds__(256) void fbr_expand_rows_kernel(int cols, int k, int Pra, const int *__restrict__ Eb, const int *__restrict__ Er,
+                                                               const double *__restrict__ Ev, const double *__restrict__ Rred, double *__restrict__ dst,
+                                                               int ldd)
+{
+    const int Pa = cols + k;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pra * Pa; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / Pa), j = (int)(e - (long)r * Pa);
+        double acc = 0.0;
+        for (int b = Eb[j]; b < Eb[j + 1]; b++) acc += Ev[b] * Rred[(long)r * Pra + Er[b]];
+        dst[(long)r * ldd + j] = acc;
+    }
 }
 
 extern "C" void fbr_model_destroy(fbr_model *m)
 {
     if (m && m->pid != getpid()) return;  // a handle inherited through fork(): its device resources belong to the parent, nothing to free here
     delete m;  // ~fbr_model releases the device memory, streams and events
+}
+
+extern "C" int fbr_model_link_merge_info(const fbr_model *m, int32_t *moving_links, int32_t *reduced_cols)
+{
+    if (!m) {
+        set_err("null model");
+        return FBR_E_INVALID;
+    }
+    const bool on = m->red && !getenv("FBR_NO_LINK_MERGE");
+    if (moving_links) *moving_links = on ? m->red->hm.L : m->hm.L;
+    if (reduced_cols) *reduced_cols = on ? m->red->hm.cols : m->hm.cols;
+    return FBR_OK;
 }
 
 extern "C" int fbr_model_dims(const fbr_model *m, int32_t *rows, int32_t *cols)
@@ -446,6 +643,7 @@ extern "C" int fbr_model_set_stream(fbr_model *m, void *s)
         if (int rc = enter_blocking(m)) return rc;
     }
     m->stream = next;
+    if (m->red) m->red->stream = next;  // (its submissions were waited for through this model's tickets)
     return FBR_OK;
 }
 
@@ -456,6 +654,7 @@ extern "C" int fbr_profile_enable(fbr_model *m, int32_t on)
         return FBR_E_INVALID;
     }
     m->prof = on != 0;
+    if (m->red) m->red->prof = m->prof;
     return FBR_OK;
 }
 
@@ -466,6 +665,12 @@ extern "C" int fbr_profile_get(fbr_model *m, double *ms_out, int64_t *launches_o
         return FBR_E_INVALID;
     }
     for (int i = 0; i < FBR_PROF_COUNT; i++) {
+        if (m->red) {  // (the passes that ran on the link-merged model)
+            m->prof_ms[i] += m->red->prof_ms[i];
+            m->prof_n[i] += m->red->prof_n[i];
+            m->red->prof_ms[i] = 0;
+            m->red->prof_n[i] = 0;
+        }
         if (ms_out) ms_out[i] = m->prof_ms[i];
         if (launches_out) launches_out[i] = m->prof_n[i];
         m->prof_ms[i] = 0;
@@ -912,6 +1117,7 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
     }
     fbr_model *m = const_cast<fbr_model *>(mc);
     if (int rc_enter = enter(m)) return rc_enter;
+    if (m->red && !getenv("FBR_NO_LINK_MERGE")) m = m->red.get();  // what fbr_gram_accumulate runs: the program of the link-merged model
     GramHolder *h = nullptr;
     int rc = get_gram(m, k, &h);
     if (rc) return rc;
@@ -1303,9 +1509,64 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
     return finish_output(m, G, G_out, gcount, out_mem);
 }
 
+static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out, int32_t out_mem,
+                     int32_t accumulate, int32_t ngroups, int64_t *async_ticket);
+
+// The Gram through the link-merged model (build_reduction): G_red on the moving bodies' columns, then G (+)= E^T G_red E.
+static int gram_via_red(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out, int32_t out_mem,
+                        int32_t accumulate, int64_t *async_ticket)
+{
+    fbr_model *r = m->red.get();
+    const bool async = async_ticket != nullptr;
+    int rc;
+    if ((rc = enter(m))) return rc;
+    if ((rc = wait_ticket(m, async ? m->next_ticket - 2 : m->next_ticket - 1))) return rc;
+    if (async && out_mem != FBR_DEVICE) {
+        set_err("fbr_gram_submit takes a device-resident output and device-resident or PINNED host states / rhs / weights");
+        return FBR_E_INVALID;
+    }
+    r->stream = m->stream;
+    r->prof = m->prof;
+    const int par = (int)(m->next_ticket & 1), Pa = m->hm.cols + k, Pra = r->hm.cols + k;
+    const size_t cnt = (size_t)Pa * Pa;
+    if ((rc = m->red_out[par].ensure((size_t)Pra * Pra * sizeof(double)))) return rc;
+    double *Gred = m->red_out[par].as<double>();
+    int64_t tr = -1;
+    if ((rc = gram_impl(r, st, rhs, k, w, Gred, FBR_DEVICE, 0, 1, async ? &tr : nullptr))) return rc;
+    double *G = G_out;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
+        G = m->g_tmp.as<double>();
+        if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, cnt * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    }
+    hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg, m->E_row, m->E_val, Gred, G,
+                       accumulate ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    if (async) {
+        const int64_t t = m->next_ticket++;
+        m->ticket_kind[t & 1] = 0;
+        m->ticket_via_red[t & 1] = 1;
+        m->red_ticket[t & 1] = tr;
+        m->last_submit_kind = 0;
+        HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
+        *async_ticket = t;
+        return FBR_OK;
+    }
+    return finish_output(m, G, G_out, cnt, out_mem);
+}
+
 static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
                      int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
 {
+    if (m && m->red && st && ngroups == 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && !getenv("FBR_NO_LINK_MERGE")) {
+        int rc = gram_via_red(m, st, rhs, k, w, G_out, out_mem, accumulate, async_ticket);
+        if (rc && m->stream) {
+            const std::string msg = g_err;
+            drain_after_failed_submit(m);
+            set_err(msg);
+        }
+        return rc;
+    }
     int rc = gram_impl_inner(m, st, rhs, k, w, G_out, out_mem, accumulate, ngroups, async_ticket);
     // a failed submission issues no ticket, and a blocking call that fails half way may have launched on the producer / copy streams:
     // nothing of either may stay in flight when the error is returned
@@ -1333,6 +1594,12 @@ static int wait_ticket(fbr_model *m, int64_t ticket)
     }
     const int64_t first = m->waited_ticket + 1;
     m->waited_ticket = ticket;
+    if (m->red)
+        for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)
+            if (m->ticket_via_red[t & 1]) {  // the pass ran on the link-merged model: its bookkeeping, profile and error word
+                m->ticket_via_red[t & 1] = 0;
+                if (int rc = wait_ticket(m->red.get(), m->red_ticket[t & 1])) return rc;
+            }
     for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)  // (at most two submissions were in flight)
         if (m->ticket_kind[t & 1] == 1 && m->tsqr_err_host && m->tsqr_err_host[t & 1]) {
             char hx[16];
@@ -2212,6 +2479,8 @@ static int tsqr_impl_inner(fbr_model *m, const fbr_states *st, const int32_t *co
 static int drain_after_failed_submit(fbr_model *m)
 {
     if (!m) return FBR_OK;
+    if (m->red) drain_after_failed_submit(m->red.get());
+    m->ticket_via_red[0] = m->ticket_via_red[1] = 0;
     (void)hipStreamSynchronize(m->stream);
     if (m->side) (void)hipStreamSynchronize(m->side);
     if (m->copy) (void)hipStreamSynchronize(m->copy);
@@ -2224,9 +2493,107 @@ static int drain_after_failed_submit(fbr_model *m)
     return FBR_OK;
 }
 
+// The factor through the link-merged model (build_reduction): R_red over the moving bodies' columns, then R = qr([R_in ; R_red E]) --
+// the Pra dense rows R_red E become working factor 1 beside R_in (or zero) in working factor 0, and ONE level of the merge tree,
+// pipelined across workgroups, folds them (wide factors; narrow ones fold them as ordinary rows).
+static int tsqr_via_red(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, const double *R_in, double *R_out,
+                        int32_t out_mem, int64_t *async_ticket)
+{
+    fbr_model *r = m->red.get();
+    const bool async = async_ticket != nullptr;
+    int rc;
+    if ((rc = enter(m))) return rc;
+    if ((rc = wait_ticket(m, async ? m->next_ticket - 2 : m->next_ticket - 1))) return rc;
+    if (async && out_mem != FBR_DEVICE) {
+        set_err("fbr_tsqr_submit takes device-resident states, rhs, weights, R_in and R_out");
+        return FBR_E_INVALID;
+    }
+    r->stream = m->stream;
+    r->prof = m->prof;
+    const int par = (int)(m->next_ticket & 1), Pa = m->hm.cols + k, Pra = r->hm.cols + k;
+    const size_t cnt = (size_t)Pa * Pa;
+    if ((rc = m->red_out[par].ensure((size_t)Pra * Pra * sizeof(double)))) return rc;
+    double *Rred = m->red_out[par].as<double>();
+    int64_t tr = -1;
+    if ((rc = tsqr_impl(r, st, nullptr, 0, rhs, k, w, nullptr, Rred, FBR_DEVICE, async ? &tr : nullptr))) return rc;
+    double *R = R_out;
+    const double *Rin_dev = nullptr;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
+        R = m->g_tmp.as<double>();
+        if (R_in) {
+            HIPCHK(hipMemcpyAsync(R, R_in, cnt * sizeof(double), hipMemcpyHostToDevice, m->stream));
+            Rin_dev = R;
+        }
+    } else {
+        Rin_dev = R_in;
+    }
+    auto fail = [&](int code, const char *what) {
+        set_err(std::string(what) + ": " + fbr_tsqr_error());
+        return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
+    };
+    HIPCHK(hipMemsetAsync(m->tsqr_err, 0, sizeof(unsigned), m->stream));
+    FbrTsqrShape sh;
+    if (fbr_tsqr_shape(Pa, m->num_cus, 1, &sh)) return fail(-4, "tsqr shape");
+    FbrTsqrWork &wk = m->tsqr;
+    {
+        ProfScope ps(m, FBR_PROF_TREE);
+        bool done_wide = false;
+        if (!sh.narrow && !getenv("FBR_TSQR_TREE_ONE_WG") && !getenv("FBR_LINK_MERGE_ROWS")) {
+            if ((rc = fbr_tsqr_begin(wk, m->stream, Pa, Rin_dev, m->num_cus, 2L * sh.mb, m->tsqr_err))) return fail(rc, "tsqr begin");
+            if (wk.NW == 2) {
+                hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg, m->E_row, m->E_val, Rred,
+                                   wk.Rw + (size_t)wk.n * wk.ld, wk.ld);
+                HIPCHK(hipGetLastError());
+                if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, 2, Pra)) || (rc = fbr_tsqr_copy_out(wk, m->stream, R))) return fail(rc, "tsqr expansion");
+                done_wide = true;
+            }
+        }
+        if (!done_wide) {  // narrow factors: the expanded rows as ordinary data rows of a one-workgroup factorisation
+            if ((rc = m->tsqr_embed.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
+            hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg, m->E_row, m->E_val, Rred,
+                               m->tsqr_embed.as<double>(), Pa);
+            HIPCHK(hipGetLastError());
+            if ((rc = fbr_tsqr_begin(wk, m->stream, Pa, Rin_dev, m->num_cus, 1, m->tsqr_err)) ||
+                (rc = fbr_tsqr_fold_rows(wk, m->stream, Pra, Pa, m->tsqr_embed.as<double>(), 0, nullptr, nullptr, Pa)) ||
+                (rc = fbr_tsqr_finish_async(wk, m->stream, R)))
+                return fail(rc, "tsqr expansion");
+        }
+    }
+    HIPCHK(hipMemcpyAsync(&m->tsqr_err_host[par], m->tsqr_err, sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
+    if (async) {
+        const int64_t t = m->next_ticket++;
+        m->ticket_kind[t & 1] = 1;
+        m->ticket_via_red[t & 1] = 1;
+        m->red_ticket[t & 1] = tr;
+        m->last_submit_kind = 1;
+        HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
+        *async_ticket = t;
+        return FBR_OK;
+    }
+    if ((rc = finish_output(m, R, R_out, cnt, out_mem))) return rc;
+    if (m->tsqr_err_host[par]) {
+        char hx[16];
+        snprintf(hx, sizeof hx, "%08x", m->tsqr_err_host[par]);
+        m->tsqr_err_host[par] = 0;
+        set_err("TSQR pipeline flag wait timed out (internal error, code " + std::string(hx) + ")");
+        return FBR_E_HIP;
+    }
+    return FBR_OK;
+}
+
 static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
                      const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
+    if (m && m->red && st && !cols && R_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && !getenv("FBR_NO_LINK_MERGE")) {
+        int rc = tsqr_via_red(m, st, rhs, k, w, R_in, R_out, out_mem, async_ticket);
+        if (rc && m->stream) {
+            const std::string msg = g_err;
+            drain_after_failed_submit(m);
+            set_err(msg);
+        }
+        return rc;
+    }
     int rc = tsqr_impl_inner(m, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem, async_ticket);
     if (rc && m && m->pid == getpid() && m->stream) {  // (blocking calls too: the groups' trees run on side streams)
         const std::string msg = g_err;
@@ -2272,6 +2639,25 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
     if (!m || k < 0 || k > FBR_MAX_RHS || num_samples < 0 || (cols && (ncols <= 0 || ncols > m->hm.cols))) {
         set_err("bad arguments");
         return FBR_E_INVALID;
+    }
+    if (m->red && !cols && !getenv("FBR_NO_LINK_MERGE")) {
+        // what fbr_tsqr runs on a link-merged model: the factorisation of the reduced robot, then the Pra expanded rows folded into the
+        // final factor by one tree level; block_rows / n_padded describe the FINAL factor (what fbr_tsqr_merge works on)
+        int64_t l0 = 0, tr = 0;
+        if (int rc = fbr_tsqr_work_info(m->red.get(), nullptr, 0, k, num_samples, &l0, &tr, nullptr, nullptr)) return rc;
+        FbrTsqrShape sh;
+        const int Pa = m->hm.cols + k, Pra = m->red->hm.cols + k;
+        if (fbr_tsqr_shape(Pa, m->num_cus, 1, &sh)) {
+            set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
+            return FBR_E_UNSUPPORTED;
+        }
+        const long NP = sh.n / 16;
+        for (long r0 = 0; r0 < Pra; r0 += sh.tmb) tr += (8L * sh.tsub + 4) * (NP * (NP - 1) / 2);
+        if (mfma_level0) *mfma_level0 = l0;
+        if (mfma_tree) *mfma_tree = tr;
+        if (block_rows) *block_rows = sh.mb;
+        if (n_padded) *n_padded = sh.n;
+        return FBR_OK;
     }
     const FbrHostModel &hm = m->hm;
     const TsqrPlan plan = tsqr_plan(hm, cols, ncols, k, (long)num_samples);

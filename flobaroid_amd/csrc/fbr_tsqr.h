@@ -456,9 +456,10 @@ struct FbrTsqrFoldDesc {
     const double *B;  // block rows (row-major, leading dimension ldb), rows >= mrows are zero
     int ldb, mrows, first_col;
     // XWG (cross-workgroup merge pipeline): per-wave progress counters (global memory, [waves]) of the block folded into the same factor
-    // right before this one by ANOTHER workgroup (null: none), and of this block.  Counter of wave w = number of panel iterations wave w
-    // has completed: after iteration q it is q + 1, and the R rows of panel q under the wave's tiles and the R_pp of panel q + 1 (if the
-    // wave owns it) are final for this block and visible.
+    // right before this one by ANOTHER workgroup (null: none), and of this block.  Counter of wave w: after iteration q it is q + 2 (0 =
+    // not started; the block's opening iteration q0 - 1, which only factorises panel q0, counts -- for blocks of DENSE rows q0 = 0 and the
+    // successor's first read, R_pp of panel 0, waits for it), and the R rows of panel q under the wave's tiles and the R_pp of panel
+    // q + 1 (if the wave owns it) are final for this block and visible.
     const int *prev = nullptr;
     int *mine = nullptr;
 };
@@ -569,7 +570,7 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
         int *wmine = XWG ? fd.mine + wave : nullptr;
         if constexpr (XWG) {
             if (wave == q0 % W) {
-                if (wprev && ok) note(fbr_xwg_wait(wprev, q0), 3u, q0);
+                if (wprev && ok) note(fbr_xwg_wait(wprev, q0 + 1), 3u, q0);
                 fetch_rpp(q0);
             }
         } else {
@@ -711,9 +712,9 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
             if constexpr (XWG) {
                 // this wave's part of iteration q is final: publish, then -- behind the predecessor's iteration q + 1 -- request what
                 // iteration q + 1 reads: the R rows under the first tile it will update and, for the owner of panel q + 2, its R_pp
-                fbr_xwg_publish(wmine, q + 1, lane);
+                fbr_xwg_publish(wmine, q + 2, lane);
                 if (q + 1 < NP) {
-                    if (wprev && ok) note(fbr_xwg_wait(wprev, q + 2), 4u, q);
+                    if (wprev && ok) note(fbr_xwg_wait(wprev, q + 3), 4u, q);
                     const int tf = first_tile(q + 1);
                     if (tf < t1) rn = fbr_tsqr_load_rrows<true>(R, ld, q + 1, wave + W * tf, lane);
                     if (q + 2 < NP && wave == (q + 2) % W) fetch_rpp(q + 2);
@@ -799,8 +800,10 @@ __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_
 // not fully resident; the waits are bounded and report through errflag).
 template <int TPW, int SUB, int W = FBR_TSQR_WAVES>
 __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_tree_x_kernel(double *__restrict__ Rw, int n, int stride, int count, int G,
-                                                                                 int *__restrict__ prog, unsigned *errflag)
+                                                                                 int *__restrict__ prog, unsigned *errflag, int brows)
 {
+    // brows > 0: the partner is not a triangular factor but `brows` DENSE rows (the expanded reduced factor R_red E of a link-merged
+    // model): every block is folded from column 0 and only the blocks that hold rows are visited
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB;
     constexpr int LD = 16 * W * TPW;
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_
     const long a = (long)2 * p * stride, b = a + stride;
     if (b >= count) return;
     const double *Rb = Rw + b * n * LD;
-    const int nblk = (n + MB - 1) / MB;
+    const int nblk = ((brows > 0 ? brows : n) + MB - 1) / MB;
     // Blocks are CLAIMED, not assigned: the workgroups of a merge take the next block of their pair from a counter as they come
     // (the first wave of a workgroup to reach its fold f claims for the workgroup, through the LDS).  A block's predecessor has then
     // always been claimed by a workgroup that is already running -- the waits below never depend on the order in which the hardware
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_
         const int bi = __builtin_amdgcn_readfirstlane(v);
         if (bi >= nblk) return FbrTsqrFoldDesc{Rb, LD, 0, n};  // nothing left to claim: an empty fold (first column = n)
         const int i0 = bi * MB;
-        FbrTsqrFoldDesc fd{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), i0};
+        FbrTsqrFoldDesc fd{Rb + (long)i0 * LD, LD, std::min(MB, n - i0), brows > 0 ? 0 : i0};
         fd.prev = bi > 0 ? prog + ((long)p * nblk + bi - 1) * W : nullptr;
         fd.mine = prog + ((long)p * nblk + bi) * W;
         return fd;
@@ -1369,7 +1372,8 @@ static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, i
 // (several factorisations can run their latency-bound trees on different streams; fbr_tsqr_check() collects the error word).
 // Levels of the binary tree with stride_from <= stride < stride_to (strides are powers of two; the factors alive after the level of
 // stride s are the slots that are multiples of 2 s).
-static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stride_from, int stride_to)
+// brows > 0 (one level over two working factors only): the partner slot holds `brows` dense rows instead of a triangular factor
+static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stride_from, int stride_to, int brows = 0)
 {
     if (!wk.active) {
         g_tsqr_err = "tsqr finish without begin";
@@ -1389,7 +1393,7 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
     } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw && !getenv("FBR_TSQR_TREE_ONE_WG")) {
         // four-wave shapes (two workgroups per CU): the same cross-workgroup merge pipeline (fbr_tsqr_tree_x_kernel)
         constexpr int HW = FBR_TSQR_HALF_WAVES;
-        const int nblk = (n + wk.mb - 1) / wk.mb;
+        const int nblk = ((brows > 0 ? brows : n) + wk.mb - 1) / wk.mb;
         auto level_ints = [&](int stride) { const size_t pr = (wk.NW + 2 * stride - 1) / (2 * stride); return pr * nblk * HW + pr; };  // flags + claim counters
         size_t all_ints = 0;
         for (int stride = 1; stride < wk.NW; stride *= 2) all_ints += level_ints(stride);
@@ -1416,7 +1420,7 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
             if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
             FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB, HW>), dim3(pairs * G), dim3(64 * HW),
                                                               (fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
-                                                              wk.prog + off, wk.err));
+                                                              wk.prog + off, wk.err, brows));
             off += level_ints(stride);
             TSQR_HIP(hipGetLastError());
         }
@@ -1436,7 +1440,7 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
     if (!getenv("FBR_TSQR_TREE_ONE_WG") && wk.n / 16 > FBR_TSQR_NARROW_MAX_TILES) {
         // merges pipelined across workgroups (fbr_tsqr_tree_x_kernel): as many workgroups per merge as keep the level's grid within one
         // round of CUs (2 at the 128 merges of level 1, 4 at 64, 8 from 32 merges on)
-        const int sub_t = fbr_tsqr_sub_for(wk.ttpw), nblk = (n + 16 * sub_t - 1) / (16 * sub_t);
+        const int sub_t = fbr_tsqr_sub_for(wk.ttpw), nblk = ((brows > 0 ? brows : n) + 16 * sub_t - 1) / (16 * sub_t);
         // progress flags + claim counters of EVERY level, one region per level, cleared once in front of the first level (a clear per
         // level was a 20 - 40 us launch on the tree's critical path each time)
         auto level_ints = [&](int stride) { const size_t pr = (wk.NW + 2 * stride - 1) / (2 * stride); return pr * nblk * FBR_TSQR_WAVES + pr; };
@@ -1465,7 +1469,7 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
             if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
             FBR_TSQR_DISPATCH(wk.ttpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB>), dim3(pairs * G), dim3(FBR_TSQR_THREADS),
                                                           (fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
-                                                          wk.prog + off, wk.err));
+                                                          wk.prog + off, wk.err, brows));
             off += level_ints(stride);
             TSQR_HIP(hipGetLastError());
         }

@@ -256,6 +256,16 @@ int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t ncols, int32_t
 int fbr_gram_program_info(const fbr_model *m, int32_t k, int32_t *num_tiles, int32_t *num_pairs,
                           int64_t *mfma_per_sample, int32_t *num_parts);
 
+/*
+ * Link merging (on unless FBR_NO_LINK_MERGE is set in the environment when the model is created / a reduction is called).  The
+ * regressor columns of a link attached by a FIXED joint are an exact, constant linear combination of the columns of the moving body it
+ * rides on (the 10 x 10 change of frame of the inertial parameters).  fbr_gram / fbr_gram_submit / fbr_tsqr / fbr_tsqr_submit
+ * therefore reduce over the moving bodies only and expand the small result with that constant matrix E:
+ * G = E^T G_red E, R = qr([R_in ; R_red E]) -- the same G and the same R^T R to rounding (1e-15 relative), same layout, same
+ * arguments.  moving_links / reduced_cols: what the reductions run on (== the model's own counts when nothing is merged).
+ */
+int fbr_model_link_merge_info(const fbr_model *m, int32_t *moving_links, int32_t *reduced_cols);
+
 #ifdef __cplusplus
 }
 #endif

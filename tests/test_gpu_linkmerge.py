@@ -1,0 +1,112 @@
+"""Link merging (fbr.h fbr_model_link_merge_info): the reductions run on the moving bodies and expand -- against the unmerged path
+(FBR_NO_LINK_MERGE=1) and the oracle, on robots with chains of fixed links, every base / friction / gravity-only mode, weights, R_in,
+accumulation, host and device memory, blocking calls and submissions."""
+import numpy as np
+import pytest
+
+from common import random_states, random_topology
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("seed,L,floating,fric,grav", [(1, 14, 1, 0, 0), (2, 22, 0, 1, 0), (3, 30, 1, 1, 0), (4, 18, 0, 0, 1), (5, 40, 1, 0, 0),
+                                                       (6, 9, 1, 1, 1)])
+def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav, monkeypatch):
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(100 + seed)
+    t = random_topology(rng, L, p_fixed=0.5, branchiness=0.4)  # half of the joints fixed: fixed chains, fixed leaves, moving links on fixed ones
+    if t.num_dofs + (6 if floating else 0) > 60 or t.num_dofs == 0:
+        pytest.skip("row count outside the fused kernels")
+    om = OracleModel(t, floating=bool(floating), fric=bool(fric), fric_sym=True, grav_only=bool(grav))
+    S = 700
+    st = random_states(t, S, rng, floating)
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    Yo = om.regressor(st, st["sign"])
+    k = 2
+    rhs = rng.standard_normal((Yo.shape[0], k))
+    w = 0.5 + rng.random(Yo.shape[0])
+    eng = Engine(t, floating=bool(floating), friction=bool(fric), friction_symmetric=True, gravity_only=bool(grav))
+    info = eng.link_merge_info()
+    nfixed = sum(1 for l in range(1, t.num_links) if t.dof_index[l] < 0)
+    if grav:  # (m, h) of a fixed link are not combinations of the (m, h) columns of its body alone: nothing merged
+        assert info["moving_links"] == t.num_links and info["reduced_cols"] == info["cols"]
+    else:
+        assert info["moving_links"] == t.num_links - nfixed and info["reduced_cols"] < info["cols"]
+    for wt in (None, w):
+        A = np.hstack([Yo, rhs]) * (1.0 if wt is None else wt[:, None])
+        Go = A.T @ A
+        G = eng.gram(st, rhs=rhs, w=wt)
+        R = eng.tsqr(st, rhs=rhs, w=wt)
+        monkeypatch.setenv("FBR_NO_LINK_MERGE", "1")
+        assert eng.link_merge_info()["reduced_cols"] == info["cols"]
+        Gp = eng.gram(st, rhs=rhs, w=wt)
+        Rp = eng.tsqr(st, rhs=rhs, w=wt)
+        monkeypatch.delenv("FBR_NO_LINK_MERGE")
+        assert _rel(G, Go) <= 1e-12 and _rel(Gp, Go) <= 1e-12 and _rel(G, Gp) <= 1e-13
+        assert np.array_equal(G, G.T)
+        assert np.all(np.tril(R, -1) == 0)
+        assert _rel(R.T @ R, Go) <= 1e-12 and _rel(Rp.T @ Rp, Go) <= 1e-12
+    # accumulation and a streamed factor: two halves == the whole
+    h = S // 2
+    a = {kk: v[:h] for kk, v in st.items()}
+    b = {kk: v[h:] for kk, v in st.items()}
+    r = om.rows
+    A = np.hstack([Yo, rhs])
+    Go = A.T @ A
+    G2 = eng.gram(a, rhs=rhs[: h * r])
+    G2 = eng.gram(b, rhs=rhs[h * r:], out=G2, accumulate=True)
+    assert _rel(G2, Go) <= 1e-12
+    R2 = eng.tsqr(b, rhs=rhs[h * r:], R_in=eng.tsqr(a, rhs=rhs[: h * r]))
+    assert _rel(R2.T @ R2, Go) <= 1e-12 and np.all(np.tril(R2, -1) == 0)
+    eng.close()
+
+
+def test_walkman_merged_submissions_are_bitwise_the_blocking_result():
+    """WALK-MAN (18 of 48 links fixed): device-resident blocking calls and two-in-flight submissions of the merged path return the
+    same bits; against the unmerged path to rounding."""
+    import os
+    import torch
+    from common import load_topo
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo("walkman_apriori")
+    eng = Engine(t, floating=True)
+    info = eng.link_merge_info()
+    assert (info["links"], info["moving_links"], info["cols"], info["reduced_cols"]) == (48, 30, 480, 300)
+    eng.use_torch_stream()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    S = 6000
+    sts = [{kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in random_states(t, S, rng, True).items()} for _ in range(3)]
+    rhs = [torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev) for _ in range(3)]
+    Gb = [eng.gram(s, rhs=r_) for s, r_ in zip(sts, rhs)]
+    Rb = [eng.tsqr(s, rhs=r_) for s, r_ in zip(sts, rhs)]
+    Go = [torch.zeros_like(Gb[0]) for _ in range(3)]
+    Ro = [torch.zeros_like(Rb[0]) for _ in range(3)]
+    tickets = []
+    for i in range(3):  # mixed kinds, two in flight
+        tickets.append(eng.gram_submit(sts[i], Go[i], rhs=rhs[i]))
+        if len(tickets) > 1:
+            eng.wait(tickets[-2])
+        tickets.append(eng.tsqr_submit(sts[i], Ro[i], rhs=rhs[i]))
+        eng.wait(tickets[-2])
+    eng.wait(tickets[-1])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(Go[i], Gb[i]) and torch.equal(Ro[i], Rb[i])
+    os.environ["FBR_NO_LINK_MERGE"] = "1"
+    try:
+        Gp = eng.gram(sts[0], rhs=rhs[0])
+        Rp = eng.tsqr(sts[0], rhs=rhs[0])
+    finally:
+        os.environ.pop("FBR_NO_LINK_MERGE", None)
+    gn = float(torch.linalg.norm(Gp))
+    assert float(torch.linalg.norm(Gb[0] - Gp)) <= 1e-13 * gn
+    assert float(torch.linalg.norm(Rb[0].T @ Rb[0] - Gp)) <= 1e-12 * gn and float(torch.linalg.norm(Rp.T @ Rp - Gp)) <= 1e-12 * gn
+    eng.close()

@@ -373,6 +373,7 @@ def test_tsqr_column_order_is_internal(monkeypatch):
     column subset, the same sign-normalised R; an R_in in the caller's order streams through either way; the executed-work
     counter reports the saving."""
     monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
+    monkeypatch.setenv("FBR_NO_LINK_MERGE", "1")  # (the column order of the UNMERGED factorisation is what is looked at)
     cfg = CONFIGS[7]
     t, eng, om = _engine_oracle(cfg)
     S = 1200   # (35 S rows >= 64 n: below that the final re-triangularisation is not worth it and the caller's order is kept)
