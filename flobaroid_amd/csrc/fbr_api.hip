@@ -165,12 +165,20 @@ struct fbr_model {
     // regressor columns of a fixed link are exact linear combinations of its body's columns (Y_c = Y_a T, T the 10 x 10 change of
     // frame of the inertial parameters), so the reductions run on the moving bodies' columns only and are expanded at the end:
     // G = E^T G_red E,  R = qr(R_red E).  `red` has its own workspaces and runs on this model's stream.
-    std::unique_ptr<fbr_model> red;
-    const int *E_beg = nullptr, *E_row = nullptr;   // CSC of the augmented E [(cols_red + 16) x (cols + 16)]: column j of the full
-    const double *E_val = nullptr;                  // layout = sum of E_val[e] x (reduced column E_row[e]), e in [E_beg[j], E_beg[j+1])
+    // Regrouping (second reduction): a revolute joint lets three more parameter directions of its link -- the mass, the first moment
+    // along the axis and the inertia 1 - a a^T -- act exactly like parameters of the parent body (they are invariant under the joint's
+    // rotation), the classical base-parameter regrouping.  The second reduced model computes 7 instead of 10 columns for every link
+    // behind a joint (column masks, link frames turned so that the joint axis is z: m, h_z and I_yy dropped) and E grows accordingly.
+    // rdm[0]: fixed links merged (every entry point works on it); rdm[1]: merged + regrouped (fused Gram and the row-group TSQR only).
+    std::unique_ptr<fbr_model> rdm[2];
+    const int *E_beg[2] = {nullptr, nullptr}, *E_row[2] = {nullptr, nullptr};  // CSC of the augmented E [(cols_red + 16) x (cols + 16)]: column j
+    const double *E_val[2] = {nullptr, nullptr};  // of the full layout = sum of E_val[e] x (reduced column E_row[e]), e in [E_beg[j], E_beg[j+1])
     DevBuf red_out[2];        // G_red / R_red of a pass, by ticket parity
+    DevBuf red_w;             // G_red E (Gram expansion, second half: E^T (G_red E))
     int64_t red_ticket[2] = {-1, -1};  // the reduced model's ticket behind this model's ticket of that parity
-    int ticket_via_red[2] = {0, 0};
+    int ticket_via_red[2] = {0, 0};    // 0: the pass ran on this model; 1 + i: on rdm[i]
+    bool is_reduction = false;         // this model is some model's rdm[i]
+    int rd_grouped = -1;               // rdm[1]'s factorisations take the row-group path given enough samples (-1: not looked at yet)
     // per-call state of the TSQR entry points, double buffered by the parity of the call's ticket so that a submission (fbr_tsqr_submit)
     // can be enqueued while the one before is still running
     DevBuf tsqr_tab[2];                        // device tables (index lists, entry lists, group records)
@@ -315,9 +323,10 @@ extern "C" int fbr_device_count(void)
 
 extern "C" const char *fbr_last_error(void) { return g_err.c_str(); }
 
-static int build_reduction(fbr_model *m, const fbr_topology *t);
+static int build_reduction(fbr_model *m, const fbr_topology *t, int which);
+#define FBR_E_NOT_GROUPED (-1000)  // internal: a model with column masks was asked for a factorisation its row-group path does not take
 
-static int create_model(const fbr_topology *t, int device, fbr_model **out, bool allow_merge)
+static int create_model(const fbr_topology *t, int device, fbr_model **out, bool allow_merge, const unsigned short *linkmask = nullptr)
 {
     if (!t || !out) {
         set_err("null argument");
@@ -337,7 +346,7 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
     std::unique_ptr<fbr_model> m(new fbr_model());
     try {
         m->hm.build(t->num_links, t->num_dofs, t->parent, t->dof_index, t->rest_R, t->rest_p, t->axis, t->floating_base,
-                    t->gravity, t->friction, t->friction_symmetric, t->gravity_only, t->stribeck_velocity);
+                    t->gravity, t->friction, t->friction_symmetric, t->gravity_only, t->stribeck_velocity, linkmask);
     } catch (const std::exception &e) {
         set_err(std::string("invalid topology: ") + e.what());
         return FBR_E_INVALID;
@@ -424,8 +433,10 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
     if ((rc = upload(m->tables, sub_begin, &dm.sub_begin))) return rc;
     if ((rc = upload(m->tables, sub_links, &dm.sub_links))) return rc;
     if ((rc = upload(m->tables, dof_link, &dm.dof_link))) return rc;
-    if (allow_merge && !getenv("FBR_NO_LINK_MERGE"))
-        if ((rc = build_reduction(m.get(), t))) return rc;
+    if (allow_merge && !getenv("FBR_NO_LINK_MERGE")) {
+        if ((rc = build_reduction(m.get(), t, 0))) return rc;
+        if (!getenv("FBR_NO_REGROUP") && (rc = build_reduction(m.get(), t, 1))) return rc;
+    }
     *out = m.release();
     return FBR_OK;
 }
@@ -468,15 +479,43 @@ static void fbr_param_transform(const double *R, const double *r, double T[10][1
     }
 }
 
-static int build_reduction(fbr_model *m, const fbr_topology *t)
+// rotation Q (row-major) whose third column is the unit vector along a: the frame in which a joint axis is z
+static void fbr_axis_frame(const double *a_in, double *Q)
+{
+    const double na = std::sqrt(a_in[0] * a_in[0] + a_in[1] * a_in[1] + a_in[2] * a_in[2]);
+    double a[3] = {a_in[0] / na, a_in[1] / na, a_in[2] / na};
+    int i = 0;
+    for (int c = 1; c < 3; c++)
+        if (std::fabs(a[c]) < std::fabs(a[i])) i = c;
+    double u[3] = {0, 0, 0};
+    u[i] = 1.0;
+    const double ua = a[i];
+    for (int c = 0; c < 3; c++) u[c] -= ua * a[c];
+    const double nu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (int c = 0; c < 3; c++) u[c] /= nu;
+    const double v[3] = {a[1] * u[2] - a[2] * u[1], a[2] * u[0] - a[0] * u[2], a[0] * u[1] - a[1] * u[0]};
+    for (int r = 0; r < 3; r++) {
+        Q[3 * r] = u[r];
+        Q[3 * r + 1] = v[r];
+        Q[3 * r + 2] = a[r];
+    }
+}
+
+// which = 0: fixed links merged into the moving bodies; which = 1: the same, and the three regroupable parameters of every link behind a
+// revolute joint dropped (m->rdm[which], m->E_*[which])
+static int build_reduction(fbr_model *m, const fbr_topology *t, int which)
 {
     const FbrHostModel &hm = m->hm;
     const int L = hm.L;
-    int nfixed = 0;
-    for (int l = 0; l < L; l++) nfixed += hm.parent[l] >= 0 && hm.dof[l] < 0;
-    if (nfixed == 0) return FBR_OK;
+    const bool regroup = which == 1;
+    int nfixed = 0, nrev = 0;
+    for (int l = 0; l < L; l++) {
+        nfixed += hm.parent[l] >= 0 && hm.dof[l] < 0;
+        nrev += hm.parent[l] >= 0 && hm.dof[l] >= 0;
+    }
+    if (regroup ? nrev == 0 : nfixed == 0) return FBR_OK;
     // gravity-only models keep 4 of a link's 10 columns (m, h): the frame change feeds m and h into the INERTIA of the body as well, so
-    // the kept columns of a fixed link are not combinations of the kept columns of its body -- nothing is merged there
+    // the kept columns of a fixed link are not combinations of the kept columns of its body -- nothing is reduced there
     if (hm.grav_only) return FBR_OK;
     // moving bodies in link order; for every link: its body and the constant transform body <- link
     std::vector<int> red_of(L, -1), body(L, -1), moving;
@@ -485,12 +524,19 @@ static int build_reduction(fbr_model *m, const fbr_topology *t)
             red_of[l] = (int)moving.size();
             moving.push_back(l);
         }
+    // (regrouping: the frame of a body behind a joint is turned so that the joint axis becomes z, x_link = Q x_body)
+    std::vector<double> Q((size_t)9 * L, 0.0);
+    for (int l = 0; l < L; l++) {
+        for (int i = 0; i < 3; i++) Q[9 * l + 4 * i] = 1.0;
+        if (regroup && hm.parent[l] >= 0 && hm.dof[l] >= 0) fbr_axis_frame(&hm.axis[3 * l], &Q[9 * l]);
+    }
     std::vector<double> bR((size_t)9 * L), bp((size_t)3 * L);  // x_body = bR x_link + bp
     for (int l : hm.order) {  // parents first
         double *R = &bR[9 * l], *p = &bp[3 * l];
         if (red_of[l] >= 0) {
             body[l] = l;
-            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) R[3 * i + j] = Q[9 * l + 3 * j + i];  // Q^T
             p[0] = p[1] = p[2] = 0.0;
         } else {
             const int q = hm.parent[l];
@@ -506,20 +552,25 @@ static int build_reduction(fbr_model *m, const fbr_topology *t)
     const int Lr = (int)moving.size();
     std::vector<int32_t> rparent(Lr), rdof(Lr);
     std::vector<double> rR((size_t)9 * Lr), rp((size_t)3 * Lr), rax((size_t)3 * Lr);
+    std::vector<unsigned short> masks(Lr, 0x3ff);
     for (int i = 0; i < Lr; i++) {
         const int l = moving[i], q = hm.parent[l];
         rdof[i] = hm.dof[l];
-        for (int c = 0; c < 3; c++) rax[3 * i + c] = hm.axis[3 * l + c];
         if (q < 0) {
             rparent[i] = -1;
             for (int c = 0; c < 9; c++) rR[9 * i + c] = hm.restR[9 * l + c];
             for (int c = 0; c < 3; c++) rp[3 * i + c] = hm.restp[3 * l + c];
+            for (int c = 0; c < 3; c++) rax[3 * i + c] = hm.axis[3 * l + c];
         } else {
             rparent[i] = red_of[body[q]];
-            fbr_mm(&bR[9 * q], &hm.restR[9 * l], &rR[9 * i]);
-            double tmp[3];
+            double tmpR[9], tmp[3];
+            fbr_mm(&bR[9 * q], &hm.restR[9 * l], tmpR);
+            fbr_mm(tmpR, &Q[9 * l], &rR[9 * i]);
             fbr_mv(&bR[9 * q], &hm.restp[3 * l], tmp);
             for (int c = 0; c < 3; c++) rp[3 * i + c] = bp[3 * q + c] + tmp[c];
+            for (int c = 0; c < 3; c++)  // Q^T axis (= |axis| z when regrouping)
+                rax[3 * i + c] = Q[9 * l + c] * hm.axis[3 * l] + Q[9 * l + 3 + c] * hm.axis[3 * l + 1] + Q[9 * l + 6 + c] * hm.axis[3 * l + 2];
+            if (regroup) masks[i] = 0x3ff & ~((1u << 0) | (1u << 3) | (1u << 7));  // m, h_z, I_yy
         }
     }
     fbr_topology tr = *t;
@@ -530,28 +581,65 @@ static int build_reduction(fbr_model *m, const fbr_topology *t)
     tr.rest_p = rp.data();
     tr.axis = rax.data();
     fbr_model *red = nullptr;
-    if (int rc = create_model(&tr, m->device, &red, false)) return rc;
-    m->red.reset(red);
+    if (int rc = create_model(&tr, m->device, &red, false, regroup ? masks.data() : nullptr)) return rc;
+    m->rdm[which].reset(red);
+    red->is_reduction = true;
+    const FbrHostModel &rh = red->hm;
+    // X_i [Pr x 10]: the 10 standard columns of reduced link i (its own frame) in terms of the columns the reduced model computes.
+    // Kept parameters: unit vectors.  Dropped ones (regrouping), with T the frame change link i -> parent body at q = 0:
+    //     Y_i[m] = Y_par T e_m,   Y_i[h_z] = Y_par T e_hz,   Y_i[I_yy] = Y_par T (e_Ixx + e_Iyy) - Y_i[I_xx]
+    // (mass, first moment along the axis and the inertia 1 - z z^T of the link do not notice the joint's rotation)
+    const int Pr = rh.cols, Pf = hm.cols, cpl = hm.cpl;
+    std::vector<std::vector<double>> X((size_t)Lr * 10, std::vector<double>(Pr, 0.0));
+    std::vector<int> colof((size_t)Lr * 10, -1);
+    for (int c = 0; c < rh.ninert; c++) colof[(size_t)rh.coldesc[c].link * 10 + rh.coldesc[c].pidx] = c;
+    for (int i : rh.order) {
+        for (int p = 0; p < 10; p++)
+            if (colof[(size_t)i * 10 + p] >= 0) X[(size_t)i * 10 + p][colof[(size_t)i * 10 + p]] = 1.0;
+        if (masks[i] == 0x3ff) continue;
+        double T[10][10];
+        fbr_param_transform(&rR[9 * i], &rp[3 * i], T);
+        const int par = rparent[i];
+        auto add = [&](int pdst, int psrc, double sgn) {
+            std::vector<double> &dst = X[(size_t)i * 10 + pdst];
+            for (int pr = 0; pr < 10; pr++) {
+                const double tv = sgn * T[pr][psrc];
+                if (tv == 0.0) continue;
+                const std::vector<double> &src = X[(size_t)par * 10 + pr];
+                for (int c = 0; c < Pr; c++) dst[c] += tv * src[c];
+            }
+        };
+        add(0, 0, 1.0);
+        add(3, 3, 1.0);
+        add(7, 4, 1.0);
+        add(7, 7, 1.0);
+        for (int c = 0; c < Pr; c++) X[(size_t)i * 10 + 7][c] -= X[(size_t)i * 10 + 4][c];
+    }
     // E, augmented with 16 rhs columns, column by column of the FULL layout
-    const int cpl = hm.cpl, Pr = red->hm.cols, Pf = hm.cols;
     std::vector<int> beg(Pf + FBR_MAX_RHS + 1, 0), row;
-    std::vector<double> val;
+    std::vector<double> val, col(Pr);
     for (int l = 0; l < L; l++) {
         double T[10][10];
         fbr_param_transform(&bR[9 * l], &bp[3 * l], T);
         const int b = red_of[body[l]];
         for (int p = 0; p < cpl; p++) {
             beg[cpl * l + p] = (int)row.size();
-            for (int pr = 0; pr < cpl; pr++)
-                if (T[pr][p] != 0.0) {
-                    row.push_back(cpl * b + pr);
-                    val.push_back(T[pr][p]);
+            std::fill(col.begin(), col.end(), 0.0);
+            for (int pr = 0; pr < 10; pr++) {
+                if (T[pr][p] == 0.0) continue;
+                const std::vector<double> &src = X[(size_t)b * 10 + pr];
+                for (int c = 0; c < Pr; c++) col[c] += T[pr][p] * src[c];
+            }
+            for (int c = 0; c < Pr; c++)
+                if (col[c] != 0.0) {
+                    row.push_back(c);
+                    val.push_back(col[c]);
                 }
         }
     }
-    for (int j = cpl * L; j < Pf; j++) {  // friction columns: the same joints in the same layout
+    for (int j = hm.ninert; j < Pf; j++) {  // friction columns: the same joints in the same layout
         beg[j] = (int)row.size();
-        row.push_back(cpl * Lr + (j - cpl * L));
+        row.push_back(rh.ninert + (j - hm.ninert));
         val.push_back(1.0);
     }
     for (int r = 0; r < FBR_MAX_RHS; r++) {
@@ -561,11 +649,14 @@ static int build_reduction(fbr_model *m, const fbr_topology *t)
     }
     beg[Pf + FBR_MAX_RHS] = (int)row.size();
     int rc;
-    if ((rc = upload(m->tables, beg, &m->E_beg)) || (rc = upload(m->tables, row, &m->E_row)) || (rc = upload(m->tables, val, &m->E_val))) return rc;
+    if ((rc = upload(m->tables, beg, &m->E_beg[which])) || (rc = upload(m->tables, row, &m->E_row[which])) ||
+        (rc = upload(m->tables, val, &m->E_val[which])))
+        return rc;
     return FBR_OK;
 }
 
-// G (+)= E^T G_red E on the augmented layouts (Pa = cols + k, Pra = cols_red + k); the k rhs columns of E sit at E_beg[cols + r]
+// G (+)= E^T W, W = G_red E [Pra x Pa] (fbr_expand_rows_kernel) on the augmented layouts (Pa = cols + k, Pra = cols_red + k); the k rhs
+// columns of E sit at E_beg[cols + r]
 __global__ __launch_bounds__(256) void fbr_expand_gram_kernel(int cols, int k, int Pra, const int *__restrict__ Eb, const int *__restrict__ Er,
                                                                const double *__restrict__ Ev, const double *__restrict__ Gred, double *__restrict__ G,
                                                                int accumulate)
@@ -574,14 +665,8 @@ __global__ __launch_bounds__(256) void fbr_expand_gram_kernel(int cols, int k, i
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pa * Pa; e += (long)gridDim.x * blockDim.x) {
         const int i = (int)(e / Pa), j = (int)(e - (long)i * Pa);
         if (i > j) continue;  // the upper triangle is computed, the lower one mirrored: G is symmetric to the bit, like the fused Gram's
-        const int a0 = Eb[i], a1 = Eb[i + 1], b0 = Eb[j], b1 = Eb[j + 1];  // (rhs column r of this call: E column cols + r, one unit entry)
-        double acc = 0.0;
-        for (int a = a0; a < a1; a++) {
-            const double *Grow = Gred + (long)Er[a] * Pra;
-            double t = 0.0;
-            for (int b = b0; b < b1; b++) t += Ev[b] * Grow[Er[b]];
-            acc += Ev[a] * t;
-        }
+        double acc = 0.0;  // (Gred here: W = G_red E [Pra x Pa], fbr_expand_rows_kernel)
+        for (int a = Eb[i]; a < Eb[i + 1]; a++) acc += Ev[a] * Gred[(long)Er[a] * Pa + j];
         G[e] = accumulate ? G[e] + acc : acc;
         if (i != j) G[(long)j * Pa + i] = accumulate ? G[(long)j * Pa + i] + acc : acc;
     }
@@ -607,15 +692,24 @@ extern "C" void fbr_model_destroy(fbr_model *m)
     delete m;  // ~fbr_model releases the device memory, streams and events
 }
 
+// the reduced model a fused Gram pass runs on (-1: the model itself)
+static int pick_gram_reduction(const fbr_model *m)
+{
+    if (getenv("FBR_NO_LINK_MERGE")) return -1;
+    // (robots beyond the fused kernel's 60 rows take their Gram from a TSQR factor, gram_via_tsqr: every path of the merged model)
+    if (m->rdm[1] && !getenv("FBR_NO_REGROUP") && (m->hm.rows + 3) / 4 * 4 <= 60) return 1;
+    return m->rdm[0] ? 0 : -1;
+}
+
 extern "C" int fbr_model_link_merge_info(const fbr_model *m, int32_t *moving_links, int32_t *reduced_cols)
 {
     if (!m) {
         set_err("null model");
         return FBR_E_INVALID;
     }
-    const bool on = m->red && !getenv("FBR_NO_LINK_MERGE");
-    if (moving_links) *moving_links = on ? m->red->hm.L : m->hm.L;
-    if (reduced_cols) *reduced_cols = on ? m->red->hm.cols : m->hm.cols;
+    const int w = pick_gram_reduction(m);
+    if (moving_links) *moving_links = w >= 0 ? m->rdm[w]->hm.L : m->hm.L;
+    if (reduced_cols) *reduced_cols = w >= 0 ? m->rdm[w]->hm.cols : m->hm.cols;
     return FBR_OK;
 }
 
@@ -643,7 +737,8 @@ extern "C" int fbr_model_set_stream(fbr_model *m, void *s)
         if (int rc = enter_blocking(m)) return rc;
     }
     m->stream = next;
-    if (m->red) m->red->stream = next;  // (its submissions were waited for through this model's tickets)
+    for (auto &r : m->rdm)
+        if (r) r->stream = next;  // (their submissions were waited for through this model's tickets)
     return FBR_OK;
 }
 
@@ -654,7 +749,8 @@ extern "C" int fbr_profile_enable(fbr_model *m, int32_t on)
         return FBR_E_INVALID;
     }
     m->prof = on != 0;
-    if (m->red) m->red->prof = m->prof;
+    for (auto &r : m->rdm)
+        if (r) r->prof = m->prof;
     return FBR_OK;
 }
 
@@ -665,12 +761,13 @@ extern "C" int fbr_profile_get(fbr_model *m, double *ms_out, int64_t *launches_o
         return FBR_E_INVALID;
     }
     for (int i = 0; i < FBR_PROF_COUNT; i++) {
-        if (m->red) {  // (the passes that ran on the link-merged model)
-            m->prof_ms[i] += m->red->prof_ms[i];
-            m->prof_n[i] += m->red->prof_n[i];
-            m->red->prof_ms[i] = 0;
-            m->red->prof_n[i] = 0;
-        }
+        for (auto &r : m->rdm)
+            if (r) {  // (the passes that ran on the reduced models)
+                m->prof_ms[i] += r->prof_ms[i];
+                m->prof_n[i] += r->prof_n[i];
+                r->prof_ms[i] = 0;
+                r->prof_n[i] = 0;
+            }
         if (ms_out) ms_out[i] = m->prof_ms[i];
         if (launches_out) launches_out[i] = m->prof_n[i];
         m->prof_ms[i] = 0;
@@ -1117,7 +1214,7 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
     }
     fbr_model *m = const_cast<fbr_model *>(mc);
     if (int rc_enter = enter(m)) return rc_enter;
-    if (m->red && !getenv("FBR_NO_LINK_MERGE")) m = m->red.get();  // what fbr_gram_accumulate runs: the program of the link-merged model
+    if (const int wr = pick_gram_reduction(m); wr >= 0) m = m->rdm[wr].get();  // what fbr_gram_accumulate runs: the program of the reduced model
     GramHolder *h = nullptr;
     int rc = get_gram(m, k, &h);
     if (rc) return rc;
@@ -1513,10 +1610,10 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
                      int32_t accumulate, int32_t ngroups, int64_t *async_ticket);
 
 // The Gram through the link-merged model (build_reduction): G_red on the moving bodies' columns, then G (+)= E^T G_red E.
-static int gram_via_red(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out, int32_t out_mem,
+static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out, int32_t out_mem,
                         int32_t accumulate, int64_t *async_ticket)
 {
-    fbr_model *r = m->red.get();
+    fbr_model *r = m->rdm[which].get();
     const bool async = async_ticket != nullptr;
     int rc;
     if ((rc = enter(m))) return rc;
@@ -1539,13 +1636,16 @@ static int gram_via_red(fbr_model *m, const fbr_states *st, const double *rhs, i
         G = m->g_tmp.as<double>();
         if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, cnt * sizeof(double), hipMemcpyHostToDevice, m->stream));
     }
-    hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg, m->E_row, m->E_val, Gred, G,
-                       accumulate ? 1 : 0);
+    if ((rc = m->red_w.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which], m->E_val[which],
+                       Gred, m->red_w.as<double>(), Pa);
+    hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
+                       m->E_val[which], m->red_w.as<double>(), G, accumulate ? 1 : 0);
     HIPCHK(hipGetLastError());
     if (async) {
         const int64_t t = m->next_ticket++;
         m->ticket_kind[t & 1] = 0;
-        m->ticket_via_red[t & 1] = 1;
+        m->ticket_via_red[t & 1] = 1 + which;
         m->red_ticket[t & 1] = tr;
         m->last_submit_kind = 0;
         HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
@@ -1558,8 +1658,9 @@ static int gram_via_red(fbr_model *m, const fbr_states *st, const double *rhs, i
 static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
                      int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
 {
-    if (m && m->red && st && ngroups == 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && !getenv("FBR_NO_LINK_MERGE")) {
-        int rc = gram_via_red(m, st, rhs, k, w, G_out, out_mem, accumulate, async_ticket);
+    const int which = (m && st && ngroups == 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid()) ? pick_gram_reduction(m) : -1;
+    if (which >= 0) {
+        int rc = gram_via_red(m, which, st, rhs, k, w, G_out, out_mem, accumulate, async_ticket);
         if (rc && m->stream) {
             const std::string msg = g_err;
             drain_after_failed_submit(m);
@@ -1594,12 +1695,12 @@ static int wait_ticket(fbr_model *m, int64_t ticket)
     }
     const int64_t first = m->waited_ticket + 1;
     m->waited_ticket = ticket;
-    if (m->red)
-        for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)
-            if (m->ticket_via_red[t & 1]) {  // the pass ran on the link-merged model: its bookkeeping, profile and error word
-                m->ticket_via_red[t & 1] = 0;
-                if (int rc = wait_ticket(m->red.get(), m->red_ticket[t & 1])) return rc;
-            }
+    for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)
+        if (m->ticket_via_red[t & 1]) {  // the pass ran on a reduced model: its bookkeeping, profile and error word
+            fbr_model *r = m->rdm[m->ticket_via_red[t & 1] - 1].get();
+            m->ticket_via_red[t & 1] = 0;
+            if (int rc = wait_ticket(r, m->red_ticket[t & 1])) return rc;
+        }
     for (int64_t t = std::max(first, ticket - 1); t <= ticket; t++)  // (at most two submissions were in flight)
         if (m->ticket_kind[t & 1] == 1 && m->tsqr_err_host && m->tsqr_err_host[t & 1]) {
             char hx[16];
@@ -1795,7 +1896,7 @@ static TsqrPlan tsqr_plan(const FbrHostModel &hm, const int32_t *cols, int32_t n
     for (int j = 0; j < p.Pa; j++) p.inv[p.perm[j]] = j;
     p.fcols = p.reorder ? sorted : ucols;
     p.fc = p.reorder ? fc_sorted : fc_user;
-    if (!cols) {
+    if (!cols && !hm.masked) {
         p.linkpos.assign(hm.L, 0);
         for (int l = 0; l < hm.L; l++) p.linkpos[l] = p.inv[hm.cpl * l] / hm.cpl;
     }
@@ -1877,7 +1978,11 @@ static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols
             for (int r : grows[g]) any = any || touches(r, uc);
             if (any) (hm.coldesc[uc].kind == 0 ? inert : fric).push_back(j);
         }
-        auto cdepth = [&](int j) { return (int)hm.path[hm.coldesc[cols ? cols[j] : j].link].size(); };
+        // (the unpaired columns of a model with column masks go behind the paired ones: pairs stay at even positions in every group)
+        auto cdepth = [&](int j) {
+            const FbrCol &cd = hm.coldesc[cols ? cols[j] : j];
+            return (int)hm.path[cd.link].size() + (cd.joint == -2 ? (1 << 16) : 0);
+        };
         std::stable_sort(inert.begin(), inert.end(), [&](int a, int b) { return cdepth(a) < cdepth(b); });
         G.sel = inert;
         G.sel.insert(G.sel.end(), fric.begin(), fric.end());
@@ -2014,8 +2119,14 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     }
     // the same lists per PAIR of adjacent inertial columns (16-byte stores, fbr_regressor_groups2_kernel): possible when both columns
     // of every pair sit side by side at an even position in every group that holds them
-    const int npairs = (hm.cpl % 2 == 0) ? hm.cpl * hm.L / 2 : 0;
-    bool pairable = npairs > 0 && !getenv("FBR_TSQR_WRITER8");
+    const int npairs = hm.npaircols / 2;
+    // threads per work item of the pair writer (fbr_regressor_groups2_kernel: 256 threads, an item's entries dealt to `wsplit` of them)
+    const int wsplit = getenv("FBR_TSQR_WRITER_SPLIT") ? std::max(1, atoi(getenv("FBR_TSQR_WRITER_SPLIT")))
+                                                       : std::max(1, std::min(4, 256 / std::max(1, npairs + (hm.cols - 2 * npairs))));
+    // (with fewer work items than half a workgroup -- the regrouped WALK-MAN: 92 pairs + 29 single columns -- the pair writer leaves
+    // most threads idle behind twice the work per busy thread: 12.6 ms per 1 M samples with the entries split, 15.9 without, against
+    // 11.8 ms of the one-column-per-thread writer)
+    bool pairable = npairs > 0 && !getenv("FBR_TSQR_WRITER8") && (npairs + (hm.cols - 2 * npairs) >= 128 || getenv("FBR_TSQR_WRITER16"));
     std::vector<int> pents[2];
     size_t o_pbeg[2] = {0, 0};
     for (int var = 0; var < 2 && pairable; var++) {
@@ -2116,7 +2227,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
                                    t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)),
-                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_pent1 : o_pent0)), npairs);
+                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_pent1 : o_pent0)), npairs, hm.ninert, wsplit);
             else
                 hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
@@ -2371,6 +2482,7 @@ static int tsqr_impl_inner(fbr_model *m, const fbr_states *st, const int32_t *co
             return done();
         }
     }
+    if (hm.masked) return FBR_E_NOT_GROUPED;  // (internal models with column masks factorise by row groups only: the caller takes the merged model)
     // device tables: [fcols (Psel) | perm (Pa) | inv (Pa) | linkpos (L) | row first columns (rows)]
     const int *dcols = nullptr, *dperm = nullptr, *dinv = nullptr, *dlinkpos = nullptr, *dfc = nullptr;
     {
@@ -2479,7 +2591,8 @@ static int tsqr_impl_inner(fbr_model *m, const fbr_states *st, const int32_t *co
 static int drain_after_failed_submit(fbr_model *m)
 {
     if (!m) return FBR_OK;
-    if (m->red) drain_after_failed_submit(m->red.get());
+    for (auto &r : m->rdm)
+        if (r) drain_after_failed_submit(r.get());
     m->ticket_via_red[0] = m->ticket_via_red[1] = 0;
     (void)hipStreamSynchronize(m->stream);
     if (m->side) (void)hipStreamSynchronize(m->side);
@@ -2493,13 +2606,28 @@ static int drain_after_failed_submit(fbr_model *m)
     return FBR_OK;
 }
 
+// the reduced model a factorisation of every column runs on (-1: the model itself); the regrouped model factorises by row groups only
+static int pick_tsqr_reduction(fbr_model *m, long S)
+{
+    if (getenv("FBR_NO_LINK_MERGE")) return -1;
+    if (m->rdm[1] && !getenv("FBR_NO_REGROUP") && !getenv("FBR_TSQR_NO_GROUPS")) {
+        if (m->rd_grouped < 0) {
+            const TsqrGroupPlan gp = tsqr_group_plan(m->rdm[1]->hm, nullptr, 0, 0);
+            m->rd_grouped = gp.groups.size() > 1 && m->rdm[1]->hm.rows <= 255;
+        }
+        const char *e = getenv("FBR_TSQR_GROUP_MIN_SAMPLES");
+        if (m->rd_grouped && S >= (e ? atol(e) : 24000)) return 1;
+    }
+    return m->rdm[0] ? 0 : -1;
+}
+
 // The factor through the link-merged model (build_reduction): R_red over the moving bodies' columns, then R = qr([R_in ; R_red E]) --
 // the Pra dense rows R_red E become working factor 1 beside R_in (or zero) in working factor 0, and ONE level of the merge tree,
 // pipelined across workgroups, folds them (wide factors; narrow ones fold them as ordinary rows).
-static int tsqr_via_red(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, const double *R_in, double *R_out,
+static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const double *rhs, int32_t k, const double *w, const double *R_in, double *R_out,
                         int32_t out_mem, int64_t *async_ticket)
 {
-    fbr_model *r = m->red.get();
+    fbr_model *r = m->rdm[which].get();
     const bool async = async_ticket != nullptr;
     int rc;
     if ((rc = enter(m))) return rc;
@@ -2542,7 +2670,7 @@ static int tsqr_via_red(fbr_model *m, const fbr_states *st, const double *rhs, i
         if (!sh.narrow && !getenv("FBR_TSQR_TREE_ONE_WG") && !getenv("FBR_LINK_MERGE_ROWS")) {
             if ((rc = fbr_tsqr_begin(wk, m->stream, Pa, Rin_dev, m->num_cus, 2L * sh.mb, m->tsqr_err))) return fail(rc, "tsqr begin");
             if (wk.NW == 2) {
-                hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg, m->E_row, m->E_val, Rred,
+                hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which], m->E_val[which], Rred,
                                    wk.Rw + (size_t)wk.n * wk.ld, wk.ld);
                 HIPCHK(hipGetLastError());
                 if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, 2, Pra)) || (rc = fbr_tsqr_copy_out(wk, m->stream, R))) return fail(rc, "tsqr expansion");
@@ -2551,7 +2679,7 @@ static int tsqr_via_red(fbr_model *m, const fbr_states *st, const double *rhs, i
         }
         if (!done_wide) {  // narrow factors: the expanded rows as ordinary data rows of a one-workgroup factorisation
             if ((rc = m->tsqr_embed.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
-            hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg, m->E_row, m->E_val, Rred,
+            hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which], m->E_val[which], Rred,
                                m->tsqr_embed.as<double>(), Pa);
             HIPCHK(hipGetLastError());
             if ((rc = fbr_tsqr_begin(wk, m->stream, Pa, Rin_dev, m->num_cus, 1, m->tsqr_err)) ||
@@ -2564,7 +2692,7 @@ static int tsqr_via_red(fbr_model *m, const fbr_states *st, const double *rhs, i
     if (async) {
         const int64_t t = m->next_ticket++;
         m->ticket_kind[t & 1] = 1;
-        m->ticket_via_red[t & 1] = 1;
+        m->ticket_via_red[t & 1] = 1 + which;
         m->red_ticket[t & 1] = tr;
         m->last_submit_kind = 1;
         HIPCHK(hipEventRecord(m->ev_done[t & 1], m->stream));
@@ -2585,8 +2713,13 @@ static int tsqr_via_red(fbr_model *m, const fbr_states *st, const double *rhs, i
 static int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
                      const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
-    if (m && m->red && st && !cols && R_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && !getenv("FBR_NO_LINK_MERGE")) {
-        int rc = tsqr_via_red(m, st, rhs, k, w, R_in, R_out, out_mem, async_ticket);
+    int which = (m && st && !cols && R_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid()) ? pick_tsqr_reduction(m, (long)st->num_samples) : -1;
+    while (which >= 0) {
+        int rc = tsqr_via_red(m, which, st, rhs, k, w, R_in, R_out, out_mem, async_ticket);
+        if (rc == FBR_E_NOT_GROUPED && which == 1) {  // (row weights left the regrouped model without row groups: nothing was enqueued)
+            which = m->rdm[0] ? 0 : -1;
+            continue;
+        }
         if (rc && m->stream) {
             const std::string msg = g_err;
             drain_after_failed_submit(m);
@@ -2640,13 +2773,13 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
         set_err("bad arguments");
         return FBR_E_INVALID;
     }
-    if (m->red && !cols && !getenv("FBR_NO_LINK_MERGE")) {
+    if (const int which = cols ? -1 : pick_tsqr_reduction(m, (long)num_samples); which >= 0) {
         // what fbr_tsqr runs on a link-merged model: the factorisation of the reduced robot, then the Pra expanded rows folded into the
         // final factor by one tree level; block_rows / n_padded describe the FINAL factor (what fbr_tsqr_merge works on)
         int64_t l0 = 0, tr = 0;
-        if (int rc = fbr_tsqr_work_info(m->red.get(), nullptr, 0, k, num_samples, &l0, &tr, nullptr, nullptr)) return rc;
+        if (int rc = fbr_tsqr_work_info(m->rdm[which].get(), nullptr, 0, k, num_samples, &l0, &tr, nullptr, nullptr)) return rc;
         FbrTsqrShape sh;
-        const int Pa = m->hm.cols + k, Pra = m->red->hm.cols + k;
+        const int Pa = m->hm.cols + k, Pra = m->rdm[which]->hm.cols + k;
         if (fbr_tsqr_shape(Pa, m->num_cus, 1, &sh)) {
             set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
             return FBR_E_UNSUPPORTED;

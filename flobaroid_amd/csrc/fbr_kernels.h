@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
                                                                      const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,
                                                                      const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
                                                                      const int *__restrict__ ebeg, const int *__restrict__ ent,
-                                                                     const int *__restrict__ pbeg, const int *__restrict__ pent, int npairs)
+                                                                     const int *__restrict__ pbeg, const int *__restrict__ pent, int npairs,
+                                                                     int ninert, int split)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *rs = smem;                                    // [rec]
@@ -492,37 +493,62 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
             if (wts) v *= wts[s * m.rows + r];
             rowptr[r][grp[g].psel + i] = v;
         }
-        for (int pr = tid; pr < npairs; pr += blockDim.x) {
-            const int e0 = pbeg[pr], e1 = pbeg[pr + 1];
-            if (e0 == e1) continue;
-            const int4 ca = m.coldesc[2 * pr], cb = m.coldesc[2 * pr + 1];
-            double wa[6], wb[6];
-            fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, ca.z, wa);
-            fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, cb.z, wb);
-            int en_next = pent[e0];
-            for (int e = e0; e < e1; e++) {
-                const int en = en_next;
-                en_next = pent[e + 1 < e1 ? e + 1 : e];
-                const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
-                fbr_d2 v = {0.0, 0.0};
-                if (kind == 0) {
-                    v[0] = wa[r];
-                    v[1] = wb[r];
-                } else if (kind == 1) {
-                    const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb);
-                    v[0] = fbr_dot6(Sd, wa);
-                    v[1] = fbr_dot6(Sd, wb);
+        // work items: the pairs, then the single columns.  With fewer items than threads an item's entry list is SPLIT over `split`
+        // threads (thread t: item t % nitems, entries part, part + split, ...): the sample's critical path is the longest entry walk of
+        // a thread, and half a workgroup of idle threads beside 120 busy ones made the 16-byte writer slower than the 8-byte one
+        const int nitems = npairs + (m.cols - 2 * npairs);
+        for (int t = tid; t < nitems * split; t += blockDim.x) {
+            const int part = t / nitems, it = t - part * nitems;
+            if (it < npairs) {
+                const int pr = it;
+                const int e0 = pbeg[pr], e1 = pbeg[pr + 1];
+                if (e0 + part >= e1) continue;
+                const int4 ca = m.coldesc[2 * pr], cb = m.coldesc[2 * pr + 1];
+                double wa[6], wb[6];
+                fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, ca.z, wa);
+                fbr_unit_wrench(rs + FBR_LINK_REC * ca.y, cb.z, wb);
+                int en_next = pent[e0 + part];
+                for (int e = e0 + part; e < e1; e += split) {
+                    const int en = en_next;
+                    en_next = pent[e + split < e1 ? e + split : e];
+                    const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
+                    fbr_d2 v = {0.0, 0.0};
+                    if (kind == 0) {
+                        v[0] = wa[r];
+                        v[1] = wb[r];
+                    } else if (kind == 1) {
+                        const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb);
+                        v[0] = fbr_dot6(Sd, wa);
+                        v[1] = fbr_dot6(Sd, wb);
+                    }
+                    if (wts) v *= wts[s * m.rows + r];
+                    __builtin_nontemporal_store(v, (fbr_d2 *)(rowptr[r] + pos));
                 }
-                if (wts) v *= wts[s * m.rows + r];
-                __builtin_nontemporal_store(v, (fbr_d2 *)(rowptr[r] + pos));
+                continue;
             }
-        }
-        for (int c = 2 * npairs + tid; c < m.cols; c += blockDim.x) {  // friction columns
+            // inertial columns without a partner (models with column masks: one per link with an odd column count), then the friction columns
+            const int c = 2 * npairs + (it - npairs);
             const int e0 = ebeg[c], e1 = ebeg[c + 1];
-            if (e0 == e1) continue;
+            if (e0 + part >= e1) continue;
             const int4 cd = m.coldesc[c];
+            if (c < ninert) {
+                double w6[6];
+                fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
+                for (int e = e0 + part; e < e1; e += split) {
+                    const int en = ent[e];
+                    const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
+                    double v = 0.0;
+                    if (kind == 0)
+                        v = w6[r];
+                    else if (kind == 1)
+                        v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
+                    if (wts) v *= wts[s * m.rows + r];
+                    __builtin_nontemporal_store(v, rowptr[r] + pos);
+                }
+                continue;
+            }
             const double fv = fbr_friction_value(cd.z, dq[s * m.n + cd.w], sign ? sign[s * m.n + cd.w] : 0.0, m.stribeck);
-            for (int e = e0; e < e1; e++) {
+            for (int e = e0 + part; e < e1; e += split) {
                 const int en = ent[e];
                 const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
                 double v = kind == 3 ? fv : 0.0;

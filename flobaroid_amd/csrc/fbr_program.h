@@ -62,7 +62,7 @@ struct FbrCol {
     int kind;  // 0 inertial, 1 friction
     int link;  // inertial: link index
     int pidx;  // inertial: parameter 0..9 ; friction: fkind (0 Fc,1 Fv,2 Fv+,3 Fv-,4 off,5 Fs)
-    int joint; // friction: dof index
+    int joint; // friction: dof index ; inertial: -1, or -2 for the unpaired column of a link with a column mask (see linkmask)
 };
 
 struct FbrHostModel {
@@ -83,10 +83,18 @@ struct FbrHostModel {
     std::vector<int> pdepth;             // per link: packed rows used (last position + 1)
     std::vector<FbrCol> coldesc;         // identified columns
     int maxdepth = 0;
+    // Column masks (internal models of the link-merged / regrouped reductions, fbr_api.hip build_reduction): link l identifies only the
+    // parameters whose bit is set in linkmask[l].  The inertial columns are then laid out as [pairs of columns of one link, link by
+    // link | the unpaired column of every link with an odd count | friction]: every pair sits at an even column in any selection of
+    // whole links (16-byte stores of the grouped TSQR writer).  Without masks: cpl columns per link, link by link.
+    bool masked = false;
+    int ninert = 0;     // inertial columns
+    int npaircols = 0;  // leading inertial columns that form same-link pairs (c, c + 1), c even
+    std::vector<std::vector<int>> linkcols;  // per link: its columns
 
     void build(int L_, int n_, const int32_t *parent_, const int32_t *dof_, const double *restR_, const double *restp_,
                const double *axis_, int floating_, const double *g, int fric_, int fric_sym_, int grav_only_,
-               double stribeck_)
+               double stribeck_, const unsigned short *linkmask = nullptr)
     {
         L = L_; n = n_; floating = floating_ ? 1 : 0; fric = fric_ ? 1 : 0; fric_sym = fric_sym_ ? 1 : 0;
         grav_only = grav_only_ ? 1 : 0; stribeck = stribeck_;
@@ -170,8 +178,39 @@ struct FbrHostModel {
         }
         // identified columns (model.py:134-168, 459-503)
         coldesc.clear();
-        for (int l = 0; l < L; l++)
-            for (int p = 0; p < cpl; p++) coldesc.push_back({0, l, p, -1});
+        linkcols.assign(L, {});
+        masked = linkmask != nullptr;
+        if (!masked) {
+            for (int l = 0; l < L; l++)
+                for (int p = 0; p < cpl; p++) {
+                    linkcols[l].push_back((int)coldesc.size());
+                    coldesc.push_back({0, l, p, -1});
+                }
+            npaircols = (cpl % 2 == 0) ? cpl * L : 0;
+        } else {
+            if (grav_only) throw std::runtime_error("column masks and gravity-only models do not combine");
+            std::vector<int> single(L, -1);
+            for (int l = 0; l < L; l++) {
+                std::vector<int> kept;
+                for (int p = 0; p < 10; p++)
+                    if (linkmask[l] >> p & 1) kept.push_back(p);
+                if (kept.size() & 1) {
+                    single[l] = kept.back();
+                    kept.pop_back();
+                }
+                for (int p : kept) {
+                    linkcols[l].push_back((int)coldesc.size());
+                    coldesc.push_back({0, l, p, -1});
+                }
+            }
+            npaircols = (int)coldesc.size();
+            for (int l = 0; l < L; l++)
+                if (single[l] >= 0) {
+                    linkcols[l].push_back((int)coldesc.size());
+                    coldesc.push_back({0, l, single[l], -2});
+                }
+        }
+        ninert = (int)coldesc.size();
         if (fric) {
             for (int j = 0; j < n; j++) coldesc.push_back({1, -1, 0, j});
             if (!grav_only) {
@@ -291,7 +330,7 @@ struct FbrGramProgram {
         //      A friction column of joint j is a chain column that is non-zero in one packed row only, the position of j
         //      (model.py:459-503): stored like this it shares the positional addressing of the chain tiles and its
         //      products with links that do not hang below j vanish from the pair list.
-        const int F = hm.n > 0 ? (hm.cols - hm.cpl * hm.L) / hm.n : 0;  // friction columns per joint
+        const int F = hm.n > 0 ? (hm.cols - hm.ninert) / hm.n : 0;  // friction columns per joint
         for (int pass = 0; pass < (F > 0 ? 2 : 1); pass++) {
             FbrTile cur;
             int fill = 0;
@@ -305,7 +344,7 @@ struct FbrGramProgram {
             for (size_t oi = 0; oi < hm.order.size(); oi++) {
                 const int l = hm.order[oi];
                 if (pass == 1 && hm.dof[l] < 0) continue;
-                const int ncol = pass == 0 ? hm.cpl : F;
+                const int ncol = pass == 0 ? (int)hm.linkcols[l].size() : F;
                 for (int p = 0; p < ncol; p++) {
                     if (open && (fill == FBR_TILE || !nested(cur.tpath, hm.path[l]))) close();
                     if (!open) {
@@ -323,7 +362,7 @@ struct FbrGramProgram {
                         cur.tpos = hm.ppos[l];
                         cur.depth = hm.pdepth[l];
                     }
-                    cur.col[fill++] = pass == 0 ? hm.cpl * l + p : hm.cpl * hm.L + p * hm.n + hm.dof[l];
+                    cur.col[fill++] = pass == 0 ? hm.linkcols[l][p] : hm.ninert + p * hm.n + hm.dof[l];
                     cur.okey = 2 * (int)oi + pass;
                 }
             }

@@ -1,5 +1,5 @@
-"""Link merging (fbr.h fbr_model_link_merge_info): the reductions run on the moving bodies and expand -- against the unmerged path
-(FBR_NO_LINK_MERGE=1) and the oracle, on robots with chains of fixed links, every base / friction / gravity-only mode, weights, R_in,
+"""Link merging and regrouping (fbr.h fbr_model_link_merge_info): the reductions run on 7 columns per moving body (10 for the base link)
+and expand -- against the unmerged path (FBR_NO_LINK_MERGE=1), the merged-only path (FBR_NO_REGROUP=1) and the oracle, on robots with chains of fixed links, every base / friction / gravity-only mode, weights, R_in,
 accumulation, host and device memory, blocking calls and submissions."""
 import numpy as np
 import pytest
@@ -37,7 +37,9 @@ def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav, monkey
     if grav:  # (m, h) of a fixed link are not combinations of the (m, h) columns of its body alone: nothing merged
         assert info["moving_links"] == t.num_links and info["reduced_cols"] == info["cols"]
     else:
-        assert info["moving_links"] == t.num_links - nfixed and info["reduced_cols"] < info["cols"]
+        # 7 columns per link behind a joint, 10 for the base link: the reductions run on a full-rank set of columns
+        nrev = t.num_links - 1 - nfixed
+        assert info["moving_links"] == t.num_links - nfixed and info["reduced_cols"] == 10 + 7 * nrev + (info["cols"] - 10 * t.num_links)
     for wt in (None, w):
         A = np.hstack([Yo, rhs]) * (1.0 if wt is None else wt[:, None])
         Go = A.T @ A
@@ -48,6 +50,21 @@ def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav, monkey
         Gp = eng.gram(st, rhs=rhs, w=wt)
         Rp = eng.tsqr(st, rhs=rhs, w=wt)
         monkeypatch.delenv("FBR_NO_LINK_MERGE")
+        if not grav:  # fixed links merged, revolute links not regrouped: the middle model, which also takes the short factorisations
+            monkeypatch.setenv("FBR_NO_REGROUP", "1")
+            assert eng.link_merge_info()["reduced_cols"] == 10 * (t.num_links - nfixed) + (info["cols"] - 10 * t.num_links)
+            Gm = eng.gram(st, rhs=rhs, w=wt)
+            Rm = eng.tsqr(st, rhs=rhs, w=wt)
+            monkeypatch.delenv("FBR_NO_REGROUP")
+            assert _rel(Gm, Go) <= 1e-12 and _rel(Rm.T @ Rm, Go) <= 1e-12
+            # the regrouped model's factorisation by row groups at this size, with both writers
+            monkeypatch.setenv("FBR_TSQR_GROUP_MIN_SAMPLES", "1")
+            for writer in ("FBR_TSQR_WRITER8", "FBR_TSQR_WRITER16"):
+                monkeypatch.setenv(writer, "1")
+                Rg = eng.tsqr(st, rhs=rhs, w=wt)
+                monkeypatch.delenv(writer)
+                assert _rel(Rg.T @ Rg, Go) <= 1e-12 and np.all(np.tril(Rg, -1) == 0), writer
+            monkeypatch.delenv("FBR_TSQR_GROUP_MIN_SAMPLES")
         assert _rel(G, Go) <= 1e-12 and _rel(Gp, Go) <= 1e-12 and _rel(G, Gp) <= 1e-13
         assert np.array_equal(G, G.T)
         assert np.all(np.tril(R, -1) == 0)
@@ -78,7 +95,7 @@ def test_walkman_merged_submissions_are_bitwise_the_blocking_result():
     t = load_topo("walkman_apriori")
     eng = Engine(t, floating=True)
     info = eng.link_merge_info()
-    assert (info["links"], info["moving_links"], info["cols"], info["reduced_cols"]) == (48, 30, 480, 300)
+    assert (info["links"], info["moving_links"], info["cols"], info["reduced_cols"]) == (48, 30, 480, 213)  # 10 + 29 x 7: the rank of the regressor
     eng.use_torch_stream()
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(5)
