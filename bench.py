@@ -511,6 +511,12 @@ def run_rank(args) -> int:
             # which engine ran the steps: the HIP library unless a test injected a stand-in with --engine (then this names it)
             "engine": f"{type(eng).__module__}.{type(eng).__qualname__}" + (f" (injected with --engine {args.engine})" if args.engine else ""),
             "serialisation": "links / DOFs in iDynTree traversal order (tests/golden/reference_joint_orders.json)",
+            # the columns the reductions run on (fbr.h fbr_model_link_merge_info): fixed links merged into the bodies they ride on,
+            # the three joint-invariant parameters of every link behind a revolute joint regrouped into the parent body -- exact,
+            # constant column dependencies; the (P+1)^2 Gram of ALL columns is expanded from the reduced one inside the timed step
+            "reduction": (lambda li: f"{li['cols']} columns reduced over {li['reduced_cols']} ({li['links']} links, {li['moving_links']} moving bodies); "
+                                     "G = E^T G_red E expanded on the device every step; FBR_NO_LINK_MERGE=1 runs all columns")(eng.link_merge_info())
+                         if hasattr(eng, "link_merge_info") else "none",
         },
         # `value` is the rate with the inputs resident in HBM (the bench contract: timed steps bracketed by barriers; ms_per_step is
         # that region).  SURVEY 8(d) words the metric "incl. H2D of states": that rate is `value_incl_h2d` below (N = 1), measured on
@@ -536,7 +542,8 @@ def run_rank(args) -> int:
             # SURVEY 8(d) contract figure: dense-symmetric algorithmic flop / launch time / peak.  > 1 is possible and expected: the
             # kernel skips the structurally zero k-steps, so this is NOT a hardware utilisation (`frac` is)
             "contract_frac_dense": (alg_flop_per_sample * samples_per_launch / avg_launch_s / 1e12 / PEAK_FP64_MFMA_TFLOPS) if avg_launch_s > 0 else 0.0,
-            "contract_frac_dense_note": ">1: structural zeros skipped; executed fraction is `frac`",
+            "contract_frac_dense_note": ">1: structural zeros skipped and, since round 4, linearly dependent columns not recomputed (config.reduction); "
+                                        "executed fraction is `frac`",
             "avg_launch_ms": avg_launch_s * 1e3,
             "launches": gram_n,
             "samples_per_launch": samples_per_launch,
@@ -614,9 +621,10 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
         "executed_TFLOP_per_s": executed_flop / dt / 1e12,
         "executed_frac_of_fp64_mfma_peak": executed_flop / dt / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world),
         "dense_model_TFLOP_per_s": dense_flop / dt / 1e12,
-        "flop_models": "executed: 2048 flop x MFMAs the folds run (fbr_tsqr_work_info: rows grouped along the kinematic tree, every group "
-                       "factorised over the columns it can touch, blocks folded from their first supported column); dense: 2*rows*(P+k)^2 per "
-                       "sample (SURVEY 8d)",
+        "flop_models": "executed: 2048 flop x MFMAs the folds run (fbr_tsqr_work_info: the factorisation of the reduced column set -- "
+                       "config.reduction --, rows grouped along the kinematic tree, every group factorised over the columns it can touch, "
+                       "blocks folded from their first supported column, plus the merge that expands R_red E into the factor of all columns); "
+                       "dense: 2*rows*(P+k)^2 per sample (SURVEY 8d)",
         "rank_tree_levels": merges, "relerr_RtR_vs_allreduced_gram": err,
         # device time per class on the call's own stream: `tree` = merge tree of the main row group (the latency-bound tail of a call:
         # 8 levels over 256 private factors, a handful of workgroups each), `tsqr` = the level-0 folds + the embedded group factors

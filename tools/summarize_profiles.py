@@ -112,7 +112,7 @@ if os.path.exists(tr):
         if "fbr_gram_kernel" in r["Kernel_Name"]:
             gl.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 full = [x for x in gl if x > 0.8 * statistics.median(gl)] if gl else []
-gram_line = (f"`fbr_gram_kernel`: {len(gl)} launches in the bench command, {len(full)} of them full-size (62 500 samples): median {statistics.median(full):.3f} ms, "
+gram_line = (f"`fbr_gram_kernel`: {len(gl)} launches in the bench command, {len(full)} of them full-size ({bench['roofline']['samples_per_launch']:.0f} samples): median {statistics.median(full):.3f} ms, "
              f"mean {statistics.mean(full):.3f} ms (the bench's HIP events: {bench['roofline']['avg_launch_ms']:.3f} ms over the timed steps)") if full else ""
 
 # ---- profiles/README.md is GENERATED here (numbers cannot go stale)
@@ -150,7 +150,8 @@ if splits:
 lines += [
     "* `r02_coissue_probe.txt` – `tools/coissue_probe.hip`: fp64 VALU beside fp64 MFMA on one SIMD (they share the DP pipe)",
     "* `r02_tsqr_timing.txt` – `FBR_TSQR_TIMING=1 tools/tsqr_timing_probe.py`: per-phase cycles of the wide TSQR fold",
-    "* `r03b_*` – round 3; `r02a/b/c_*` – round 2 (before / after the link-depth column order / with the tree-structured TSQR); `r01n_*`, `r01_mfma_f64_peak.txt` – round 1",
+    "* `r04_*` – this round BEFORE the column reductions (all 480 columns: 12.7 M samples/s on that box, Gram kernel 0.41, TSQR 160.6 ms); "
+    "`r03b_*` – round 3; `r02a/b/c_*` – round 2 (before / after the link-depth column order / with the tree-structured TSQR); `r01n_*`, `r01_mfma_f64_peak.txt` – round 1",
     "",
 ]
 open(os.path.join(dst, "README.md"), "w").write("\n".join(lines))
