@@ -138,8 +138,22 @@ lines = [
     f"* `{tag}_gram_pmc_traffic.json` – HBM-side bytes per sample of the Gram kernel (FETCH_SIZE × 2 on gfx950, MI355X_MICROARCH.md)"
     + (f": {traffic / 1024:.0f} KB; read by bench.py for `roofline.traffic`" if traffic else ""),
     f"* `{tag}_tsqr_pmc.json`, `{tag}_tsqr_kernel_stats.csv` – the same counter sets and the kernel trace of `tools/tsqr_pmc_probe.py` "
-    "(WALK-MAN 150 k samples × 481 columns, left arm 500 k × 91)",
+    "(WALK-MAN 150 k samples × 481 columns -- factorised over the regrouped 214 --, left arm 500 k × 91)",
 ]
+# executed-MFMA model of the TSQR (fbr_tsqr_work_info, what bench.py's TSQR fractions are computed from) against the PMC count of the same calls
+try:
+    import ast
+    wi_sum = 0
+    for l in open(os.path.join(src, "tsqr_pmc_stdout.txt")):
+        if "'mfma_level0'" in l:
+            dct = ast.literal_eval(l[l.index("{"):].strip())
+            wi_sum += dct["mfma_level0"] + dct["mfma_tree"]
+    mops_sum = sum(v["per_launch"] * v["launches"] for v in tpmc.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).values())
+    if wi_sum and mops_sum:
+        lines.append(f"  - executed-MFMA model against the counters: `fbr_tsqr_work_info` of the two probe calls {wi_sum} MFMAs, "
+                     f"`SQ_INSTS_VALU_MFMA_MOPS_F64` / 4 summed over their kernels {mops_sum / 4:.0f} (ratio {mops_sum / 4 / wi_sum:.4f})")
+except Exception as e:  # noqa: BLE001
+    print("tsqr work-info check skipped:", e)
 if splits:
     for name, what in (("tsqr_full", "1 M samples"), ("tsqr_shard", "125 k samples (one rank's share at 8 GPUs)")):
         if name in splits:
