@@ -93,6 +93,9 @@ struct GramHolder {
     DevGram dev;
     std::vector<DevBuf> pool;
     DevBuf pimg[2];           // packed tile images of one chunk of samples, double buffered (zeroed when (re)allocated)
+    bool moments = false;     // the rhs columns have no tiles: their products come from the pack kernel (fbr_gram_rhs_moments)
+    DevBuf mom[2];            // [pack workgroups][256][4] partial rhs moments of a call, by ticket parity
+    const int *itemcol = nullptr;  // [256] regressor column of pack thread t (-1: none)
     size_t lds_bytes = 0;     // streaming Gram kernel
     size_t pack_lds_bytes = 0;
     struct Deal { const int2 *tab; const int *begin; };
@@ -1089,16 +1092,18 @@ extern "C" int fbr_contact_torques(fbr_model *m, const fbr_states *st, int32_t l
 // ------------------------------------------------------------------------------------------------
 // fused Gram
 // ------------------------------------------------------------------------------------------------
-static int get_gram(fbr_model *m, int k, GramHolder **out)
+static int get_gram(fbr_model *m, int k, GramHolder **out, bool moments = false)
 {
-    auto it = m->gram.find(k);
+    const int key = k + (moments ? 64 : 0);
+    auto it = m->gram.find(key);
     if (it != m->gram.end()) {
         *out = it->second.get();
         return FBR_OK;
     }
     std::unique_ptr<GramHolder> h(new GramHolder());
+    h->moments = moments;
     try {
-        fbr_gram_build_best(h->prog, m->hm, k, getenv("FBR_GRAM_SHAPE"));  // "one" / "two": force a kernel shape
+        fbr_gram_build_best(h->prog, m->hm, k, getenv("FBR_GRAM_SHAPE"), !moments);  // "one" / "two": force a kernel shape
     } catch (const std::exception &e) {
         set_err(std::string("gram program: ") + e.what());
         return FBR_E_INVALID;
@@ -1187,6 +1192,17 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
     if ((rc = upload(h->pool, ridl, &dg.ridl))) return rc;
     if ((rc = upload(h->pool, slot_tiles, &dg.slot_tiles))) return rc;
     if ((rc = upload(h->pool, tilecol, &dg.tilecol))) return rc;
+    if (moments) {
+        std::vector<int> itemcol(256, -1);
+        for (size_t i = 0; i < gp.items.size() && i < 256; i++) {
+            const int off = gp.items[i].off;
+            for (int t = 0; t < gp.NT; t++) {  // (a friction item's offset points at the image row of its joint)
+                const int end = t + 1 < gp.NT ? gp.tiles[t + 1].off : gp.image_doubles;
+                if (off >= gp.tiles[t].off && off < end) itemcol[i] = gp.tiles[t].col[(off - gp.tiles[t].off) % FBR_TILE];
+            }
+        }
+        if ((rc = upload(h->pool, itemcol, &h->itemcol))) return rc;
+    }
     size_t max_pieces = 0;
     for (auto &v : gp.pieces) max_pieces = std::max(max_pieces, v.size());
     h->lds_bytes = (size_t)2 * gp.part_image_max * sizeof(double) +
@@ -1201,7 +1217,7 @@ static int get_gram(fbr_model *m, int k, GramHolder **out)
         return FBR_E_UNSUPPORTED;
     }
     *out = h.get();
-    m->gram[k] = std::move(h);
+    m->gram[key] = std::move(h);
     return FBR_OK;
 }
 
@@ -1216,7 +1232,7 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int32_t *nu
     if (int rc_enter = enter(m)) return rc_enter;
     if (const int wr = pick_gram_reduction(m); wr >= 0) m = m->rdm[wr].get();  // what fbr_gram_accumulate runs: the program of the reduced model
     GramHolder *h = nullptr;
-    int rc = get_gram(m, k, &h);
+    int rc = get_gram(m, k, &h, fbr_gram_rhs_moments(m->hm, k));  // (what fbr_gram_accumulate / fbr_gram_submit run)
     if (rc) return rc;
     if (num_tiles) *num_tiles = h->prog.NT;
     if (num_pairs) *num_pairs = (int32_t)h->prog.pairs.size();
@@ -1328,7 +1344,10 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
         return gram_via_tsqr(m, st, rhs, k, w, G_out, out_mem, accumulate);
     }
     GramHolder *h = nullptr;
-    if ((rc = get_gram(m, k, &h))) return rc;
+    // few rhs columns: their products come from the pack kernel instead of a dense tile (one Gram per call only: a pack workgroup's
+    // samples straddle the groups of a grouped launch)
+    const bool moments = ngroups == 1 && fbr_gram_rhs_moments(hm, k) && !getenv("FBR_GRAM_TIMING");
+    if ((rc = get_gram(m, k, &h, moments))) return rc;
     const int Pa = h->prog.Pa;
     const size_t gcount = (size_t)Pa * Pa * ngroups;
     const long S = d.S;
@@ -1512,13 +1531,19 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
                 hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs, cs / items[ci].ng,
                                    m->rec2.as<double>(), dc.dq + o * hm.n, dc.sign ? dc.sign + o * hm.n : nullptr,
                                    crhs ? crhs + (size_t)o * hm.rows * k : nullptr, cw ? cw + (size_t)o * hm.rows : nullptr,
-                                   h->pimg[b].as<double>(), base_only ? 1 : 0);
+                                   h->pimg[b].as<double>(), base_only ? 1 : 0, moments ? h->mom[(int)(m->next_ticket & 1)].as<double>() : nullptr);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(m->ev_pack[b], side));
             m->ev_pack_rec[b] = true;
             return FBR_OK;
         };
+        const int mpar = (int)(m->next_ticket & 1);
+        const int pack_blocks_max = m->num_cus * 8;
+        if (moments) {
+            if ((rc = h->mom[mpar].ensure((size_t)pack_blocks_max * 256 * 4 * sizeof(double)))) return rc;
+            HIPCHK(hipMemsetAsync(h->mom[mpar].p, 0, (size_t)pack_blocks_max * 256 * 4 * sizeof(double), side));
+        }
         if ((rc = produce(0))) return rc;
         for (long ci = 0; ci < nchunks; ci++) {
             const long cs = items[ci].cs;
@@ -1588,6 +1613,12 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
                 hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(T * FBR_WPB * FBR_NPW, ng), dim3(256), 0, m->stream, dg,
                                    m->partial.as<double>(), G + (size_t)items[ci].g0 * Pa * Pa);
             }
+            HIPCHK(hipGetLastError());
+        }
+        if (moments) {  // (the main stream has waited for the last pack launch before its last Gram launch)
+            ProfScope ps(m, FBR_PROF_REDUCE);
+            hipLaunchKernelGGL(fbr_gram_mom_reduce_kernel, dim3(256), dim3(256), 0, m->stream, hm.cols, k, pack_blocks_max, h->itemcol,
+                               h->mom[mpar].as<double>(), G);
             HIPCHK(hipGetLastError());
         }
         if (!async) {

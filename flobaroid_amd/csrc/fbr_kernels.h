@@ -690,12 +690,17 @@ __device__ __forceinline__ double fbr_stage_load(const FbrStage &sg, int i, long
 // base position of row r of a sample: even sample -> r of its own image; odd sample -> r < 2: 6 + r of its partner's image (written
 // from this workgroup), else 2 + r of its own.  Dense tiles use the same base rows, joint row j at fbp + j.  The Gram kernel skips
 // k-step 0 of the chain tiles of odd samples.  Sg = samples per group of this launch (pairs never straddle groups).
-// (256, 8): at most 64 VGPRs, two pack waves fit beside the Gram waves of a SIMD.
-__global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m, long S, long Sg, const double *__restrict__ rec,
+// (256, 7): at most 72 VGPRs, two pack waves fit beside the two 173-VGPR Gram waves of a SIMD (2 x 176 + 2 x 72 <= 512); the rhs
+// moments spill under 64.
+__global__ __launch_bounds__(256, 7) void fbr_pack_kernel(DevGram g, DevModel m, long S, long Sg, const double *__restrict__ rec,
                                                         const double *__restrict__ dq, const double *__restrict__ sign,
                                                         const double *__restrict__ rhs, const double *__restrict__ wts,
-                                                        double *__restrict__ pimg, int base_only)
+                                                        double *__restrict__ pimg, int base_only, double *__restrict__ mom)
 {
+    // mom (optional, g.k <= 2 and one work item per thread): the rhs columns have no tiles; this thread's column c accumulates
+    // sum_rows Y[r][c] rhs[r][i] over the samples of the workgroup (every entry is in a register when it is stored), thread 255
+    // rhs^T rhs -- mom[block][256][4]: [0..1] this thread's column against rhs 0 / 1 ; thread 255: [0] r0.r0, [1] r0.r1, [2] r1.r1
+    double macc[3] = {0.0, 0.0, 0.0};
     // base_only: the row weights switch every joint row off (base-wrench-only identification): their image rows are neither computed nor
     // written, the Gram kernel does not run their k-steps (DevGram::ks_limit)
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -729,12 +734,29 @@ __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m,
         // packed base position of base row r and the image it goes to
         auto bpos = [&](int r) { return odd ? (r < 2 ? 6 + r : 2 + r) : r; };
         auto bimg = [&](int r) { return (odd && r < 2) ? img - g.image_doubles : img; };
+        // weighted rhs entry (row r, rhs column i) of this sample
+        auto rw = [&](int r, int i) { return ws ? rs[sg.o_rhs + r * g.k + i] * ws[r] : rs[sg.o_rhs + r * g.k + i]; };
+        if (mom && tid == 255) {
+            for (int r = 0; r < (base_only ? m.fb : m.rows); r++) {
+                const double a = rw(r, 0), b = g.k > 1 ? rw(r, 1) : 0.0;
+                macc[0] += a * a;
+                macc[1] += a * b;
+                macc[2] += b * b;
+            }
+        }
         for (int it = tid; it < g.nitems; it += 256) {
             const int4 d = g.items[it];
             if (d.y == 0) {
                 double w6[6];
                 fbr_unit_wrench(rs + FBR_LINK_REC * d.z, d.w, w6);
-                for (int r = 0; r < m.fb; r++) bimg(r)[d.x + bpos(r) * FBR_TILE] = ws ? w6[r] * ws[r] : w6[r];
+                for (int r = 0; r < m.fb; r++) {
+                    const double v = ws ? w6[r] * ws[r] : w6[r];
+                    bimg(r)[d.x + bpos(r) * FBR_TILE] = v;
+                    if (mom) {
+                        macc[0] += v * rw(r, 0);
+                        if (g.k > 1) macc[1] += v * rw(r, 1);
+                    }
+                }
                 if (m.fb && !odd && !partner) img[d.x + 6 * FBR_TILE] = img[d.x + 7 * FBR_TILE] = 0.0;  // no partner: clear stale ghost rows
                 const int len = base_only ? 0 : plen[d.z];
                 for (int j = 0; j < len; j++) {
@@ -742,6 +764,10 @@ __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m,
                     double v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd, w6);
                     if (ws) v *= ws[m.fb + dd];
                     img[d.x + ppos[d.z * m.maxd + j] * FBR_TILE] = v;
+                    if (mom) {
+                        macc[0] += v * rw(m.fb + dd, 0);
+                        if (g.k > 1) macc[1] += v * rw(m.fb + dd, 1);
+                    }
                 }
             } else if (d.y == 1) {
                 if (base_only) continue;
@@ -749,6 +775,10 @@ __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m,
                 double v = fbr_friction_value(d.w, rs[sg.o_dq + d.z], sign ? rs[sg.o_sign + d.z] : 0.0, m.stribeck);
                 if (ws) v *= ws[r];
                 img[d.x] = v;  // d.x points at the packed row of the joint
+                if (mom) {
+                    macc[0] += v * rw(r, 0);
+                    if (g.k > 1) macc[1] += v * rw(r, 1);
+                }
             } else {
                 for (int r = 0; r < (base_only ? m.fb : m.rows); r++) {
                     double v = rs[sg.o_rhs + r * g.k + d.z];
@@ -764,6 +794,47 @@ __global__ __launch_bounds__(256, 8) void fbr_pack_kernel(DevGram g, DevModel m,
                 if (m.fb && !odd && !partner) img[d.x + 6 * FBR_TILE] = img[d.x + 7 * FBR_TILE] = 0.0;
             }
         }
+    }
+    if (mom) {  // (+=: the chunks of a call launch the same grid one after the other; zeroed once per call)
+        double *mo = mom + ((long)blockIdx.x * 256 + tid) * 4;
+        mo[0] += macc[0];
+        mo[1] += macc[1];
+        mo[2] += macc[2];
+    }
+}
+
+// rhs moments of a call -> G.  Workgroup t = pack thread t (its column itemcol[t], or -1; t = 255: rhs^T rhs): the partial sums of the
+// pack workgroups are added in a fixed order (thread j takes workgroups j, j + 256, ..., then a tree over the threads): deterministic.
+__global__ __launch_bounds__(256) void fbr_gram_mom_reduce_kernel(int P, int k, int nblocks, const int *__restrict__ itemcol,
+                                                                  const double *__restrict__ mom, double *__restrict__ G)
+{
+    __shared__ double red[3][256];
+    const int Pa = P + k, t = blockIdx.x, j = threadIdx.x;
+    const int c = itemcol[t];
+    if (c < 0 && t != 255) return;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = j; b < nblocks; b += 256)
+        for (int i = 0; i < 3; i++) s[i] += mom[((long)b * 256 + t) * 4 + i];
+    for (int i = 0; i < 3; i++) red[i][j] = s[i];
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (j < h)
+            for (int i = 0; i < 3; i++) red[i][j] += red[i][j + h];
+        __syncthreads();
+    }
+    if (j != 0) return;
+    if (t == 255) {
+        G[(long)P * Pa + P] += red[0][0];
+        if (k > 1) {
+            G[(long)P * Pa + P + 1] += red[1][0];
+            G[(long)(P + 1) * Pa + P] += red[1][0];
+            G[(long)(P + 1) * Pa + P + 1] += red[2][0];
+        }
+        return;
+    }
+    for (int i = 0; i < k; i++) {
+        G[(long)c * Pa + P + i] += red[i][0];
+        G[(long)(P + i) * Pa + c] += red[i][0];
     }
 }
 

@@ -306,6 +306,10 @@ struct FbrGramProgram {
     }
 
     FbrGramConfig cfg = FBR_CFG_TWO_PER_CU;
+    // false: the rhs columns get no tiles -- their products Y^T rhs, rhs^T rhs are accumulated by the pack kernel, which holds every
+    // regressor entry in a register anyway (fbr_gram_rhs_moments): a dense tile for ONE rhs column costs a full tile's MFMAs against
+    // every other tile (the regrouped WALK-MAN: 64 of 336 MFMAs per sample).  Pa, the stride of G, counts the rhs columns either way.
+    bool rhs_tiles = true;
     int block_edge = 0;  // > 0: edge of the square blocks in which the pair triangle is enumerated (fbr_gram_build_best tries several)
     double total_cost() const
     {
@@ -442,7 +446,7 @@ struct FbrGramProgram {
         // ---- dense tiles: rhs columns, all rows in regressor order
         {
             int c = hm.cols;
-            while (c < Pa) {
+            while (c < Pa && rhs_tiles) {
                 FbrTile t;
                 t.type = 1;
                 t.depth = hm.fbp + hm.n;  // base rows in the packed order of the chain tiles, then the joint rows
@@ -751,8 +755,15 @@ static inline std::vector<int> fbr_gram_deal(const FbrGramProgram &gp, int slots
 }
 
 // Program for the shape that suits the model: small images / two workgroups per CU unless that splits the pairs into too many parts.
-static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &hm, int k, const char *force = nullptr)
+// few rhs columns (the reference's one: tau) and one pack thread per column: their moments come from the pack kernel
+static inline bool fbr_gram_rhs_moments(const FbrHostModel &hm, int k)
 {
+    return k >= 1 && k <= 2 && hm.cols <= 255 && !getenv("FBR_GRAM_RHS_TILE");
+}
+
+static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &hm, int k, const char *force = nullptr, bool rhs_tiles = true)
+{
+    gp.rhs_tiles = rhs_tiles;
     FbrGramConfig two = FBR_CFG_TWO_PER_CU, one = FBR_CFG_ONE_PER_CU;
     if (const char *e = getenv("FBR_GRAM_COST")) {  // experiments: "c0,cload,cmfma,cimg" of the two-per-CU shape [; same for one]
         sscanf(e, "%lf,%lf,%lf,%lf;%lf,%lf,%lf,%lf", &two.c0, &two.cload, &two.cmfma, &two.cimg, &one.c0, &one.cload, &one.cmfma, &one.cimg);

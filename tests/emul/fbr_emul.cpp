@@ -156,9 +156,13 @@ int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const 
 // 0: the product's choice (fbr_gram_build_best), 1: force the one-workgroup-per-CU shape, 2: force the two-per-CU shape
 static int g_shape = 0;
 void emul_set_gram_shape(int shape) { g_shape = shape; }
+// 1: few rhs columns get no tiles, their products are accumulated where the image is packed (fbr_gram_rhs_moments: what
+// fbr_gram_accumulate runs for k <= 2); 0: dense rhs tiles whatever k
+static int g_moments = 0;
+void emul_set_rhs_moments(int on) { g_moments = on; }
 static void build_program(FbrGramProgram &gp, const FbrHostModel &hm, int k)
 {
-    fbr_gram_build_best(gp, hm, k, g_shape == 1 ? "one" : g_shape == 2 ? "two" : nullptr);
+    fbr_gram_build_best(gp, hm, k, g_shape == 1 ? "one" : g_shape == 2 ? "two" : nullptr, !(g_moments && fbr_gram_rhs_moments(hm, k)));
 }
 
 int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma, int *T, int *image_doubles,
@@ -270,6 +274,10 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
     // pack kernel: the images of all samples first (an odd sample writes its base rows into its partner's image); every image
     // starts as garbage where the kernel never writes and never reads ... except the structural zeros, which are zero
     std::vector<double> imgs((size_t)S * gp.image_doubles, 0.0);
+    // rhs moments (mirror of the pack kernel's `mom`): per work item its column's products with the rhs columns, and rhs^T rhs
+    const bool moments = !gp.rhs_tiles;
+    std::vector<double> mom(gp.items.size() * 2, 0.0);
+    double mtt[3] = {0, 0, 0};
     for (long s = 0; s < S; s++) {
         kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr,
                    hm.floating ? ba + 6 * s : nullptr, hm.floating ? rpy + 3 * s : nullptr, rec.data());
@@ -286,15 +294,30 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
             if (it.kind == 2 && hm.fb)
                 for (int r = 0; r < 8; r++) img[it.off + r * FBR_TILE] = 1e300;
         }
-        for (const FbrItem &it : gp.items) {
+        auto rw = [&](int r, int i) { return rhs[((size_t)s * hm.rows + r) * k + i] * (ws ? ws[r] : 1.0); };
+        if (moments)
+            for (int r = 0; r < hm.rows; r++) {
+                const double a = rw(r, 0), b = k > 1 ? rw(r, 1) : 0.0;
+                mtt[0] += a * a; mtt[1] += a * b; mtt[2] += b * b;
+            }
+        for (size_t ii = 0; ii < gp.items.size(); ii++) {
+            const FbrItem &it = gp.items[ii];
+            auto note = [&](double v, int r) {
+                if (moments)
+                    for (int i = 0; i < k; i++) mom[2 * ii + i] += v * rw(r, i);
+            };
             if (it.kind == 0) {
                 double w6[6];
                 fbr_unit_wrench(&rec[21 * it.a], it.b, w6);
-                for (int r = 0; r < hm.fb; r++) bimg(r)[it.off + bpos(r) * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
+                for (int r = 0; r < hm.fb; r++) {
+                    bimg(r)[it.off + bpos(r) * FBR_TILE] = w6[r] * (ws ? ws[r] : 1.0);
+                    note(w6[r] * (ws ? ws[r] : 1.0), r);
+                }
                 if (hm.fb && !odd && !partner) img[it.off + 6 * FBR_TILE] = img[it.off + 7 * FBR_TILE] = 0.0;
                 int j = 0;
                 for (int d : hm.path[it.a]) {
                     img[it.off + hm.ppos[it.a][j] * FBR_TILE] = fbr_dot6(&rec[21 * hm.L + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
+                    note(img[it.off + hm.ppos[it.a][j] * FBR_TILE], hm.fb + d);
                     j++;
                 }
             } else if (it.kind == 1) {
@@ -302,6 +325,7 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                 img[it.off] =
                     fbr_friction_value(it.b, dq[s * hm.n + it.a], sign ? sign[s * hm.n + it.a] : 0.0, hm.stribeck) *
                     (ws ? ws[r] : 1.0);
+                note(img[it.off], r);
             } else {
                 for (int r = 0; r < hm.rows; r++) {
                     const double v = rhs[((size_t)s * hm.rows + r) * k + it.a] * (ws ? ws[r] : 1.0);
@@ -379,6 +403,27 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                         if (p.I != p.J) G[(size_t)cj * Pa + ci] += v;
                     }
             }
+    if (moments) {  // mirror of fbr_gram_mom_reduce_kernel
+        const int P = hm.cols;
+        for (size_t ii = 0; ii < gp.items.size(); ii++) {
+            int c = -1;
+            for (int t2 = 0; t2 < gp.NT; t2++) {
+                const int end = t2 + 1 < gp.NT ? gp.tiles[t2 + 1].off : gp.image_doubles;
+                if (gp.items[ii].off >= gp.tiles[t2].off && gp.items[ii].off < end) c = gp.tiles[t2].col[(gp.items[ii].off - gp.tiles[t2].off) % FBR_TILE];
+            }
+            if (c < 0) return -9;
+            for (int i = 0; i < k; i++) {
+                G[(size_t)c * Pa + P + i] += mom[2 * ii + i];
+                G[(size_t)(P + i) * Pa + c] += mom[2 * ii + i];
+            }
+        }
+        G[(size_t)P * Pa + P] += mtt[0];
+        if (k > 1) {
+            G[(size_t)P * Pa + P + 1] += mtt[1];
+            G[(size_t)(P + 1) * Pa + P] += mtt[1];
+            G[(size_t)(P + 1) * Pa + P + 1] += mtt[2];
+        }
+    }
     return 0;
 }
 }

@@ -110,3 +110,28 @@ def test_random_trees(seed, L, branch, floating, fric, sym, shape, request):
     A = np.hstack([Y, rhs])
     G = em.gram(st, rhs, sign, None)
     assert np.linalg.norm(G - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=cfg_id)
+@pytest.mark.parametrize("k", [1, 2])
+def test_rhs_moments_from_the_packer_reproduce_gram(cfg, k, request):
+    """Few rhs columns (the reference's one: tau) get no dense tile: Y^T rhs and rhs^T rhs are accumulated where the image is packed
+    (fbr_gram_rhs_moments -- what fbr_gram_accumulate runs for k <= 2 and at most 255 columns), with row weights, odd sample counts
+    (the last sample has no partner) and every kernel shape's tile program built WITHOUT rhs tiles."""
+    import emul_lib
+    emul_lib.lib().emul_set_rhs_moments(1)
+    request.addfinalizer(lambda: emul_lib.lib().emul_set_rhs_moments(0))
+    t, om, em, st, sign, rng = _setup(cfg, 11, 5)
+    Y = om.regressor(st, sign)
+    rhs = rng.standard_normal((Y.shape[0], k))
+    w = rng.random(Y.shape[0]) + 0.5
+    A = np.hstack([Y, rhs]) * w[:, None]
+    G = em.gram(st, rhs, sign, w)
+    assert np.linalg.norm(G - A.T @ A) <= 1e-13 * np.linalg.norm(A.T @ A)
+    assert np.array_equal(G, G.T)
+    if om.P <= 255:
+        emul_lib.lib().emul_set_rhs_moments(0)
+        more = em.program_info(k)
+        emul_lib.lib().emul_set_rhs_moments(1)
+        less = em.program_info(k)
+        assert less["mfma"] < more["mfma"]  # the dense tile's MFMAs are gone
