@@ -877,7 +877,11 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
     mult = max(1, 4_000_000 // S1)
     Rs = eng4.gram(_np_states(topo4, 10000, 99))
     Rs = Rs.cpu().numpy() if hasattr(Rs, "cpu") else Rs
-    Q, RQ, PQ = sla.qr(Rs, pivoting=True, mode="economic")
+    # (the deterministic tie rule of the host layer, model.pivoted_qr: the independent columns -- and with them the cost of this leg, which
+    # depends on WHICH links' columns are factorised -- must not change with the last bits of the Gram)
+    from flobaroid_amd.model import pivoted_qr
+
+    Q, RQ, PQ = pivoted_qr(Rs)
     r = int(np.count_nonzero(np.abs(np.diag(RQ)) > 0.005))
     ic = np.sort(PQ[:r]).astype(np.int32)
     P = eng4.cols

@@ -95,6 +95,7 @@ struct GramHolder {
     DevBuf pimg[2];           // packed tile images of one chunk of samples, double buffered (zeroed when (re)allocated)
     bool moments = false;     // the rhs columns have no tiles: their products come from the pack kernel (fbr_gram_rhs_moments)
     DevBuf mom[2];            // [pack workgroups][256][4] partial rhs moments of a call, by ticket parity
+    bool mom_clean[2] = {false, false};  // the buffer holds zeros (left by the reduction of the call before; false after a failed call)
     const int *itemcol = nullptr;  // [256] regressor column of pack thread t (-1: none)
     size_t lds_bytes = 0;     // streaming Gram kernel
     size_t pack_lds_bytes = 0;
@@ -1541,8 +1542,11 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
         const int mpar = (int)(m->next_ticket & 1);
         const int pack_blocks_max = m->num_cus * 8;
         if (moments) {
-            if ((rc = h->mom[mpar].ensure((size_t)pack_blocks_max * 256 * 4 * sizeof(double)))) return rc;
-            HIPCHK(hipMemsetAsync(h->mom[mpar].p, 0, (size_t)pack_blocks_max * 256 * 4 * sizeof(double), side));
+            const size_t mbytes = (size_t)pack_blocks_max * 256 * 4 * sizeof(double);
+            if (h->mom[mpar].bytes < mbytes) h->mom_clean[mpar] = false;
+            if ((rc = h->mom[mpar].ensure(mbytes))) return rc;
+            if (!h->mom_clean[mpar]) HIPCHK(hipMemsetAsync(h->mom[mpar].p, 0, mbytes, side));
+            h->mom_clean[mpar] = false;  // (until this call's reduction has been enqueued)
         }
         if ((rc = produce(0))) return rc;
         for (long ci = 0; ci < nchunks; ci++) {
@@ -1620,6 +1624,7 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
             hipLaunchKernelGGL(fbr_gram_mom_reduce_kernel, dim3(256), dim3(256), 0, m->stream, hm.cols, k, pack_blocks_max, h->itemcol,
                                h->mom[mpar].as<double>(), G);
             HIPCHK(hipGetLastError());
+            h->mom_clean[mpar] = true;
         }
         if (!async) {
             HIPCHK(hipStreamSynchronize(side));

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256, 7) void fbr_pack_kernel(DevGram g, DevModel m,
             }
         }
     }
-    if (mom) {  // (+=: the chunks of a call launch the same grid one after the other; zeroed once per call)
+    if (mom && (tid < g.nitems || tid == 255)) {  // (+=: the chunks of a call launch one after the other; the reduction leaves zeros behind)
         double *mo = mom + ((long)blockIdx.x * 256 + tid) * 4;
         mo[0] += macc[0];
         mo[1] += macc[1];
@@ -806,15 +806,20 @@ __global__ __launch_bounds__(256, 7) void fbr_pack_kernel(DevGram g, DevModel m,
 // rhs moments of a call -> G.  Workgroup t = pack thread t (its column itemcol[t], or -1; t = 255: rhs^T rhs): the partial sums of the
 // pack workgroups are added in a fixed order (thread j takes workgroups j, j + 256, ..., then a tree over the threads): deterministic.
 __global__ __launch_bounds__(256) void fbr_gram_mom_reduce_kernel(int P, int k, int nblocks, const int *__restrict__ itemcol,
-                                                                  const double *__restrict__ mom, double *__restrict__ G)
+                                                                  double *__restrict__ mom, double *__restrict__ G)
 {
+    // (every partial sum is read by exactly one thread, which puts the zero back: the next call of this parity starts from a clean
+    // buffer without a 17 MB fill -- measured at 0.35 ms per call, more than a whole 50 k-sample KUKA pass)
     __shared__ double red[3][256];
     const int Pa = P + k, t = blockIdx.x, j = threadIdx.x;
     const int c = itemcol[t];
     if (c < 0 && t != 255) return;
     double s[3] = {0.0, 0.0, 0.0};
     for (int b = j; b < nblocks; b += 256)
-        for (int i = 0; i < 3; i++) s[i] += mom[((long)b * 256 + t) * 4 + i];
+        for (int i = 0; i < 3; i++) {
+            s[i] += mom[((long)b * 256 + t) * 4 + i];
+            mom[((long)b * 256 + t) * 4 + i] = 0.0;
+        }
     for (int i = 0; i < 3; i++) red[i][j] = s[i];
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
