@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -310,6 +311,8 @@ struct FbrGramProgram {
     // regressor entry in a register anyway (fbr_gram_rhs_moments): a dense tile for ONE rhs column costs a full tile's MFMAs against
     // every other tile (the regrouped WALK-MAN: 64 of 336 MFMAs per sample).  Pa, the stride of G, counts the rhs columns either way.
     bool rhs_tiles = true;
+    bool orient = false;    // turn chain x chain pairs so that the row segments fill up (build(): orientation); oriented: it was done
+    bool oriented = false;
     int block_edge = 0;  // > 0: edge of the square blocks in which the pair triangle is enumerated (fbr_gram_build_best tries several)
     double total_cost() const
     {
@@ -537,6 +540,90 @@ struct FbrGramProgram {
                         if (p.kmask == 0) continue;  // structurally zero block (fixed base, disjoint branches, friction of other joints)
                         pairs.push_back(p);
                     }
+        // ---- orientation.  Y_I^T Y_J and Y_J^T Y_I hold the same numbers: which of the two tiles of a chain x chain pair is the "row"
+        //      (the A operand, shared by the pairs of a row segment) is free.  Listed as I <= J the rows have NT, NT - 1, ..., 1 pairs and
+        //      cut into segments of SEGW they leave many short ones (15 tiles: 27 segments for 120 pairs, more than the 24 of one
+        //      workgroup: 2 parts).  The pairs are turned so that every row holds a multiple of SEGW pairs (20 full segments: ONE part,
+        //      every image streamed once, twice the MFMAs between two barriers): targets by degree, orientation by augmenting paths.
+        if (orient && !pairs.empty()) {
+            bool ok = true;
+            for (const FbrPair &pr : pairs) ok = ok && pr.mode == 0 && pr.kbegin() == pairs[0].kbegin();
+            const int npq = (int)pairs.size();
+            std::vector<int> deg(NT, 0), target(NT, 0), has_diag(NT, 0);
+            for (const FbrPair &pr : pairs) {
+                deg[pr.I]++;
+                if (pr.J != pr.I) deg[pr.J]++;
+                else has_diag[pr.I] = 1;
+            }
+            int left = npq;
+            if (ok) {
+                // every tile that has pairs gets one segment's worth (or all it can take), the rest goes out in whole segments to the
+                // tiles with the most room, the remainder to one more
+                for (int t = 0; t < NT; t++) {
+                    target[t] = std::min(deg[t], FBR_SEGW);
+                    left -= target[t];
+                }
+                ok = left >= 0;
+                while (ok && left > 0) {
+                    int best = -1;
+                    for (int t = 0; t < NT; t++)
+                        if (deg[t] - target[t] > 0 && (best < 0 || deg[t] - target[t] > deg[best] - target[best])) best = t;
+                    if (best < 0) {
+                        ok = false;
+                        break;
+                    }
+                    const int give = std::min({left, FBR_SEGW, deg[best] - target[best]});
+                    target[best] += give;
+                    left -= give;
+                }
+            }
+            if (ok) {
+                // owner[p]: the tile whose row holds pair p; capacities = targets (a diagonal pair stays where it is)
+                std::vector<int> owner(npq, -1), load(NT, 0);
+                for (int i = 0; i < npq; i++)
+                    if (pairs[i].I == pairs[i].J) {
+                        owner[i] = pairs[i].I;
+                        load[pairs[i].I]++;
+                    }
+                for (int t = 0; t < NT; t++) ok = ok && load[t] <= target[t];
+                // augmenting paths: pair i wants an endpoint with room; a full endpoint may push one of its pairs to that pair's other end
+                std::vector<char> seen;
+                std::function<bool(int)> make_room = [&](int t) -> bool {  // free one unit of capacity at tile t
+                    if (load[t] < target[t]) return true;
+                    if (seen[t]) return false;
+                    seen[t] = 1;
+                    for (int i = 0; i < npq; i++) {
+                        if (owner[i] != t || pairs[i].I == pairs[i].J) continue;
+                        const int other = pairs[i].I == t ? pairs[i].J : pairs[i].I;
+                        if (make_room(other)) {
+                            owner[i] = other;
+                            load[other]++;
+                            load[t]--;
+                            return true;
+                        }
+                    }
+                    return false;
+                };
+                for (int i = 0; i < npq && ok; i++) {
+                    if (owner[i] >= 0) continue;
+                    bool placed = false;
+                    for (int e = 0; e < 2 && !placed; e++) {
+                        const int t = e == 0 ? pairs[i].I : pairs[i].J;
+                        seen.assign(NT, 0);
+                        if (make_room(t)) {
+                            owner[i] = t;
+                            load[t]++;
+                            placed = true;
+                        }
+                    }
+                    ok = placed;
+                }
+                if (ok)
+                    for (int i = 0; i < npq; i++)
+                        if (owner[i] != pairs[i].I) std::swap(pairs[i].I, pairs[i].J);
+            }
+            oriented = ok;
+        }
         // ---- parts: contiguous chunks of the pair list.  Inside a part the pairs are grouped into ROW SEGMENTS
         //      (same tile I, <= SEGW tiles J, sorted by k-steps descending): a wave loads the A fragment of (I, ks)
         //      once and feeds up to SEGW independent accumulators with it.  A part holds <= WPB*NSEG segments, dealt to
@@ -770,7 +857,7 @@ static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &h
     }
     // the order of the pair list decides which tiles a contiguous part touches: a few block edges are tried and the one with
     // the lowest modelled cost kept (WALK-MAN: edge 6 instead of 5 saves one part and 7 % of the image traffic)
-    auto build_shape = [&](const FbrGramConfig &cfg) {
+    auto build_shape_plain = [&](const FbrGramConfig &cfg) {
         gp.block_edge = 0;
         if (const char *e = getenv("FBR_GRAM_BE")) {  // experiments
             gp.block_edge = std::max(1, atoi(e));
@@ -793,6 +880,16 @@ static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &h
             gp.block_edge = best_edge;
             gp.build(hm, k, cfg);
         }
+    };
+    // a program of several parts is also built with its pairs turned for full row segments, and kept when it needs fewer parts
+    auto build_shape = [&](const FbrGramConfig &cfg) {
+        gp.orient = false;
+        build_shape_plain(cfg);
+        if (gp.T <= 1 || getenv("FBR_GRAM_NO_ORIENT")) return;
+        FbrGramProgram keep = gp;
+        gp.orient = true;
+        build_shape_plain(cfg);
+        if (!gp.oriented || gp.T >= keep.T) gp = keep;
     };
     if (force && force[0] == 'o') {  // "one"
         build_shape(one);
