@@ -1647,7 +1647,7 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
 
 // The Gram through the link-merged model (build_reduction): G_red on the moving bodies' columns, then G (+)= E^T G_red E.
 static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out, int32_t out_mem,
-                        int32_t accumulate, int64_t *async_ticket)
+                        int32_t accumulate, int32_t ngroups, int64_t *async_ticket)
 {
     fbr_model *r = m->rdm[which].get();
     const bool async = async_ticket != nullptr;
@@ -1661,11 +1661,15 @@ static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const dou
     r->stream = m->stream;
     r->prof = m->prof;
     const int par = (int)(m->next_ticket & 1), Pa = m->hm.cols + k, Pra = r->hm.cols + k;
-    const size_t cnt = (size_t)Pa * Pa;
-    if ((rc = m->red_out[par].ensure((size_t)Pra * Pra * sizeof(double)))) return rc;
+    if (ngroups < 1 || (async && ngroups != 1)) {
+        set_err("bad number of groups");
+        return FBR_E_INVALID;
+    }
+    const size_t cnt = (size_t)Pa * Pa * ngroups;  // (grouped: one Gram per group of samples, each expanded on its own)
+    if ((rc = m->red_out[par].ensure((size_t)Pra * Pra * ngroups * sizeof(double)))) return rc;
     double *Gred = m->red_out[par].as<double>();
     int64_t tr = -1;
-    if ((rc = gram_impl(r, st, rhs, k, w, Gred, FBR_DEVICE, 0, 1, async ? &tr : nullptr))) return rc;
+    if ((rc = gram_impl(r, st, rhs, k, w, Gred, FBR_DEVICE, 0, ngroups, async ? &tr : nullptr))) return rc;
     double *G = G_out;
     if (out_mem == FBR_HOST) {
         if ((rc = m->g_tmp.ensure(cnt * sizeof(double)))) return rc;
@@ -1673,10 +1677,12 @@ static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const dou
         if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, cnt * sizeof(double), hipMemcpyHostToDevice, m->stream));
     }
     if ((rc = m->red_w.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
-    hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which], m->E_val[which],
-                       Gred, m->red_w.as<double>(), Pa);
-    hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
-                       m->E_val[which], m->red_w.as<double>(), G, accumulate ? 1 : 0);
+    for (int g = 0; g < ngroups; g++) {
+        hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
+                           m->E_val[which], Gred + (size_t)g * Pra * Pra, m->red_w.as<double>(), Pa);
+        hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
+                           m->E_val[which], m->red_w.as<double>(), G + (size_t)g * Pa * Pa, accumulate ? 1 : 0);
+    }
     HIPCHK(hipGetLastError());
     if (async) {
         const int64_t t = m->next_ticket++;
@@ -1694,9 +1700,11 @@ static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const dou
 static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
                      int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket = nullptr)
 {
-    const int which = (m && st && ngroups == 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid()) ? pick_gram_reduction(m) : -1;
+    // (many small groups: two launches per group for the expansion -- worth it while a group's pass is longer than that)
+    const bool grouped_ok = st && (ngroups == 1 || (ngroups >= 1 && st->num_samples / ngroups >= 512 && !getenv("FBR_NO_GROUPED_REDUCTION")));
+    const int which = (m && st && ngroups >= 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && grouped_ok) ? pick_gram_reduction(m) : -1;
     if (which >= 0) {
-        int rc = gram_via_red(m, which, st, rhs, k, w, G_out, out_mem, accumulate, async_ticket);
+        int rc = gram_via_red(m, which, st, rhs, k, w, G_out, out_mem, accumulate, ngroups, async_ticket);
         if (rc && m->stream) {
             const std::string msg = g_err;
             drain_after_failed_submit(m);
