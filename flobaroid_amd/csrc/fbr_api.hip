@@ -1472,6 +1472,11 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
         if (h2d_chunked)
             for (int b = 0; b < (nchunks > 1 ? 2 : 1); b++)
                 if ((rc = m->st_chunk[b].ensure(std::max<size_t>(1, (size_t)ch * stage_per) * sizeof(double)))) return rc;
+        // pack workgroups per CU of a launch's grid (each walks its share of the chunk's samples).  More than are ever resident (7 per CU
+        // alone, 2 beside the Gram kernel): with 8 the workgroups of the last, partial round ran on a half-empty chip at the end of every
+        // launch (measured per 1 M-sample step, two runs each: 8 -> 24.1, 16 -> 23.5 ... 24.0, 24 -> 23.1 ... 23.4, 32 / 48 -> 23.4)
+        static const int pack_wgs_per_cu = getenv("FBR_PACK_WGS_PER_CU") ? std::max(1, atoi(getenv("FBR_PACK_WGS_PER_CU"))) : 24;
+        const int pack_blocks_max = m->num_cus * pack_wgs_per_cu;
         auto produce = [&](long ci) -> int {
             const long s0 = items[ci].s0, cs = items[ci].cs;
             const int b = (int)(ci & 1);
@@ -1528,7 +1533,7 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
             if (rc2) return rc2;
             {
                 ProfScope ps(m, FBR_PROF_PACK, side);
-                const int blocks = (int)std::min<long>(cs, (long)m->num_cus * 8);
+                const int blocks = (int)std::min<long>(cs, (long)pack_blocks_max);
                 hipLaunchKernelGGL(fbr_pack_kernel, dim3(blocks), dim3(256), h->pack_lds_bytes, side, h->dev, m->dm, cs, cs / items[ci].ng,
                                    m->rec2.as<double>(), dc.dq + o * hm.n, dc.sign ? dc.sign + o * hm.n : nullptr,
                                    crhs ? crhs + (size_t)o * hm.rows * k : nullptr, cw ? cw + (size_t)o * hm.rows : nullptr,
@@ -1540,7 +1545,6 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
             return FBR_OK;
         };
         const int mpar = (int)(m->next_ticket & 1);
-        const int pack_blocks_max = m->num_cus * 8;
         if (moments) {
             const size_t mbytes = (size_t)pack_blocks_max * 256 * 4 * sizeof(double);
             if (h->mom[mpar].bytes < mbytes) h->mom_clean[mpar] = false;
