@@ -127,3 +127,32 @@ def test_walkman_merged_submissions_are_bitwise_the_blocking_result():
     assert float(torch.linalg.norm(Gb[0] - Gp)) <= 1e-13 * gn
     assert float(torch.linalg.norm(Rb[0].T @ Rb[0] - Gp)) <= 1e-12 * gn and float(torch.linalg.norm(Rp.T @ Rp - Gp)) <= 1e-12 * gn
     eng.close()
+
+
+def test_walkman_tile_program_of_the_reductions():
+    """What the fused pass of WALK-MAN runs: 213 columns in 15 tiles, tau's products from the packer (no dense tile), the 120
+    tile pairs turned into full row segments -- ONE part; with the switches off, the programs the round started from."""
+    import os
+    from common import load_topo
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo("walkman_apriori")
+
+    def info(env, k=1):
+        for kk, v in env.items():
+            os.environ[kk] = v
+        try:
+            eng = Engine(t, floating=True)
+            out = eng.gram_program_info(k)
+            eng.close()
+        finally:
+            for kk in env:
+                os.environ.pop(kk, None)
+        return out
+
+    assert info({}) == {"tiles": 15, "pairs": 120, "mfma_per_sample": 272, "parts": 1}
+    assert info({"FBR_GRAM_NO_ORIENT": "1"})["parts"] == 2
+    assert info({"FBR_GRAM_RHS_TILE": "1"}) == {"tiles": 16, "pairs": 136, "mfma_per_sample": 336, "parts": 2}
+    assert info({}, k=16)["tiles"] == 16  # many rhs columns keep their dense tile
+    assert info({"FBR_NO_REGROUP": "1", "FBR_GRAM_RHS_TILE": "1"})["mfma_per_sample"] == 537
+    assert info({"FBR_NO_LINK_MERGE": "1", "FBR_GRAM_RHS_TILE": "1"}) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
