@@ -895,7 +895,10 @@ static int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, hipStream
     const int blocks = (int)((cs + threads - 1) / threads);
     ProfScope ps(m, FBR_PROF_KIN, st);
     // (the instance that fits beside the Gram kernel's waves on the producer stream of the fused pass; the uncapped one everywhere else)
-    if (beside_gram && !getenv("FBR_KIN_UNCAPPED"))
+    // (the 96-VGPR instance spills 41 registers and, like the 128-VGPR one, fits ONE wave beside the two Gram waves of a SIMD: since the
+    // column reductions the uncapped instance is the faster one there as well -- kin 5.3 instead of 6.2 ms per 1 M samples, step -1.5 %;
+    // FBR_KIN_CAPPED=1 brings the capped one back)
+    if (beside_gram && getenv("FBR_KIN_CAPPED"))
         hipLaunchKernelGGL(fbr_kin_kernel<FBR_KIN_WAVES>, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n,
                            d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,
                            d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
