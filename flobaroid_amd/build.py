@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libfbr.so")
 SOURCES = ["fbr_api.hip"]
-HEADERS = ["fbr_kernels.h", "fbr_math.h", "fbr_program.h", "fbr_tsqr.h", "fbr_signal.h", os.path.join("..", "..", "include", "fbr.h")]
+HEADERS = ["fbr_kernels.h", "fbr_math.h", "fbr_program.h", "fbr_tsqr.h", "fbr_signal.h", "fbr_reduce.h", os.path.join("..", "..", "include", "fbr.h")]
 
 
 def hipcc_path() -> str:

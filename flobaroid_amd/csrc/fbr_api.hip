@@ -16,6 +16,7 @@
 #include "../../include/fbr.h"
 #include "fbr_kernels.h"
 #include "fbr_tsqr.h"
+#include "fbr_reduce.h"
 #include "fbr_signal.h"
 
 static thread_local std::string g_err;
@@ -448,210 +449,28 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
 extern "C" int fbr_model_create(const fbr_topology *t, int device, fbr_model **out) { return create_model(t, device, out, true); }
 
 // ------------------------------------------------------------------------------------------------
-// Link merging.  A link attached to its parent by a FIXED joint has no kinematics of its own: a rigid body with parameters pi_c given
-// in the link's frame c is the same body with parameters T pi_c in the frame a of the moving body it rides on (x_a = R x_c + r):
-//     m' = m,   h' = R h + m r,   I' = R I R^T + 2 (r . Rh) 1 - (r (Rh)^T + (Rh) r^T) + m (|r|^2 1 - r r^T)
-// (first moment h = m c, inertia about the frame origin -- the reference's parameter convention, model.py:220-231,
-// helpers.py:374-407).  Hence the link's regressor columns are Y_c = Y_a T, for every row and every state: exact column dependencies
-// known from the URDF alone (they are why WALK-MAN's 480 columns have rank 213).  The reductions therefore run on the REDUCED robot --
-// moving bodies only (WALK-MAN: 30 of 48 links, 300 of 480 columns; rest transforms composed across the fixed links) -- and are
-// expanded with the constant E = [T blocks | identity]:  [Y|rhs] = [Y_red|rhs] E^  =>  G = E^T G_red E,  R = qr(R_red E).
-// Same results (to rounding), 0.39 of the column pairs.
+// Column reductions (fbr_reduce.h has the mathematics: fixed links merged into the bodies they ride on, revolute links regrouped, and the
+// constant matrix E with [Y | rhs] = [Y_red | rhs] E).  The reductions run on the REDUCED robot and are expanded at the end of the call:
+// G = E^T G_red E,  R = qr(R_red E).  which = 0: merged (m->rdm[0]); which = 1: merged + regrouped (column masks, m->rdm[1]).
 // ------------------------------------------------------------------------------------------------
-static void fbr_param_transform(const double *R, const double *r, double T[10][10])
-{
-    static const int I0[6] = {0, 0, 0, 1, 1, 2}, I1[6] = {0, 1, 2, 1, 2, 2};
-    for (int p = 0; p < 10; p++) {
-        double pi[10] = {0};
-        pi[p] = 1.0;
-        const double mass = pi[0], *h = pi + 1;
-        double I[3][3];
-        for (int e = 0; e < 6; e++) I[I0[e]][I1[e]] = I[I1[e]][I0[e]] = pi[4 + e];
-        double Rh[3], RI[3][3], Ia[3][3];
-        for (int i = 0; i < 3; i++) Rh[i] = R[3 * i] * h[0] + R[3 * i + 1] * h[1] + R[3 * i + 2] * h[2];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) RI[i][j] = R[3 * i] * I[0][j] + R[3 * i + 1] * I[1][j] + R[3 * i + 2] * I[2][j];
-        const double rRh = r[0] * Rh[0] + r[1] * Rh[1] + r[2] * Rh[2], rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                Ia[i][j] = RI[i][0] * R[3 * j] + RI[i][1] * R[3 * j + 1] + RI[i][2] * R[3 * j + 2];
-                Ia[i][j] += (i == j ? 2.0 * rRh : 0.0) - (r[i] * Rh[j] + Rh[i] * r[j]) + mass * ((i == j ? rr : 0.0) - r[i] * r[j]);
-            }
-        T[0][p] = mass;
-        for (int i = 0; i < 3; i++) T[1 + i][p] = Rh[i] + mass * r[i];
-        for (int e = 0; e < 6; e++) T[4 + e][p] = Ia[I0[e]][I1[e]];
-    }
-}
-
-// rotation Q (row-major) whose third column is the unit vector along a: the frame in which a joint axis is z
-static void fbr_axis_frame(const double *a_in, double *Q)
-{
-    const double na = std::sqrt(a_in[0] * a_in[0] + a_in[1] * a_in[1] + a_in[2] * a_in[2]);
-    double a[3] = {a_in[0] / na, a_in[1] / na, a_in[2] / na};
-    int i = 0;
-    for (int c = 1; c < 3; c++)
-        if (std::fabs(a[c]) < std::fabs(a[i])) i = c;
-    double u[3] = {0, 0, 0};
-    u[i] = 1.0;
-    const double ua = a[i];
-    for (int c = 0; c < 3; c++) u[c] -= ua * a[c];
-    const double nu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    for (int c = 0; c < 3; c++) u[c] /= nu;
-    const double v[3] = {a[1] * u[2] - a[2] * u[1], a[2] * u[0] - a[0] * u[2], a[0] * u[1] - a[1] * u[0]};
-    for (int r = 0; r < 3; r++) {
-        Q[3 * r] = u[r];
-        Q[3 * r + 1] = v[r];
-        Q[3 * r + 2] = a[r];
-    }
-}
-
-// which = 0: fixed links merged into the moving bodies; which = 1: the same, and the three regroupable parameters of every link behind a
-// revolute joint dropped (m->rdm[which], m->E_*[which])
 static int build_reduction(fbr_model *m, const fbr_topology *t, int which)
 {
-    const FbrHostModel &hm = m->hm;
-    const int L = hm.L;
-    const bool regroup = which == 1;
-    int nfixed = 0, nrev = 0;
-    for (int l = 0; l < L; l++) {
-        nfixed += hm.parent[l] >= 0 && hm.dof[l] < 0;
-        nrev += hm.parent[l] >= 0 && hm.dof[l] >= 0;
-    }
-    if (regroup ? nrev == 0 : nfixed == 0) return FBR_OK;
-    // gravity-only models keep 4 of a link's 10 columns (m, h): the frame change feeds m and h into the INERTIA of the body as well, so
-    // the kept columns of a fixed link are not combinations of the kept columns of its body -- nothing is reduced there
-    if (hm.grav_only) return FBR_OK;
-    // moving bodies in link order; for every link: its body and the constant transform body <- link
-    std::vector<int> red_of(L, -1), body(L, -1), moving;
-    for (int l = 0; l < L; l++)
-        if (hm.parent[l] < 0 || hm.dof[l] >= 0) {
-            red_of[l] = (int)moving.size();
-            moving.push_back(l);
-        }
-    // (regrouping: the frame of a body behind a joint is turned so that the joint axis becomes z, x_link = Q x_body)
-    std::vector<double> Q((size_t)9 * L, 0.0);
-    for (int l = 0; l < L; l++) {
-        for (int i = 0; i < 3; i++) Q[9 * l + 4 * i] = 1.0;
-        if (regroup && hm.parent[l] >= 0 && hm.dof[l] >= 0) fbr_axis_frame(&hm.axis[3 * l], &Q[9 * l]);
-    }
-    std::vector<double> bR((size_t)9 * L), bp((size_t)3 * L);  // x_body = bR x_link + bp
-    for (int l : hm.order) {  // parents first
-        double *R = &bR[9 * l], *p = &bp[3 * l];
-        if (red_of[l] >= 0) {
-            body[l] = l;
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) R[3 * i + j] = Q[9 * l + 3 * j + i];  // Q^T
-            p[0] = p[1] = p[2] = 0.0;
-        } else {
-            const int q = hm.parent[l];
-            body[l] = body[q];
-            const double *Rq = &bR[9 * q], *pq = &bp[3 * q], *Rl = &hm.restR[9 * l], *pl = &hm.restp[3 * l];
-            fbr_mm(Rq, Rl, R);
-            double tmp[3];
-            fbr_mv(Rq, pl, tmp);
-            for (int i = 0; i < 3; i++) p[i] = pq[i] + tmp[i];
-        }
-    }
-    // the reduced robot: a moving link hangs off the body of its parent, its rest transform composed across the fixed links between
-    const int Lr = (int)moving.size();
-    std::vector<int32_t> rparent(Lr), rdof(Lr);
-    std::vector<double> rR((size_t)9 * Lr), rp((size_t)3 * Lr), rax((size_t)3 * Lr);
-    std::vector<unsigned short> masks(Lr, 0x3ff);
-    for (int i = 0; i < Lr; i++) {
-        const int l = moving[i], q = hm.parent[l];
-        rdof[i] = hm.dof[l];
-        if (q < 0) {
-            rparent[i] = -1;
-            for (int c = 0; c < 9; c++) rR[9 * i + c] = hm.restR[9 * l + c];
-            for (int c = 0; c < 3; c++) rp[3 * i + c] = hm.restp[3 * l + c];
-            for (int c = 0; c < 3; c++) rax[3 * i + c] = hm.axis[3 * l + c];
-        } else {
-            rparent[i] = red_of[body[q]];
-            double tmpR[9], tmp[3];
-            fbr_mm(&bR[9 * q], &hm.restR[9 * l], tmpR);
-            fbr_mm(tmpR, &Q[9 * l], &rR[9 * i]);
-            fbr_mv(&bR[9 * q], &hm.restp[3 * l], tmp);
-            for (int c = 0; c < 3; c++) rp[3 * i + c] = bp[3 * q + c] + tmp[c];
-            for (int c = 0; c < 3; c++)  // Q^T axis (= |axis| z when regrouping)
-                rax[3 * i + c] = Q[9 * l + c] * hm.axis[3 * l] + Q[9 * l + 3 + c] * hm.axis[3 * l + 1] + Q[9 * l + 6 + c] * hm.axis[3 * l + 2];
-            if (regroup) masks[i] = 0x3ff & ~((1u << 0) | (1u << 3) | (1u << 7));  // m, h_z, I_yy
-        }
-    }
+    FbrReducedRobot rr;
+    if (!fbr_reduce_robot(m->hm, which, rr)) return FBR_OK;
     fbr_topology tr = *t;
-    tr.num_links = Lr;
-    tr.parent = rparent.data();
-    tr.dof_index = rdof.data();
-    tr.rest_R = rR.data();
-    tr.rest_p = rp.data();
-    tr.axis = rax.data();
+    tr.num_links = rr.Lr;
+    tr.parent = rr.parent.data();
+    tr.dof_index = rr.dof.data();
+    tr.rest_R = rr.restR.data();
+    tr.rest_p = rr.restp.data();
+    tr.axis = rr.axis.data();
     fbr_model *red = nullptr;
-    if (int rc = create_model(&tr, m->device, &red, false, regroup ? masks.data() : nullptr)) return rc;
+    if (int rc = create_model(&tr, m->device, &red, false, rr.masked ? rr.masks.data() : nullptr)) return rc;
     m->rdm[which].reset(red);
     red->is_reduction = true;
-    const FbrHostModel &rh = red->hm;
-    // X_i [Pr x 10]: the 10 standard columns of reduced link i (its own frame) in terms of the columns the reduced model computes.
-    // Kept parameters: unit vectors.  Dropped ones (regrouping), with T the frame change link i -> parent body at q = 0:
-    //     Y_i[m] = Y_par T e_m,   Y_i[h_z] = Y_par T e_hz,   Y_i[I_yy] = Y_par T (e_Ixx + e_Iyy) - Y_i[I_xx]
-    // (mass, first moment along the axis and the inertia 1 - z z^T of the link do not notice the joint's rotation)
-    const int Pr = rh.cols, Pf = hm.cols, cpl = hm.cpl;
-    std::vector<std::vector<double>> X((size_t)Lr * 10, std::vector<double>(Pr, 0.0));
-    std::vector<int> colof((size_t)Lr * 10, -1);
-    for (int c = 0; c < rh.ninert; c++) colof[(size_t)rh.coldesc[c].link * 10 + rh.coldesc[c].pidx] = c;
-    for (int i : rh.order) {
-        for (int p = 0; p < 10; p++)
-            if (colof[(size_t)i * 10 + p] >= 0) X[(size_t)i * 10 + p][colof[(size_t)i * 10 + p]] = 1.0;
-        if (masks[i] == 0x3ff) continue;
-        double T[10][10];
-        fbr_param_transform(&rR[9 * i], &rp[3 * i], T);
-        const int par = rparent[i];
-        auto add = [&](int pdst, int psrc, double sgn) {
-            std::vector<double> &dst = X[(size_t)i * 10 + pdst];
-            for (int pr = 0; pr < 10; pr++) {
-                const double tv = sgn * T[pr][psrc];
-                if (tv == 0.0) continue;
-                const std::vector<double> &src = X[(size_t)par * 10 + pr];
-                for (int c = 0; c < Pr; c++) dst[c] += tv * src[c];
-            }
-        };
-        add(0, 0, 1.0);
-        add(3, 3, 1.0);
-        add(7, 4, 1.0);
-        add(7, 7, 1.0);
-        for (int c = 0; c < Pr; c++) X[(size_t)i * 10 + 7][c] -= X[(size_t)i * 10 + 4][c];
-    }
-    // E, augmented with 16 rhs columns, column by column of the FULL layout
-    std::vector<int> beg(Pf + FBR_MAX_RHS + 1, 0), row;
-    std::vector<double> val, col(Pr);
-    for (int l = 0; l < L; l++) {
-        double T[10][10];
-        fbr_param_transform(&bR[9 * l], &bp[3 * l], T);
-        const int b = red_of[body[l]];
-        for (int p = 0; p < cpl; p++) {
-            beg[cpl * l + p] = (int)row.size();
-            std::fill(col.begin(), col.end(), 0.0);
-            for (int pr = 0; pr < 10; pr++) {
-                if (T[pr][p] == 0.0) continue;
-                const std::vector<double> &src = X[(size_t)b * 10 + pr];
-                for (int c = 0; c < Pr; c++) col[c] += T[pr][p] * src[c];
-            }
-            for (int c = 0; c < Pr; c++)
-                if (col[c] != 0.0) {
-                    row.push_back(c);
-                    val.push_back(col[c]);
-                }
-        }
-    }
-    for (int j = hm.ninert; j < Pf; j++) {  // friction columns: the same joints in the same layout
-        beg[j] = (int)row.size();
-        row.push_back(rh.ninert + (j - hm.ninert));
-        val.push_back(1.0);
-    }
-    for (int r = 0; r < FBR_MAX_RHS; r++) {
-        beg[Pf + r] = (int)row.size();
-        row.push_back(Pr + r);
-        val.push_back(1.0);
-    }
-    beg[Pf + FBR_MAX_RHS] = (int)row.size();
+    std::vector<int> beg, row;
+    std::vector<double> val;
+    fbr_reduction_matrix(m->hm, rr, red->hm, beg, row, val);
     int rc;
     if ((rc = upload(m->tables, beg, &m->E_beg[which])) || (rc = upload(m->tables, row, &m->E_row[which])) ||
         (rc = upload(m->tables, val, &m->E_val[which])))

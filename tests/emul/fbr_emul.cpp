@@ -9,6 +9,7 @@
 
 #include "../../flobaroid_amd/csrc/fbr_math.h"
 #include "../../flobaroid_amd/csrc/fbr_program.h"
+#include "../../flobaroid_amd/csrc/fbr_reduce.h"
 
 extern "C" {
 
@@ -20,12 +21,48 @@ struct EmulTopo {
     double gravity[3];
     int fric, fric_sym, grav_only;
     double stribeck;
+    const unsigned short *masks;  // per link: identified parameters (column masks of the regrouped model), or null
 };
 
 static void make(const EmulTopo *t, FbrHostModel &hm)
 {
     hm.build(t->L, t->n, t->parent, t->dof, t->restR, t->restp, t->axis, t->floating, t->gravity, t->fric,
-             t->fric_sym, t->grav_only, t->stribeck);
+             t->fric_sym, t->grav_only, t->stribeck, t->masks);
+}
+
+// The reduced robot of a model's column reductions and the expansion matrix (csrc/fbr_reduce.h, what fbr_api.hip's build_reduction
+// runs): which = 0 fixed links merged, 1 merged + regrouped.  Returns the reduced link count (0: nothing to reduce); the arrays hold at
+// least L links; E is dense [Pr][Pf] (reduced x full identified columns, without the rhs identity), Pr is returned through *Pr_out.
+int emul_reduction(const EmulTopo *t, int which, int32_t *parent, int32_t *dof, double *restR, double *restp, double *axis,
+                   unsigned short *masks, int *masked, int *Pr_out, double *E, long E_cap)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrReducedRobot rr;
+    if (!fbr_reduce_robot(hm, which, rr)) return 0;
+    for (int i = 0; i < rr.Lr; i++) {
+        parent[i] = rr.parent[i];
+        dof[i] = rr.dof[i];
+        masks[i] = rr.masks[i];
+        for (int c = 0; c < 9; c++) restR[9 * i + c] = rr.restR[9 * i + c];
+        for (int c = 0; c < 3; c++) {
+            restp[3 * i + c] = rr.restp[3 * i + c];
+            axis[3 * i + c] = rr.axis[3 * i + c];
+        }
+    }
+    *masked = rr.masked ? 1 : 0;
+    FbrHostModel rh;
+    rh.build(rr.Lr, t->n, rr.parent.data(), rr.dof.data(), rr.restR.data(), rr.restp.data(), rr.axis.data(), t->floating, t->gravity,
+             t->fric, t->fric_sym, t->grav_only, t->stribeck, rr.masked ? rr.masks.data() : nullptr);
+    std::vector<int> beg, row;
+    std::vector<double> val;
+    fbr_reduction_matrix(hm, rr, rh, beg, row, val);
+    *Pr_out = rh.cols;
+    if ((long)rh.cols * hm.cols > E_cap) return -1;
+    for (long i = 0; i < (long)rh.cols * hm.cols; i++) E[i] = 0.0;
+    for (int j = 0; j < hm.cols; j++)
+        for (int e = beg[j]; e < beg[j + 1]; e++) E[(long)row[e] * hm.cols + j] = val[e];
+    return rr.Lr;
 }
 
 // mirrors fbr_kin_kernel: one "lane" per sample, links in traversal order, AoS record

@@ -20,13 +20,13 @@ class EmulTopo(ctypes.Structure):
     _fields_ = [("L", ctypes.c_int), ("n", ctypes.c_int), ("parent", _ip), ("dof", _ip), ("restR", _dp),
                 ("restp", _dp), ("axis", _dp), ("floating", ctypes.c_int), ("gravity", ctypes.c_double * 3),
                 ("fric", ctypes.c_int), ("fric_sym", ctypes.c_int), ("grav_only", ctypes.c_int),
-                ("stribeck", ctypes.c_double)]
+                ("stribeck", ctypes.c_double), ("masks", ctypes.POINTER(ctypes.c_uint16))]
 
 
 def lib():
     global _lib
     if _lib is None:
-        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h")]
+        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h"), os.path.join(_CSRC, "fbr_reduce.h")]
         if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
             os.makedirs(os.path.dirname(_OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _OUT, _SRC])
@@ -39,20 +39,50 @@ def _d(a):
 
 
 class Emul:
-    def __init__(self, topo, floating=False, fric=False, fric_sym=True, grav_only=False, stribeck=0.0):
+    def __init__(self, topo, floating=False, fric=False, fric_sym=True, grav_only=False, stribeck=0.0, masks=None):
+        """topo: anything with num_links, num_dofs, parent, dof_index, rest_R, rest_p, axis; masks: per link, the identified parameters
+        (bit p = parameter p), the column masks of the regrouped model (csrc/fbr_program.h FbrHostModel::linkmask)"""
         self.keep = [np.array(topo.parent, dtype=np.int32), np.array(topo.dof_index, dtype=np.int32),
                      np.ascontiguousarray(topo.rest_R, dtype=np.float64).reshape(-1),
                      np.ascontiguousarray(topo.rest_p, dtype=np.float64).reshape(-1),
-                     np.ascontiguousarray(topo.axis, dtype=np.float64).reshape(-1)]
+                     np.ascontiguousarray(topo.axis, dtype=np.float64).reshape(-1),
+                     None if masks is None else np.ascontiguousarray(masks, dtype=np.uint16)]
+        self.opts = dict(floating=floating, fric=fric, fric_sym=fric_sym, grav_only=grav_only, stribeck=stribeck)
         self.t = EmulTopo(topo.num_links, topo.num_dofs, self.keep[0].ctypes.data_as(_ip),
                           self.keep[1].ctypes.data_as(_ip), _d(self.keep[2]), _d(self.keep[3]), _d(self.keep[4]),
                           int(floating), (ctypes.c_double * 3)(0.0, 0.0, -9.81), int(fric), int(fric_sym),
-                          int(grav_only), float(stribeck))
+                          int(grav_only), float(stribeck),
+                          None if masks is None else self.keep[5].ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
+        self.num_links = topo.num_links
         r, c, rec = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib().emul_dims(ctypes.byref(self.t), ctypes.byref(r), ctypes.byref(c), ctypes.byref(rec))
         self.rows, self.cols, self.rec = r.value, c.value, rec.value
         self.n = topo.num_dofs
         self.floating = bool(floating)
+
+    def reduction(self, which):
+        """(Emul of the reduced robot, E [Pr x P]) of this model's column reductions -- which = 0: fixed links merged into the bodies they
+        ride on; 1: merged and the joint-invariant parameters regrouped (column masks) -- or None when there is nothing to reduce.
+        [Y | rhs] = [Y_red | rhs] blockdiag(E, 1): the same code the library runs (csrc/fbr_reduce.h)."""
+        import types
+        L = self.num_links
+        parent, dof = np.zeros(L, np.int32), np.zeros(L, np.int32)
+        restR, restp, axis = np.zeros(9 * L), np.zeros(3 * L), np.zeros(3 * L)
+        masks = np.zeros(L, np.uint16)
+        masked, Pr = ctypes.c_int(), ctypes.c_int()
+        cap = (10 * L + 8 * self.n) * self.cols
+        E = np.zeros(cap)
+        Lr = lib().emul_reduction(ctypes.byref(self.t), int(which), parent.ctypes.data_as(_ip), dof.ctypes.data_as(_ip), _d(restR), _d(restp),
+                                  _d(axis), masks.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), ctypes.byref(masked), ctypes.byref(Pr),
+                                  _d(E), ctypes.c_long(cap))
+        if Lr == 0:
+            return None
+        assert Lr > 0
+        topo = types.SimpleNamespace(num_links=Lr, num_dofs=self.n, parent=parent[:Lr], dof_index=dof[:Lr], rest_R=restR[: 9 * Lr],
+                                     rest_p=restp[: 3 * Lr], axis=axis[: 3 * Lr])
+        red = Emul(topo, masks=masks[:Lr] if masked.value else None, **self.opts)
+        assert red.cols == Pr.value
+        return red, E[: Pr.value * self.cols].reshape(Pr.value, self.cols).copy()
 
     def _st(self, st):
         c = lambda k: np.ascontiguousarray(st[k], dtype=np.float64) if (k in st and st[k] is not None) else None

@@ -135,3 +135,56 @@ def test_rhs_moments_from_the_packer_reproduce_gram(cfg, k, request):
         emul_lib.lib().emul_set_rhs_moments(1)
         less = em.program_info(k)
         assert less["mfma"] < more["mfma"]  # the dense tile's MFMAs are gone
+
+
+@pytest.mark.parametrize("case", ["walkman_apriori", "kuka_lwr4", "random1", "random2", "random3"])
+@pytest.mark.parametrize("which", [0, 1], ids=["merged", "regrouped"])
+def test_column_reductions_expand_to_the_gram_of_all_columns(case, which, request):
+    """The library's column reductions without a GPU: the reduced robot and the expansion matrix E come from the very code
+    fbr_model_create runs (csrc/fbr_reduce.h); the reduced model's tile program -- column masks, tau's products from the packer, pairs
+    turned for full row segments -- is emulated lane by lane; and E^T G_red E must be the oracle's Gram of ALL columns."""
+    import emul_lib
+    from oracle.oracle import OracleModel
+    from common import random_topology
+
+    rng = np.random.default_rng(77)
+    if case.startswith("random"):
+        seed = int(case[-1])
+        rng = np.random.default_rng(300 + seed)
+        t = random_topology(rng, 8 + 6 * seed, p_fixed=0.45, branchiness=0.5)
+        floating, fric = seed != 2, seed == 3
+    else:
+        t = load_topo(case)
+        floating, fric = case == "walkman_apriori", case == "kuka_lwr4"
+    if t.num_dofs == 0:
+        pytest.skip("no joints")
+    om = OracleModel(t, floating=floating, fric=fric, fric_sym=True)
+    em = emul_lib.Emul(t, floating=floating, fric=fric, fric_sym=True)
+    red = em.reduction(which)
+    nfixed = sum(1 for l in range(1, t.num_links) if t.dof_index[l] < 0)
+    if red is None:
+        assert which == 0 and nfixed == 0
+        return
+    rem, E = red
+    nf = om.P - 10 * t.num_links  # friction columns
+    assert rem.num_links == t.num_links - nfixed
+    assert rem.cols == (10 + 7 * (rem.num_links - 1) if which else 10 * rem.num_links) + nf
+    S = 7  # (odd: the last sample has no partner for its base rows)
+    st = random_states(t, S, rng, floating)
+    sign = np.tanh(st["dq"] / 0.02)
+    Y = om.regressor(st, sign)
+    k = 1
+    rhs = rng.standard_normal((Y.shape[0], k))
+    w = rng.random(Y.shape[0]) + 0.5
+    A = np.hstack([Y, rhs]) * w[:, None]
+    # the regressor of the reduced robot spans the full one: Y = Y_red E, column by column
+    Yr = rem.regressor(st, sign)
+    assert np.abs(Yr @ E - Y).max() <= 1e-12 * max(np.abs(Y).max(), 1.0)
+    emul_lib.lib().emul_set_rhs_moments(1)
+    request.addfinalizer(lambda: emul_lib.lib().emul_set_rhs_moments(0))
+    Gr = rem.gram(st, rhs, sign, w)
+    Ea = np.zeros((rem.cols + k, om.P + k))
+    Ea[: rem.cols, : om.P] = E
+    Ea[rem.cols:, om.P:] = np.eye(k)
+    G = Ea.T @ Gr @ Ea
+    assert np.linalg.norm(G - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
