@@ -516,9 +516,15 @@ extern "C" void fbr_model_destroy(fbr_model *m)
 }
 
 // the reduced model a fused Gram pass runs on (-1: the model itself)
-static int pick_gram_reduction(const fbr_model *m)
+static int pick_gram_reduction(const fbr_model *m, long S = -1)
 {
     if (getenv("FBR_NO_LINK_MERGE")) return -1;
+    // S >= 0: a call over S samples.  The reduced pass costs a second model's launches and two expansion kernels (~0.15 ms): small
+    // robots on short batches are faster over all their columns (KUKA, 80 -> 59 columns, 50 k samples: 0.73 against 0.82 ... 1.08 ms)
+    if (S >= 0) {
+        const fbr_model *r = m->rdm[1] ? m->rdm[1].get() : m->rdm[0].get();
+        if (r && (double)S * (m->hm.cols - r->hm.cols) * m->hm.cols < 1e9 && !getenv("FBR_REDUCE_ALWAYS")) return -1;
+    }
     // (robots beyond the fused kernel's 60 rows take their Gram from a TSQR factor, gram_via_tsqr: every path of the merged model)
     if (m->rdm[1] && !getenv("FBR_NO_REGROUP") && (m->hm.rows + 3) / 4 * 4 <= 60) return 1;
     return m->rdm[0] ? 0 : -1;
@@ -1528,7 +1534,8 @@ static int gram_impl(fbr_model *m, const fbr_states *st, const double *rhs, int3
 {
     // (many small groups: two launches per group for the expansion -- worth it while a group's pass is longer than that)
     const bool grouped_ok = st && (ngroups == 1 || (ngroups >= 1 && st->num_samples / ngroups >= 512 && !getenv("FBR_NO_GROUPED_REDUCTION")));
-    const int which = (m && st && ngroups >= 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && grouped_ok) ? pick_gram_reduction(m) : -1;
+    const int which =
+        (m && st && ngroups >= 1 && G_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid() && grouped_ok) ? pick_gram_reduction(m, (long)st->num_samples) : -1;
     if (which >= 0) {
         int rc = gram_via_red(m, which, st, rhs, k, w, G_out, out_mem, accumulate, ngroups, async_ticket);
         if (rc && m->stream) {

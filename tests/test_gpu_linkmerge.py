@@ -156,3 +156,25 @@ def test_walkman_tile_program_of_the_reductions():
     assert info({}, k=16)["tiles"] == 16  # many rhs columns keep their dense tile
     assert info({"FBR_NO_REGROUP": "1", "FBR_GRAM_RHS_TILE": "1"})["mfma_per_sample"] == 537
     assert info({"FBR_NO_LINK_MERGE": "1", "FBR_GRAM_RHS_TILE": "1"}) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
+
+
+def test_small_batches_skip_the_reductions(monkeypatch):
+    """A short batch of a small robot runs over all its columns (the reduced pass costs a second model's launches and two expansion
+    kernels); the result is the same either way, and a long batch takes the reductions."""
+    import time
+    from common import load_topo
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo("kuka_lwr4")
+    rng = np.random.default_rng(3)
+    eng = Engine(t, floating=False)
+    st = random_states(t, 3000, rng, False)
+    rhs = rng.standard_normal((3000 * eng.rows, 1))
+    G_forced = eng.gram(st, rhs=rhs)
+    monkeypatch.delenv("FBR_REDUCE_ALWAYS", raising=False)
+    G_default = eng.gram(st, rhs=rhs)
+    monkeypatch.setenv("FBR_NO_LINK_MERGE", "1")
+    G_plain = eng.gram(st, rhs=rhs)
+    assert np.array_equal(G_default, G_plain)          # 3000 samples x 21 merged-away columns: not worth a second pass
+    assert not np.array_equal(G_forced, G_plain) and _rel(G_forced, G_plain) <= 1e-13
+    eng.close()

@@ -2,6 +2,7 @@
 oracle (gpurun -- python tools/stress_gpu.py).  Prints one line per case and the number of failures.  run_case(seed) is also what
 tests/test_gpu_determinism.py runs, one seed per parametrised case."""
 import os, sys, numpy as np
+os.environ.setdefault("FBR_REDUCE_ALWAYS", "1")  # (the random cases are small: the reduced paths are what is stressed)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
