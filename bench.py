@@ -477,7 +477,7 @@ def run_rank(args) -> int:
 
     ms_per_step = dt / args.steps * 1e3
     value = S_total / (dt / args.steps)
-    info = eng.gram_program_info(1)
+    info = eng.gram_program_info(1, S) if on_gpu else eng.gram_program_info(1)  # (the program a pass over S samples executes)
     gram_ms, gram_n = prof["gram"]
     samples_per_launch = S * args.steps / max(gram_n, 1)
     alg_flop_per_sample = rows * P * (P + 1) + 2 * rows * P * 1  # symmetric Gram count + 1 rhs column
@@ -515,7 +515,7 @@ def run_rank(args) -> int:
             # the three joint-invariant parameters of every link behind a revolute joint regrouped into the parent body -- exact,
             # constant column dependencies; the (P+1)^2 Gram of ALL columns is expanded from the reduced one inside the timed step
             "reduction": (lambda li: f"{li['cols']} columns reduced over {li['reduced_cols']} ({li['links']} links, {li['moving_links']} moving bodies); "
-                                     "G = E^T G_red E expanded on the device every step; FBR_NO_LINK_MERGE=1 runs all columns")(eng.link_merge_info())
+                                     "G = E^T G_red E expanded on the device every step; the option link_merge = 0 (fbr_model_set_option) runs all columns")(eng.link_merge_info(S) if on_gpu else eng.link_merge_info())
                          if hasattr(eng, "link_merge_info") else "none",
         },
         # `value` is the rate with the inputs resident in HBM (the bench contract: timed steps bracketed by barriers; ms_per_step is
@@ -965,11 +965,11 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
         Gg = eng4.gram_grouped(sub, ng)
         G1 = eng4.gram(sub)
         t_gg = timed(lambda: eng4.gram_grouped(sub, ng, out=Gg), reps=10)  # (out=: no 118 MB allocation inside the timed calls)
-        os.environ["FBR_NO_GROUPED_REDUCTION"] = "1"
+        eng4.set_option("reduce_grouped_min_samples", 1e18)  # (no group is that long: the grouped pass over all columns)
         try:
             t_gg_all = timed(lambda: eng4.gram_grouped(sub, ng, out=Gg), reps=10)
         finally:
-            os.environ.pop("FBR_NO_GROUPED_REDUCTION", None)
+            eng4.set_option("reduce_grouped_min_samples", 512)
         res["walkman_64_candidates_x_2000_grouped_gram"] = {
             "groups": ng, "samples_per_group": per, "grouped_gram_ms": t_gg * 1e3, "samples_per_s": ng * per / t_gg,
             "grouped_gram_ms_over_all_columns": t_gg_all * 1e3,

@@ -127,10 +127,18 @@ _SIGNATURES = {
     "fbr_profile_get": (ctypes.c_int, [ctypes.c_void_p, _dp, ctypes.POINTER(ctypes.c_int64)]),
     "fbr_gram_program_info": (
         ctypes.c_int,
-        [ctypes.c_void_p, ctypes.c_int32, _ip, _ip, ctypes.POINTER(ctypes.c_int64), _ip],
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, _ip, _ip, ctypes.POINTER(ctypes.c_int64), _ip],
     ),
-    "fbr_model_link_merge_info": (ctypes.c_int, [ctypes.c_void_p, _ip, _ip]),
+    "fbr_model_link_merge_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _ip, _ip]),
+    "fbr_model_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
+    "fbr_model_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
+    "fbr_model_option_name": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p)]),
 }
+
+# Options every new Engine starts with (``fbr_model_set_option``, include/fbr.h lists the keys), on top of the library's defaults and below
+# the ``options`` argument of the constructor.  A plain Python dict: the library itself never reads the process environment.  The test
+# suite uses it to run whole modules with the column reductions forced / switched off (tests/conftest.py: reduction_mode).
+DEFAULT_OPTIONS: dict = {}
 
 
 def load_library():
@@ -214,7 +222,7 @@ class Engine:
     """One ``fbr_model`` handle: device tables of a robot + identified-column layout."""
 
     def __init__(self, topo, floating=False, friction=False, friction_symmetric=True, gravity_only=False,
-                 stribeck_velocity=0.0, gravity=(0.0, 0.0, -9.81), device: int = 0):
+                 stribeck_velocity=0.0, gravity=(0.0, 0.0, -9.81), device: int = 0, options: dict | None = None):
         lib = load_library()
         self._lib = lib
         self.topo = topo
@@ -248,6 +256,25 @@ class Engine:
         self.floating = bool(floating)
         self.friction = bool(friction)
         self.device = int(device)
+        for key, val in {**DEFAULT_OPTIONS, **(options or {})}.items():
+            self.set_option(key, val)
+
+    # ------------------------------------------------------------------ options (fbr_model_set_option)
+    def set_option(self, key: str, value: float) -> None:
+        _check(self._lib.fbr_model_set_option(self._h, key.encode(), float(value)), f"fbr_model_set_option({key})")
+
+    def get_option(self, key: str) -> float:
+        v = ctypes.c_double()
+        _check(self._lib.fbr_model_get_option(self._h, key.encode(), ctypes.byref(v)), f"fbr_model_get_option({key})")
+        return float(v.value)
+
+    def options(self) -> dict:
+        """Every option of the handle with its current value."""
+        out, i, name = {}, 0, ctypes.c_char_p()
+        while self._lib.fbr_model_option_name(i, ctypes.byref(name)) == 0:
+            out[name.value.decode()] = self.get_option(name.value.decode())
+            i += 1
+        return out
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -584,18 +611,19 @@ class Engine:
         _check(self._lib.fbr_profile_get(self._h, ms, cnt), "fbr_profile_get")
         return {c: (float(ms[i]), int(cnt[i])) for i, c in enumerate(self.PROF_CLASSES)}
 
-    def link_merge_info(self) -> dict:
-        """What the Gram / TSQR reductions run on: the moving bodies (links attached by fixed joints are merged into the body they
-        ride on and the result expanded, fbr.h fbr_model_link_merge_info)."""
+    def link_merge_info(self, num_samples: int = -1) -> dict:
+        """What a Gram pass over ``num_samples`` samples runs on (-1: a batch large enough for the column reductions): the moving bodies
+        (links attached by fixed joints are merged into the body they ride on and the result expanded, fbr.h fbr_model_link_merge_info)."""
         ml, rc = ctypes.c_int32(), ctypes.c_int32()
-        _check(self._lib.fbr_model_link_merge_info(self._h, ctypes.byref(ml), ctypes.byref(rc)), "fbr_model_link_merge_info")
+        _check(self._lib.fbr_model_link_merge_info(self._h, int(num_samples), ctypes.byref(ml), ctypes.byref(rc)), "fbr_model_link_merge_info")
         return {"moving_links": ml.value, "reduced_cols": rc.value, "links": self.topo.num_links, "cols": self.cols}
 
-    def gram_program_info(self, k: int = 0) -> dict:
+    def gram_program_info(self, k: int = 0, num_samples: int = -1) -> dict:
+        """Tile program ``gram(..)`` executes for a batch of ``num_samples`` samples (-1: large batches)."""
         nt, npairs, parts = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         mf = ctypes.c_int64()
         _check(
-            self._lib.fbr_gram_program_info(self._h, int(k), ctypes.byref(nt), ctypes.byref(npairs), ctypes.byref(mf),
+            self._lib.fbr_gram_program_info(self._h, int(k), int(num_samples), ctypes.byref(nt), ctypes.byref(npairs), ctypes.byref(mf),
                                             ctypes.byref(parts)),
             "fbr_gram_program_info",
         )

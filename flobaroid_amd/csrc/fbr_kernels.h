@@ -1,4 +1,5 @@
-// fbr_kernels.h -- device tables and HIP kernels of libfbr (gfx950).  Included once by fbr_api.hip.
+// fbr_kernels.h -- device tables and HIP kernels of libfbr (gfx950).  Every translation unit of the library includes it with the
+// section(s) it launches switched on (FBR_KERNELS_CORE / _GROUPS / _GRAM): a __global__ function is defined in exactly one unit.
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -46,6 +47,7 @@ struct DevGram {
     const int *tilecol;       // [NT*16] augmented column of each slot, -1 = padding
 };
 
+#ifdef FBR_KERNELS_CORE  // kinematics, materialising regressor, finite-difference scores, inverse dynamics, contact (fbr_api.hip)
 // ------------------------------------------------------------------------------------------------
 // K1: link kinematics, one lane per sample, AoS records  rec[s][21*L + 6*n]
 // ------------------------------------------------------------------------------------------------
@@ -113,6 +115,11 @@ __global__ __launch_bounds__(256, WAVES) void fbr_kin_kernel(DevModel m, long S,
     }
 }
 
+#endif  // FBR_KERNELS_CORE
+
+typedef double fbr_d2 __attribute__((ext_vector_type(2)));
+typedef double fbr_d4 __attribute__((ext_vector_type(4)));
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)): in
 // the per-sample producer loops below that made every sample wait for the write acknowledgements of the one before.
 __device__ __forceinline__ void fbr_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -131,6 +138,7 @@ template <int NT_, int U_ = 6> __device__ __forceinline__ void fbr_stage_copy(do
     }
 }
 
+#ifdef FBR_KERNELS_CORE
 // ------------------------------------------------------------------------------------------------
 // K2: materialised standard regressor  Y[s][rows][cols]; one workgroup per sample (grid-stride), one
 // thread per column, every row of a sample written as one contiguous, coalesced run of `cols` doubles.
@@ -290,7 +298,6 @@ __global__ __launch_bounds__(256) void fbr_score_kernel(DevModel m, long S, int 
     }
 }
 
-typedef double fbr_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S, int spb, const double *__restrict__ rec,
                                                               const double *__restrict__ dq,
                                                               const double *__restrict__ sign, double *__restrict__ Y, int ldy, long rs_s,
@@ -360,6 +367,8 @@ __global__ __launch_bounds__(256) void fbr_row_active_kernel(const double *__res
         if (w[i] != 0.0) active[i % rows] = 1;  // (benign race: every writer stores 1)
 }
 
+#endif  // FBR_KERNELS_CORE
+#ifdef FBR_KERNELS_GROUPS  // row-group writers of the tree-structured TSQR (fbr_tsqr_api.hip)
 // ------------------------------------------------------------------------------------------------
 // K2c: the regressor written as the ROW GROUPS of the tree-structured TSQR (fbr_api.hip: tsqr_group_plan).  A regressor row
 // belongs to one group; a group g owns a packed chunk A_g [slot][sample][ld_g] that holds only the columns its rows can touch,
@@ -559,6 +568,8 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
     }
 }
 
+#endif  // FBR_KERNELS_GROUPS
+#ifdef FBR_KERNELS_CORE
 // ------------------------------------------------------------------------------------------------
 // K3: inverse dynamics / prediction, one wavefront per sample.
 //   mode 0: x = full standard vector (10 per link + friction slots), friction model of model.py:299-326
@@ -663,12 +674,13 @@ __global__ __launch_bounds__(256) void fbr_contact_kernel(DevModel m, long S, co
     }
 }
 
+#endif  // FBR_KERNELS_CORE
+#ifdef FBR_KERNELS_GRAM  // tile-image packer and fused Gram (fbr_gram_api.hip)
 // ------------------------------------------------------------------------------------------------
 // K5a: packed tile image of [Y_s | rhs_s] (row weights applied), one workgroup per sample (grid-stride),
 // one thread per real column.  pimg[s][image_doubles]; structural zeros and padding are never written
 // (the buffer is zeroed once when it is allocated).  Bound: HBM write of the non-zero entries.
 // ------------------------------------------------------------------------------------------------
-typedef double fbr_d4 __attribute__((ext_vector_type(4)));
 
 struct FbrStage {
     int o_rhs, o_w, o_dq, o_sign, total;
@@ -1055,3 +1067,5 @@ __global__ __launch_bounds__(256) void fbr_gram_reduce_kernel(DevGram g, const d
     Gg[(long)ci * g.Pa + cj] += v;
     if (I != J) Gg[(long)cj * g.Pa + ci] += v;
 }
+
+#endif  // FBR_KERNELS_GRAM

@@ -343,7 +343,7 @@ struct FbrGramProgram {
         // walk with the fewest inertial tiles is kept (the regrouped WALK-MAN: base + waist + one arm fill 5 tiles exactly, 16 tiles
         // instead of 17 -- a nearly empty tile costs as many MFMAs as a full one).
         std::vector<int> torder = hm.order;
-        if (!getenv("FBR_GRAM_TILE_ORDER_INDEX")) {
+        {
             std::vector<std::vector<int>> children(hm.L);
             int base = 0;
             for (int l = 0; l < hm.L; l++) (hm.parent[l] < 0 ? (void)(base = l) : children[hm.parent[l]].push_back(l));
@@ -843,27 +843,20 @@ static inline std::vector<int> fbr_gram_deal(const FbrGramProgram &gp, int slots
 
 // Program for the shape that suits the model: small images / two workgroups per CU unless that splits the pairs into too many parts.
 // few rhs columns (the reference's one: tau) and one pack thread per column: their moments come from the pack kernel
-static inline bool fbr_gram_rhs_moments(const FbrHostModel &hm, int k)
+static inline bool fbr_gram_rhs_moments(const FbrHostModel &hm, int k, bool rhs_tile_forced = false)
 {
-    return k >= 1 && k <= 2 && hm.cols <= 255 && !getenv("FBR_GRAM_RHS_TILE");
+    return k >= 1 && k <= 2 && hm.cols <= 255 && !rhs_tile_forced;
 }
 
-static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &hm, int k, const char *force = nullptr, bool rhs_tiles = true)
+// shape: 0 = by model, 1 = one workgroup per CU, 2 = two per CU (option "gram_shape"); orient: option "gram_orient"
+static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &hm, int k, int shape = 0, bool rhs_tiles = true, bool orient = true)
 {
     gp.rhs_tiles = rhs_tiles;
     FbrGramConfig two = FBR_CFG_TWO_PER_CU, one = FBR_CFG_ONE_PER_CU;
-    if (const char *e = getenv("FBR_GRAM_COST")) {  // experiments: "c0,cload,cmfma,cimg" of the two-per-CU shape [; same for one]
-        sscanf(e, "%lf,%lf,%lf,%lf;%lf,%lf,%lf,%lf", &two.c0, &two.cload, &two.cmfma, &two.cimg, &one.c0, &one.cload, &one.cmfma, &one.cimg);
-    }
     // the order of the pair list decides which tiles a contiguous part touches: a few block edges are tried and the one with
     // the lowest modelled cost kept (WALK-MAN: edge 6 instead of 5 saves one part and 7 % of the image traffic)
     auto build_shape_plain = [&](const FbrGramConfig &cfg) {
         gp.block_edge = 0;
-        if (const char *e = getenv("FBR_GRAM_BE")) {  // experiments
-            gp.block_edge = std::max(1, atoi(e));
-            gp.build(hm, k, cfg);
-            return;
-        }
         gp.build(hm, k, cfg);
         if (gp.T == 1) return;
         double best = gp.total_cost();
@@ -885,17 +878,17 @@ static inline void fbr_gram_build_best(FbrGramProgram &gp, const FbrHostModel &h
     auto build_shape = [&](const FbrGramConfig &cfg) {
         gp.orient = false;
         build_shape_plain(cfg);
-        if (gp.T <= 1 || getenv("FBR_GRAM_NO_ORIENT")) return;
+        if (gp.T <= 1 || !orient) return;
         FbrGramProgram keep = gp;
         gp.orient = true;
         build_shape_plain(cfg);
         if (!gp.oriented || gp.T >= keep.T) gp = keep;
     };
-    if (force && force[0] == 'o') {  // "one"
+    if (shape == 1) {
         build_shape(one);
         return;
     }
     build_shape(two);
-    if (!(force && force[0] == 't') && gp.T > FBR_MAX_PARTS_TWO_PER_CU) build_shape(one);
+    if (shape != 2 && gp.T > FBR_MAX_PARTS_TWO_PER_CU) build_shape(one);
 }
 

@@ -18,6 +18,7 @@
 // Everything is deterministic (fixed block -> workgroup assignment, fixed tree, fixed evaluation order per wave).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "fbr_tsqr_work.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -26,8 +27,6 @@
 #include <utility>
 #include <vector>
 
-#define FBR_TSQR_THREADS 512
-#define FBR_TSQR_WAVES (FBR_TSQR_THREADS / 64)
 #ifndef FBR_TSQR_SUB2
 #define FBR_TSQR_SUB2 6           // 16-row sub-blocks per fold of the two-tiles-per-wave kernels (n <= 256): 96-row blocks
 #endif
@@ -1051,33 +1050,6 @@ __global__ void fbr_tsqr_copy_kernel(int Pa, const double *__restrict__ src, int
     }
 }
 
-struct FbrTsqrWork {
-    double *Rw = nullptr;   // [NW][n][ld]
-    double *A = nullptr;    // packed chunk [Mpad][n]
-    unsigned *err = nullptr;  // device word: set when a wave gave up waiting on a pipeline flag
-    bool own_err = true;      // false: the word belongs to the caller (one per model, cleared once per call and read once at its end)
-    size_t rw_bytes = 0, a_bytes = 0;
-    int *prog = nullptr;      // progress counters of the cross-workgroup merge pipeline (fbr_tsqr_tree_x_kernel)
-    size_t prog_bytes = 0;
-    long clean_key = -1;  // (Pa, n) for which the padding columns [Pa, n) of the whole chunk buffer are zero and stay zero (writers that
-                          // fill the chunk in place never touch them): the per-chunk tail pass then only clears the rows M..Mpad
-    int n = 0, ld = 0, NW = 0, Pa = 0, mb = 0, tpw = 0, sub = 0, waves = FBR_TSQR_WAVES, ttpw = 0;
-    bool active = false, narrow = false;
-    void release()
-    {
-        if (Rw) (void)hipFree(Rw);
-        if (A) (void)hipFree(A);
-        if (prog) (void)hipFree(prog);
-        prog = nullptr;
-        prog_bytes = 0;
-        if (err && own_err) (void)hipFree(err);
-        err = nullptr;
-        own_err = true;
-        Rw = A = nullptr;
-        rw_bytes = a_bytes = 0;
-        active = false;
-    }
-};
 
 #define TSQR_HIP(call)                                                                   \
     do {                                                                                 \
@@ -1127,9 +1099,7 @@ static inline long fbr_tsqr_chunk_samples(int rows, int Pa)
     switch (TPWV) {                                    \
     case 3: { constexpr int TPW = 3, SUB = FBR_TSQR_SUB3; CALL; } break; \
     case 4: { constexpr int TPW = 4, SUB = FBR_TSQR_SUB4; CALL; } break; \
-    case 5: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
-    case 6: { constexpr int TPW = 6, SUB = FBR_TSQR_SUB6H; CALL; } break; \
-    default: { constexpr int TPW = 8, SUB = FBR_TSQR_SUB8H; CALL; } break; \
+    default: { constexpr int TPW = 5, SUB = 3; CALL; } break; \
     }
 static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : (tpw == 3 ? FBR_TSQR_SUB3 : (tpw == 4 ? FBR_TSQR_SUB4 : (tpw <= 1 ? 4 : (tpw == 5 ? 3 : 2)))); }
 
@@ -1158,29 +1128,25 @@ struct FbrTsqrShape {
     int waves;  // waves per workgroup of the wide kernels (8, or 4 with two workgroups per CU)
     int ttpw, tsub, tmb;  // tiles per wave / block rows of the kernel that runs the merge tree (the eight-wave one for the RREG shapes)
 };
-static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrShape *out)
+static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrShape *out, const FbrTsqrOpts &opts = FbrTsqrOpts())
 {
     const int n = (Pa + 15) & ~15;
     if (n > FBR_TSQR_MAXN) {
         g_tsqr_err = "TSQR supports at most " + std::to_string(FBR_TSQR_MAXN) + " columns";
         return -4;
     }
-    const bool narrow = n / 16 <= FBR_TSQR_NARROW_MAX_TILES && !getenv("FBR_TSQR_NO_NARROW");
-    // two 32- / 48-row folds per CU (RREG) instead of one 64-row fold.  MEASURED SLOWER (round 4: WALK-MAN 1 M samples 196 vs 175 ms per
-    // call -- 1.5 x the panel-chain work per row, 11 % more MFMAs, and twice the R traffic per row: 512 private factors of 2 MB are
-    // streamed per 32 rows) and therefore OFF unless FBR_TSQR_DUAL is set; kept so that the measurement can be repeated
-    const bool dual = !narrow && n / 16 > FBR_TSQR_HALF_MAX_TILES && n / 16 <= FBR_TSQR_DUAL_MAX_TILES && rows_hint >= 64L * 8 * num_cus &&
-                      getenv("FBR_TSQR_DUAL") && !getenv("FBR_TSQR_TIMING");
-    const bool half = dual || (!narrow && n / 16 > FBR_TSQR_NARROW_MAX_TILES && n / 16 <= FBR_TSQR_HALF_MAX_TILES && !getenv("FBR_TSQR_NO_HALF") &&
-                               !getenv("FBR_TSQR_TIMING"));
+    const bool narrow = n / 16 <= FBR_TSQR_NARROW_MAX_TILES && opts.narrow;
+    // (two 32- / 48-row folds per CU with the R rows through registers, for more than 20 column tiles: measured 12 % slower in round 4
+    // -- 1.5 x the panel-chain work per row, 11 % more MFMAs, twice the R traffic per row -- and removed in round 5: DESIGN.md 10)
+    const bool dual = false;
+    const bool half = !narrow && n / 16 > FBR_TSQR_NARROW_MAX_TILES && n / 16 <= FBR_TSQR_HALF_MAX_TILES && !opts.timing;
     const int waves = half ? FBR_TSQR_HALF_WAVES : FBR_TSQR_WAVES;
     const int tpw8 = (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
     const int tpw = narrow ? n / 16 : (dual ? (n / 16 <= 24 ? 6 : 8) : (n / 16 + waves - 1) / waves);
     const int sub = narrow ? fbr_tsqr_narrow_sub_for(tpw) : (dual ? (tpw == 6 ? FBR_TSQR_SUB6H : FBR_TSQR_SUB8H) : fbr_tsqr_sub_for(tpw));
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
-    const char *envw = getenv("FBR_TSQR_WG_PER_CU");  // experiments only
-    const long per_cu = envw ? std::max(1, atoi(envw)) : (narrow ? 2 * FBR_TSQR_NARROW_WAVES : (half ? 2 : 1));  // narrow: private R per WAVE
+    const long per_cu = narrow ? 2 * FBR_TSQR_NARROW_WAVES : (half ? 2 : 1);  // narrow: private R per WAVE
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
     const int ld = narrow ? n : 16 * waves * tpw;
     // (the RREG shapes share their leading dimension with the eight-wave kernel of the same width: 16 x 4 x 6 = 16 x 8 x 3, 16 x 4 x 8 = 16 x 8 x 4)
@@ -1192,7 +1158,7 @@ static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrSha
 static inline int fbr_tsqr_begin(FbrTsqrWork &wk, hipStream_t st, int Pa, const double *R_in, int num_cus, long rows_hint, unsigned *shared_err = nullptr)
 {
     FbrTsqrShape sh;
-    if (int rc = fbr_tsqr_shape(Pa, num_cus, rows_hint, &sh)) return rc;
+    if (int rc = fbr_tsqr_shape(Pa, num_cus, rows_hint, &sh, wk.opts)) return rc;
     const int n = sh.n, tpw = sh.tpw, sub = sh.sub, mb = sh.mb, NW = sh.NW, ld = sh.ld;
     const bool narrow = sh.narrow;
     const size_t need = (size_t)NW * n * ld * sizeof(double);
@@ -1290,7 +1256,7 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         TSQR_HIP(hipGetLastError());
         return 0;
     }
-    if (getenv("FBR_TSQR_TIMING")) {
+    if (wk.opts.timing) {
         TSQR_HIP(hipMalloc((void **)&dbg, (size_t)grid * FBR_TSQR_WAVES * 16 * 8));
         TSQR_HIP(hipMemsetAsync(dbg, 0, (size_t)grid * FBR_TSQR_WAVES * 16 * 8, st));
     }
@@ -1350,7 +1316,7 @@ static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, i
     }
     if (M <= 0) return 0;
     const long Mpad = (M + 15) & ~15L;
-    if (k == 0 && !getenv("FBR_TSQR_NO_CLEAN_PAD")) {
+    if (k == 0) {
         // the writer has stored every column < Pa (rhs columns included): what is left are the zero padding columns -- written once per
         // buffer instead of once per chunk (WALK-MAN: 15 columns x 6 M base-wrench rows per 1 M samples) -- and the rows M..Mpad
         const long key = (long)wk.Pa * 4096 + wk.n;
@@ -1381,6 +1347,13 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
     }
     const int n = wk.n;
     stride_to = std::min(stride_to, wk.NW);
+    // dense partner rows are understood by the cross-workgroup merge kernel only (fbr_tsqr_tree_x_kernel); every other tree kernel would
+    // fold the partner slot as a triangular factor and silently return a wrong R
+    const bool x_kernel = !wk.narrow && !wk.opts.tree_one_wg && wk.n / 16 > FBR_TSQR_NARROW_MAX_TILES && (wk.waves != FBR_TSQR_HALF_WAVES || wk.ttpw == wk.tpw);
+    if (brows > 0 && !x_kernel) {
+        g_tsqr_err = "dense partner rows need the cross-workgroup merge kernel (wide factor, tsqr_tree_one_wg off)";
+        return -1;
+    }
     if (wk.narrow) {
         for (int stride = stride_from; stride < stride_to; stride *= 2) {
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
@@ -1390,7 +1363,7 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
                                                                 stride, wk.NW));
             TSQR_HIP(hipGetLastError());
         }
-    } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw && !getenv("FBR_TSQR_TREE_ONE_WG")) {
+    } else if (wk.waves == FBR_TSQR_HALF_WAVES && wk.ttpw == wk.tpw && !wk.opts.tree_one_wg) {
         // four-wave shapes (two workgroups per CU): the same cross-workgroup merge pipeline (fbr_tsqr_tree_x_kernel)
         constexpr int HW = FBR_TSQR_HALF_WAVES;
         const int nblk = ((brows > 0 ? brows : n) + wk.mb - 1) / wk.mb;
@@ -1417,7 +1390,6 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
             int G = 1;
             while (G < 8 && 2 * G <= nblk && pairs * 2 * G <= 2 * std::max(cus, 1)) G *= 2;
-            if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
             FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB, HW>), dim3(pairs * G), dim3(64 * HW),
                                                               (fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
                                                               wk.prog + off, wk.err, brows));
@@ -1437,7 +1409,7 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
     } else {
     // (wk.ttpw: the RREG shapes run their merge tree on the eight-wave kernel of the same leading dimension: taller blocks, half the
     // serial panel steps per merge)
-    if (!getenv("FBR_TSQR_TREE_ONE_WG") && wk.n / 16 > FBR_TSQR_NARROW_MAX_TILES) {
+    if (!wk.opts.tree_one_wg && wk.n / 16 > FBR_TSQR_NARROW_MAX_TILES) {
         // merges pipelined across workgroups (fbr_tsqr_tree_x_kernel): as many workgroups per merge as keep the level's grid within one
         // round of CUs (2 at the 128 merges of level 1, 4 at 64, 8 from 32 merges on)
         const int sub_t = fbr_tsqr_sub_for(wk.ttpw), nblk = ((brows > 0 ? brows : n) + 16 * sub_t - 1) / (16 * sub_t);
@@ -1466,7 +1438,6 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
             int G = 1;
             while (G < 8 && 2 * G <= nblk && pairs * 2 * G <= std::max(cus, 1)) G *= 2;
-            if (const char *e = getenv("FBR_TSQR_TREE_G")) G = std::max(1, std::min(atoi(e), nblk));
             FBR_TSQR_DISPATCH(wk.ttpw, hipLaunchKernelGGL((fbr_tsqr_tree_x_kernel<TPW, SUB>), dim3(pairs * G), dim3(FBR_TSQR_THREADS),
                                                           (fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double)), st, wk.Rw, n, stride, wk.NW, G,
                                                           wk.prog + off, wk.err, brows));

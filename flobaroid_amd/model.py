@@ -216,7 +216,7 @@ class Model:
                                   friction_symmetric=o["identifySymmetricVelFriction"],
                                   gravity_only=o["identifyGravityParamsOnly"],
                                   stribeck_velocity=float(o.get("stribeckVelocity", 0) or 0.0),
-                                  gravity=self.gravity[:3], device=self.device)
+                                  gravity=self.gravity[:3], device=self.device, options=o.get("engineOptions"))
             assert self._engine.rows == self.N_OUT and self._engine.cols == self.num_identified_params
         return self._engine
 

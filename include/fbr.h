@@ -251,20 +251,53 @@ int fbr_profile_get(fbr_model *m, double *ms_out /*[FBR_PROF_COUNT]*/, int64_t *
 int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t ncols, int32_t k, int64_t num_samples, int64_t *mfma_level0,
                        int64_t *mfma_tree, int32_t *block_rows, int32_t *n_padded);
 
-/* Tile program of the fused Gram kernel: counts of padded column tiles / tile pairs / MFMA k-steps per
-   sample, so tests and bench.py can report executed vs algorithmic flops. */
-int fbr_gram_program_info(const fbr_model *m, int32_t k, int32_t *num_tiles, int32_t *num_pairs,
+/* Tile program of the fused Gram kernel that fbr_gram_accumulate runs for a batch of num_samples samples (< 0: a batch large enough
+   for the column reductions below): counts of padded column tiles / tile pairs / MFMA k-steps per sample, so tests and bench.py can
+   report executed vs algorithmic flops of the program that was actually executed. */
+int fbr_gram_program_info(const fbr_model *m, int32_t k, int64_t num_samples, int32_t *num_tiles, int32_t *num_pairs,
                           int64_t *mfma_per_sample, int32_t *num_parts);
 
 /*
- * Link merging (on unless FBR_NO_LINK_MERGE is set in the environment when the model is created / a reduction is called).  The
- * regressor columns of a link attached by a FIXED joint are an exact, constant linear combination of the columns of the moving body it
- * rides on (the 10 x 10 change of frame of the inertial parameters).  fbr_gram / fbr_gram_submit / fbr_tsqr / fbr_tsqr_submit
- * therefore reduce over the moving bodies only and expand the small result with that constant matrix E:
- * G = E^T G_red E, R = qr([R_in ; R_red E]) -- the same G and the same R^T R to rounding (1e-15 relative), same layout, same
- * arguments.  moving_links / reduced_cols: what the reductions run on (== the model's own counts when nothing is merged).
+ * Column reductions (options "link_merge" / "regroup" / "reduce_min_work" below).  The regressor columns of a link attached by a FIXED
+ * joint are an exact, constant linear combination of the columns of the moving body it rides on (the 10 x 10 change of frame of the
+ * inertial parameters), and three parameter directions of a link behind a revolute joint act like parameters of its parent.
+ * fbr_gram_accumulate / fbr_gram_submit / fbr_tsqr / fbr_tsqr_submit therefore reduce over a full-rank subset of the columns where that
+ * pays and expand the small result with a constant matrix E: G = E^T G_red E, R = qr([R_in ; R_red E]) -- the same G and the same R^T R
+ * to rounding (1e-15 relative), same layout, same arguments.  moving_links / reduced_cols: what a Gram pass over num_samples samples
+ * runs on (< 0: a batch large enough for the reductions; == the model's own counts when nothing is reduced).
  */
-int fbr_model_link_merge_info(const fbr_model *m, int32_t *moving_links, int32_t *reduced_cols);
+int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *moving_links, int32_t *reduced_cols);
+
+/* ---- options ------------------------------------------------------------------------------------ */
+/*
+ * Per-model switches and thresholds.  The library never reads the process environment: what a call does is decided by its arguments
+ * and by these options.  Setting an option first waits for every submission in flight; unknown keys fail with FBR_E_INVALID.
+ *   "link_merge"                 1     column reductions on (0: every reduction runs over all columns of the model)
+ *   "regroup"                    1     ... including the revolute regrouping (0: fixed links merged only)
+ *   "reduce_min_work"            1e9   a Gram call takes the reductions when S (P - P_red) P >= this, a factorisation from an eighth of
+ *                                      it on (0: always; the reduced pass costs a second model's launches and the expansion kernels)
+ *   "reduce_grouped_min_samples" 512   fbr_gram_grouped takes them for groups of at least this many samples
+ *   "chunk_samples"              0     > 0: samples per chunk of every pass (0: sized by memory)
+ *   "min_chunks"                 4     a short fused pass is still cut into this many chunks
+ *   "h2d_chunked"                1     pinned host inputs staged chunk by chunk on a copy stream, overlapped with the kernels
+ *   "gram_shape"                 0     fused Gram kernel shape: 0 by model, 1 one workgroup per CU, 2 two per CU
+ *   "gram_rhs_tile"              0     1: dense tiles for the rhs columns even for k <= 2 (default: their products come from the packer)
+ *   "gram_orient"                1     tile pairs turned so that the row segments fill up
+ *   "tsqr_groups"                1     rows grouped along the kinematic tree ...
+ *   "tsqr_group_min_samples"     24000 ... from this many samples on
+ *   "tsqr_reorder"               1     columns factorised in link-depth order (single-factorisation path)
+ *   "tsqr_narrow"                1     wave-private kernels for <= 128 columns
+ *   "tsqr_writer"                0     grouped regressor writer: 0 by work-item count, 8 / 16: store width in bytes forced
+ *   "tsqr_tree_one_wg"           0     merges by one workgroup instead of pipelined across workgroups (bit-identical, slower)
+ *   "tsqr_prologue_overlap"      1     a submission's kinematics / first writer beside the merge trees of the one before
+ *   "tsqr_short_call_factors"    1     fewer private factors (shallower merge trees) for calls too short to amortise them
+ *   "gram_serial", "gram_timing", "tsqr_timing"  0   diagnostics (producer on the main stream; cycle counters printed to stderr)
+ * fbr_model_option_name enumerates the keys (index 0 .. until it fails).
+ */
+int fbr_model_set_option(fbr_model *m, const char *key, double value);
+int fbr_model_get_option(const fbr_model *m, const char *key, double *value);
+int fbr_model_option_name(int32_t index, const char **name);
+
 
 #ifdef __cplusplus
 }

@@ -199,7 +199,7 @@ static int g_moments = 0;
 void emul_set_rhs_moments(int on) { g_moments = on; }
 static void build_program(FbrGramProgram &gp, const FbrHostModel &hm, int k)
 {
-    fbr_gram_build_best(gp, hm, k, g_shape == 1 ? "one" : g_shape == 2 ? "two" : nullptr, !(g_moments && fbr_gram_rhs_moments(hm, k)));
+    fbr_gram_build_best(gp, hm, k, g_shape, !(g_moments && fbr_gram_rhs_moments(hm, k)));
 }
 
 int emul_program_info(const EmulTopo *t, int k, int *NT, int *npairs, long *mfma, int *T, int *image_doubles,

@@ -80,20 +80,16 @@ def test_gram_two_submissions_in_flight_bitwise(walkman):
 
 
 def test_gram_shape_two_repeats_bitwise():
-    """The two-workgroups-per-CU kernel shape forced on WALK-MAN (FBR_GRAM_SHAPE=two), 300 k samples."""
+    """The two-workgroups-per-CU kernel shape forced on WALK-MAN (option gram_shape = 2), 300 k samples."""
     from flobaroid_amd._lib import Engine
 
     topo = load_topo("walkman_apriori")
     st, dev = _device_states(topo, 300_000, 6)
-    os.environ["FBR_GRAM_SHAPE"] = "two"
-    try:
-        eng = Engine(topo, floating=True)
-        eng.use_torch_stream()
-        G0 = eng.gram(st).clone()
-        assert _all_equal(G0, [eng.gram(st) for _ in range(REPS)])
-        eng.close()
-    finally:
-        del os.environ["FBR_GRAM_SHAPE"]
+    eng = Engine(topo, floating=True, options={"gram_shape": 2})
+    eng.use_torch_stream()
+    G0 = eng.gram(st).clone()
+    assert _all_equal(G0, [eng.gram(st) for _ in range(REPS)])
+    eng.close()
 
 
 def test_grouped_gram_repeats_bitwise(walkman):

@@ -12,7 +12,7 @@ import pytest
 
 import fb_chain
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reduction_mode")]  # three modes of the column reductions: conftest.py
 
 
 @pytest.mark.parametrize("name", ["threelinks", "walkman"])

@@ -17,7 +17,7 @@ import pytest
 from common import load_topo, random_states
 from test_gpu_model import _opt, _synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reduction_mode")]  # three modes of the column reductions: conftest.py
 
 
 def _walkman_model(tmp_path, seed=11, **over):

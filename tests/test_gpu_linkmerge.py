@@ -1,5 +1,5 @@
 """Link merging and regrouping (fbr.h fbr_model_link_merge_info): the reductions run on 7 columns per moving body (10 for the base link)
-and expand -- against the unmerged path (FBR_NO_LINK_MERGE=1), the merged-only path (FBR_NO_REGROUP=1) and the oracle, on robots with chains of fixed links, every base / friction / gravity-only mode, weights, R_in,
+and expand -- against the unmerged path (option link_merge = 0), the merged-only path (regroup = 0) and the oracle, on robots with chains of fixed links, every base / friction / gravity-only mode, weights, R_in,
 accumulation, host and device memory, blocking calls and submissions."""
 import numpy as np
 import pytest
@@ -9,13 +9,21 @@ from common import random_states, random_topology
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _reductions_whatever_the_size(engine_options):
+    """This module is about the reduced paths: they are taken at the few hundred samples the oracle can check (the library's own
+    threshold is looked at in test_small_batches_skip_the_reductions, which sets the option itself)."""
+    with engine_options(reduce_min_work=0):
+        yield
+
+
 def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
 @pytest.mark.parametrize("seed,L,floating,fric,grav", [(1, 14, 1, 0, 0), (2, 22, 0, 1, 0), (3, 30, 1, 1, 0), (4, 18, 0, 0, 1), (5, 40, 1, 0, 0),
                                                        (6, 9, 1, 1, 1)])
-def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav, monkeypatch):
+def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav):
     from flobaroid_amd._lib import Engine
     from oracle.oracle import OracleModel
 
@@ -45,26 +53,26 @@ def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav, monkey
         Go = A.T @ A
         G = eng.gram(st, rhs=rhs, w=wt)
         R = eng.tsqr(st, rhs=rhs, w=wt)
-        monkeypatch.setenv("FBR_NO_LINK_MERGE", "1")
+        eng.set_option("link_merge", 0)
         assert eng.link_merge_info()["reduced_cols"] == info["cols"]
         Gp = eng.gram(st, rhs=rhs, w=wt)
         Rp = eng.tsqr(st, rhs=rhs, w=wt)
-        monkeypatch.delenv("FBR_NO_LINK_MERGE")
+        eng.set_option("link_merge", 1)
         if not grav:  # fixed links merged, revolute links not regrouped: the middle model, which also takes the short factorisations
-            monkeypatch.setenv("FBR_NO_REGROUP", "1")
+            eng.set_option("regroup", 0)
             assert eng.link_merge_info()["reduced_cols"] == 10 * (t.num_links - nfixed) + (info["cols"] - 10 * t.num_links)
             Gm = eng.gram(st, rhs=rhs, w=wt)
             Rm = eng.tsqr(st, rhs=rhs, w=wt)
-            monkeypatch.delenv("FBR_NO_REGROUP")
+            eng.set_option("regroup", 1)
             assert _rel(Gm, Go) <= 1e-12 and _rel(Rm.T @ Rm, Go) <= 1e-12
             # the regrouped model's factorisation by row groups at this size, with both writers
-            monkeypatch.setenv("FBR_TSQR_GROUP_MIN_SAMPLES", "1")
-            for writer in ("FBR_TSQR_WRITER8", "FBR_TSQR_WRITER16"):
-                monkeypatch.setenv(writer, "1")
+            eng.set_option("tsqr_group_min_samples", 1)
+            for writer in (8, 16):
+                eng.set_option("tsqr_writer", writer)
                 Rg = eng.tsqr(st, rhs=rhs, w=wt)
-                monkeypatch.delenv(writer)
                 assert _rel(Rg.T @ Rg, Go) <= 1e-12 and np.all(np.tril(Rg, -1) == 0), writer
-            monkeypatch.delenv("FBR_TSQR_GROUP_MIN_SAMPLES")
+            eng.set_option("tsqr_writer", 0)
+            eng.set_option("tsqr_group_min_samples", 24000)
         assert _rel(G, Go) <= 1e-12 and _rel(Gp, Go) <= 1e-12 and _rel(G, Gp) <= 1e-13
         assert np.array_equal(G, G.T)
         assert np.all(np.tril(R, -1) == 0)
@@ -117,12 +125,9 @@ def test_walkman_merged_submissions_are_bitwise_the_blocking_result():
     torch.cuda.synchronize()
     for i in range(3):
         assert torch.equal(Go[i], Gb[i]) and torch.equal(Ro[i], Rb[i])
-    os.environ["FBR_NO_LINK_MERGE"] = "1"
-    try:
-        Gp = eng.gram(sts[0], rhs=rhs[0])
-        Rp = eng.tsqr(sts[0], rhs=rhs[0])
-    finally:
-        os.environ.pop("FBR_NO_LINK_MERGE", None)
+    eng.set_option("link_merge", 0)
+    Gp = eng.gram(sts[0], rhs=rhs[0])
+    Rp = eng.tsqr(sts[0], rhs=rhs[0])
     gn = float(torch.linalg.norm(Gp))
     assert float(torch.linalg.norm(Gb[0] - Gp)) <= 1e-13 * gn
     assert float(torch.linalg.norm(Rb[0].T @ Rb[0] - Gp)) <= 1e-12 * gn and float(torch.linalg.norm(Rp.T @ Rp - Gp)) <= 1e-12 * gn
@@ -138,27 +143,24 @@ def test_walkman_tile_program_of_the_reductions():
 
     t = load_topo("walkman_apriori")
 
-    def info(env, k=1):
-        for kk, v in env.items():
-            os.environ[kk] = v
-        try:
-            eng = Engine(t, floating=True)
-            out = eng.gram_program_info(k)
-            eng.close()
-        finally:
-            for kk in env:
-                os.environ.pop(kk, None)
+    def info(options, k=1, num_samples=-1):
+        eng = Engine(t, floating=True, options=options)
+        out = eng.gram_program_info(k, num_samples)
+        eng.close()
         return out
 
     assert info({}) == {"tiles": 15, "pairs": 120, "mfma_per_sample": 272, "parts": 1}
-    assert info({"FBR_GRAM_NO_ORIENT": "1"})["parts"] == 2
-    assert info({"FBR_GRAM_RHS_TILE": "1"}) == {"tiles": 16, "pairs": 136, "mfma_per_sample": 336, "parts": 2}
+    assert info({"gram_orient": 0})["parts"] == 2
+    assert info({"gram_rhs_tile": 1}) == {"tiles": 16, "pairs": 136, "mfma_per_sample": 336, "parts": 2}
     assert info({}, k=16)["tiles"] == 16  # many rhs columns keep their dense tile
-    assert info({"FBR_NO_REGROUP": "1", "FBR_GRAM_RHS_TILE": "1"})["mfma_per_sample"] == 537
-    assert info({"FBR_NO_LINK_MERGE": "1", "FBR_GRAM_RHS_TILE": "1"}) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
+    assert info({"regroup": 0, "gram_rhs_tile": 1})["mfma_per_sample"] == 537
+    assert info({"link_merge": 0, "gram_rhs_tile": 1}) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
+    # the info calls describe the program a batch of THAT size executes: below the pay-off threshold (7.8 k samples) all 480 columns
+    assert info({"gram_rhs_tile": 1}, num_samples=5000) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
+    assert info({}, num_samples=8000) == info({})
 
 
-def test_small_batches_skip_the_reductions(monkeypatch):
+def test_small_batches_skip_the_reductions():
     """A short batch of a small robot runs over all its columns (the reduced pass costs a second model's launches and two expansion
     kernels); the result is the same either way, and a long batch takes the reductions."""
     import time
@@ -170,10 +172,13 @@ def test_small_batches_skip_the_reductions(monkeypatch):
     eng = Engine(t, floating=False)
     st = random_states(t, 3000, rng, False)
     rhs = rng.standard_normal((3000 * eng.rows, 1))
+    eng.set_option("reduce_min_work", 0)
     G_forced = eng.gram(st, rhs=rhs)
-    monkeypatch.delenv("FBR_REDUCE_ALWAYS", raising=False)
+    assert eng.link_merge_info(3000)["reduced_cols"] < eng.cols
+    eng.set_option("reduce_min_work", 1e9)
+    assert eng.link_merge_info(3000)["reduced_cols"] == eng.cols and eng.link_merge_info(10**6)["reduced_cols"] < eng.cols
     G_default = eng.gram(st, rhs=rhs)
-    monkeypatch.setenv("FBR_NO_LINK_MERGE", "1")
+    eng.set_option("link_merge", 0)
     G_plain = eng.gram(st, rhs=rhs)
     assert np.array_equal(G_default, G_plain)          # 3000 samples x 21 merged-away columns: not worth a second pass
     assert not np.array_equal(G_forced, G_plain) and _rel(G_forced, G_plain) <= 1e-13

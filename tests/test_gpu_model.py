@@ -8,7 +8,7 @@ import pytest
 
 from common import ROBOTS, load_topo, random_states
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reduction_mode")]  # three modes of the column reductions: conftest.py
 
 
 def _opt(**kw):

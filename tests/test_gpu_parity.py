@@ -11,7 +11,8 @@ import pytest
 
 from common import CONFIGS, cfg_id, load_topo, random_states
 
-pytestmark = pytest.mark.gpu
+# every test runs with the product's own choice of the column reductions, with the reductions forced and with them switched off (conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reduction_mode")]
 
 
 def _engine_oracle(cfg):
@@ -303,8 +304,8 @@ def test_grouped_gram_odd_group_sizes_floating_base(Sg):
     assert np.linalg.norm(G - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A)
 
 
-def test_multi_chunk_paths_at_small_sizes(monkeypatch):
-    """FBR_CHUNK_SAMPLES forces the chunked code paths (double-buffered producer stream of the Gram, groups larger /
+def test_multi_chunk_paths_at_small_sizes():
+    """The option chunk_samples forces the chunked code paths (double-buffered producer stream of the Gram, groups larger /
     smaller than a chunk, several TSQR chunks, chunked regressor / inverse dynamics) at sizes the oracle can check."""
     cfg = CONFIGS[7]
     t, eng, om = _engine_oracle(cfg)
@@ -314,7 +315,7 @@ def test_multi_chunk_paths_at_small_sizes(monkeypatch):
     A = _aug(om, st, rhs)
     Go = A.T @ A
     x = rng.standard_normal(om.P)
-    monkeypatch.setenv("FBR_CHUNK_SAMPLES", "70")
+    eng.set_option("chunk_samples", 70)
     G = eng.gram(st, rhs=rhs)
     assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go)
     R = eng.tsqr(st, rhs=rhs)
@@ -333,7 +334,7 @@ def test_multi_chunk_paths_at_small_sizes(monkeypatch):
             assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * np.linalg.norm(Ag.T @ Ag)
 
 
-def test_pinned_host_inputs_are_staged_chunk_by_chunk(monkeypatch):
+def test_pinned_host_inputs_are_staged_chunk_by_chunk():
     """Pinned host states / rhs / weights take the chunked staging path of fbr_gram_accumulate (copy stream, double-buffered staging
     buffers, events against the producer stream); pageable ones the up-front copy.  Both must give the device-resident result bit for
     bit (same chunking, same kernels), also for grouped Grams and with a friction layout (sign series staged as well)."""
@@ -345,7 +346,7 @@ def test_pinned_host_inputs_are_staged_chunk_by_chunk(monkeypatch):
         st, rng = _states(t, cfg, S, 17)
         rhs = rng.standard_normal((S * om.rows, 2))
         w = 0.5 + rng.random(S * om.rows)
-        monkeypatch.setenv("FBR_CHUNK_SAMPLES", "90")   # 8 chunks: both staging buffers are reused several times
+        eng.set_option("chunk_samples", 90)   # 8 chunks: both staging buffers are reused several times
         G_pageable = eng.gram(st, rhs=rhs, w=w)
         pin = {k: torch.from_numpy(v).pin_memory() for k, v in st.items()}
         G_pinned = eng.gram(pin, rhs=torch.from_numpy(rhs).pin_memory(), w=torch.from_numpy(w).pin_memory())
@@ -367,15 +368,15 @@ def test_pinned_host_inputs_are_staged_chunk_by_chunk(monkeypatch):
         eng.close()
 
 
-def test_tsqr_column_order_is_internal(monkeypatch):
+def test_tsqr_column_order_is_internal():
     """The single wide factorisation (short batches, unbranched robots) orders the inertial columns by link depth internally
      and returns the factor in the caller's order: with the reordering switched off the same R^T R and, for a full-rank
     column subset, the same sign-normalised R; an R_in in the caller's order streams through either way; the executed-work
     counter reports the saving."""
-    monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
-    monkeypatch.setenv("FBR_NO_LINK_MERGE", "1")  # (the column order of the UNMERGED factorisation is what is looked at)
     cfg = CONFIGS[7]
     t, eng, om = _engine_oracle(cfg)
+    eng.set_option("tsqr_groups", 0)
+    eng.set_option("link_merge", 0)  # (the column order of the UNMERGED factorisation is what is looked at)
     S = 1200   # (35 S rows >= 64 n: below that the final re-triangularisation is not worth it and the caller's order is kept)
     st, rng = _states(t, cfg, S, 23)
     rhs = rng.standard_normal((S * om.rows, 1))
@@ -397,7 +398,7 @@ def test_tsqr_column_order_is_internal(monkeypatch):
         return R, Rc, Rs, eng.tsqr_work_info(S, k=1)
 
     R1, Rc1, Rs1, wi1 = run()
-    monkeypatch.setenv("FBR_TSQR_NO_REORDER", "1")
+    eng.set_option("tsqr_reorder", 0)
     R0, Rc0, Rs0, wi0 = run()
     for R in (R0, R1):
         assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
@@ -410,7 +411,7 @@ def test_tsqr_column_order_is_internal(monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[8], CONFIGS[4]], ids=cfg_id)
-def test_tsqr_row_groups_along_the_tree(cfg, monkeypatch):
+def test_tsqr_row_groups_along_the_tree(cfg):
     """Tree-structured TSQR: the base-wrench rows and every unbranched chain of joints are factorised on their own, over
     the columns their rows can touch, and the group factors are folded into the final factor.  Same R^T R as the single
     factorisation, the same sign-normalised R for a full-rank column subset (also with row weights and a streamed R_in), and the
@@ -438,9 +439,9 @@ def test_tsqr_row_groups_along_the_tree(cfg, monkeypatch):
                       R_in=eng.tsqr(first, rhs=rhs[: h * om.rows], w=w[: h * om.rows], cols=cols))
         return R, Rc, Rs, eng.tsqr_work_info(S, k=2), eng.tsqr_work_info(1000000, k=2)
 
-    monkeypatch.setenv("FBR_TSQR_GROUP_MIN_SAMPLES", "1")
+    eng.set_option("tsqr_group_min_samples", 1)
     R1, Rc1, Rs1, wi1, big1 = run()
-    monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
+    eng.set_option("tsqr_groups", 0)
     R0, Rc0, Rs0, wi0, big0 = run()
     for R in (R0, R1):
         assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * np.linalg.norm(Go)
@@ -456,12 +457,12 @@ def test_tsqr_row_groups_along_the_tree(cfg, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[6]], ids=cfg_id)
-def test_tsqr_row_mask_skips_masked_rows(cfg, monkeypatch):
+def test_tsqr_row_mask_skips_masked_rows(cfg):
     """Base-wrench-only identification (identifier.py:629-636: only the 6 base rows of every sample enter the fit) is a 0/1 row
     weight: rows that no sample weights are left out of the factorisation altogether (their groups are not formed).  Same R^T R as
     the weighted Gram, also for a mask that keeps single joint rows, and the same sign-normalised R as the unskipped path."""
-    monkeypatch.setenv("FBR_TSQR_GROUP_MIN_SAMPLES", "1")
     t, eng, om = _engine_oracle(cfg)
+    eng.set_option("tsqr_group_min_samples", 1)
     S = 700
     st, rng = _states(t, cfg, S, 41)
     rhs = rng.standard_normal((S * om.rows, 1))
@@ -481,9 +482,9 @@ def test_tsqr_row_mask_skips_masked_rows(cfg, monkeypatch):
         ncol = min(60, int(np.linalg.matrix_rank(Go[: om.P, : om.P])) - 3)
         cols = np.sort(sla.qr(Go[: om.P, : om.P], pivoting=True, mode="r")[1][:ncol]).astype(np.int32)
         Rc = eng.tsqr(st, rhs=rhs, w=w, cols=cols)
-        monkeypatch.setenv("FBR_TSQR_NO_GROUPS", "1")
+        eng.set_option("tsqr_groups", 0)
         Rc0 = eng.tsqr(st, rhs=rhs, w=w, cols=cols)
-        monkeypatch.delenv("FBR_TSQR_NO_GROUPS")
+        eng.set_option("tsqr_groups", 1)
         norm = lambda R: R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
         assert np.linalg.norm(norm(Rc) - norm(Rc0)) <= 1e-9 * np.linalg.norm(Rc0)
 
@@ -647,7 +648,7 @@ def test_tsqr_badly_scaled_and_tiny_columns():
 @pytest.mark.parametrize("seed,L,branch,floating,fric,sym", [
     (11, 14, 0.5, 1, 1, 0), (12, 30, 0.3, 1, 1, 1), (13, 44, 0.7, 0, 1, 0), (14, 55, 0.0, 1, 0, 1), (15, 60, 0.4, 0, 1, 1),
 ])
-def test_random_trees_all_entry_points(seed, L, branch, floating, fric, sym, monkeypatch):
+def test_random_trees_all_entry_points(seed, L, branch, floating, fric, sym):
     """Random kinematic trees (nothing tuned to the bundled robots): regressor, fused Gram (both kernel shapes), TSQR and
     prediction against the oracle."""
     from common import random_topology
@@ -667,8 +668,7 @@ def test_random_trees_all_entry_points(seed, L, branch, floating, fric, sym, mon
     A = np.hstack([Yo, rhs])
     Go = A.T @ A
     for shape in ("two", "one"):
-        monkeypatch.setenv("FBR_GRAM_SHAPE", shape)
-        eng = Engine(t, floating=bool(floating), friction=bool(fric), friction_symmetric=bool(sym))
+        eng = Engine(t, floating=bool(floating), friction=bool(fric), friction_symmetric=bool(sym), options={"gram_shape": 2 if shape == "two" else 1})
         G = eng.gram(st, rhs=rhs)
         assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go), shape
         if shape == "two":

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import synth_states
 from flobaroid_amd._lib import Engine
+import _opts  # noqa: F401  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 dev = torch.device("cuda", 0)

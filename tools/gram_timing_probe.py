@@ -13,6 +13,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 from bench import synth_states  # noqa: E402
 from flobaroid_amd._lib import Engine  # noqa: E402
+import _opts  # noqa: F401  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology  # noqa: E402
 
 fric = "friction" in sys.argv

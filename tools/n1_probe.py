@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 from bench import synth_states
 from flobaroid_amd._lib import Engine
+import _opts  # noqa: F401  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology
 
 dev = torch.device("cuda", 0)

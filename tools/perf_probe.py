@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import synth_states  # noqa: E402
 from flobaroid_amd._lib import Engine  # noqa: E402
+import _opts  # noqa: F401  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology  # noqa: E402
 
 

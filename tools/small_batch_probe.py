@@ -2,6 +2,7 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from bench import synth_states
 from flobaroid_amd._lib import Engine
+import _opts  # noqa: F401  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology
 ROOT="/root/repo"
 dev = torch.device("cuda", 0)

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import synth_states
 from flobaroid_amd._lib import Engine
+import _opts  # noqa: F401  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology
 dev = torch.device("cuda", 0)
 for robot, S in (("walkman_apriori", 150000), ("walkman_left_arm", 500000)):
