@@ -156,3 +156,26 @@ def test_bench_refuses_a_mislabelled_world():
     r = _run_bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert r.returncode != 0 and b"refusing" in r.stderr
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_bench_gpus_8_dry_run_over_gloo():
+    """The world size the driver's scaling run uses, before the first real node sees it: ``bench.py --gpus 8`` over gloo with the CPU
+    stand-in -- eight ranks spawned by the bench itself, the self-check over every one of the 7 edges of the depth-3 rank tree,
+    ``warm_p2p``, the watchdog armed around every exchange step, the sharded Gram + all-reduce, the TSQR rank tree (3 levels) checked
+    against the all-reduced Gram, and the weak-scaling leg.  Same checksums as the one-rank run of the same 512 samples."""
+    import json
+
+    r8 = _run_bench(["--gpus", "8", "--samples", "512", "--dist-timeout", "240"], timeout=900)
+    assert r8.returncode == 0, r8.stderr.decode()[-3000:]
+    js = [l for l in r8.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(js) == 1
+    eight = json.loads(js[0])
+    r1 = _run_bench(["--gpus", "1", "--samples", "512"])
+    one = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert eight["n_gpus"] == 8 and eight["ranks_seen_by_process_group"] == 8 and eight["config"]["samples_per_gpu"] == 64
+    for key in ("trace", "fro"):
+        assert abs(one["gram_checksum"][key] - eight["gram_checksum"][key]) <= 1e-11 * abs(one["gram_checksum"][key])
+    assert eight["tsqr"]["rank_tree_levels"] == 3 and eight["tsqr"]["relerr_RtR_vs_allreduced_gram"] <= 1e-11
+    sc = eight["selfcheck_dist"]
+    assert sc["world"] == 8 and sc["tsqr_tree_relerr"] <= 1e-12 and sc.get("tree_edges", 7) == 7
+    assert len(eight["per_rank_ms_per_step"]) == 8 and eight["weak_scaling"]["relerr_vs_world_x_sharded_gram"] <= 1e-11

@@ -156,8 +156,8 @@ def test_walkman_tile_program_of_the_reductions():
     assert info({"regroup": 0, "gram_rhs_tile": 1})["mfma_per_sample"] == 537
     assert info({"link_merge": 0, "gram_rhs_tile": 1}) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
     # the info calls describe the program a batch of THAT size executes: below the pay-off threshold (7.8 k samples) all 480 columns
-    assert info({"gram_rhs_tile": 1}, num_samples=5000) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
-    assert info({}, num_samples=8000) == info({})
+    assert info({"gram_rhs_tile": 1, "reduce_min_work": 1e9}, num_samples=5000) == {"tiles": 33, "pairs": 561, "mfma_per_sample": 1235, "parts": 5}
+    assert info({"reduce_min_work": 1e9}, num_samples=8000) == info({})
 
 
 def test_small_batches_skip_the_reductions():

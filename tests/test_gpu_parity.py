@@ -839,3 +839,32 @@ def test_gram_of_a_robot_beyond_60_rows_per_sample_comes_from_the_tsqr_factor():
     with pytest.raises(FbrError, match="60 rows"):
         eng.gram_grouped(st, 3)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["threeLinks", "kuka_lwr4", "walkman_left_arm", "walkman_apriori"])
+def test_hip_against_idyntree_outputs(name):
+    """The HIP path against iDynTree's own outputs (tests/golden/idyntree_<robot>.npz, written by tools/pin_idyntree.py where the
+    reference's environment exists; skipped while the files are not committed): regressor, inverse dynamics and J^T w on the seeded
+    states, fixed and floating base -- the same comparison tests/test_oracle.py makes for the oracle, so that a green run here does not
+    rest on the oracle at all."""
+    from flobaroid_amd._lib import Engine
+    from test_oracle import idyntree_fixture
+
+    fx = idyntree_fixture(name)
+    t = load_topo(name)
+    assert list(fx["link_names"]) == list(t.link_names) and list(fx["dof_names"]) == list(t.dof_names)
+    S = fx["fb1_q"].shape[0]
+    for fl in (0, 1):
+        st = {k: fx[f"fb{fl}_{k}"] for k in ("q", "dq", "ddq")}
+        if fl:
+            st.update({k: fx[f"fb1_{k}"] for k in ("base_vel", "base_acc", "rpy")})
+        eng = Engine(t, floating=bool(fl))
+        Yi = fx[f"fb{fl}_Y"][:, (0 if fl else 6):, :].reshape(S * eng.rows, eng.cols)
+        ti = fx[f"fb{fl}_tau"][:, (0 if fl else 6):]
+        assert np.abs(eng.regressor(st) - Yi).max() <= 1e-9 * np.abs(Yi).max()
+        assert np.abs(eng.inverse_dynamics(st, t.x_std()) - ti).max() <= 1e-9 * np.abs(ti).max()
+        if fl and bool(fx["fb1_have_frame"]):
+            w = np.random.default_rng(7).standard_normal((S, 6))
+            ci = np.einsum("sij,si->sj", fx["fb1_J"], w)
+            assert np.abs(eng.contact_torques(st, str(fx["frame"]), w) - ci).max() <= 1e-9 * np.abs(ci).max()
+        eng.close()
