@@ -74,6 +74,20 @@ if gk:
                            "write_bytes_per_sample": write_kb * 1024 / spl},
            "hbm_bytes_per_sample": 2.0 * fetch_kb * 1024 / spl + write_kb * 1024 / spl,
            "correction": "FETCH_SIZE x2 on gfx950 for 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported"}
+    # staging traffic of the whole fused pass: every kernel of the step (kinematics, packer, Gram, reductions), counter bytes per sample.
+    # FETCH_SIZE x2 only for the Gram kernel's 16-byte-per-lane LDS-DMA stream (the calibrated case of the guide); the 8-byte reads of the
+    # kinematics / packer are taken as reported (uncalibrated there: a lower bound)
+    per_kernel = {}
+    for k in sorted(set(pmc.get("FETCH_SIZE", {})) | set(pmc.get("WRITE_SIZE", {}))):
+        f = pmc.get("FETCH_SIZE", {}).get(k, {"per_launch": 0.0, "launches": 0})
+        w = pmc.get("WRITE_SIZE", {}).get(k, {"per_launch": 0.0, "launches": 0})
+        fb = f["per_launch"] * f["launches"] * 1024 / S * (2.0 if k.startswith("fbr_gram_kernel") else 1.0)
+        wb = w["per_launch"] * w["launches"] * 1024 / S
+        if fb + wb > 1.0:
+            per_kernel[k] = {"fetch": round(fb, 1), "write": round(wb, 1)}
+    out["staging"] = {"per_kernel_bytes_per_sample": per_kernel,
+                      "hbm_bytes_per_sample_all_kernels": round(sum(v["fetch"] + v["write"] for v in per_kernel.values()), 1),
+                      "note": "sum over the launches of the 200000-sample pass / 200000"}
     json.dump(out, open(os.path.join(dst, tag + "_gram_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 print("bench:", bench["value"], bench["roofline"]["avg_launch_ms"], bench.get("tsqr", {}).get("executed_TFLOP_per_s"))
