@@ -77,14 +77,23 @@ if gk:
     # staging traffic of the whole fused pass: every kernel of the step (kinematics, packer, Gram, reductions), counter bytes per sample.
     # FETCH_SIZE x2 only for the Gram kernel's 16-byte-per-lane LDS-DMA stream (the calibrated case of the guide); the 8-byte reads of the
     # kinematics / packer are taken as reported (uncalibrated there: a lower bound)
+    # (only the launches of the PASS: the kinematics launches on the packer's queue -- bench.py's data generation runs the kinematics
+    # and fbr_id_kernel of the unreduced model on the main stream before the step)
+    def raw(prefix):
+        path = os.path.join(src, prefix + "_counter_collection.csv")
+        return list(csv.DictReader(open(path))) if os.path.exists(path) else []
+
     per_kernel = {}
-    for k in sorted(set(pmc.get("FETCH_SIZE", {})) | set(pmc.get("WRITE_SIZE", {}))):
-        f = pmc.get("FETCH_SIZE", {}).get(k, {"per_launch": 0.0, "launches": 0})
-        w = pmc.get("WRITE_SIZE", {}).get(k, {"per_launch": 0.0, "launches": 0})
-        fb = f["per_launch"] * f["launches"] * 1024 / S * (2.0 if k.startswith("fbr_gram_kernel") else 1.0)
-        wb = w["per_launch"] * w["launches"] * 1024 / S
-        if fb + wb > 1.0:
-            per_kernel[k] = {"fetch": round(fb, 1), "write": round(wb, 1)}
+    for prefix, field, factor_gram in (("pmc_fetch", "fetch", 2.0), ("pmc_write", "write", 1.0)):
+        rows_ = raw(prefix)
+        pq = {r["Queue_Id"] for r in rows_ if short(r["Kernel_Name"]).startswith("fbr_pack_kernel")}
+        for r in rows_:
+            k = short(r["Kernel_Name"])
+            if not k.startswith("fbr_") or k.startswith("fbr_id_kernel") or (k.startswith("fbr_kin_kernel") and r["Queue_Id"] not in pq):
+                continue
+            v = float(r["Counter_Value"]) * 1024 / S * (factor_gram if k.startswith("fbr_gram_kernel") else 1.0)
+            per_kernel.setdefault(k, {"fetch": 0.0, "write": 0.0})[field] += v
+    per_kernel = {k: {f: round(x, 1) for f, x in v.items()} for k, v in per_kernel.items() if v["fetch"] + v["write"] > 1.0}
     out["staging"] = {"per_kernel_bytes_per_sample": per_kernel,
                       "hbm_bytes_per_sample_all_kernels": round(sum(v["fetch"] + v["write"] for v in per_kernel.values()), 1),
                       "note": "sum over the launches of the 200000-sample pass / 200000"}
