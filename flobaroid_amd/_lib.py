@@ -41,6 +41,7 @@ class fbr_topology(ctypes.Structure):
         ("friction_symmetric", ctypes.c_int32),
         ("gravity_only", ctypes.c_int32),
         ("stribeck_velocity", ctypes.c_double),
+        ("joint_type", _ip),
     ]
 
 
@@ -245,6 +246,8 @@ class Engine:
         t.friction_symmetric = int(bool(friction_symmetric))
         t.gravity_only = int(bool(gravity_only))
         t.stribeck_velocity = float(stribeck_velocity)
+        self._jtype = np.array(topo.joint_type, dtype=np.int32)  # 0 fixed, 1 revolute, 2 prismatic
+        t.joint_type = self._jtype.ctypes.data_as(_ip)
         h = ctypes.c_void_p()
         _check(lib.fbr_model_create(ctypes.byref(t), int(device), ctypes.byref(h)), "fbr_model_create")
         self._h = h

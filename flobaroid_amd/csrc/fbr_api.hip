@@ -51,7 +51,7 @@ extern "C" int fbr_device_count(void)
 extern "C" const char *fbr_last_error(void) { return g_fbr_err.c_str(); }
 
 static int build_reduction(fbr_model *m, const fbr_topology *t, int which);
-static int create_model(const fbr_topology *t, int device, fbr_model **out, bool allow_merge, const unsigned short *linkmask = nullptr)
+static int create_model(const fbr_topology *t, int device, fbr_model **out, bool allow_merge, const unsigned short *linkmask = nullptr)  // (t->joint_type: NULL or [L])
 {
     if (!t || !out) {
         set_err("null argument");
@@ -71,7 +71,7 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
     std::unique_ptr<fbr_model> m(new fbr_model());
     try {
         m->hm.build(t->num_links, t->num_dofs, t->parent, t->dof_index, t->rest_R, t->rest_p, t->axis, t->floating_base,
-                    t->gravity, t->friction, t->friction_symmetric, t->gravity_only, t->stribeck_velocity, linkmask);
+                    t->gravity, t->friction, t->friction_symmetric, t->gravity_only, t->stribeck_velocity, linkmask, t->joint_type);
     } catch (const std::exception &e) {
         set_err(std::string("invalid topology: ") + e.what());
         return FBR_E_INVALID;
@@ -143,6 +143,7 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
     if ((rc = upload(m->tables, hm.order, &dm.order))) return rc;
     if ((rc = upload(m->tables, hm.parent, &dm.parent))) return rc;
     if ((rc = upload(m->tables, hm.dof, &dm.dof))) return rc;
+    if ((rc = upload(m->tables, hm.jtype, &dm.jtype))) return rc;
     if ((rc = upload(m->tables, hm.restR, &dm.restR))) return rc;
     if ((rc = upload(m->tables, hm.restp, &dm.restp))) return rc;
     if ((rc = upload(m->tables, hm.axis, &dm.axis))) return rc;
@@ -180,6 +181,7 @@ static int build_reduction(fbr_model *m, const fbr_topology *t, int which)
     tr.rest_R = rr.restR.data();
     tr.rest_p = rr.restp.data();
     tr.axis = rr.axis.data();
+    tr.joint_type = rr.jtype.data();
     fbr_model *red = nullptr;
     if (int rc = create_model(&tr, m->device, &red, false, rr.masked ? rr.masks.data() : nullptr)) return rc;
     m->rdm[which].reset(red);

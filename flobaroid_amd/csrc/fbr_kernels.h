@@ -16,6 +16,7 @@ struct DevModel {
     double g[3];
     double stribeck;
     const int *order, *parent, *dof;
+    const int *jtype;                 // [L] 0 fixed / base, 1 revolute, 2 prismatic
     const double *restR, *restp, *axis;
     const int *pathlen, *pathtab;     // [L], [L*maxd]  movable joints root -> link
     const int *pathpos;               // [L*maxd] packed image row of each joint of the path (FbrHostModel::ppos)
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, WAVES) void fbr_kin_kernel(DevModel m, long S,
                 dqv = dqs[d];
                 ddqv = ddqs[d];
             }
-            fbr_kin_child(P, rR, rp, ax, d >= 0, qv, dqv, ddqv, out, Sv);
+            fbr_kin_child(P, rR, rp, ax, m.jtype[l], qv, dqv, ddqv, out, Sv);
         }
         if (d >= 0)
             for (int i = 0; i < 6; i++) r[FBR_LINK_REC * m.L + FBR_DOF_REC * d + i] = Sv[i];

@@ -90,13 +90,13 @@ FBR_HD void fbr_kin_base(int floating, const double *g, const double *base_vel, 
     rec[FBR_OFF_P] = rec[FBR_OFF_P + 1] = rec[FBR_OFF_P + 2] = 0.0;
 }
 
-// Child link record from the parent's.  has_dof: revolute about `s` (unit, child frame) by q.
-// Srec (6) receives the joint motion vector in A when has_dof.
-FBR_HD void fbr_kin_child(const double *par, const double *restR, const double *r, const double *s, int has_dof,
+// Child link record from the parent's.  jt: 0 fixed, 1 revolute about `s` (unit, child frame) by q, 2 prismatic along `s` by q.
+// Srec (6) receives the joint motion vector in A when jt != 0.
+FBR_HD void fbr_kin_child(const double *par, const double *restR, const double *r0, const double *s, int jt,
                           double q, double dq, double ddq, double *rec, double *Srec)
 {
-    double Rj[9];
-    if (has_dof) {
+    double Rj[9], r[3] = {r0[0], r0[1], r0[2]}, sp[3] = {0, 0, 0};
+    if (jt == 1) {
         const double c = cos(q), sn = sin(q), v = 1.0 - c;
         double Rq[9];
         Rq[0] = c + s[0] * s[0] * v;
@@ -111,6 +111,10 @@ FBR_HD void fbr_kin_child(const double *par, const double *restR, const double *
         fbr_mm(restR, Rq, Rj);
     } else {
         for (int i = 0; i < 9; i++) Rj[i] = restR[i];
+        if (jt == 2) {  // the child origin slides along the axis (parent axes: restR s)
+            fbr_mv(restR, s, sp);
+            for (int i = 0; i < 3; i++) r[i] += sp[i] * q;
+        }
     }
     const double *Rp = par + FBR_OFF_R, *wp = par + FBR_OFF_W, *dwp = par + FBR_OFF_DW, *ap = par + FBR_OFF_A;
     fbr_mm(Rp, Rj, rec + FBR_OFF_R);
@@ -123,11 +127,16 @@ FBR_HD void fbr_kin_child(const double *par, const double *restR, const double *
     fbr_cross(wp, r, wxr);
     fbr_cross(wp, wxr, wxwxr);
     for (int i = 0; i < 3; i++) acc[i] = ap[i] + dwxr[i] + wxwxr[i];
+    if (jt == 2) {  // relative motion of the origin along the axis: Coriolis 2 w x (s dq) + s ddq
+        double wxs[3];
+        fbr_cross(wp, sp, wxs);
+        for (int i = 0; i < 3; i++) acc[i] += 2.0 * wxs[i] * dq + sp[i] * ddq;
+    }
     fbr_mtv(Rj, acc, rec + FBR_OFF_A);
     double wl[3], dwl[3];
     fbr_mtv(Rj, wp, wl);
     fbr_mtv(Rj, dwp, dwl);
-    if (has_dof) {
+    if (jt == 1) {
         double wxs[3];
         fbr_cross(wl, s, wxs);
         for (int i = 0; i < 3; i++) {
@@ -141,6 +150,10 @@ FBR_HD void fbr_kin_child(const double *par, const double *restR, const double *
         for (int i = 0; i < 3; i++) {
             rec[FBR_OFF_W + i] = wl[i];
             rec[FBR_OFF_DW + i] = dwl[i];
+        }
+        if (jt == 2) {  // S = [sA ; 0]: a unit velocity along the axis, the same at every point
+            fbr_mv(rec + FBR_OFF_R, s, Srec);
+            Srec[3] = Srec[4] = Srec[5] = 0.0;
         }
     }
 }

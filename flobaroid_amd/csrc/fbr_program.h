@@ -78,6 +78,7 @@ struct FbrHostModel {
     double stribeck = 0.0;
     double gravity[3] = {0, 0, -9.81};
     std::vector<int> order, parent, dof;
+    std::vector<int> jtype;  // [L] 0 fixed / base, 1 revolute, 2 prismatic
     std::vector<double> restR, restp, axis;
     std::vector<std::vector<int>> path;  // per link: movable joints root -> link
     std::vector<std::vector<int>> ppos;  // per link: PACKED row position of each joint of its path (see FbrTile)
@@ -95,7 +96,7 @@ struct FbrHostModel {
 
     void build(int L_, int n_, const int32_t *parent_, const int32_t *dof_, const double *restR_, const double *restp_,
                const double *axis_, int floating_, const double *g, int fric_, int fric_sym_, int grav_only_,
-               double stribeck_, const unsigned short *linkmask = nullptr)
+               double stribeck_, const unsigned short *linkmask = nullptr, const int32_t *jtype_ = nullptr)
     {
         L = L_; n = n_; floating = floating_ ? 1 : 0; fric = fric_ ? 1 : 0; fric_sym = fric_sym_ ? 1 : 0;
         grav_only = grav_only_ ? 1 : 0; stribeck = stribeck_;
@@ -110,6 +111,13 @@ struct FbrHostModel {
         restR.assign(restR_, restR_ + 9 * L);
         restp.assign(restp_, restp_ + 3 * L);
         axis.assign(axis_, axis_ + 3 * L);
+        jtype.assign(L, 0);
+        for (int l = 0; l < L; l++) {
+            if (parent_[l] < 0 || dof_[l] < 0) continue;
+            const int jt = jtype_ ? jtype_[l] : 1;
+            if (jt != 1 && jt != 2) throw std::runtime_error("joint_type of a link with a DOF must be 1 (revolute) or 2 (prismatic)");
+            jtype[l] = jt;
+        }
         // traversal: stable DFS, parents first
         std::vector<std::vector<int>> children(L);
         int base = -1;

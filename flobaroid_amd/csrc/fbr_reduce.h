@@ -69,7 +69,7 @@ static inline void fbr_axis_frame(const double *a_in, double *Q)
 
 struct FbrReducedRobot {
     int Lr = 0;
-    std::vector<int32_t> parent, dof;          // [Lr]
+    std::vector<int32_t> parent, dof, jtype;   // [Lr]
     std::vector<double> restR, restp, axis;    // [9 Lr], [3 Lr], [3 Lr]
     std::vector<unsigned short> masks;         // [Lr] identified parameters of every reduced link (0x3ff: all ten)
     bool masked = false;                       // some link has a mask (regrouping)
@@ -77,8 +77,8 @@ struct FbrReducedRobot {
     std::vector<double> bR, bp;                // [9 L], [3 L]  x_body = bR x_link + bp
 };
 
-// which = 0: fixed links merged into the moving bodies; which = 1: the same, and the three regroupable parameters of every link behind a
-// revolute joint dropped.  false: nothing to reduce (no such links, or a gravity-only model).
+// which = 0: fixed links merged into the moving bodies; which = 1: the same, and the regroupable parameters of every link behind a joint
+// dropped (revolute: three -- m, h along the axis, the inertia 1 - a a^T; prismatic: the six inertia entries).  false: nothing to reduce (no such links, or a gravity-only model).
 static inline bool fbr_reduce_robot(const FbrHostModel &hm, int which, FbrReducedRobot &rr)
 {
     const int L = hm.L;
@@ -105,7 +105,7 @@ static inline bool fbr_reduce_robot(const FbrHostModel &hm, int which, FbrReduce
     std::vector<double> Q((size_t)9 * L, 0.0);
     for (int l = 0; l < L; l++) {
         for (int i = 0; i < 3; i++) Q[9 * l + 4 * i] = 1.0;
-        if (regroup && hm.parent[l] >= 0 && hm.dof[l] >= 0) fbr_axis_frame(&hm.axis[3 * l], &Q[9 * l]);
+        if (regroup && hm.parent[l] >= 0 && hm.dof[l] >= 0 && hm.jtype[l] == 1) fbr_axis_frame(&hm.axis[3 * l], &Q[9 * l]);  // (revolute)
     }
     std::vector<double> &bR = rr.bR, &bp = rr.bp;  // x_body = bR x_link + bp
     bR.assign((size_t)9 * L, 0.0);
@@ -131,6 +131,7 @@ static inline bool fbr_reduce_robot(const FbrHostModel &hm, int which, FbrReduce
     const int Lr = (int)moving.size();
     rr.Lr = Lr;
     std::vector<int32_t> &rparent = rr.parent, &rdof = rr.dof;
+    rr.jtype.assign(moving.size(), 0);
     std::vector<double> &rR = rr.restR, &rp = rr.restp, &rax = rr.axis;
     std::vector<unsigned short> &masks = rr.masks;
     rparent.assign(Lr, -1);
@@ -142,6 +143,7 @@ static inline bool fbr_reduce_robot(const FbrHostModel &hm, int which, FbrReduce
     for (int i = 0; i < Lr; i++) {
         const int l = moving[i], q = hm.parent[l];
         rdof[i] = hm.dof[l];
+        rr.jtype[i] = hm.jtype[l];
         if (q < 0) {
             rparent[i] = -1;
             for (int c = 0; c < 9; c++) rR[9 * i + c] = hm.restR[9 * l + c];
@@ -156,7 +158,9 @@ static inline bool fbr_reduce_robot(const FbrHostModel &hm, int which, FbrReduce
             for (int c = 0; c < 3; c++) rp[3 * i + c] = bp[3 * q + c] + tmp[c];
             for (int c = 0; c < 3; c++)  // Q^T axis (= |axis| z when regrouping)
                 rax[3 * i + c] = Q[9 * l + c] * hm.axis[3 * l] + Q[9 * l + 3 + c] * hm.axis[3 * l + 1] + Q[9 * l + 6 + c] * hm.axis[3 * l + 2];
-            if (regroup) masks[i] = 0x3ff & ~((1u << 0) | (1u << 3) | (1u << 7));  // m, h_z, I_yy
+            // revolute: m, h_z, I_yy dropped.  prismatic: the link turns with its parent whatever the joint does, so all six inertia entries
+            // act like inertia of the parent body (Y_i[I] = Y_par T e_I); m and h feel the displacement and stay
+            if (regroup) masks[i] = hm.jtype[l] == 2 ? 0x00f : (0x3ff & ~((1u << 0) | (1u << 3) | (1u << 7)));
         }
     }
     rr.masked = regroup;
@@ -197,6 +201,10 @@ static inline void fbr_reduction_matrix(const FbrHostModel &hm, const FbrReduced
                 for (int c = 0; c < Pr; c++) dst[c] += tv * src[c];
             }
         };
+        if (masks[i] == 0x00f) {  // prismatic: the whole inertia tensor rides on the parent
+            for (int e = 4; e < 10; e++) add(e, e, 1.0);
+            continue;
+        }
         add(0, 0, 1.0);
         add(3, 3, 1.0);
         add(7, 4, 1.0);

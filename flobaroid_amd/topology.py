@@ -40,6 +40,7 @@ import numpy as np
 
 JOINT_FIXED = 0
 JOINT_REVOLUTE = 1
+JOINT_PRISMATIC = 2
 
 
 def rpy_to_matrix(rpy) -> np.ndarray:
@@ -87,7 +88,7 @@ class Topology:
     link_names: list[str]
     parent: list[int]  # parent link index, -1 for the base
     joint_names: list[str]  # name of the joint connecting link to its parent ("" for the base)
-    joint_type: list[int]  # JOINT_FIXED / JOINT_REVOLUTE
+    joint_type: list[int]  # JOINT_FIXED / JOINT_REVOLUTE / JOINT_PRISMATIC
     dof_index: list[int]  # DOF index of that joint, -1 when fixed / base
     rest_R: np.ndarray  # (L,3,3) child frame orientation in the parent frame at q=0
     rest_p: np.ndarray  # (L,3)   child frame origin in the parent frame
@@ -345,14 +346,16 @@ def parse_urdf(path: str, joint_names: list[str] | None = None, link_order: str 
         jtype = je.attrib.get("type", "fixed")
         if jtype in ("revolute", "continuous"):
             t = JOINT_REVOLUTE
+        elif jtype == "prismatic":
+            t = JOINT_PRISMATIC
         elif jtype == "fixed":
             t = JOINT_FIXED
-        else:
+        else:  # floating / planar joints: several DOFs per joint, which neither the reference's per-joint friction layout nor this path has
             raise NotImplementedError(f"joint type '{jtype}' of joint {je.attrib.get('name')} is not supported")
         R, p = _origin(je)
         ax_e = je.find("axis")
         ax = _vec(ax_e.attrib.get("xyz") if ax_e is not None else None, [1, 0, 0])
-        if t == JOINT_REVOLUTE:
+        if t != JOINT_FIXED:
             nrm = np.linalg.norm(ax)
             if nrm == 0:
                 raise ValueError(f"joint {je.attrib['name']} has a zero axis")
@@ -441,7 +444,9 @@ def parse_urdf(path: str, joint_names: list[str] | None = None, link_order: str 
     friction: dict[str, dict[str, float]] = {}
     for j in raw_joints:
         je = j["elem"]
-        if je.attrib.get("type") != "revolute":
+        # (the reference reads limits / friction of revolute joints only, helpers.py:907,957; prismatic joints are read the same way here
+        # so that the random-state generator of getRandomRegressor has their ranges)
+        if je.attrib.get("type") not in ("revolute", "prismatic"):
             continue
         le = je.find("limit")
         if le is not None:

@@ -53,13 +53,15 @@ typedef struct {
     const int32_t *dof_index; /* [L] DOF of the joint to the parent, -1 when fixed / base */
     const double *rest_R;     /* [L][9] child orientation in the parent frame at q = 0 */
     const double *rest_p;     /* [L][3] child origin in the parent frame */
-    const double *axis;       /* [L][3] unit revolute axis in the child frame */
+    const double *axis;       /* [L][3] unit joint axis in the child frame (rotation axis / sliding direction) */
     int32_t floating_base;    /* opt['floatingBase']: rows per sample = num_dofs + 6 */
     double gravity[3];        /* reference: (0, 0, -9.81), model.py:182-187 */
     int32_t friction;           /* opt['identifyFrictionSimultaneously'] */
     int32_t friction_symmetric; /* opt['identifySymmetricVelFriction'] */
     int32_t gravity_only;       /* opt['identifyGravityParamsOnly'] (keeps 4 columns per link) */
     double stribeck_velocity;   /* opt['stribeckVelocity'] (> 0 adds the Fs block) */
+    const int32_t *joint_type;  /* [L] type of the joint to the parent for links with a DOF: 1 revolute / continuous, 2 prismatic (other
+                                   entries ignored); NULL: every DOF is revolute.  iDynTree's loader takes any URDF (model.py:60-67) */
 } fbr_topology;
 
 /*

@@ -48,6 +48,8 @@ typedef struct {
     const double *restR; /* [L][9] child orientation in parent frame at q=0 (row-major) */
     const double *restp; /* [L][3] child origin in parent frame */
     const double *axis;  /* [L][3] unit joint axis in child frame */
+    const int *jtype;    /* [L] joint type of the links with a DOF: 1 revolute (also when NULL), 2 prismatic -- iDynTree's loader takes
+                            any URDF (identification/model.py:60-67); a prismatic joint is S = [axis; 0] in place of [0; axis] */
     int floating;        /* 1: rows = 6+n, state has base twist/acc/rpy ; 0: rows = n */
     double gravity[3];   /* world gravity, reference uses (0,0,-9.81) model.py:182-187 */
 } orc_model;
@@ -181,7 +183,8 @@ static void orc_kinematics(const orc_model *m, const double *q, const double *dq
         const link_state *ps = &st[par];
         int d = m->dof[l];
         const double *ax = m->axis + 3 * l;
-        if (d >= 0) {
+        const int prismatic = d >= 0 && m->jtype && m->jtype[l] == 2;
+        if (d >= 0 && !prismatic) {
             double Rq[9];
             axis_angle(ax, q[d], Rq);
             mat3_mul(m->restR + 9 * l, Rq, s->pRc);
@@ -189,6 +192,11 @@ static void orc_kinematics(const orc_model *m, const double *q, const double *dq
             memcpy(s->pRc, m->restR + 9 * l, sizeof(s->pRc));
         }
         memcpy(s->pj, m->restp + 3 * l, sizeof(s->pj));
+        if (prismatic) { /* the child frame slides along its own axis: origin moved by restR * axis * q in the parent frame */
+            double sp[3];
+            mat3_vec(m->restR + 9 * l, ax, sp);
+            for (int i = 0; i < 3; i++) s->pj[i] += sp[i] * q[d];
+        }
         mat3_mul(ps->R, s->pRc, s->R);
         double t[3];
         mat3_vec(ps->R, s->pj, t);
@@ -196,18 +204,24 @@ static void orc_kinematics(const orc_model *m, const double *q, const double *dq
         xform_motion_to_child(s->pRc, s->pj, ps->v, s->v);
         xform_motion_to_child(s->pRc, s->pj, ps->a, s->a);
         if (d >= 0) {
-            /* S = [0; axis] in the child frame (revolute about the child origin) */
-            double vj[6] = {0, 0, 0, ax[0] * dq[d], ax[1] * dq[d], ax[2] * dq[d]};
+            /* S = [0; axis] in the child frame (revolute about the child origin), [axis; 0] for a prismatic joint */
+            double S6[6] = {0, 0, 0, ax[0], ax[1], ax[2]};
+            if (prismatic) {
+                S6[0] = ax[0]; S6[1] = ax[1]; S6[2] = ax[2];
+                S6[3] = S6[4] = S6[5] = 0.0;
+            }
+            double vj[6];
+            for (int i = 0; i < 6; i++) vj[i] = S6[i] * dq[d];
             for (int i = 0; i < 6; i++) s->v[i] += vj[i];
             /* a += S ddq + v x S dq   (motion cross product, [lin;ang]) */
             double c1[3], c2[3];
-            cross3(s->v + 3, vj, c1);     /* w x vj.lin (=0) */
+            cross3(s->v + 3, vj, c1);     /* w x vj.lin (= 0 for a revolute joint) */
             cross3(s->v, vj + 3, c2);     /* v.lin x vj.ang */
             double c3[3];
             cross3(s->v + 3, vj + 3, c3); /* w x vj.ang */
             for (int i = 0; i < 3; i++) {
-                s->a[i] += c1[i] + c2[i];
-                s->a[3 + i] += ax[i] * ddq[d] + c3[i];
+                s->a[i] += S6[i] * ddq[d] + c1[i] + c2[i];
+                s->a[3 + i] += S6[3 + i] * ddq[d] + c3[i];
             }
         }
     }
@@ -307,9 +321,10 @@ static void orc_regressor_sample(const orc_model *m, const orc_layout *lay, cons
             int d = m->dof[cur];
             if (d >= 0) {
                 const double *ax = m->axis + 3 * cur;
+                const int o = (m->jtype && m->jtype[cur] == 2) ? 0 : 30; /* prismatic: axis . force, revolute: axis . moment */
                 for (int c = 0; c < cpl; c++)
                     Y[(size_t)(fb + d) * P + cpl * l + c] =
-                        ax[0] * W[30 + c] + ax[1] * W[40 + c] + ax[2] * W[50 + c];
+                        ax[0] * W[o + c] + ax[1] * W[o + 10 + c] + ax[2] * W[o + 20 + c];
             }
             for (int c = 0; c < 10; c++) {
                 double f[6] = {W[c], W[10 + c], W[20 + c], W[30 + c], W[40 + c], W[50 + c]}, g[6];
@@ -390,7 +405,8 @@ static void orc_rnea_sample(const orc_model *m, const link_state *st, const doub
         int d = m->dof[l];
         if (d >= 0) {
             const double *ax = m->axis + 3 * l;
-            tau[fb + d] = ax[0] * f_links[6 * l + 3] + ax[1] * f_links[6 * l + 4] + ax[2] * f_links[6 * l + 5];
+            const int o = (m->jtype && m->jtype[l] == 2) ? 0 : 3;
+            tau[fb + d] = ax[0] * f_links[6 * l + o] + ax[1] * f_links[6 * l + o + 1] + ax[2] * f_links[6 * l + o + 2];
         }
         double g[6];
         xform_wrench_to_parent(st[l].pRc, st[l].pj, f_links + 6 * l, g);
@@ -406,24 +422,24 @@ typedef struct {
 } orc_states;
 
 static void make_model(orc_model *m, int L, int n, const int *order, const int *parent, const int *dof,
-                       const double *restR, const double *restp, const double *axis, int floating,
+                       const double *restR, const double *restp, const double *axis, const int *jtype, int floating,
                        const double *gravity)
 {
     m->L = L; m->n = n; m->order = order; m->parent = parent; m->dof = dof;
-    m->restR = restR; m->restp = restp; m->axis = axis; m->floating = floating;
+    m->restR = restR; m->restp = restp; m->axis = axis; m->jtype = jtype; m->floating = floating;
     m->gravity[0] = gravity[0]; m->gravity[1] = gravity[1]; m->gravity[2] = gravity[2];
 }
 
 /* Y_out: [S][rows][P_id] row-major (== the reference's regressor_stack, model.py:349-354,520-523) */
 int orc_regressor_batch(int L, int n, const int *order, const int *parent, const int *dof, const double *restR,
-                        const double *restp, const double *axis, int floating, const double *gravity,
+                        const double *restp, const double *axis, const int *jtype, int floating, const double *gravity,
                         int fric, int fric_sym, int grav_only, double stribeck,
                         long S, const double *q, const double *dq, const double *ddq, const double *base_vel,
                         const double *base_acc, const double *rpy, const double *sign, double *Y_out)
 {
     if (L > ORC_MAX_LINKS) return -1;
     orc_model m;
-    make_model(&m, L, n, order, parent, dof, restR, restp, axis, floating, gravity);
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, jtype, floating, gravity);
     orc_layout lay = {fric, fric_sym, grav_only, stribeck};
     const int rows = n + (floating ? 6 : 0);
     const int P = orc_num_cols(L, n, &lay);
@@ -444,7 +460,7 @@ int orc_regressor_batch(int L, int n, const int *order, const int *parent, const
  * asymmetric layout, model.py:310-315).
  */
 int orc_inverse_dynamics_batch(int L, int n, const int *order, const int *parent, const int *dof,
-                               const double *restR, const double *restp, const double *axis, int floating,
+                               const double *restR, const double *restp, const double *axis, const int *jtype, int floating,
                                const double *gravity, int fric, int fric_sym, int grav_only, double stribeck,
                                long S, const double *q, const double *dq, const double *ddq,
                                const double *base_vel, const double *base_acc, const double *rpy,
@@ -452,7 +468,7 @@ int orc_inverse_dynamics_batch(int L, int n, const int *order, const int *parent
 {
     if (L > ORC_MAX_LINKS) return -1;
     orc_model m;
-    make_model(&m, L, n, order, parent, dof, restR, restp, axis, floating, gravity);
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, jtype, floating, gravity);
     const int fb = floating ? 6 : 0;
     const int rows = n + fb;
     link_state st[ORC_MAX_LINKS];
@@ -493,14 +509,14 @@ int orc_inverse_dynamics_batch(int L, int n, const int *order, const int *parent
  * (the last `rows` entries of J^T w, model.py:552-555).
  */
 int orc_contact_torques(int L, int n, const int *order, const int *parent, const int *dof, const double *restR,
-                        const double *restp, const double *axis, int floating, const double *gravity, long S,
+                        const double *restp, const double *axis, const int *jtype, int floating, const double *gravity, long S,
                         const double *q, const double *rpy, int flink, const double *fR, const double *fp,
                         const double *wrench, double *out)
 {
     if (L > ORC_MAX_LINKS) return -1;
     (void)fR;
     orc_model m;
-    make_model(&m, L, n, order, parent, dof, restR, restp, axis, floating, gravity);
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, jtype, floating, gravity);
     const int fb = floating ? 6 : 0;
     const int rows = n + fb;
     link_state st[ORC_MAX_LINKS];
@@ -535,7 +551,10 @@ int orc_contact_torques(int L, int n, const int *order, const int *parent, const
                 mat3_vec(st[cur].R, m.axis + 3 * cur, sA);
                 for (int i = 0; i < 3; i++) r[i] = pf[i] - st[cur].p[i];
                 cross3(r, w, rxf);
-                o[fb + d] = sA[0] * (w[3] + rxf[0]) + sA[1] * (w[4] + rxf[1]) + sA[2] * (w[5] + rxf[2]);
+                if (m.jtype && m.jtype[cur] == 2)
+                    o[fb + d] = sA[0] * w[0] + sA[1] * w[1] + sA[2] * w[2]; /* prismatic: the force along the axis */
+                else
+                    o[fb + d] = sA[0] * (w[3] + rxf[0]) + sA[1] * (w[4] + rxf[1]) + sA[2] * (w[5] + rxf[2]);
             }
             cur = m.parent[cur];
         }

@@ -74,6 +74,8 @@ class OracleModel:
         self.restR = np.ascontiguousarray(topo.rest_R, dtype=np.float64).reshape(-1)
         self.restp = np.ascontiguousarray(topo.rest_p, dtype=np.float64).reshape(-1)
         self.axis = np.ascontiguousarray(topo.axis, dtype=np.float64).reshape(-1)
+        jt = getattr(topo, "joint_type", None)
+        self.jtype = np.array([1 if d >= 0 else 0 for d in topo.dof_index] if jt is None else list(jt), dtype=np.int32)  # 2: prismatic
         self.gravity = np.array(gravity, dtype=np.float64)
         self.rows = self.n + (6 if self.floating else 0)
         P = 4 * self.L if self.grav_only else 10 * self.L
@@ -88,7 +90,7 @@ class OracleModel:
 
     def _model_args(self):
         return (self.L, self.n, _i(self.order), _i(self.parent), _i(self.dof), _d(self.restR), _d(self.restp),
-                _d(self.axis), self.floating, _d(self.gravity))
+                _d(self.axis), _i(self.jtype), self.floating, _d(self.gravity))
 
     def _states(self, st):
         q = _c(st["q"])

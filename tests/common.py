@@ -54,8 +54,8 @@ def cfg_id(c):
     return f"{c[0]}-fb{c[1]}-fr{c[2]}{'s' if c[3] else 'a'}-g{c[4]}-st{c[5]}"
 
 
-def random_topology(rng, num_links, p_fixed=0.2, branchiness=0.5):
-    """Random kinematic tree (revolute and fixed joints, random rest transforms and axes) for structure tests of the
+def random_topology(rng, num_links, p_fixed=0.2, branchiness=0.5, p_prismatic=0.0):
+    """Random kinematic tree (revolute, fixed and -- p_prismatic > 0 -- prismatic joints, random rest transforms and axes) for structure tests of the
     tile program: nothing about it resembles a bundled robot."""
     from scipy.spatial.transform import Rotation
 
@@ -67,7 +67,7 @@ def random_topology(rng, num_links, p_fixed=0.2, branchiness=0.5):
         par = l - 1 if rng.random() > branchiness else int(rng.integers(0, l))
         fixed = rng.random() < p_fixed
         parent.append(par)
-        jtype.append(0 if fixed else 1)
+        jtype.append(0 if fixed else (2 if (p_prismatic > 0 and rng.random() < p_prismatic) else 1))  # (no draw when 0: the seeded trees of the older tests stay what they were)
         dof.append(-1 if fixed else n)
         n += 0 if fixed else 1
         names.append(f"l{l}")

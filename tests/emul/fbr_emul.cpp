@@ -22,19 +22,20 @@ struct EmulTopo {
     int fric, fric_sym, grav_only;
     double stribeck;
     const unsigned short *masks;  // per link: identified parameters (column masks of the regrouped model), or null
+    const int32_t *jtype;         // per link: 1 revolute, 2 prismatic (links with a DOF), or null: all revolute
 };
 
 static void make(const EmulTopo *t, FbrHostModel &hm)
 {
     hm.build(t->L, t->n, t->parent, t->dof, t->restR, t->restp, t->axis, t->floating, t->gravity, t->fric,
-             t->fric_sym, t->grav_only, t->stribeck, t->masks);
+             t->fric_sym, t->grav_only, t->stribeck, t->masks, t->jtype);
 }
 
 // The reduced robot of a model's column reductions and the expansion matrix (csrc/fbr_reduce.h, what fbr_api.hip's build_reduction
 // runs): which = 0 fixed links merged, 1 merged + regrouped.  Returns the reduced link count (0: nothing to reduce); the arrays hold at
 // least L links; E is dense [Pr][Pf] (reduced x full identified columns, without the rhs identity), Pr is returned through *Pr_out.
 int emul_reduction(const EmulTopo *t, int which, int32_t *parent, int32_t *dof, double *restR, double *restp, double *axis,
-                   unsigned short *masks, int *masked, int *Pr_out, double *E, long E_cap)
+                   unsigned short *masks, int *masked, int *Pr_out, double *E, long E_cap, int32_t *jtype)
 {
     FbrHostModel hm;
     make(t, hm);
@@ -44,6 +45,7 @@ int emul_reduction(const EmulTopo *t, int which, int32_t *parent, int32_t *dof, 
         parent[i] = rr.parent[i];
         dof[i] = rr.dof[i];
         masks[i] = rr.masks[i];
+        jtype[i] = rr.jtype[i];
         for (int c = 0; c < 9; c++) restR[9 * i + c] = rr.restR[9 * i + c];
         for (int c = 0; c < 3; c++) {
             restp[3 * i + c] = rr.restp[3 * i + c];
@@ -53,7 +55,7 @@ int emul_reduction(const EmulTopo *t, int which, int32_t *parent, int32_t *dof, 
     *masked = rr.masked ? 1 : 0;
     FbrHostModel rh;
     rh.build(rr.Lr, t->n, rr.parent.data(), rr.dof.data(), rr.restR.data(), rr.restp.data(), rr.axis.data(), t->floating, t->gravity,
-             t->fric, t->fric_sym, t->grav_only, t->stribeck, rr.masked ? rr.masks.data() : nullptr);
+             t->fric, t->fric_sym, t->grav_only, t->stribeck, rr.masked ? rr.masks.data() : nullptr, rr.jtype.data());
     std::vector<int> beg, row;
     std::vector<double> val;
     fbr_reduction_matrix(hm, rr, rh, beg, row, val);
@@ -75,7 +77,7 @@ static void kin_sample(const FbrHostModel &hm, const double *q, const double *dq
             fbr_kin_base(hm.floating, hm.gravity, bv, ba, rpy, r);
         } else {
             int d = hm.dof[l];
-            fbr_kin_child(rec + 21 * hm.parent[l], &hm.restR[9 * l], &hm.restp[3 * l], &hm.axis[3 * l], d >= 0,
+            fbr_kin_child(rec + 21 * hm.parent[l], &hm.restR[9 * l], &hm.restp[3 * l], &hm.axis[3 * l], hm.jtype[l],
                           d >= 0 ? q[d] : 0.0, d >= 0 ? dq[d] : 0.0, d >= 0 ? ddq[d] : 0.0, r,
                           d >= 0 ? rec + 21 * hm.L + 6 * d : nullptr);
         }

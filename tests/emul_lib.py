@@ -20,7 +20,7 @@ class EmulTopo(ctypes.Structure):
     _fields_ = [("L", ctypes.c_int), ("n", ctypes.c_int), ("parent", _ip), ("dof", _ip), ("restR", _dp),
                 ("restp", _dp), ("axis", _dp), ("floating", ctypes.c_int), ("gravity", ctypes.c_double * 3),
                 ("fric", ctypes.c_int), ("fric_sym", ctypes.c_int), ("grav_only", ctypes.c_int),
-                ("stribeck", ctypes.c_double), ("masks", ctypes.POINTER(ctypes.c_uint16))]
+                ("stribeck", ctypes.c_double), ("masks", ctypes.POINTER(ctypes.c_uint16)), ("jtype", _ip)]
 
 
 def lib():
@@ -46,13 +46,15 @@ class Emul:
                      np.ascontiguousarray(topo.rest_R, dtype=np.float64).reshape(-1),
                      np.ascontiguousarray(topo.rest_p, dtype=np.float64).reshape(-1),
                      np.ascontiguousarray(topo.axis, dtype=np.float64).reshape(-1),
-                     None if masks is None else np.ascontiguousarray(masks, dtype=np.uint16)]
+                     None if masks is None else np.ascontiguousarray(masks, dtype=np.uint16),
+                     None if getattr(topo, "joint_type", None) is None else np.array(topo.joint_type, dtype=np.int32)]
         self.opts = dict(floating=floating, fric=fric, fric_sym=fric_sym, grav_only=grav_only, stribeck=stribeck)
         self.t = EmulTopo(topo.num_links, topo.num_dofs, self.keep[0].ctypes.data_as(_ip),
                           self.keep[1].ctypes.data_as(_ip), _d(self.keep[2]), _d(self.keep[3]), _d(self.keep[4]),
                           int(floating), (ctypes.c_double * 3)(0.0, 0.0, -9.81), int(fric), int(fric_sym),
                           int(grav_only), float(stribeck),
-                          None if masks is None else self.keep[5].ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
+                          None if masks is None else self.keep[5].ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                          None if self.keep[6] is None else self.keep[6].ctypes.data_as(_ip))
         self.num_links = topo.num_links
         r, c, rec = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib().emul_dims(ctypes.byref(self.t), ctypes.byref(r), ctypes.byref(c), ctypes.byref(rec))
@@ -69,17 +71,18 @@ class Emul:
         parent, dof = np.zeros(L, np.int32), np.zeros(L, np.int32)
         restR, restp, axis = np.zeros(9 * L), np.zeros(3 * L), np.zeros(3 * L)
         masks = np.zeros(L, np.uint16)
+        jtype = np.zeros(L, np.int32)
         masked, Pr = ctypes.c_int(), ctypes.c_int()
         cap = (10 * L + 8 * self.n) * self.cols
         E = np.zeros(cap)
         Lr = lib().emul_reduction(ctypes.byref(self.t), int(which), parent.ctypes.data_as(_ip), dof.ctypes.data_as(_ip), _d(restR), _d(restp),
                                   _d(axis), masks.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), ctypes.byref(masked), ctypes.byref(Pr),
-                                  _d(E), ctypes.c_long(cap))
+                                  _d(E), ctypes.c_long(cap), jtype.ctypes.data_as(_ip))
         if Lr == 0:
             return None
         assert Lr > 0
         topo = types.SimpleNamespace(num_links=Lr, num_dofs=self.n, parent=parent[:Lr], dof_index=dof[:Lr], rest_R=restR[: 9 * Lr],
-                                     rest_p=restp[: 3 * Lr], axis=axis[: 3 * Lr])
+                                     rest_p=restp[: 3 * Lr], axis=axis[: 3 * Lr], joint_type=jtype[:Lr])
         red = Emul(topo, masks=masks[:Lr] if masked.value else None, **self.opts)
         assert red.cols == Pr.value
         return red, E[: Pr.value * self.cols].reshape(Pr.value, self.cols).copy()

@@ -72,17 +72,24 @@ def world_kinematics(topo, q, dq, ddq, R_wb, v_b, w_b, a_b, dw_b, p_b=None):
             v[l], w[l], a[l], dw[l] = v_b, w_b, a_b, dw_b
             continue
         d = topo.dof_index[l]
+        prismatic = d >= 0 and topo.joint_type[l] == 2
         Rj = topo.rest_R[l][None]
-        if d >= 0:
+        if d >= 0 and not prismatic:
             Rj = Rj @ axis_angle_R(topo.axis[l], q[:, d])
         R[l] = R[par] @ Rj
         r = np.einsum("sij,j->si", R[par], topo.rest_p[l])
+        if prismatic:  # the origin slides along the (world) axis: relative velocity / acceleration terms of a moving point
+            sw = np.einsum("sij,j->si", R[l], topo.axis[l])
+            r = r + sw * q[:, d : d + 1]
         p[l] = p[par] + r
         v[l] = v[par] + np.cross(w[par], r)
         a[l] = a[par] + np.cross(dw[par], r) + np.cross(w[par], np.cross(w[par], r))
         w[l] = w[par]
         dw[l] = dw[par]
-        if d >= 0:
+        if prismatic:
+            v[l] = v[l] + sw * dq[:, d : d + 1]
+            a[l] = a[l] + 2 * np.cross(w[par], sw) * dq[:, d : d + 1] + sw * ddq[:, d : d + 1]
+        elif d >= 0:
             sw = np.einsum("sij,j->si", R[l], topo.axis[l])
             w[l] = w[par] + sw * dq[:, d : d + 1]
             dw[l] = dw[par] + sw * ddq[:, d : d + 1] + np.cross(w[par], sw) * dq[:, d : d + 1]
@@ -131,6 +138,9 @@ def inverse_dynamics_world(topo, q, dq, ddq, floating, base_vel=None, base_acc=N
         for d in anc[l]:
             jl = joint_link[d]
             sw = np.einsum("sij,j->si", k["R"][jl], topo.axis[jl])
+            if topo.joint_type[jl] == 2:  # prismatic: the force along the axis
+                tau[:, fb + d] += np.einsum("si,si->s", sw, F[l])
+                continue
             mom = N[l] + np.cross(PC[l] - k["p"][jl], F[l])
             tau[:, fb + d] += np.einsum("si,si->s", sw, mom)
     return tau

@@ -137,7 +137,7 @@ def test_rhs_moments_from_the_packer_reproduce_gram(cfg, k, request):
         assert less["mfma"] < more["mfma"]  # the dense tile's MFMAs are gone
 
 
-@pytest.mark.parametrize("case", ["walkman_apriori", "kuka_lwr4", "random1", "random2", "random3"])
+@pytest.mark.parametrize("case", ["walkman_apriori", "kuka_lwr4", "random1", "random2", "random3", "prismatic4", "prismatic5", "prismatic6"])
 @pytest.mark.parametrize("which", [0, 1], ids=["merged", "regrouped"])
 def test_column_reductions_expand_to_the_gram_of_all_columns(case, which, request):
     """The library's column reductions without a GPU: the reduced robot and the expansion matrix E come from the very code
@@ -148,11 +148,12 @@ def test_column_reductions_expand_to_the_gram_of_all_columns(case, which, reques
     from common import random_topology
 
     rng = np.random.default_rng(77)
-    if case.startswith("random"):
+    if case.startswith("random") or case.startswith("prismatic"):
         seed = int(case[-1])
         rng = np.random.default_rng(300 + seed)
-        t = random_topology(rng, 8 + 6 * seed, p_fixed=0.45, branchiness=0.5)
-        floating, fric = seed != 2, seed == 3
+        # (prismatic*: half of the movable joints slide -- their links keep m and h, the six inertia entries ride on the parent)
+        t = random_topology(rng, 8 + 6 * (seed % 4), p_fixed=0.45, branchiness=0.5, p_prismatic=0.5 if case.startswith("prismatic") else 0.0)
+        floating, fric = seed != 2, seed in (3, 5)
     else:
         t = load_topo(case)
         floating, fric = case == "walkman_apriori", case == "kuka_lwr4"
@@ -168,7 +169,11 @@ def test_column_reductions_expand_to_the_gram_of_all_columns(case, which, reques
     rem, E = red
     nf = om.P - 10 * t.num_links  # friction columns
     assert rem.num_links == t.num_links - nfixed
-    assert rem.cols == (10 + 7 * (rem.num_links - 1) if which else 10 * rem.num_links) + nf
+    npris = sum(1 for j in t.joint_type if j == 2)
+    assert rem.cols == (10 + 7 * (rem.num_links - 1 - npris) + 4 * npris if which else 10 * rem.num_links) + nf
+    if which and floating:  # the regrouped columns are a BASIS: as many as the regressor's numerical rank (with a floating base)
+        Yb = om.regressor(random_states(t, 200, np.random.default_rng(1), floating), None if not fric else np.zeros((200, t.num_dofs)))
+        assert np.linalg.matrix_rank(Yb[:, : 10 * t.num_links]) == rem.cols - nf
     S = 7  # (odd: the last sample has no partner for its base rows)
     st = random_states(t, S, rng, floating)
     sign = np.tanh(st["dq"] / 0.02)

@@ -868,3 +868,49 @@ def test_hip_against_idyntree_outputs(name):
             ci = np.einsum("sij,si->sj", fx["fb1_J"], w)
             assert np.abs(eng.contact_torques(st, str(fx["frame"]), w) - ci).max() <= 1e-9 * np.abs(ci).max()
         eng.close()
+
+
+@pytest.mark.parametrize("seed,L,floating,fric", [(21, 9, 1, 0), (22, 16, 0, 1), (23, 24, 1, 1), (24, 33, 1, 0), (25, 12, 0, 0)])
+def test_prismatic_joints_all_entry_points(seed, L, floating, fric):
+    """Random trees in which half of the movable joints are PRISMATIC (fbr_topology.joint_type; iDynTree's loader takes any URDF,
+    model.py:60-67): every per-sample entry point and both reductions against the oracle, whose prismatic arithmetic is pinned on two
+    independent formulations and a power balance (tests/test_oracle.py)."""
+    from common import random_topology
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(seed)
+    t = random_topology(rng, L, p_fixed=0.25, branchiness=0.4, p_prismatic=0.5)
+    assert any(j == 2 for j in t.joint_type)
+    if t.num_dofs + (6 if floating else 0) > 60:
+        pytest.skip("more than 60 regressor rows")
+    om = OracleModel(t, floating=bool(floating), fric=bool(fric))
+    eng = Engine(t, floating=bool(floating), friction=bool(fric))
+    S = 350
+    st = random_states(t, S, rng, floating)
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    Yo = om.regressor(st, st["sign"])
+    assert np.abs(eng.regressor(st) - Yo).max() <= 1e-11 * np.abs(Yo).max()
+    x = t.x_std()
+    to = om.inverse_dynamics(st, x, st["sign"])
+    assert np.abs(eng.inverse_dynamics(st, x) - to).max() <= 1e-11 * np.abs(to).max()
+    xi = rng.standard_normal(om.P)
+    assert np.abs(eng.predict(st, xi).reshape(-1) - Yo @ xi).max() <= 1e-10 * np.abs(Yo @ xi).max()
+    rhs = rng.standard_normal((Yo.shape[0], 1))
+    w = 0.5 + rng.random(Yo.shape[0])
+    A = np.hstack([Yo, rhs]) * w[:, None]
+    Go = A.T @ A
+    assert np.linalg.norm(eng.gram(st, rhs=rhs, w=w) - Go) <= 1e-11 * np.linalg.norm(Go)
+    R = eng.tsqr(st, rhs=rhs, w=w)
+    assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-10 * np.linalg.norm(Go)
+    link = t.num_links - 1
+    wr = rng.standard_normal((S, 6))
+    co = om.contact_torques(st, t.link_names[link], wr)
+    assert np.abs(eng.contact_torques(st, t.link_names[link], wr) - co).max() <= 1e-11 * np.abs(co).max()
+    # what the reductions run on: 4 columns for a link behind a prismatic joint, 7 behind a revolute one, 10 for the base link
+    info = eng.link_merge_info()
+    nfix = sum(1 for l in range(1, t.num_links) if t.dof_index[l] < 0)
+    npris = sum(1 for j in t.joint_type if j == 2)
+    nrev = t.num_links - 1 - nfix - npris
+    assert info["reduced_cols"] == 10 + 7 * nrev + 4 * npris + (om.P - 10 * t.num_links)
+    eng.close()

@@ -157,3 +157,30 @@ def test_urdf_write_back_round_trip(tmp_path):
     for j, name in enumerate(topo.dof_names):
         assert abs(t2.friction[name]["f_constant"] - xnew[10 * L + j]) < 1e-14
         assert abs(t2.friction[name]["f_velocity"] - xnew[10 * L + topo.num_dofs + j]) < 1e-14
+
+
+def test_prismatic_joints_are_parsed(tmp_path):
+    """Any joint type with one DOF that iDynTree's loader takes (model.py:60-67): revolute / continuous / prismatic; limits of prismatic
+    joints are read like those of revolute ones; multi-DOF joint types are refused by name."""
+    from flobaroid_amd.topology import JOINT_PRISMATIC, JOINT_REVOLUTE
+
+    urdf = """<robot name="slider">
+      <link name="base"><inertial><mass value="1"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial></link>
+      <link name="cart"><inertial><mass value="2"/><origin xyz="0.1 0 0"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial></link>
+      <link name="arm"><inertial><mass value="3"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial></link>
+      <joint name="slide" type="prismatic"><parent link="base"/><child link="cart"/><origin xyz="0 0 0.5" rpy="0 0 0.3"/><axis xyz="0 2 0"/>
+        <limit effort="10" lower="-0.4" upper="0.6" velocity="1.5"/><dynamics friction="0.1" damping="0.2"/></joint>
+      <joint name="hinge" type="revolute"><parent link="cart"/><child link="arm"/><axis xyz="0 0 1"/><limit effort="5" lower="-1" upper="1" velocity="2"/></joint>
+    </robot>"""
+    p = tmp_path / "s.urdf"
+    p.write_text(urdf)
+    t = parse_urdf(str(p))
+    l = t.link_names.index("cart")
+    assert t.joint_type[l] == JOINT_PRISMATIC and t.joint_type[t.link_names.index("arm")] == JOINT_REVOLUTE and t.num_dofs == 2
+    assert np.allclose(t.axis[l], [0, 1, 0]) and t.limits["slide"] == {"torque": 10.0, "lower": -0.4, "upper": 0.6, "velocity": 1.5}
+    assert t.friction["slide"] == {"f_constant": 0.1, "f_velocity": 0.2}
+    t2 = Topology.from_dict(json.loads(json.dumps(t.to_dict())))
+    assert t2.joint_type == t.joint_type
+    p.write_text(urdf.replace('type="prismatic"', 'type="planar"'))
+    with pytest.raises(NotImplementedError, match="planar"):
+        parse_urdf(str(p))
