@@ -169,14 +169,11 @@ static int get_gram(fbr_model *m, int k, GramHolder **out, bool moments = false)
     if ((rc = upload(h->pool, slot_tiles, &dg.slot_tiles))) return rc;
     if ((rc = upload(h->pool, tilecol, &dg.tilecol))) return rc;
     if (moments) {
+        // (the column comes from the item itself: looking it up through the image offset fails for tiles WITHOUT rows -- the base link and
+        // the links welded to it on a fixed base -- which share their offset with the next tile: their all-zero items were then taken for
+        // that tile's columns, and two reduction workgroups raced on one G entry.  Found in round 5 by the prismatic-joint tests.)
         std::vector<int> itemcol(256, -1);
-        for (size_t i = 0; i < gp.items.size() && i < 256; i++) {
-            const int off = gp.items[i].off;
-            for (int t = 0; t < gp.NT; t++) {  // (a friction item's offset points at the image row of its joint)
-                const int end = t + 1 < gp.NT ? gp.tiles[t + 1].off : gp.image_doubles;
-                if (off >= gp.tiles[t].off && off < end) itemcol[i] = gp.tiles[t].col[(off - gp.tiles[t].off) % FBR_TILE];
-            }
-        }
+        for (size_t i = 0; i < gp.items.size() && i < 256; i++) itemcol[i] = gp.items[i].col;
         if ((rc = upload(h->pool, itemcol, &h->itemcol))) return rc;
     }
     size_t max_pieces = 0;

@@ -267,6 +267,7 @@ struct FbrItem {  // one producer work item = one real column of one tile
     int kind;     // 0 inertial, 1 friction, 2 rhs
     int a;        // inertial: link ; friction: joint ; rhs: rhs column
     int b;        // inertial: pidx ; friction: fkind
+    int col;      // the augmented column it produces (what the packer's rhs moments of this item belong to)
 };
 struct FbrSlot {  // one accumulator of one wave
     int pair;     // -1 = unused
@@ -484,6 +485,7 @@ struct FbrGramProgram {
                 if (c < 0) continue;
                 FbrItem it;
                 it.off = tiles[ti].off + s;
+                it.col = c;
                 if (c >= hm.cols) {
                     it.kind = 2; it.a = c - hm.cols; it.b = 0;
                 } else if (hm.coldesc[c].kind == 0) {

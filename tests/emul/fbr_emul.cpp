@@ -444,12 +444,13 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
             }
     if (moments) {  // mirror of fbr_gram_mom_reduce_kernel
         const int P = hm.cols;
+        // on the device one workgroup per item adds into G[c][P] without atomics: a column owned by two items is a lost update there
+        // (sequential code would not notice)
+        std::vector<int> owners(P + k, 0);
+        for (size_t ii = 0; ii < gp.items.size(); ii++)
+            if (gp.items[ii].col >= 0 && gp.items[ii].col < P + k && ++owners[gp.items[ii].col] > 1) return -10;
         for (size_t ii = 0; ii < gp.items.size(); ii++) {
-            int c = -1;
-            for (int t2 = 0; t2 < gp.NT; t2++) {
-                const int end = t2 + 1 < gp.NT ? gp.tiles[t2 + 1].off : gp.image_doubles;
-                if (gp.items[ii].off >= gp.tiles[t2].off && gp.items[ii].off < end) c = gp.tiles[t2].col[(gp.items[ii].off - gp.tiles[t2].off) % FBR_TILE];
-            }
+            const int c = gp.items[ii].col;
             if (c < 0) return -9;
             for (int i = 0; i < k; i++) {
                 G[(size_t)c * Pa + P + i] += mom[2 * ii + i];

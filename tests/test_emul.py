@@ -193,3 +193,30 @@ def test_column_reductions_expand_to_the_gram_of_all_columns(case, which, reques
     Ea[rem.cols:, om.P:] = np.eye(k)
     G = Ea.T @ Gr @ Ea
     assert np.linalg.norm(G - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
+
+
+def test_rhs_moments_of_a_tile_without_rows(request):
+    """A fixed base whose first 16 columns (the base link and a link welded to it) have no regressor rows at all: their tile occupies no
+    image space and shares its offset with the next tile.  The packer's rhs moments are attributed through the item's own column (not
+    through the image offset): every column has exactly one reduction workgroup on the device -- round 5 found two of them racing on one
+    G entry for such robots (a lost update the sequential emulation cannot see; it checks the ownership instead)."""
+    import emul_lib
+
+    rng = np.random.default_rng(22)
+    t = random_topology(rng, 16, p_fixed=0.25, branchiness=0.4)
+    assert t.dof_index[1] < 0 and t.parent[1] == 0   # link 1 is welded to the fixed base: columns 0..19 never move
+    om = OracleModel(t, floating=False)
+    em = emul_lib.Emul(t, floating=False)
+    S = 9
+    st = random_states(t, S, rng, False)
+    Y = om.regressor(st)
+    assert not Y[:, :16].any()
+    rhs = rng.standard_normal((Y.shape[0], 1))
+    A = np.hstack([Y, rhs])
+    emul_lib.lib().emul_set_rhs_moments(1)
+    request.addfinalizer(lambda: emul_lib.lib().emul_set_rhs_moments(0))
+    for shape in (0, 1, 2):
+        emul_lib.lib().emul_set_gram_shape(shape)
+        request.addfinalizer(lambda: emul_lib.lib().emul_set_gram_shape(0))
+        G = em.gram(st, rhs)
+        assert np.linalg.norm(G - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A), shape

@@ -891,7 +891,7 @@ def test_prismatic_joints_all_entry_points(seed, L, floating, fric):
     st["sign"] = np.tanh(st["dq"] / 0.02)
     Yo = om.regressor(st, st["sign"])
     assert np.abs(eng.regressor(st) - Yo).max() <= 1e-11 * np.abs(Yo).max()
-    x = t.x_std()
+    x = np.concatenate([t.x_std(), rng.random(om.P - 10 * t.num_links + 4 * t.num_dofs)])  # (+ friction slots)
     to = om.inverse_dynamics(st, x, st["sign"])
     assert np.abs(eng.inverse_dynamics(st, x) - to).max() <= 1e-11 * np.abs(to).max()
     xi = rng.standard_normal(om.P)
@@ -914,3 +914,29 @@ def test_prismatic_joints_all_entry_points(seed, L, floating, fric):
     nrev = t.num_links - 1 - nfix - npris
     assert info["reduced_cols"] == 10 + 7 * nrev + 4 * npris + (om.P - 10 * t.num_links)
     eng.close()
+
+
+def test_rhs_moments_of_a_tile_without_rows_repeat():
+    """The robot of tests/test_emul.py::test_rhs_moments_of_a_tile_without_rows (fixed base, a link welded to it: the first tile has no
+    image rows): Y^T tau from the packer's moments in all three kernel-shape settings, 15 repetitions each -- before round 5 two
+    reduction workgroups raced on one entry of G here and a column's product with tau was lost now and then."""
+    from common import random_topology
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(22)
+    t = random_topology(rng, 16, p_fixed=0.25, branchiness=0.4)
+    om = OracleModel(t, floating=False)
+    S = 350
+    st = random_states(t, S, rng, False)
+    Yo = om.regressor(st)
+    rhs = rng.standard_normal((Yo.shape[0], 1))
+    A = np.hstack([Yo, rhs])
+    Go = A.T @ A
+    for shape in (0, 1, 2):
+        eng = Engine(t, floating=False, options={"gram_shape": shape})
+        for rep in range(15):
+            G = eng.gram(st, rhs=rhs)
+            assert np.linalg.norm(G - Go) <= 1e-11 * np.linalg.norm(Go), (shape, rep)
+            assert np.array_equal(G, G.T)
+        eng.close()
