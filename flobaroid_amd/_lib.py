@@ -100,6 +100,11 @@ _SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32],
     ),
+    "fbr_fourier_states": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_int32],
+    ),
     "fbr_tsqr": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.POINTER(fbr_states), ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -516,6 +521,28 @@ class Engine:
         r, ret = self._out(out, (S, 1 + 3 * self.topo.num_dofs), mem)
         _check(self._lib.fbr_fd_scores(self._h, ctypes.byref(s), Wr.ptr, float(eps), r.ptr, r.mem), "fbr_fd_scores")
         return ret
+
+    def fourier_states(self, wf, a, b, q_offset, T: int, freq: float, q_range=None, device: bool = True) -> dict:
+        """q, dq, ddq of C candidate trajectories x T samples from their Fourier coefficients (``fbr_fourier_states``): ``wf`` (C,),
+        ``a`` / ``b`` (C, n, nharm), ``q_offset`` (C, n), ``q_range`` (C, n) or None.  Returns {"q", "dq", "ddq"} of shape (C * T, n) --
+        CUDA tensors (``device=True``: they stay in HBM for ``gram_grouped``) or NumPy arrays."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        C, n, nh = a.shape
+        if n != self.n or b.shape != a.shape:
+            raise ValueError(f"a / b: expected (C, {self.n}, nharm)")
+        wf = np.ascontiguousarray(np.broadcast_to(np.asarray(wf, dtype=np.float64), (C,)))
+        qo = np.ascontiguousarray(q_offset, dtype=np.float64).reshape(C, n)
+        qr = None if q_range is None else np.ascontiguousarray(q_range, dtype=np.float64).reshape(C, n)
+        outs, refs = [], []
+        for _ in range(3):
+            r, ret = self._out(None, (C * int(T), n), FBR_DEVICE if device else FBR_HOST)
+            outs.append(ret)
+            refs.append(r)
+        _check(self._lib.fbr_fourier_states(self._h, C, int(T), nh, float(freq), wf.ctypes.data_as(_dp), a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                            qo.ctypes.data_as(_dp), None if qr is None else qr.ctypes.data_as(_dp), refs[0].ptr, refs[1].ptr, refs[2].ptr,
+                                            refs[0].mem), "fbr_fourier_states")
+        return {"q": outs[0], "dq": outs[1], "ddq": outs[2]}
 
     def tsqr(self, st: dict, rhs=None, w=None, R_in=None, out=None, cols=None):
         """Upper-triangular R with R^T R = [Y[:, cols]|rhs]^T [Y[:, cols]|rhs] (blocked Householder TSQR);

@@ -771,6 +771,52 @@ extern "C" int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W
     }
     return finish_output(m, dout, out, (size_t)S * nper, out_mem);
 }
+// ------------------------------------------------------------------------------------------------
+// Fourier-series states of candidate trajectories, generated on the device (fbr.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int fbr_fourier_states(fbr_model *m, int32_t ncand, int64_t T, int32_t nharm, double freq, const double *wf, const double *a, const double *b,
+                                  const double *q_offset, const double *q_range, double *q, double *dq, double *ddq, int32_t out_mem)
+{
+    if (!m || ncand < 1 || T < 1 || nharm < 1 || !(freq > 0) || !wf || !a || !b || !q_offset || !q || !dq || !ddq ||
+        (out_mem != FBR_HOST && out_mem != FBR_DEVICE)) {
+        set_err("fbr_fourier_states: bad arguments");
+        return FBR_E_INVALID;
+    }
+    if (int rc = enter_blocking(m)) return rc;
+    const int n = m->hm.n;
+    const size_t nc = (size_t)ncand * n, ncoef = nc * nharm, count = (size_t)ncand * (size_t)T * n;
+    // coefficients: [wf (C) | a | b | q_offset | q_range] in one staging buffer (host arrays, a few KB)
+    std::vector<double> h;
+    h.insert(h.end(), wf, wf + ncand);
+    h.insert(h.end(), a, a + ncoef);
+    h.insert(h.end(), b, b + ncoef);
+    h.insert(h.end(), q_offset, q_offset + nc);
+    if (q_range) h.insert(h.end(), q_range, q_range + nc);
+    int rc;
+    if ((rc = m->st_x.ensure(h.size() * sizeof(double)))) return rc;
+    HIPCHK(hipMemcpyAsync(m->st_x.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));  // (h is a local)
+    const double *d = m->st_x.as<double>();
+    const double *dwf = d, *da = d + ncand, *db = da + ncoef, *doff = db + ncoef, *drng = q_range ? doff + nc : nullptr;
+    double *oq = q, *odq = dq, *oddq = ddq;
+    if (out_mem == FBR_HOST) {
+        if ((rc = m->out_tmp.ensure(3 * count * sizeof(double)))) return rc;
+        oq = m->out_tmp.as<double>();
+        odq = oq + count;
+        oddq = odq + count;
+    }
+    hipLaunchKernelGGL(fbr_fourier_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, (size_t)m->num_cus * 32)), dim3(256), 0, m->stream, (int)ncand, (long)T, n,
+                       (int)nharm, freq, dwf, da, db, doff, drng, oq, odq, oddq);
+    HIPCHK(hipGetLastError());
+    if (out_mem == FBR_HOST) {
+        HIPCHK(hipMemcpyAsync(q, oq, count * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(dq, odq, count * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(ddq, oddq, count * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return FBR_OK;
+}
+
 // A submission that fails after work was enqueued has no ticket its caller could wait on: everything in flight is drained before the
 // error is returned (the same for the Gram pass, gram_impl below), so that the inputs may be freed and later calls start from a quiet device.
 int drain_after_failed_submit(fbr_model *m)

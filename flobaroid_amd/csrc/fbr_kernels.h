@@ -675,6 +675,60 @@ __global__ __launch_bounds__(256) void fbr_contact_kernel(DevModel m, long S, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K6: Fourier-series joint trajectories of the trajectory optimiser's candidates (excitation/trajectoryGenerator.py:
+// OscillationGenerator 411-460, BoundedOscillationGenerator 462-560, the vectorised evaluation of computeTrajectoryDynamics 83-128):
+// one thread per (candidate c, sample t, joint j).  With x_l = wf_c * (t / freq * l):
+//   classic:  q = sum_l a_l / (wf l) sin x_l - b_l / (wf l) cos x_l + qoff,  dq = sum a_l cos x_l + b_l sin x_l,
+//             ddq = sum -a_l wf l sin x_l + b_l wf l cos x_l                                   (qoff = nf * q0)
+//   bounded:  raw = sum b_l cos x_l + a_l sin x_l,  q = qoff + qrange tanh(raw)  and its two time derivatives (qoff = q_center)
+// coef = [a | b] [C][n][nh] each (harmonics beyond a joint's own nf are zero), so that the candidates never cross PCIe as samples.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fbr_fourier_kernel(int C, long T, int n, int nh, double freq, const double *__restrict__ wf,
+                                                          const double *__restrict__ a, const double *__restrict__ b,
+                                                          const double *__restrict__ qoff, const double *__restrict__ qrange,
+                                                          double *__restrict__ q, double *__restrict__ dq, double *__restrict__ ddq)
+{
+    const long total = (long)C * T * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e % n);
+        const long ct = e / n, t = ct % T;
+        const int c = (int)(ct / T);
+        const double w = wf[c], ts = (double)t / freq;
+        const double *aa = a + ((long)c * n + j) * nh, *bb = b + ((long)c * n + j) * nh;
+        if (!qrange) {
+            double sq = 0.0, sv = 0.0, sa = 0.0;
+            for (int l = 1; l <= nh; l++) {
+                const double x = w * (ts * (double)l), wl = w * (double)l;
+                double sn, cs;
+                sincos(x, &sn, &cs);
+                const double al = aa[l - 1], bl = bb[l - 1];
+                sq += (al / wl) * sn - (bl / wl) * cs;
+                sv += al * cs + bl * sn;
+                sa += -(al * wl) * sn + (bl * wl) * cs;
+            }
+            q[e] = sq + qoff[(long)c * n + j];
+            dq[e] = sv;
+            ddq[e] = sa;
+        } else {
+            double raw = 0.0, rd = 0.0, rdd = 0.0;
+            for (int l = 1; l <= nh; l++) {
+                const double x = w * (ts * (double)l), wl = w * (double)l;
+                double sn, cs;
+                sincos(x, &sn, &cs);
+                const double al = aa[l - 1], bl = bb[l - 1];
+                raw += bl * cs + al * sn;
+                rd += (al * wl) * cs - (bl * wl) * sn;
+                rdd += -(al * wl * wl) * sn - (bl * wl * wl) * cs;
+            }
+            const double th = tanh(raw), sech2 = 1.0 - th * th, qr = qrange[(long)c * n + j];
+            q[e] = qoff[(long)c * n + j] + qr * th;
+            dq[e] = qr * sech2 * rd;
+            ddq[e] = qr * (sech2 * rdd - 2.0 * th * sech2 * rd * rd);
+        }
+    }
+}
+
 #endif  // FBR_KERNELS_CORE
 #ifdef FBR_KERNELS_GRAM  // tile-image packer and fused Gram (fbr_gram_api.hip)
 // ------------------------------------------------------------------------------------------------

@@ -50,3 +50,76 @@ def dopt_sensitivities(engine, states: dict, W_iner, epsilon: float, W_visc=None
         Wv = np.asarray(W_visc, dtype=float).reshape(sc.shape[0], engine.rows)
         sens_dq += Wv[:, fb:fb + n]
     return sens_q, sens_dq, sens_ddq
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Candidate trajectories generated on the device (round 5): the optimiser's search variables are Fourier coefficients; their samples never
+# have to exist on the host.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def fourier_coefficients(a, b, q, nf, wf: float = 1.0, joint_limits=None, use_deg: bool = False):
+    """Pack the parameters of ONE candidate as the reference's ``PulsedTrajectory.initWithParams(a, b, q, nf, wf, joint_limits)`` takes
+    them (trajectoryGenerator.py:322-383: per-joint coefficient arrays of length nf[i]) into the padded arrays of
+    ``Engine.fourier_states``: dict(wf, a (n, nh), b (n, nh), q_offset (n,), q_range (n,) or None).
+
+    classic (``joint_limits`` None, OscillationGenerator 411-460): q_offset = nf * q0;  bounded (BoundedOscillationGenerator 462-510):
+    q_offset = q_center = clip(midpoint + q0, lower, upper), q_range = 0.95 * min(q_center - lower, upper - q_center).  ``use_deg``: q
+    is given in degrees (the generators convert it)."""
+    n = len(nf)
+    nh = max(int(k) for k in nf)
+    A, B = np.zeros((n, nh)), np.zeros((n, nh))
+    for j in range(n):
+        A[j, : int(nf[j])] = np.asarray(a[j], dtype=float)[: int(nf[j])]
+        B[j, : int(nf[j])] = np.asarray(b[j], dtype=float)[: int(nf[j])]
+    q0 = np.deg2rad(np.asarray(q, dtype=float)) if use_deg else np.asarray(q, dtype=float)
+    if joint_limits is None:
+        return {"wf": float(wf), "a": A, "b": B, "q_offset": np.asarray(nf, dtype=float) * q0, "q_range": None}
+    lo = np.array([l[0] for l in joint_limits], dtype=float)
+    hi = np.array([l[1] for l in joint_limits], dtype=float)
+    qc = np.clip(0.5 * (lo + hi) + q0, lo, hi)
+    return {"wf": float(wf), "a": A, "b": B, "q_offset": qc, "q_range": np.minimum(qc - lo, hi - qc) * 0.95}
+
+
+def candidate_states(engine, candidates: list, T: int, freq: float, device: bool = True, use_deg_vectorised_quirk: bool = False) -> dict:
+    """States of ``len(candidates)`` candidate trajectories (dicts of ``fourier_coefficients``), T samples each at ``freq`` Hz, as ONE
+    stacked batch ready for ``Engine.gram_grouped`` / ``candidate_dopt`` -- what ``computeTrajectoryDynamics`` builds per candidate on the
+    host (trajectoryGenerator.py:83-155): joint states from the Fourier series, a stationary base (zero twist / acceleration / rpy).
+
+    ``use_deg_vectorised_quirk``: with ``useDeg`` the reference's vectorised evaluation converts radians with ``deg2rad`` once more
+    (lines 126-128 after a block that never produced degrees), i.e. its q, dq, ddq are pi / 180 of the per-sample generators' values;
+    True reproduces that output."""
+    C = len(candidates)
+    n = engine.n
+    nh = max(c["a"].shape[1] for c in candidates)
+    A, B = np.zeros((C, n, nh)), np.zeros((C, n, nh))
+    for i, c in enumerate(candidates):
+        A[i, :, : c["a"].shape[1]] = c["a"]
+        B[i, :, : c["b"].shape[1]] = c["b"]
+    bounded = [c["q_range"] is not None for c in candidates]
+    if any(bounded) and not all(bounded):
+        raise ValueError("classic and bounded candidates cannot share one batch")
+    st = engine.fourier_states([c["wf"] for c in candidates], A, B, np.stack([c["q_offset"] for c in candidates]), int(T), float(freq),
+                               q_range=np.stack([c["q_range"] for c in candidates]) if all(bounded) else None, device=device)
+    if use_deg_vectorised_quirk:
+        st = {k: v * (np.pi / 180.0) for k, v in st.items()}
+    if engine.floating:
+        S = C * int(T)
+        if device:
+            import torch
+
+            z = lambda k: torch.zeros((S, k), dtype=torch.float64, device=st["q"].device)  # noqa: E731
+        else:
+            z = lambda k: np.zeros((S, k))  # noqa: E731
+        st.update(base_vel=z(6), base_acc=z(6), rpy=z(3))
+    return st
+
+
+def candidate_dopt_from_coefficients(engine, candidates: list, T: int, freq: float, independent_cols, dopt_regularization: float = 1e-4,
+                                     YtY_prior=None) -> np.ndarray:
+    """D-optimality of every candidate without its samples ever leaving the device: Fourier coefficients -> states (``fbr_fourier_states``)
+    -> one Gram per candidate (``fbr_gram_grouped``) -> eigenvalues on the host (trajectoryOptimizer.py:240-272 per candidate)."""
+    st = candidate_states(engine, candidates, T, freq, device=True)
+    if engine.friction:
+        import torch
+
+        st["sign"] = torch.tanh(st["dq"] / 0.02)
+    return candidate_dopt(engine, st, len(candidates), independent_cols, dopt_regularization, YtY_prior=YtY_prior)

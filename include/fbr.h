@@ -173,6 +173,20 @@ int fbr_gram_grouped(fbr_model *m, const fbr_states *st, int32_t ngroups, const 
 int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W, double eps, double *out, int32_t out_mem);
 
 /*
+ * Joint states of ncand candidate trajectories, T samples each, generated ON THE DEVICE from their Fourier coefficients -- the
+ * parametrisation the trajectory optimiser searches over (excitation/trajectoryGenerator.py: OscillationGenerator 411-460,
+ * BoundedOscillationGenerator 462-560; evaluated per candidate by computeTrajectoryDynamics 83-128 before every objective call,
+ * trajectoryOptimizer.py:240-272).  q / dq / ddq [ncand * T][n] (out_mem space) are laid out like fbr_states of ncand groups, i.e. ready
+ * for fbr_gram_grouped: a candidate crosses PCIe as 2 n nharm + n + 1 coefficients instead of 3 n T samples.
+ *   wf [ncand], a / b [ncand][n][nharm] (harmonics beyond a joint's own nf: 0), q_offset [ncand][n], q_range [ncand][n] or NULL: host arrays.
+ *   q_range == NULL (classic, Swevers 1997):  dq = sum_l a_l cos(wf l t) + b_l sin(wf l t), q its integral + q_offset (= nf q0), ddq its derivative
+ *   q_range != NULL (bounded):                 q = q_offset + q_range tanh(sum_l a_l sin(wf l t) + b_l cos(wf l t)) (q_offset = q_center), dq, ddq by the chain rule
+ * t = sample index / freq (radians; useDeg of the reference converts on the host before / after).
+ */
+int fbr_fourier_states(fbr_model *m, int32_t ncand, int64_t T, int32_t nharm, double freq, const double *wf, const double *a, const double *b,
+                       const double *q_offset, const double *q_range, double *q, double *dq, double *ddq, int32_t out_mem);
+
+/*
  * R_out [(cols+k)][(cols+k)] upper triangular with R^T R = [Y|rhs]^T [Y|rhs], by blocked Householder
  * TSQR over sample blocks (no Gram squaring of the condition number; on branched robots the rows are grouped along
  * the kinematic tree and every group is factorised over the columns it can touch -- same R).  If R_in != NULL it is an

@@ -818,9 +818,83 @@ def reference_identification_fb(golden):
     np.savez_compressed(os.path.join(golden, "ref_identification_fb.npz"), **out)
 
 
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Round 5 (N1): the reference's Fourier-series trajectory generator -- pure NumPy, no iDynTree on this path
+# ------------------------------------------------------------------------------------------------------------------------------------
+def reference_trajectories(golden):
+    """tests/golden/ref_trajectories.npz: positions / velocities / accelerations of candidate trajectories from the reference's own
+    excitation/trajectoryGenerator.py -- PulsedTrajectory.initWithParams (322-383) with OscillationGenerator (411-460, classic, rad and
+    useDeg) and BoundedOscillationGenerator (462-560, joint limits), evaluated (i) through the vectorised block of
+    computeTrajectoryDynamics (83-128: run unmodified with a model whose computeRegressors does nothing and the reference's own Data)
+    and (ii) sample by sample through getAngle / getVelocity / getAcceleration (the fallback path, 129-150)."""
+    tg = _import_reference("excitation.trajectoryGenerator")
+
+    class NoModel:  # computeTrajectoryDynamics only calls model.computeRegressors(data) and reads data.samples["torques"] afterwards
+        def computeRegressors(self, data, only_simulate=False):
+            pass
+
+    rng = np.random.default_rng(515)
+    n, freq = 7, 25.0
+    out = {"freq": freq, "num_dofs": n}
+    limits = [(-1.0 - 0.2 * i, 0.8 + 0.3 * i) for i in range(n)]
+    cases = []
+    for c in range(4):
+        nf = rng.integers(1, 6, n)
+        a = [rng.standard_normal(int(k)) * 0.6 for k in nf]
+        b = [rng.standard_normal(int(k)) * 0.6 for k in nf]
+        q0 = rng.uniform(-0.4, 0.4, n)
+        wf = float(rng.uniform(0.6, 1.6))
+        cases.append((nf, a, b, q0, wf))
+    out["num_cases"] = len(cases)
+    for c, (nf, a, b, q0, wf) in enumerate(cases):
+        for mode in ("classic", "classic_deg", "bounded"):
+            use_deg = mode == "classic_deg"
+            qq = np.rad2deg(q0) if use_deg else q0
+            tr = tg.PulsedTrajectory(n, use_deg=use_deg).initWithParams(a, b, qq, nf, wf, joint_limits=limits if mode == "bounded" else None)
+            cfg = {"simulateTorques": False, "floatingBase": 0, "excitationFrequency": freq, "num_dofs": n, "useDeg": use_deg, "skipSamples": 0,
+                   "startOffset": 0, "verbose": 0, "showTiming": 0, "selectBlocksFromMeasurements": 0}
+            td, data = tg.computeTrajectoryDynamics(cfg, tr, model=NoModel())
+            T = td["positions"].shape[0]
+            assert T == int(tr.getPeriodLength() * freq)
+            # the same numbers sample by sample through the generator objects
+            P2, V2, A2 = np.empty((T, n)), np.empty((T, n)), np.empty((T, n))
+            for t in range(T):
+                tr.setTime(t / freq)
+                for d in range(n):
+                    P2[t, d], V2[t, d], A2[t, d] = tr.getAngle(d), tr.getVelocity(d), tr.getAcceleration(d)
+            if use_deg:
+                P2, V2, A2 = np.deg2rad(P2), np.deg2rad(V2), np.deg2rad(A2)
+            for nm, X, Y in (("q", td["positions"], P2), ("dq", td["velocities"], V2), ("ddq", td["accelerations"], A2)):
+                err = np.abs(X - Y).max() / max(np.abs(Y).max(), 1.0)
+                # (useDeg: the vectorised block never applies the generators' rad2deg but still converts with deg2rad -- its output is the
+                # per-sample path's times pi / 180; both are stored, excitation.fourier_coefficients reproduces either)
+                assert err <= 1e-11 or (use_deg and abs(err - (1 - np.pi / 180)) < 1e-9), (c, mode, nm, err)
+            tag = f"c{c}_{mode}_"
+            out.update({tag + "positions": td["positions"], tag + "velocities": td["velocities"], tag + "accelerations": td["accelerations"],
+                        tag + "times": td["times"]})
+            if use_deg:
+                out.update({tag + "persample_positions": P2, tag + "persample_velocities": V2, tag + "persample_accelerations": A2})
+            if mode == "bounded":
+                out[tag + "q_center"] = np.array([o.q_center for o in tr.oscillators])
+                out[tag + "q_range"] = np.array([o.q_range for o in tr.oscillators])
+        amax = max(int(k) for k in nf)
+        A = np.zeros((n, amax))
+        B = np.zeros((n, amax))
+        for j in range(n):
+            A[j, : len(a[j])] = a[j]
+            B[j, : len(b[j])] = b[j]
+        out.update({f"c{c}_a": A, f"c{c}_b": B, f"c{c}_nf": np.asarray(nf), f"c{c}_q0": q0, f"c{c}_wf": wf})
+    out["joint_limits"] = np.array(limits)
+    np.savez_compressed(os.path.join(golden, "ref_trajectories.npz"), **out)
+    print("ref_trajectories.npz:", len(out), "arrays")
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "blocks_wls":
         reference_blocks_and_wls(os.path.join(REPO, "tests", "golden"))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trajectories":
+        reference_trajectories(os.path.join(REPO, "tests", "golden"))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fb":
         reference_identification_fb(os.path.join(REPO, "tests", "golden"))
@@ -831,3 +905,4 @@ if __name__ == "__main__":
     reference_compute_regressors(os.path.join(REPO, "tests", "golden"))
     reference_blocks_and_wls(os.path.join(REPO, "tests", "golden"))
     reference_identification_fb(os.path.join(REPO, "tests", "golden"))
+    reference_trajectories(os.path.join(REPO, "tests", "golden"))
