@@ -384,11 +384,21 @@ struct FbrDevGroup {
     double *A;
     int ld, psel;
 };
+// Rows [S, Sslot) of every slot of every group's chunk := 0 (the last chunk of a call is padded to whole fold blocks per slot, so that a
+// block never straddles two regressor rows; padded rows are zero rows of the factorisation).  grid = (groups, slots), nrows[g] slots each.
+__global__ __launch_bounds__(256) void fbr_groups_clear_pad_kernel(const FbrDevGroup *__restrict__ grp, const int *__restrict__ nrows, long S, long Sslot)
+{
+    const int g = blockIdx.x, slot = blockIdx.y;
+    if (slot >= nrows[g]) return;
+    double *p = grp[g].A + ((long)slot * Sslot + S) * grp[g].ld;
+    const long cnt = (Sslot - S) * grp[g].ld;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) p[i] = 0.0;
+}
 __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, long S, const double *__restrict__ rec, const double *__restrict__ dq,
                                                                     const double *__restrict__ sign, const double *__restrict__ rhs, int k,
                                                                     const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,
                                                                     const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
-                                                                    const int *__restrict__ ebeg, const int *__restrict__ ent)
+                                                                    const int *__restrict__ ebeg, const int *__restrict__ ent, long Sslot)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *rs = smem;                                    // [rec]
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
         }
         if (tid < m.rows) {
             const int g = rowgroup[tid];
-            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * S + s) * grp[g].ld : nullptr;
+            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * Sslot + s) * grp[g].ld : nullptr;  // (Sslot >= S: slot stride of the chunk, padded to whole blocks)
         }
         fbr_barrier_lds();
         // rhs columns: one element per thread (a single thread walking all rows would be the critical path of the sample)
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
                                                                      const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
                                                                      const int *__restrict__ ebeg, const int *__restrict__ ent,
                                                                      const int *__restrict__ pbeg, const int *__restrict__ pent, int npairs,
-                                                                     int ninert, int split)
+                                                                     int ninert, int split, long Sslot)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *rs = smem;                                    // [rec]
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
         }
         if (tid < m.rows) {
             const int g = rowgroup[tid];
-            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * S + s) * grp[g].ld : nullptr;
+            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * Sslot + s) * grp[g].ld : nullptr;  // (Sslot >= S: slot stride of the chunk, padded to whole blocks)
         }
         fbr_barrier_lds();
         for (int t = tid; t < m.rows * k; t += blockDim.x) {

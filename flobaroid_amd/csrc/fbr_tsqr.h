@@ -1037,6 +1037,13 @@ __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow
     for (int i0 = 0; i0 < n; i0 += MB) fbr_tsqr_wave_fold<NPT, SUB>(Rw + a * n * n, Rb + (long)i0 * n, n, std::min(MB, n - i0), i0, lds, lane);
 }
 
+// progress flags / claim counters of a merge tree := 0 (a kernel instead of hipMemsetAsync: the runtime's fill path costs 40 - 80 us per
+// call on the stream, and this clear sits between the last level-0 fold and the first tree level of every factorisation)
+__global__ __launch_bounds__(256) void fbr_tsqr_zero_kernel(int *__restrict__ p, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
 // copy between the caller's Pa x Pa factor and the padded n x n working factor (upper triangle only)
 __global__ void fbr_tsqr_copy_kernel(int Pa, const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd,
                                      int rows_dst, int cols_dst)
@@ -1355,8 +1362,24 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         return -1;
     }
     if (wk.narrow) {
+        // 128-column factors (8 tiles: the leading dimension of the wave-private layout equals that of the eight-wave kernels with one
+        // tile per wave): once a level has no more merges than CUs, a merge is folded by a whole workgroup -- panel chain on one wave, the
+        // seven tile updates beside it -- instead of by one wave: the late levels of the tree are pure latency (one merge = 125 ... 170 us
+        // by a single wave; eleven levels over 2048 private factors were 1.8 ms at the end of a short call)
+        int cus = 0, dev = 0;
+        TSQR_HIP(hipGetDevice(&dev));
+        TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const bool coop = wk.tpw == FBR_TSQR_NARROW_MAX_TILES && wk.opts.short_calls;
+        if (coop)
+            TSQR_HIP(hipFuncSetAttribute((const void *)fbr_tsqr_tree_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fbr_tsqr_lds_doubles<1, 4>() * sizeof(double))));
         for (int stride = stride_from; stride < stride_to; stride *= 2) {
             const int pairs = (wk.NW + 2 * stride - 1) / (2 * stride);
+            if (coop && pairs <= std::max(cus, 1)) {
+                hipLaunchKernelGGL((fbr_tsqr_tree_kernel<1, 4>), dim3(pairs), dim3(FBR_TSQR_THREADS), (fbr_tsqr_lds_doubles<1, 4>() * sizeof(double)), st, wk.Rw, n, stride,
+                                   wk.NW, wk.err);
+                TSQR_HIP(hipGetLastError());
+                continue;
+            }
             const int grid = (pairs + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
             FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_tree_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
                                                                 (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, wk.Rw,
@@ -1383,7 +1406,10 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_x_kernel<TPW, SUB, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                  (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW, true>() * sizeof(double))));
-        if (stride_from == 1) TSQR_HIP(hipMemsetAsync(wk.prog, 0, need, st));
+        if (stride_from == 1) {
+            hipLaunchKernelGGL(fbr_tsqr_zero_kernel, dim3((unsigned)std::min<size_t>((need / sizeof(int) + 255) / 256, 1024)), dim3(256), 0, st, wk.prog, (long)(need / sizeof(int)));
+            TSQR_HIP(hipGetLastError());
+        }
         size_t off = 0;
         for (int stride = 1; stride < stride_from; stride *= 2) off += level_ints(stride);
         for (int stride = stride_from; stride < stride_to; stride *= 2) {
@@ -1431,7 +1457,10 @@ static inline int fbr_tsqr_tree_levels(FbrTsqrWork &wk, hipStream_t st, int stri
         TSQR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         FBR_TSQR_DISPATCH(wk.ttpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_tree_x_kernel<TPW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)(fbr_tsqr_lds_doubles<TPW, SUB, FBR_TSQR_WAVES, true>() * sizeof(double))));
-        if (stride_from == 1) TSQR_HIP(hipMemsetAsync(wk.prog, 0, need, st));
+        if (stride_from == 1) {
+            hipLaunchKernelGGL(fbr_tsqr_zero_kernel, dim3((unsigned)std::min<size_t>((need / sizeof(int) + 255) / 256, 1024)), dim3(256), 0, st, wk.prog, (long)(need / sizeof(int)));
+            TSQR_HIP(hipGetLastError());
+        }
         size_t off = 0;
         for (int stride = 1; stride < stride_from; stride *= 2) off += level_ints(stride);
         for (int stride = stride_from; stride < stride_to; stride *= 2) {

@@ -215,7 +215,11 @@ static bool tsqr_use_groups(const fbr_model *m, const TsqrGroupPlan &gp, long S)
     const long min_s = (long)m->opt.tsqr_group_min_samples;  // (tests force the path at small sizes) default 24000: measured on WALK-MAN, groups vs one factorisation: 16 k samples 16 vs 15.8 ms, 32 k 18.5 vs 21.4, 64 k 24 vs 32, 125 k 34 vs 52
     return (gp.groups.size() > 1 || (gp.masked && !gp.groups.empty())) && S >= min_s && m->opt.tsqr_groups != 0;
 }
-static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp, long S)
+// Samples per chunk of a call over S samples, and (*lcm_out) the block granularity: every chunk is a whole number of fold blocks per
+// regressor row in every group.  The chunks are cut EVENLY (a call that exceeds the memory-sized chunk by a few samples used to end with
+// a chunk of a handful of samples that cost a dozen launches: 0.66 of the 10.3 ms of a 125 k-sample WALK-MAN call), a call up to 5 %
+// longer than one chunk stays one chunk, and the last chunk is padded to the granularity with zero rows (tsqr_groups_impl).
+static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp, long S, long *lcm_out = nullptr)
 {
     double per = 0.0;  // chunk bytes per sample over all groups
     long lcm = 1;
@@ -226,9 +230,14 @@ static long tsqr_group_chunk_samples(const fbr_model *m, const TsqrGroupPlan &gp
         lcm = std::lcm(lcm, (long)sh.mb);
     }
     long ch = std::max(1L, (long)(4.0 * 1024 * 1024 * 1024 / per));
-    ch = std::min(ch, chunk_size(m, S));
-    if (ch > lcm) ch -= ch % lcm;  // whole blocks per slot in every group
-    return ch;
+    ch = std::min(ch, chunk_size(m, 1L << 40));  // (the memory-sized chunk; chunk_size caps at the call's own length otherwise)
+    if (m->opt.chunk_samples >= 1) ch = (long)m->opt.chunk_samples;
+    ch = std::max(lcm, ch - ch % lcm);
+    if (lcm_out) *lcm_out = lcm;
+    if (S <= 0) return ch;
+    const long nch = std::max(1L, (long)std::ceil((double)S / (1.05 * (double)ch)));
+    const long even = (S + nch - 1) / nch;
+    return (even + lcm - 1) / lcm * lcm;  // whole blocks per slot in every group
 }
 
 // Device tables of a TSQR call: assembled in pinned host memory that belongs to the call's ticket parity and copied asynchronously on
@@ -268,7 +277,8 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         return code == -4 ? FBR_E_UNSUPPORTED : (code == -3 ? FBR_E_HIP : FBR_E_INVALID);
     };
     if ((int)m->tsqr_groups.size() < G) m->tsqr_groups.resize(G);
-    const long ch = tsqr_group_chunk_samples(m, gp, S);
+    long lcm = 1;
+    const long ch = tsqr_group_chunk_samples(m, gp, S, &lcm);
     if (ch < 0) return tsqr_fail(-4, "tsqr group shape");
     // device tables: ints [rowgroup | rowslot | entry ranges (cols + 1) x 2 | per group: slot first columns | per group: embedding (Pa)],
     // then the entry lists (int4) and the FbrDevGroup records
@@ -339,6 +349,8 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         }
         tab.push_back((int)pents[var].size());
     }
+    const size_t o_nrows = tab.size();  // slots (regressor rows) of every group
+    for (int g = 0; g < G; g++) tab.push_back((int)gp.groups[g].rows.size());
     std::vector<size_t> o_fc(G), o_emb(G);
     for (int g = 0; g < G; g++) {
         o_fc[g] = tab.size();
@@ -387,7 +399,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         const TsqrGroup &Gg = gp.groups[g];
         FbrTsqrWork &wk = work(g);
         double *A = nullptr;
-        if ((rc = fbr_tsqr_chunk_buffer(wk, std::min(ch, S) * (long)Gg.rows.size(), &A)) || (rc = fbr_tsqr_chunk_clean(wk, pst)))
+        if ((rc = fbr_tsqr_chunk_buffer(wk, ch * (long)Gg.rows.size(), &A)) || (rc = fbr_tsqr_chunk_clean(wk, pst)))
             return tsqr_fail(rc, "tsqr group chunk");
         hg[g] = FbrDevGroup{A, wk.n, (int)Gg.sel.size()};
     }
@@ -403,54 +415,6 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     const size_t lds = (size_t)((hm.rec_size() + 1) & ~1) * sizeof(double) + (size_t)hm.rows * sizeof(double *);
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // the kinematic records are produced for several chunks at a time: one lane per sample needs tens of thousands of waves in flight
-    // to hide its latencies (1 M samples: 6.4 ms in one launch, 11 ms in twelve)
-    const long kin_span = std::max(ch, std::min(S, (long)((size_t)(6ull << 30) / ((size_t)hm.rec_size() * sizeof(double))) / ch * ch));
-    for (long s0 = 0; s0 < S; s0 += ch) {
-        const long cs = std::min(ch, S - s0);
-        const long k0 = s0 / kin_span * kin_span;
-        hipStream_t cst = s0 == 0 ? pst : m->stream;  // the first chunk's kinematics and writer belong to the prologue
-        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0), cst))) return rc;
-        const double *recs = m->rec.as<double>() + (size_t)(s0 - k0) * hm.rec_size();
-        // structural zeros left of a row's first supported column tile are skipped when every block holds rows of one slot
-        skipzeros = true;
-        for (int g = 0; g < G; g++) skipzeros = skipzeros && cs % work(g).mb == 0;
-        {
-            ProfScope ps(m, FBR_PROF_REGRESSOR, cst);
-            if (pairable)
-                hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
-                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
-                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
-                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)),
-                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_pent1 : o_pent0)), npairs, hm.ninert, wsplit);
-            else
-                hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
-                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
-                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
-                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)));
-        }
-        HIPCHK(hipGetLastError());
-        if (cst != m->stream) {  // the folds (main stream) wait for the prologue
-            HIPCHK(hipEventRecord(m->ev_tsqr_pro, cst));
-            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_tsqr_pro, 0));
-        }
-        ProfScope ps(m, FBR_PROF_TSQR);
-        for (int g = 0; g < G; g++) {
-            const TsqrGroup &Gg = gp.groups[g];
-            FbrTsqrRowOrder ro;
-            ro.first_col = t + o_fc[g];
-            ro.rows = (int)Gg.rows.size();
-            ro.group = cs;
-            if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, cs * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
-        }
-    }
-    bool l0_recorded = false;
-    auto record_l0 = [&]() -> int {  // what a following submission's prologue waits for
-        if (!l0_recorded) HIPCHK(hipEventRecord(m->ev_tsqr_l0, m->stream));
-        l0_recorded = true;
-        m->tsqr_l0_rec = true;
-        return FBR_OK;
-    };
     // Merge trees are latency bound (a level of the full-width tree is 0.93 ms on a handful of workgroups, 8 levels over 256 private
     // factors).  The groups' trees run on side streams beside the main group's.  Their factors, embedded into the caller's column
     // order, are dense rows of the final factorisation: they are folded INSIDE the main tree -- once at most 8 of its factors are
@@ -479,40 +443,110 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     }
     if ((rc = m->tsqr_rtmp.ensure(rt * sizeof(double)))) return rc;
     double *rtmp = m->tsqr_rtmp.as<double>();
-    HIPCHK(hipEventRecord(m->tsqr_ev[NSIDE], m->stream));
-    for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->tsqr_streams[i], m->tsqr_ev[NSIDE], 0));
     // the longest trees first, one stream each as far as they go (a short tree queued behind the waist chain's tree was the last to finish)
     std::vector<int> side_order;
     for (int g = 0; g < G; g++)
         if (g != gp.main) side_order.push_back(g);
     std::stable_sort(side_order.begin(), side_order.end(), [&](int a, int b) { return gp.groups[a].Pa > gp.groups[b].Pa; });
-    // (narrow factors of one shape -- the two arms, the two legs -- share their launches: fbr_tsqr_finish_narrow_batch)
-    int nside = 0;
-    std::vector<char> finished(G, 0);
-    for (int g : side_order) {
-        if (finished[g]) continue;
-        FbrTsqrWork &wg = m->tsqr_groups[g];
-        FbrTsqrWork *batch[FBR_TSQR_NARROW_BATCH];
-        double *outs[FBR_TSQR_NARROW_BATCH];
-        int nb = 0;
-        if (wg.narrow)
-            for (int h : side_order)
-                if (!finished[h] && nb < FBR_TSQR_NARROW_BATCH && m->tsqr_groups[h].narrow && m->tsqr_groups[h].n == wg.n && m->tsqr_groups[h].NW == wg.NW &&
-                    m->tsqr_groups[h].tpw == wg.tpw) {
-                    batch[nb] = &m->tsqr_groups[h];
-                    outs[nb++] = rtmp + o_r[h];
-                    finished[h] = 1;
-                }
-        hipStream_t sst = m->tsqr_streams[nside++ % NSIDE];
-        if (nb >= 2) {
-            if ((rc = fbr_tsqr_finish_narrow_batch(batch, nb, sst, outs))) return tsqr_fail(rc, "tsqr group finish");
-        } else {
-            for (int i = 0; i < nb; i++) finished[(int)(batch[i] - &m->tsqr_groups[0])] = 0;  // (a batch of one: the plain path)
-            finished[g] = 1;
-            if ((rc = fbr_tsqr_finish_async(wg, sst, rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+    // The side groups' trees are started as soon as their last level-0 fold has been enqueued -- BEFORE the main (base-wrench) group's last
+    // fold: they are latency bound (eleven levels over 2048 wave-private factors, a handful of waves each at the end: 1.9 ms for the waist
+    // chain's group of a 125 k-sample call) and then run beside the throughput-bound fold of the main group instead of behind it.
+    bool side_trees_launched = false;
+    auto launch_side_trees = [&]() -> int {
+        side_trees_launched = true;
+        HIPCHK(hipEventRecord(m->tsqr_ev[NSIDE], m->stream));
+        for (int i = 0; i < NSIDE; i++) HIPCHK(hipStreamWaitEvent(m->tsqr_streams[i], m->tsqr_ev[NSIDE], 0));
+        // (narrow factors of one shape -- the two arms, the two legs -- share their launches: fbr_tsqr_finish_narrow_batch)
+        int nside = 0;
+        std::vector<char> finished(G, 0);
+        for (int g : side_order) {
+            if (finished[g]) continue;
+            FbrTsqrWork &wg = m->tsqr_groups[g];
+            FbrTsqrWork *batch[FBR_TSQR_NARROW_BATCH];
+            double *outs[FBR_TSQR_NARROW_BATCH];
+            int nb = 0;
+            if (wg.narrow)
+                for (int h : side_order)
+                    if (!finished[h] && nb < FBR_TSQR_NARROW_BATCH && m->tsqr_groups[h].narrow && m->tsqr_groups[h].n == wg.n && m->tsqr_groups[h].NW == wg.NW &&
+                        m->tsqr_groups[h].tpw == wg.tpw) {
+                        batch[nb] = &m->tsqr_groups[h];
+                        outs[nb++] = rtmp + o_r[h];
+                        finished[h] = 1;
+                    }
+            hipStream_t sst = m->tsqr_streams[nside++ % NSIDE];
+            if (nb >= 2) {
+                if ((rc = fbr_tsqr_finish_narrow_batch(batch, nb, sst, outs))) return tsqr_fail(rc, "tsqr group finish");
+            } else {
+                for (int i = 0; i < nb; i++) finished[(int)(batch[i] - &m->tsqr_groups[0])] = 0;  // (a batch of one: the plain path)
+                finished[g] = 1;
+                if ((rc = fbr_tsqr_finish_async(wg, sst, rtmp + o_r[g]))) return tsqr_fail(rc, "tsqr group finish");
+            }
         }
+        for (int i = 0; i < NSIDE; i++) HIPCHK(hipEventRecord(m->tsqr_ev[i], m->tsqr_streams[i]));
+        return FBR_OK;
+    };
+    // the kinematic records are produced for several chunks at a time: one lane per sample needs tens of thousands of waves in flight
+    // to hide its latencies (1 M samples: 6.4 ms in one launch, 11 ms in twelve)
+    const long kin_span = std::max(ch, std::min(S, (long)((size_t)(6ull << 30) / ((size_t)hm.rec_size() * sizeof(double))) / ch * ch));
+    for (long s0 = 0; s0 < S; s0 += ch) {
+        const long cs = std::min(ch, S - s0);
+        const long k0 = s0 / kin_span * kin_span;
+        hipStream_t cst = s0 == 0 ? pst : m->stream;  // the first chunk's kinematics and writer belong to the prologue
+        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0), cst))) return rc;
+        const double *recs = m->rec.as<double>() + (size_t)(s0 - k0) * hm.rec_size();
+        // every slot of the chunk holds csp >= cs rows, a whole number of fold blocks in every group (the last chunk is padded with zero
+        // rows): a block never straddles two regressor rows, and the structural zeros left of a row's first supported column tile are
+        // never written (the folds do not read them)
+        const long csp = (cs + lcm - 1) / lcm * lcm;
+        skipzeros = true;
+        if (csp > cs) {
+            size_t maxrows = 1;
+            for (int g = 0; g < G; g++) maxrows = std::max(maxrows, gp.groups[g].rows.size());
+            hipLaunchKernelGGL(fbr_groups_clear_pad_kernel, dim3(G, (unsigned)maxrows), dim3(256), 0, cst, dgrp, t + o_nrows, cs, csp);
+            HIPCHK(hipGetLastError());
+        }
+        {
+            ProfScope ps(m, FBR_PROF_REGRESSOR, cst);
+            if (pairable)
+                hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
+                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
+                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)),
+                                   t + o_pbeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_pent1 : o_pent0)), npairs, hm.ninert, wsplit, csp);
+            else
+                hipLaunchKernelGGL(fbr_regressor_groups_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
+                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
+                                   t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)), csp);
+        }
+        HIPCHK(hipGetLastError());
+        if (cst != m->stream) {  // the folds (main stream) wait for the prologue
+            HIPCHK(hipEventRecord(m->ev_tsqr_pro, cst));
+            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_tsqr_pro, 0));
+        }
+        ProfScope ps(m, FBR_PROF_TSQR);
+        auto fold_group = [&](int g) -> int {
+            const TsqrGroup &Gg = gp.groups[g];
+            FbrTsqrRowOrder ro;
+            ro.first_col = t + o_fc[g];
+            ro.rows = (int)Gg.rows.size();
+            ro.group = csp;
+            if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, csp * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
+            return FBR_OK;
+        };
+        for (int g = 0; g < G; g++)
+            if (g != gp.main && (rc = fold_group(g))) return rc;
+        if (s0 + ch >= S && gp.main >= 0 && (rc = launch_side_trees())) return rc;  // (last chunk: the side trees beside the main group's fold)
+        if (gp.main >= 0 && (rc = fold_group(gp.main))) return rc;
     }
-    for (int i = 0; i < NSIDE; i++) HIPCHK(hipEventRecord(m->tsqr_ev[i], m->tsqr_streams[i]));
+    if (!side_trees_launched && (rc = launch_side_trees())) return rc;
+    bool l0_recorded = false;
+    auto record_l0 = [&]() -> int {  // what a following submission's prologue waits for
+        if (!l0_recorded) HIPCHK(hipEventRecord(m->ev_tsqr_l0, m->stream));
+        l0_recorded = true;
+        m->tsqr_l0_rec = true;
+        return FBR_OK;
+    };
     // rows of the embedded group factors, stacked: [sum of the groups' Pa][n] in the final factor's column order
     long erows = 0;
     for (int g : side_order) erows += gp.groups[g].Pa;
@@ -961,7 +995,8 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
         // that folds the embedded group factors (dense rows) and runs its own tree
         const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k);
         if (hm.rows <= 255 && tsqr_use_groups(m, gp, (long)num_samples)) {
-            const long ch = tsqr_group_chunk_samples(m, gp, (long)num_samples);
+            long lcm = 1;
+            const long ch = tsqr_group_chunk_samples(m, gp, (long)num_samples, &lcm);
             long l0 = 0, tr = 0, mrows = 0;
             FbrTsqrShape sh;
             auto fold_mfma = [&](int first_col) -> long {
@@ -987,7 +1022,7 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
                     return FBR_E_UNSUPPORTED;
                 }
                 for (long s0 = 0; s0 < num_samples; s0 += ch) {
-                    const long cs = std::min(ch, (long)num_samples - s0), M = cs * ns, Mpad = (M + 15) & ~15L;
+                    const long cs = (std::min(ch, (long)num_samples - s0) + lcm - 1) / lcm * lcm, M = cs * ns, Mpad = (M + 15) & ~15L;  // (padded slots)
                     for (long b = 0; b < (Mpad + sh.mb - 1) / sh.mb; b++) {
                         const long r0 = b * sh.mb;
                         int f = sh.n;
