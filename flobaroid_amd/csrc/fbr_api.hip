@@ -193,6 +193,9 @@ static int build_reduction(fbr_model *m, const fbr_topology *t, int which)
     if ((rc = upload(m->tables, beg, &m->E_beg[which])) || (rc = upload(m->tables, row, &m->E_row[which])) ||
         (rc = upload(m->tables, val, &m->E_val[which])))
         return rc;
+    m->hE_beg[which] = beg;
+    m->hE_row[which] = row;
+    m->hE_val[which] = val;
     return FBR_OK;
 }
 extern "C" void fbr_model_destroy(fbr_model *m)
@@ -522,6 +525,27 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
 static int run_id(fbr_model *m, const fbr_states *st, const double *x, int nx, const double *vel_sign, int mode,
                   double *tau_out, int32_t out_mem)
 {
+    // Y x = Y_red (E x): torques are linear in the parameters, and the parameters of a link welded to a moving body are parameters of that
+    // body (build_reduction, merged model rdm[0]: every moving link keeps its ten columns).  The kinematics and the per-link wrench loop
+    // then run over the moving bodies only (WALK-MAN: 30 of 48 links) -- same rows, same result to rounding.
+    if (m && x && st && m->rdm[0] && m->opt.link_merge && m->pid == getpid()) {
+        fbr_model *r = m->rdm[0].get();
+        const FbrHostModel &hm = m->hm, &rh = r->hm;
+        const int ninert = hm.cpl * hm.L, rin = rh.cpl * rh.L;
+        const int full = mode == 0 ? ninert : hm.cols;  // mode 0: the inertial block of x_std; mode 1: every identified column
+        if (hm.cpl == 10 && nx >= full) {
+            std::vector<double> xr((size_t)std::max(rin + (nx - ninert), rh.cols), 0.0);
+            const std::vector<int> &eb = m->hE_beg[0], &er = m->hE_row[0];
+            const std::vector<double> &ev = m->hE_val[0];
+            for (int j = 0; j < ninert; j++)
+                for (int e = eb[j]; e < eb[j + 1]; e++) xr[er[e]] += ev[e] * x[j];
+            for (int j = ninert; j < nx; j++) xr[rin + (j - ninert)] = x[j];  // friction slots / columns: the same joints in the same layout
+            if (int rc = enter_blocking(m)) return rc;
+            r->stream = m->stream;
+            r->prof = m->prof;
+            return run_id(r, st, xr.data(), rin + (nx - ninert), vel_sign, mode, tau_out, out_mem);
+        }
+    }
     DevStates d;
     int rc = stage_states(m, st, &d);
     if (rc) return rc;

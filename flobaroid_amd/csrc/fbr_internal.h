@@ -152,7 +152,9 @@ struct fbr_model {
     // rdm[0]: fixed links merged (every entry point works on it); rdm[1]: merged + regrouped (fused Gram and the row-group TSQR only).
     std::unique_ptr<fbr_model> rdm[2];
     const int *E_beg[2] = {nullptr, nullptr}, *E_row[2] = {nullptr, nullptr};  // CSC of the augmented E [(cols_red + 16) x (cols + 16)]: column j
-    const double *E_val[2] = {nullptr, nullptr};  // of the full layout = sum of E_val[e] x (reduced column E_row[e]), e in [E_beg[j], E_beg[j+1])
+    const double *E_val[2] = {nullptr, nullptr};
+    std::vector<int> hE_beg[2], hE_row[2];  // the same CSC on the host: x_red = E x of the streaming prediction / inverse dynamics (run_id)
+    std::vector<double> hE_val[2];  // of the full layout = sum of E_val[e] x (reduced column E_row[e]), e in [E_beg[j], E_beg[j+1])
     DevBuf red_out[2];        // G_red / R_red of a pass, by ticket parity
     DevBuf red_w;             // G_red E (Gram expansion, second half: E^T (G_red E))
     int64_t red_ticket[2] = {-1, -1};  // the reduced model's ticket behind this model's ticket of that parity
