@@ -838,7 +838,15 @@ __global__ __launch_bounds__(256, 7) void fbr_pack_kernel(DevGram g, DevModel m,
                 const int len = base_only ? 0 : plen[d.z];
                 for (int j = 0; j < len; j++) {
                     const int dd = ptab[d.z * m.maxd + j];
+#if defined(FBR_PACK_TIMING_CHEAPDOT)  // timing-only experiments (results wrong): 1 = one multiply and one LDS read per joint row,
+                    const double *Sx = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd;  // 2 = one multiply, all six LDS reads kept
+                    double v = Sx[0] * w6[0];
+#if FBR_PACK_TIMING_CHEAPDOT == 2
+                    asm volatile("" ::"v"(Sx[1]), "v"(Sx[2]), "v"(Sx[3]), "v"(Sx[4]), "v"(Sx[5]));
+#endif
+#else
                     double v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd, w6);
+#endif
                     if (ws) v *= ws[m.fb + dd];
                     img[d.x + ppos[d.z * m.maxd + j] * FBR_TILE] = v;
                     if (mom) {
