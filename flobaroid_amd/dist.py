@@ -168,8 +168,19 @@ def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.T
 
     out: dict = {"world": world}
 
-    def fail(msg):
-        raise RuntimeError(f"[rank {rank}] distributed self-check failed: {msg}.  {Watchdog.HINT}")
+    bad: list = []
+
+    def fail(msg):  # recorded, raised by EVERY rank together at the end of the step (agree): a rank that raised at once would leave its
+        bad.append(msg)  # peers blocked in the next exchange until their watchdogs fire, with N - 1 misleading "did not finish" messages
+
+    def agree(step: str):
+        flag = torch.tensor([1.0 if bad else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+        if bad:
+            raise RuntimeError(f"[rank {rank}] distributed self-check failed: {bad[0]}.  {Watchdog.HINT}")
+        if float(flag.item()) > 0:
+            raise RuntimeError(f"[rank {rank}] distributed self-check: {int(flag.item())} other rank(s) reported a failure in step '{step}' (see their "
+                               "message); this rank's own checks passed")
 
     with Watchdog(timeout, "all-reduce", rank) as wd:
         t0 = time.perf_counter()
@@ -178,6 +189,7 @@ def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.T
         want = world * (world + 1) / 2.0
         if not bool((x.cpu() == want).all()):
             fail(f"all-reduce over {world} ranks gave {x.cpu().tolist()} instead of {want}")
+        agree("all-reduce")
         out["allreduce_s"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()
@@ -191,6 +203,8 @@ def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.T
                 if not torch.equal(buf.cpu(), _edge_payload(recv, send)):
                     bad = int((buf.cpu() != _edge_payload(recv, send)).sum())
                     fail(f"payload received over tree edge {send} -> {recv} differs from what rank {send} sends in {bad} of 4096 entries")
+        wd.step("status exchange after the tree edges")
+        agree("send/recv over the tree edges")
         out["edges_s"] = time.perf_counter() - t0
 
         wd.step("tsqr_tree on random triangles")
@@ -217,6 +231,7 @@ def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.T
         e2 = float(torch.linalg.norm(Rc - ref) / torch.linalg.norm(ref))
         if not (e1 <= 1e-12 and e2 <= 1e-12):
             fail(f"tsqr_tree over {world} ranks: ||R^T R - sum R_r^T R_r|| / ||.|| = {e1:.2e}, vs the locally merged tree {e2:.2e} (expected <= 1e-12)")
+        agree("tsqr_tree on random triangles")
         out["tsqr_tree_s"] = time.perf_counter() - t0
         out["tsqr_tree_relerr"] = max(e1, e2)
 
@@ -226,5 +241,6 @@ def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.T
         dist.broadcast(y, src=g(0), group=group)
         if not bool((y.cpu() == 42.0).all()):
             fail("broadcast from rank 0 did not arrive")
+        agree("broadcast")
         out["broadcast_s"] = time.perf_counter() - t0
     return out
