@@ -45,23 +45,25 @@ __global__ __launch_bounds__(256) void fbr_expand_gram_kernel(int cols, int k, i
     }
 }
 
-// dst[r][j] (leading dimension ldd) = (R_red E)[r][j] for r < Pra, j < Pa: the rows the final factor of a TSQR folds
+// dst[r][jj] (leading dimension ldd) = (R_red E)[r][j] for r < Pra and the Pout output columns jj: j = colmap[jj] (a column subset of the
+// augmented layout, fbr_tsqr_cols through the reductions) or jj itself (colmap == NULL, Pout = cols + k): the rows the final factor folds
 __global__ __launch_bounds__(256) void fbr_expand_rows_kernel(int cols, int k, int Pra, const int *__restrict__ Eb, const int *__restrict__ Er,
                                                                const double *__restrict__ Ev, const double *__restrict__ Rred, double *__restrict__ dst,
-                                                               int ldd)
+                                                               int ldd, const int *__restrict__ colmap, int Pout)
 {
-    const int Pa = cols + k;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pra * Pa; e += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(e / Pa), j = (int)(e - (long)r * Pa);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pra * Pout; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / Pout), jj = (int)(e - (long)r * Pout);
+        const int j = colmap ? colmap[jj] : jj;
         double acc = 0.0;
         for (int b = Eb[j]; b < Eb[j + 1]; b++) acc += Ev[b] * Rred[(long)r * Pra + Er[b]];
-        dst[(long)r * ldd + j] = acc;
+        dst[(long)r * ldd + jj] = acc;
     }
 }
 
-int launch_expand_rows(fbr_model *m, int which, int k, int Pra, const double *Rred, double *dst, int ldd)
+int launch_expand_rows(fbr_model *m, int which, int k, int Pra, const double *Rred, double *dst, int ldd, const int *colmap, int Pout)
 {
-    hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which], m->E_val[which], Rred, dst, ldd);
+    hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which], m->E_val[which], Rred, dst, ldd,
+                       colmap, colmap ? Pout : m->hm.cols + k);
     HIPCHK(hipGetLastError());
     return FBR_OK;
 }
@@ -623,7 +625,7 @@ static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const dou
     if ((rc = m->red_w.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
     for (int g = 0; g < ngroups; g++) {
         hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
-                           m->E_val[which], Gred + (size_t)g * Pra * Pra, m->red_w.as<double>(), Pa);
+                           m->E_val[which], Gred + (size_t)g * Pra * Pra, m->red_w.as<double>(), Pa, (const int *)nullptr, Pa);
         hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
                            m->E_val[which], m->red_w.as<double>(), G + (size_t)g * Pa * Pa, accumulate ? 1 : 0);
     }

@@ -287,7 +287,7 @@ int pick_gram_reduction(const fbr_model *m, long S = -1);
 int launch_regressor(fbr_model *m, const DevStates &d, long s0, long cs, double *dst, int ldy, long rs_s, long rs_r, const int *linkpos, const int *skipfc);
 // ---- fbr_gram_api.hip --------------------------------------------------------------------------------------------------------
 // dst[r][j] (leading dimension ldd) = (R_red E)[r][j] on the model's stream (Gram expansion, TSQR expansion)
-int launch_expand_rows(fbr_model *m, int which, int k, int Pra, const double *Rred, double *dst, int ldd);
+int launch_expand_rows(fbr_model *m, int which, int k, int Pra, const double *Rred, double *dst, int ldd, const int *colmap = nullptr, int Pout = 0);
 // ---- fbr_tsqr_api.hip --------------------------------------------------------------------------------------------------------
 int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k, const double *w,
               const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket);

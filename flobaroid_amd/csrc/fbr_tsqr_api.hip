@@ -817,8 +817,11 @@ static int pick_tsqr_reduction(fbr_model *m, long S)
 // The factor through the link-merged model (build_reduction): R_red over the moving bodies' columns, then R = qr([R_in ; R_red E]) --
 // the Pra dense rows R_red E become working factor 1 beside R_in (or zero) in working factor 0, and ONE level of the merge tree,
 // pipelined across workgroups, folds them (wide factors; narrow ones fold them as ordinary rows).
-static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const double *rhs, int32_t k, const double *w, const double *R_in, double *R_out,
-                        int32_t out_mem, int64_t *async_ticket)
+// cols != NULL: the factor of a COLUMN SUBSET (fbr_tsqr_cols): Y[:, cols] = Y_red E[:, cols], so the reduced factorisation is the same and
+// only the expansion takes the subset's columns of E -- the base regressor [YBase | tau] of WALK-MAN (213 of 480 columns, spread over
+// every link) costs the regrouped factorisation's 57 ms per 1 M samples instead of 68.
+static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k, const double *w,
+                        const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
     fbr_model *r = m->rdm[which].get();
     const bool async = async_ticket != nullptr;
@@ -831,12 +834,20 @@ static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const dou
     }
     r->stream = m->stream;
     r->prof = m->prof;
-    const int par = (int)(m->next_ticket & 1), Pa = m->hm.cols + k, Pra = r->hm.cols + k;
+    const int par = (int)(m->next_ticket & 1), Pa = (cols ? ncols : m->hm.cols) + k, Pra = r->hm.cols + k;
     const size_t cnt = (size_t)Pa * Pa;
     if ((rc = m->red_out[par].ensure((size_t)Pra * Pra * sizeof(double)))) return rc;
     double *Rred = m->red_out[par].as<double>();
     int64_t tr = -1;
     if ((rc = tsqr_impl(r, st, nullptr, 0, rhs, k, w, nullptr, Rred, FBR_DEVICE, async ? &tr : nullptr))) return rc;
+    const int *dcolmap = nullptr;  // output column jj of the subset -> column of the augmented full layout (rhs columns behind the identified ones)
+    if (cols) {
+        std::vector<int> cmap(cols, cols + ncols);
+        for (int i = 0; i < k; i++) cmap.push_back(m->hm.cols + i);
+        const char *dtab = nullptr;
+        if ((rc = tsqr_upload_tables(m, par, {{cmap.data(), cmap.size() * sizeof(int)}}, {0}, cmap.size() * sizeof(int), m->stream, &dtab))) return rc;
+        dcolmap = (const int *)dtab;
+    }
     double *R = R_out;
     const double *Rin_dev = nullptr;
     if (out_mem == FBR_HOST) {
@@ -863,14 +874,14 @@ static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const dou
         if (!sh.narrow && sh.n / 16 > FBR_TSQR_NARROW_MAX_TILES && !m->opt.tsqr_tree_one_wg) {  // (the kernels whose merge level takes dense partner rows)
             if ((rc = tsqr_begin(m, wk, m->stream, Pa, Rin_dev, m->num_cus, 2L * sh.mb, m->tsqr_err))) return fail(rc, "tsqr begin");
             if (wk.NW == 2) {
-                if ((rc = launch_expand_rows(m, which, k, Pra, Rred, wk.Rw + (size_t)wk.n * wk.ld, wk.ld))) return rc;
+                if ((rc = launch_expand_rows(m, which, k, Pra, Rred, wk.Rw + (size_t)wk.n * wk.ld, wk.ld, dcolmap, Pa))) return rc;
                 if ((rc = fbr_tsqr_tree_levels(wk, m->stream, 1, 2, Pra)) || (rc = fbr_tsqr_copy_out(wk, m->stream, R))) return fail(rc, "tsqr expansion");
                 done_wide = true;
             }
         }
         if (!done_wide) {  // narrow factors: the expanded rows as ordinary data rows of a one-workgroup factorisation
             if ((rc = m->tsqr_embed.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
-            if ((rc = launch_expand_rows(m, which, k, Pra, Rred, m->tsqr_embed.as<double>(), Pa))) return rc;
+            if ((rc = launch_expand_rows(m, which, k, Pra, Rred, m->tsqr_embed.as<double>(), Pa, dcolmap, Pa))) return rc;
             if ((rc = tsqr_begin(m, wk, m->stream, Pa, Rin_dev, m->num_cus, 1, m->tsqr_err)) ||
                 (rc = fbr_tsqr_fold_rows(wk, m->stream, Pra, Pa, m->tsqr_embed.as<double>(), 0, nullptr, nullptr, Pa)) ||
                 (rc = fbr_tsqr_finish_async(wk, m->stream, R)))
@@ -902,11 +913,22 @@ static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const dou
 int tsqr_impl(fbr_model *m, const fbr_states *st, const int32_t *cols, int32_t ncols, const double *rhs, int32_t k,
               const double *w, const double *R_in, double *R_out, int32_t out_mem, int64_t *async_ticket)
 {
-    int which = (m && st && !cols && R_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid()) ? pick_tsqr_reduction(m, (long)st->num_samples) : -1;
+    int which = (m && st && R_out && k >= 0 && k <= FBR_MAX_RHS && m->pid == getpid()) ? pick_tsqr_reduction(m, (long)st->num_samples) : -1;
+    if (cols && which >= 0) {
+        // a column subset goes through the reductions when it is about as wide as the regrouped column set (the base columns: one per
+        // direction the regressor can move in) -- a narrow subset is cheaper factorised directly -- and only through the regrouped model
+        bool ok = which == 1 && ncols > 0 && ncols <= m->hm.cols && 5L * ncols >= 4L * m->rdm[1]->hm.cols;
+        std::vector<char> seen(m->hm.cols, 0);
+        for (int i = 0; ok && i < ncols; i++) {  // (invalid lists are reported by the direct path)
+            ok = cols[i] >= 0 && cols[i] < m->hm.cols && !seen[cols[i]];
+            if (ok) seen[cols[i]] = 1;
+        }
+        if (!ok) which = -1;
+    }
     while (which >= 0) {
-        int rc = tsqr_via_red(m, which, st, rhs, k, w, R_in, R_out, out_mem, async_ticket);
+        int rc = tsqr_via_red(m, which, st, cols, ncols, rhs, k, w, R_in, R_out, out_mem, async_ticket);
         if (rc == FBR_E_NOT_GROUPED && which == 1) {  // (row weights left the regrouped model without row groups: see tsqr_impl_inner)
-            which = m->rdm[0] ? 0 : -1;
+            which = (m->rdm[0] && !cols) ? 0 : -1;
             continue;
         }
         if (rc && m->stream) {
@@ -967,13 +989,15 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
         set_err("bad arguments");
         return FBR_E_INVALID;
     }
-    if (const int which = cols ? -1 : pick_tsqr_reduction(m, (long)num_samples); which >= 0) {
+    int which_wi = pick_tsqr_reduction(m, (long)num_samples);
+    if (cols && !(which_wi == 1 && 5L * ncols >= 4L * m->rdm[1]->hm.cols)) which_wi = -1;  // (a column subset: the rule of tsqr_impl)
+    if (const int which = which_wi; which >= 0) {
         // what fbr_tsqr runs on a link-merged model: the factorisation of the reduced robot, then the Pra expanded rows folded into the
         // final factor by one tree level; block_rows / n_padded describe the FINAL factor (what fbr_tsqr_merge works on)
         int64_t l0 = 0, tr = 0;
         if (int rc = fbr_tsqr_work_info(m->rdm[which].get(), nullptr, 0, k, num_samples, &l0, &tr, nullptr, nullptr)) return rc;
         FbrTsqrShape sh;
-        const int Pa = m->hm.cols + k, Pra = m->rdm[which]->hm.cols + k;
+        const int Pa = (cols ? ncols : m->hm.cols) + k, Pra = m->rdm[which]->hm.cols + k;
         if (fbr_tsqr_shape(Pa, m->num_cus, 1, &sh, topts(m))) {
             set_err(std::string("tsqr shape: ") + fbr_tsqr_error());
             return FBR_E_UNSUPPORTED;

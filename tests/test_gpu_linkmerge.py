@@ -183,3 +183,61 @@ def test_small_batches_skip_the_reductions():
     assert np.array_equal(G_default, G_plain)          # 3000 samples x 21 merged-away columns: not worth a second pass
     assert not np.array_equal(G_forced, G_plain) and _rel(G_forced, G_plain) <= 1e-13
     eng.close()
+
+
+def test_column_subset_factor_through_the_regrouped_model():
+    """fbr_tsqr_cols of a subset about as wide as the regrouped column set (WALK-MAN's 213 base columns) takes the reduced factorisation
+    and expands with the subset's columns of E: the same R^T R as the direct factorisation of the subset and as the oracle, the same
+    sign-normalised R (the subset has full column rank), with row weights, a streamed R_in and as a submission; a narrow subset and a
+    base-wrench-only row mask keep the direct path."""
+    import scipy.linalg as sla
+    import torch
+    from common import load_topo
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    t = load_topo("walkman_apriori")
+    rng = np.random.default_rng(12)
+    S = 900
+    st = random_states(t, S, rng, True, use_limits=True)
+    om = OracleModel(t, floating=True)
+    Y = om.regressor(st)
+    rhs = rng.standard_normal((Y.shape[0], 1))
+    w = 0.5 + rng.random(Y.shape[0])
+    eng = Engine(t, floating=True, options={"tsqr_group_min_samples": 1})
+    ic = np.sort(sla.qr(eng.gram(random_states(t, 3000, rng, True, use_limits=True)), pivoting=True, mode="r")[1][:213]).astype(np.int32)
+    norm = lambda R: R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
+    for wt in (None, w):
+        A = np.hstack([Y[:, ic], rhs]) * (1.0 if wt is None else wt[:, None])
+        Go = A.T @ A
+        wi_red = eng.tsqr_work_info(S, k=1, cols=ic)
+        R = eng.tsqr(st, rhs=rhs, w=wt, cols=ic)
+        eng.set_option("link_merge", 0)
+        wi_dir = eng.tsqr_work_info(S, k=1, cols=ic)
+        Rd = eng.tsqr(st, rhs=rhs, w=wt, cols=ic)
+        eng.set_option("link_merge", 1)
+        assert wi_red != wi_dir                                    # two different programs ...
+        assert np.all(np.tril(R, -1) == 0) and _rel(R.T @ R, Go) <= 1e-11 and _rel(Rd.T @ Rd, Go) <= 1e-11
+        assert _rel(norm(R), norm(Rd)) <= 1e-8                     # ... the same factor
+        h = S // 2
+        first = {k: v[:h] for k, v in st.items()}
+        second = {k: v[h:] for k, v in st.items()}
+        wa, wb = (None, None) if wt is None else (wt[: h * om.rows], wt[h * om.rows:])
+        Rs = eng.tsqr(second, rhs=rhs[h * om.rows:], w=wb, cols=ic, R_in=eng.tsqr(first, rhs=rhs[: h * om.rows], w=wa, cols=ic))
+        assert _rel(Rs.T @ Rs, Go) <= 1e-11
+    # submission with device tensors == the blocking call, bit for bit
+    dev = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    drhs = torch.from_numpy(rhs).cuda()
+    Rb = eng.tsqr(dev, rhs=drhs, cols=ic)
+    Ro = torch.zeros_like(Rb)
+    eng.wait(eng.tsqr_submit(dev, Ro, rhs=drhs, cols=ic))
+    assert torch.equal(Ro, Rb)
+    # narrow subset / masked joint rows: the direct path (same answers)
+    few = ic[:60]
+    A = np.hstack([Y[:, few], rhs])
+    assert _rel((lambda R: R.T @ R)(eng.tsqr(st, rhs=rhs, cols=few)), A.T @ A) <= 1e-11
+    mask = np.zeros((S, om.rows))
+    mask[:, :6] = 1.0
+    A = np.hstack([Y[:, ic], rhs]) * mask.reshape(-1)[:, None]
+    assert _rel((lambda R: R.T @ R)(eng.tsqr(st, rhs=rhs, w=mask.reshape(-1), cols=ic)), A.T @ A) <= 1e-11
+    eng.close()
