@@ -465,6 +465,101 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
     }
 }
 
+// K2e (round 5): the same writer with the rows of a sample STAGED IN THE LDS and copied out with 16-byte stores.  A regressor row of a
+// sample is one contiguous run of its group's chunk (ld_g doubles), so instead of one 8-byte global store per entry -- what bounds K2c at
+// 1.9 TB/s (22.9 KB per sample in 12.1 ms per 1 M samples; 8-byte stores saturate at 2.5 TB/s) -- a column thread writes its entries into
+// an LDS image of the sample's rows (rowoff[r]: LDS offset of regressor row r, ld_g doubles each; zero where nothing is ever written:
+// the image is cleared once per workgroup, every sample rewrites the same positions) and the workgroup then streams the image out in
+// 16-byte pieces, a wave instruction covering 1 KiB of consecutive addresses.  Structural zeros and padding columns are written too
+// (25.6 instead of 22.9 KB per sample on the regrouped WALK-MAN).  total = doubles of the image (even); used when it fits the LDS.
+__global__ __launch_bounds__(256) void fbr_regressor_groups_lds_kernel(DevModel m, long S, const double *__restrict__ rec, const double *__restrict__ dq,
+                                                                        const double *__restrict__ sign, const double *__restrict__ rhs, int k,
+                                                                        const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,
+                                                                        const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
+                                                                        const int *__restrict__ ebeg, const int *__restrict__ ent,
+                                                                        const int *__restrict__ rowoff, int total, long Sslot)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *rs = smem;                                                  // [rec]
+    double **rowptr = (double **)(smem + ((m.rec + 1) & ~1));           // [rows] chunk row of this sample's regressor row r
+    double *img = (double *)(rowptr + ((m.rows + 1) & ~1));             // [total] the sample's rows, group by group
+    unsigned short *piece_row = (unsigned short *)(img + total);       // [total / 2] regressor row of every 16-byte piece of the image
+    int *roff = (int *)(piece_row + ((total / 2 + 3) & ~3));            // [rows] LDS offset of row r (-1: the row belongs to no group)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < total; i += 256) img[i] = 0.0;
+    for (int r = tid; r < m.rows; r += 256) roff[r] = rowoff[r];
+    fbr_barrier_lds();
+    for (int r = tid; r < m.rows; r += 256) {
+        const int g = rowgroup[r];
+        if (g < 0) continue;
+        for (int c = roff[r] / 2; c < (roff[r] + grp[g].ld) / 2; c++) piece_row[c] = (unsigned short)r;
+    }
+    constexpr int PU = 6;
+    const bool pre = m.rec <= 256 * PU;
+    double pv[PU];
+    if (pre && (long)blockIdx.x < S)
+#pragma unroll
+        for (int u = 0; u < PU; u++) pv[u] = rec[blockIdx.x * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+    for (long s = blockIdx.x; s < S; s += gridDim.x) {
+        fbr_barrier_lds();  // (the copy-out of the sample before has read the image)
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < PU; u++)
+                if (tid + 256 * u < m.rec) rs[tid + 256 * u] = pv[u];
+            if (s + gridDim.x < S)
+#pragma unroll
+                for (int u = 0; u < PU; u++) pv[u] = rec[(s + gridDim.x) * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+        } else {
+            fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
+        }
+        if (tid < m.rows) {
+            const int g = rowgroup[tid];
+            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * Sslot + s) * grp[g].ld : nullptr;
+        }
+        fbr_barrier_lds();
+        for (int t = tid; t < m.rows * k; t += blockDim.x) {
+            const int r = t / k, i = t - r * k;
+            const int g = rowgroup[r];
+            if (g < 0) continue;
+            double v = rhs[(s * m.rows + r) * k + i];
+            if (wts) v *= wts[s * m.rows + r];
+            img[roff[r] + grp[g].psel + i] = v;
+        }
+        for (int c = tid; c < m.cols; c += blockDim.x) {
+            const int e0 = ebeg[c], e1 = ebeg[c + 1];
+            if (e0 == e1) continue;
+            const int4 cd = m.coldesc[c];
+            double w6[6] = {0, 0, 0, 0, 0, 0}, fv = 0.0;
+            if (cd.x == 0)
+                fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
+            else
+                fv = fbr_friction_value(cd.z, dq[s * m.n + cd.w], sign ? sign[s * m.n + cd.w] : 0.0, m.stribeck);
+            int en_next = ent[e0];
+            for (int e = e0; e < e1; e++) {
+                const int en = en_next;  // row | kind << 8 | position << 10
+                en_next = ent[e + 1 < e1 ? e + 1 : e];
+                const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
+                double v = 0.0;
+                if (kind == 0)
+                    v = w6[r];
+                else if (kind == 1)
+                    v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
+                else if (kind == 3)
+                    v = fv;
+                if (wts) v *= wts[s * m.rows + r];
+                img[roff[r] + pos] = v;
+            }
+        }
+        fbr_barrier_lds();
+        // copy-out: piece p = image doubles [2p, 2p + 2) -> its place in the chunk row of its regressor row
+        for (int p = tid; p < total / 2; p += 256) {
+            const int r = piece_row[p];
+            const fbr_d2 v = *(const fbr_d2 *)(img + 2 * p);
+            __builtin_nontemporal_store(v, (fbr_d2 *)(rowptr[r] + (2 * p - roff[r])));
+        }
+    }
+}
+
 // K2d: the same writer with one thread per PAIR of adjacent inertial columns and 16-byte stores (a wave instruction covers 1 KiB of a
 // chunk row instead of 512 B; the 8-byte form is bound by its store instructions at 2.5 TB/s).  The two columns of a pair belong to one
 // link, so they share their entry list: pent[pbeg[pr] .. pbeg[pr+1]) = regressor row | kind << 8 | (even) position of the first column

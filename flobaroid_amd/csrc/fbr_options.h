@@ -26,7 +26,7 @@ struct FbrOptions {
     double tsqr_reorder = 1;                // columns factorised in link-depth order (single factorisation path)
     double tsqr_tree_one_wg = 0;            // merges by one workgroup instead of pipelined across workgroups (bit-identical, slower)
     double tsqr_narrow = 1;                 // wave-private kernels for <= 128 columns
-    double tsqr_writer = 0;                 // grouped regressor writer: 0 by work-item count, 8 / 16: store width forced
+    double tsqr_writer = 0;                 // grouped regressor writer: 0 by work-item count; 8 / 16: store width forced; 32: rows staged in the LDS
     double tsqr_prologue_overlap = 1;       // a submission's kinematics / first writer beside the trees of the one before
     double tsqr_timing = 0;                 // diagnostic: per-phase cycle counters of the wide level-0 kernel
     double tsqr_short_call_factors = 1;     // fewer private factors (shallower merge trees) for calls too short to amortise them

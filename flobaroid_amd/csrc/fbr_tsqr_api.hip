@@ -349,6 +349,10 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         }
         tab.push_back((int)pents[var].size());
     }
+    // LDS image of one sample's rows (fbr_regressor_groups_lds_kernel): offset of regressor row r, ld_g doubles each -- the padded width
+    // of a group is only known once its factorisation has begun (below): the offsets are filled in there
+    const size_t o_rowoff = tab.size();
+    tab.resize(tab.size() + hm.rows, -1);
     const size_t o_nrows = tab.size();  // slots (regressor rows) of every group
     for (int g = 0; g < G; g++) tab.push_back((int)gp.groups[g].rows.size());
     std::vector<size_t> o_fc(G), o_emb(G);
@@ -403,6 +407,22 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             return tsqr_fail(rc, "tsqr group chunk");
         hg[g] = FbrDevGroup{A, wk.n, (int)Gg.sel.size()};
     }
+    int img_total = 0;
+    for (int r = 0; r < hm.rows; r++)
+        if (gp.rowgroup[r] >= 0) {
+            tab[o_rowoff + r] = img_total;
+            img_total += hg[gp.rowgroup[r]].ld;
+        }
+    // the LDS-staged writer (option tsqr_writer = 32) needs a sample's rows to fit a third of the LDS beside the record
+    const size_t lds_img = ((size_t)((hm.rec_size() + 1) & ~1) + ((hm.rows + 1) & ~1) + img_total) * sizeof(double) +
+                           (size_t)((img_total / 2 + 3) & ~3) * sizeof(unsigned short) + (size_t)hm.rows * sizeof(int);
+    // (measured, round 5, regrouped WALK-MAN: the call of 1 M samples 54.95 instead of 55.88 ms, of 125 k samples 9.86 instead of 9.52 ms --
+    // the writer is not bound by the width of its stores; the staged writer is therefore an option, not the default)
+    const bool lds_writer = m->opt.tsqr_writer == 32 && hm.rows <= 255 && img_total > 0 && lds_img <= 52 * 1024;
+    if (m->opt.tsqr_writer == 32 && !lds_writer) {
+        set_err("tsqr_writer = 32: the rows of a sample do not fit the LDS image of the staged writer");
+        return FBR_E_UNSUPPORTED;
+    }
     const char *dtab = nullptr;
     if ((rc = tsqr_upload_tables(m, par,
                                  {{tab.data(), tab.size() * sizeof(int)}, {ents[0].data(), ents[0].size() * sizeof(int)}, {ents[1].data(), ents[1].size() * sizeof(int)},
@@ -415,6 +435,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     const size_t lds = (size_t)((hm.rec_size() + 1) & ~1) * sizeof(double) + (size_t)hm.rows * sizeof(double *);
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds_writer) HIPCHK(hipFuncSetAttribute((const void *)fbr_regressor_groups_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_img));
     // Merge trees are latency bound (a level of the full-width tree is 0.93 ms on a handful of workgroups, 8 levels over 256 private
     // factors).  The groups' trees run on side streams beside the main group's.  Their factors, embedded into the caller's column
     // order, are dense rows of the final factorisation: they are folded INSIDE the main tree -- once at most 8 of its factors are
@@ -507,7 +528,12 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         }
         {
             ProfScope ps(m, FBR_PROF_REGRESSOR, cst);
-            if (pairable)
+            if (lds_writer)
+                hipLaunchKernelGGL(fbr_regressor_groups_lds_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds_img, cst, m->dm, cs,
+                                   recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
+                                   drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
+                                   t + o_ebeg[1], (const int *)(dtab + o_ent1), t + o_rowoff, img_total, csp);
+            else if (pairable)
                 hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,

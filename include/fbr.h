@@ -303,7 +303,8 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "tsqr_group_min_samples"     24000 ... from this many samples on
  *   "tsqr_reorder"               1     columns factorised in link-depth order (single-factorisation path)
  *   "tsqr_narrow"                1     wave-private kernels for <= 128 columns
- *   "tsqr_writer"                0     grouped regressor writer: 0 by work-item count, 8 / 16: store width in bytes forced
+ *   "tsqr_writer"                0     grouped regressor writer: 0 by work-item count; 8 / 16: one thread per column / column pair, stores of that
+ *                                      width; 32: rows staged in the LDS and streamed out in 16-byte pieces (measured: no faster)
  *   "tsqr_tree_one_wg"           0     merges by one workgroup instead of pipelined across workgroups (bit-identical, slower)
  *   "tsqr_prologue_overlap"      1     a submission's kinematics / first writer beside the merge trees of the one before
  *   "tsqr_short_call_factors"    1     fewer private factors (shallower merge trees) for calls too short to amortise them

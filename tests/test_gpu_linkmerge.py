@@ -67,7 +67,7 @@ def test_merged_equals_unmerged_and_oracle(seed, L, floating, fric, grav):
             assert _rel(Gm, Go) <= 1e-12 and _rel(Rm.T @ Rm, Go) <= 1e-12
             # the regrouped model's factorisation by row groups at this size, with both writers
             eng.set_option("tsqr_group_min_samples", 1)
-            for writer in (8, 16):
+            for writer in (8, 16, 32):  # (32: rows staged in the LDS, streamed out in 16-byte pieces)
                 eng.set_option("tsqr_writer", writer)
                 Rg = eng.tsqr(st, rhs=rhs, w=wt)
                 assert _rel(Rg.T @ Rg, Go) <= 1e-12 and np.all(np.tril(Rg, -1) == 0), writer
