@@ -465,79 +465,120 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
     }
 }
 
-// K2e (round 5): the same writer with the rows of a sample STAGED IN THE LDS and copied out with 16-byte stores.  A regressor row of a
-// sample is one contiguous run of its group's chunk (ld_g doubles), so instead of one 8-byte global store per entry -- what bounds K2c at
-// 1.9 TB/s (22.9 KB per sample in 12.1 ms per 1 M samples; 8-byte stores saturate at 2.5 TB/s) -- a column thread writes its entries into
-// an LDS image of the sample's rows (rowoff[r]: LDS offset of regressor row r, ld_g doubles each; zero where nothing is ever written:
-// the image is cleared once per workgroup, every sample rewrites the same positions) and the workgroup then streams the image out in
-// 16-byte pieces, a wave instruction covering 1 KiB of consecutive addresses.  Structural zeros and padding columns are written too
-// (25.6 instead of 22.9 KB per sample on the regrouped WALK-MAN).  total = doubles of the image (even); used when it fits the LDS.
+// K2e (round 5, option tsqr_writer = 32): the same writer with the rows of a sample STAGED IN THE LDS, copied out with 16-byte stores, and
+// with no global load between a sample's stores and the next sample's compute phase.  Built to test two explanations of K2c's time
+// (10.9 - 12.1 ms per 1 M samples for 22.9 KB per sample = 1.9 TB/s): (i) the width / number of its 8-byte stores, (ii) the
+// store-acknowledge latency on every sample's critical path -- on gfx9 loads and stores share one in-order counter (vmcnt) and the compiler
+// can only wait for a load with vmcnt(0), so K2c's first global load of a sample (prefetched record, entry lists, rhs) also waits for the
+// write acknowledgements of the sample before.  Here
+//   * the entry lists are copied into the LDS once per workgroup, column descriptors and list bounds live in registers;
+//   * everything per-sample that comes from global memory (record, rhs, weights, dq, sign) is requested for sample i + 1 at the top of
+//     iteration i and taken out of its registers AFTER the compute phase of sample i, in front of that sample's copy-out: the stores the
+//     wait sits through are those of sample i - 1, a whole compute phase old;  the compute phase reads the LDS only;
+//   * a regressor row of a sample is one contiguous run of its group's chunk (ld_g doubles): the column threads write their entries into an
+//     LDS image of the sample's rows (rowoff[r]; zero where nothing is ever written: cleared once per workgroup), which the workgroup
+//     streams out in 16-byte pieces (structural zeros and padding included: 25.6 instead of 22.9 KB per sample on the regrouped WALK-MAN).
+// MEASURED: 10.9 instead of 11.0 - 12.1 ms per 1 M samples (the call 54.8 instead of 55.5 ms) -- neither explanation holds; the kernel's
+// ~600 instructions per thread and sample (unit wrench ~100, ~13 entries x ~30: decode, six LDS reads of the joint's motion vector, six
+// fused multiply-adds, one store) at 8 waves per SIMD account for its time: it is bound by what it issues.  Kept as an option.
+// total = doubles of the image (even); naux = rows k + (wts ? rows : 0) + (fric ? 2 n : 0) <= 512 staged values; nent = list entries.
 __global__ __launch_bounds__(256) void fbr_regressor_groups_lds_kernel(DevModel m, long S, const double *__restrict__ rec, const double *__restrict__ dq,
                                                                         const double *__restrict__ sign, const double *__restrict__ rhs, int k,
                                                                         const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,
                                                                         const int *__restrict__ rowgroup, const int *__restrict__ rowslot,
                                                                         const int *__restrict__ ebeg, const int *__restrict__ ent,
-                                                                        const int *__restrict__ rowoff, int total, long Sslot)
+                                                                        const int *__restrict__ rowoff, int total, long Sslot, int nent)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int o_rhs = 0, o_w = m.rows * k, o_dq = o_w + (wts ? m.rows : 0), o_sg = o_dq + (m.fric ? m.n : 0), naux = o_sg + ((m.fric && sign) ? m.n : 0);
     double *rs = smem;                                                  // [rec]
-    double **rowptr = (double **)(smem + ((m.rec + 1) & ~1));           // [rows] chunk row of this sample's regressor row r
+    double *aux = rs + ((m.rec + 1) & ~1);                              // [naux] rhs | weights | dq | sign of the sample
+    double **rowptr = (double **)(aux + ((naux + 1) & ~1));             // [rows] chunk row of regressor row r of sample 0 (constant; + s ld per sample)
     double *img = (double *)(rowptr + ((m.rows + 1) & ~1));             // [total] the sample's rows, group by group
     unsigned short *piece_row = (unsigned short *)(img + total);       // [total / 2] regressor row of every 16-byte piece of the image
     int *roff = (int *)(piece_row + ((total / 2 + 3) & ~3));            // [rows] LDS offset of row r (-1: the row belongs to no group)
+    int *psel = roff + m.rows;                                          // [rows] position of the first rhs column in row r's group
+    int *rld = psel + m.rows;                                           // [rows] leading dimension of row r's group
+    int *entl = rld + m.rows;                                           // [nent] the entry lists
     const int tid = threadIdx.x;
     for (int i = tid; i < total; i += 256) img[i] = 0.0;
-    for (int r = tid; r < m.rows; r += 256) roff[r] = rowoff[r];
+    for (int i = tid; i < nent; i += 256) entl[i] = ent[i];
+    for (int r = tid; r < m.rows; r += 256) {
+        const int g = rowgroup[r];
+        roff[r] = rowoff[r];
+        psel[r] = g >= 0 ? grp[g].psel : 0;
+        rld[r] = g >= 0 ? grp[g].ld : 0;
+        rowptr[r] = g >= 0 ? grp[g].A + (long)rowslot[r] * Sslot * grp[g].ld : nullptr;
+    }
     fbr_barrier_lds();
     for (int r = tid; r < m.rows; r += 256) {
         const int g = rowgroup[r];
         if (g < 0) continue;
         for (int c = roff[r] / 2; c < (roff[r] + grp[g].ld) / 2; c++) piece_row[c] = (unsigned short)r;
     }
+    // this thread's columns: descriptor and list bounds (loop invariant; at most two columns per thread: cols <= 512)
+    int4 cdv[2];
+    int eb0[2], eb1[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int c = tid + 256 * q;
+        eb0[q] = eb1[q] = 0;
+        cdv[q] = make_int4(0, 0, 0, 0);
+        if (c < m.cols) {
+            eb0[q] = ebeg[c];
+            eb1[q] = ebeg[c + 1];
+            cdv[q] = m.coldesc[c];
+        }
+    }
     constexpr int PU = 6;
-    const bool pre = m.rec <= 256 * PU;
-    double pv[PU];
-    if (pre && (long)blockIdx.x < S)
+    double pv[PU], pa[2];
+    auto aux_load = [&](int i, long ss) -> double {  // value i of the staged per-sample inputs of sample ss
+        if (i < o_w) return rhs[ss * m.rows * k + i];
+        if (i < o_dq) return wts[ss * m.rows + (i - o_w)];
+        if (i < o_sg) return dq[ss * m.n + (i - o_dq)];
+        return sign[ss * m.n + (i - o_sg)];
+    };
+    auto request = [&](long ss) {
 #pragma unroll
-        for (int u = 0; u < PU; u++) pv[u] = rec[blockIdx.x * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+        for (int u = 0; u < PU; u++) pv[u] = rec[ss * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
+#pragma unroll
+        for (int u = 0; u < 2; u++) pa[u] = (tid + 256 * u < naux) ? aux_load(tid + 256 * u, ss) : 0.0;
+    };
+    auto deliver = [&]() {
+#pragma unroll
+        for (int u = 0; u < PU; u++)
+            if (tid + 256 * u < m.rec) rs[tid + 256 * u] = pv[u];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (tid + 256 * u < naux) aux[tid + 256 * u] = pa[u];
+    };
+    if ((long)blockIdx.x < S) {
+        request(blockIdx.x);
+        deliver();
+        if ((long)blockIdx.x + gridDim.x < S) request(blockIdx.x + gridDim.x);
+    }
     for (long s = blockIdx.x; s < S; s += gridDim.x) {
-        fbr_barrier_lds();  // (the copy-out of the sample before has read the image)
-        if (pre) {
-#pragma unroll
-            for (int u = 0; u < PU; u++)
-                if (tid + 256 * u < m.rec) rs[tid + 256 * u] = pv[u];
-            if (s + gridDim.x < S)
-#pragma unroll
-                for (int u = 0; u < PU; u++) pv[u] = rec[(s + gridDim.x) * (long)m.rec + min(tid + 256 * u, m.rec - 1)];
-        } else {
-            fbr_stage_copy<256>(rs, rec + s * (long)m.rec, m.rec, tid);
-        }
-        if (tid < m.rows) {
-            const int g = rowgroup[tid];
-            rowptr[tid] = g >= 0 ? grp[g].A + ((long)rowslot[tid] * Sslot + s) * grp[g].ld : nullptr;
-        }
-        fbr_barrier_lds();
+        fbr_barrier_lds();  // (record and inputs of this sample in place; the copy-out of the sample before has read the image)
+        const double *ws = wts ? aux + o_w : nullptr;
         for (int t = tid; t < m.rows * k; t += blockDim.x) {
             const int r = t / k, i = t - r * k;
-            const int g = rowgroup[r];
-            if (g < 0) continue;
-            double v = rhs[(s * m.rows + r) * k + i];
-            if (wts) v *= wts[s * m.rows + r];
-            img[roff[r] + grp[g].psel + i] = v;
+            if (roff[r] < 0) continue;
+            double v = aux[o_rhs + t];
+            if (ws) v *= ws[r];
+            img[roff[r] + psel[r] + i] = v;
         }
-        for (int c = tid; c < m.cols; c += blockDim.x) {
-            const int e0 = ebeg[c], e1 = ebeg[c + 1];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e0 = eb0[q], e1 = eb1[q];
             if (e0 == e1) continue;
-            const int4 cd = m.coldesc[c];
+            const int4 cd = cdv[q];
             double w6[6] = {0, 0, 0, 0, 0, 0}, fv = 0.0;
             if (cd.x == 0)
                 fbr_unit_wrench(rs + FBR_LINK_REC * cd.y, cd.z, w6);
             else
-                fv = fbr_friction_value(cd.z, dq[s * m.n + cd.w], sign ? sign[s * m.n + cd.w] : 0.0, m.stribeck);
-            int en_next = ent[e0];
+                fv = fbr_friction_value(cd.z, aux[o_dq + cd.w], (m.fric && sign) ? aux[o_sg + cd.w] : 0.0, m.stribeck);
             for (int e = e0; e < e1; e++) {
-                const int en = en_next;  // row | kind << 8 | position << 10
-                en_next = ent[e + 1 < e1 ? e + 1 : e];
+                const int en = entl[e];  // row | kind << 8 | position << 10
                 const int r = en & 0xff, kind = (en >> 8) & 3, pos = en >> 10;
                 double v = 0.0;
                 if (kind == 0)
@@ -546,16 +587,21 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_lds_kernel(DevModel 
                     v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
                 else if (kind == 3)
                     v = fv;
-                if (wts) v *= wts[s * m.rows + r];
+                if (ws) v *= ws[r];
                 img[roff[r] + pos] = v;
             }
         }
         fbr_barrier_lds();
+        // the next sample's record and inputs (nobody reads rs / aux any more), and the request for the sample after it
+        if (s + gridDim.x < S) {
+            deliver();
+            if (s + 2 * gridDim.x < S) request(s + 2 * gridDim.x);
+        }
         // copy-out: piece p = image doubles [2p, 2p + 2) -> its place in the chunk row of its regressor row
         for (int p = tid; p < total / 2; p += 256) {
             const int r = piece_row[p];
             const fbr_d2 v = *(const fbr_d2 *)(img + 2 * p);
-            __builtin_nontemporal_store(v, (fbr_d2 *)(rowptr[r] + (2 * p - roff[r])));
+            __builtin_nontemporal_store(v, (fbr_d2 *)(rowptr[r] + s * (long)rld[r] + (2 * p - roff[r])));
         }
     }
 }

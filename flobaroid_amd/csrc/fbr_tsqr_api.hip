@@ -414,11 +414,13 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             img_total += hg[gp.rowgroup[r]].ld;
         }
     // the LDS-staged writer (option tsqr_writer = 32) needs a sample's rows to fit a third of the LDS beside the record
-    const size_t lds_img = ((size_t)((hm.rec_size() + 1) & ~1) + ((hm.rows + 1) & ~1) + img_total) * sizeof(double) +
-                           (size_t)((img_total / 2 + 3) & ~3) * sizeof(unsigned short) + (size_t)hm.rows * sizeof(int);
+    const int naux = hm.rows * k + (dw ? hm.rows : 0) + (hm.fric ? hm.n : 0) + ((hm.fric && d.sign) ? hm.n : 0);
+    const size_t lds_img = ((size_t)((hm.rec_size() + 1) & ~1) + ((naux + 1) & ~1) + ((hm.rows + 1) & ~1) + img_total) * sizeof(double) +
+                           (size_t)((img_total / 2 + 3) & ~3) * sizeof(unsigned short) + ((size_t)3 * hm.rows + ents[1].size()) * sizeof(int);
     // (measured, round 5, regrouped WALK-MAN: the call of 1 M samples 54.95 instead of 55.88 ms, of 125 k samples 9.86 instead of 9.52 ms --
     // the writer is not bound by the width of its stores; the staged writer is therefore an option, not the default)
-    const bool lds_writer = m->opt.tsqr_writer == 32 && hm.rows <= 255 && img_total > 0 && lds_img <= 52 * 1024;
+    const bool lds_writer = m->opt.tsqr_writer == 32 && hm.rows <= 255 && img_total > 0 && lds_img <= 64 * 1024 && hm.rec_size() <= 256 * 6 && naux <= 512 &&
+                            hm.cols <= 512;
     if (m->opt.tsqr_writer == 32 && !lds_writer) {
         set_err("tsqr_writer = 32: the rows of a sample do not fit the LDS image of the staged writer");
         return FBR_E_UNSUPPORTED;
@@ -532,7 +534,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
                 hipLaunchKernelGGL(fbr_regressor_groups_lds_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds_img, cst, m->dm, cs,
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
-                                   t + o_ebeg[1], (const int *)(dtab + o_ent1), t + o_rowoff, img_total, csp);
+                                   t + o_ebeg[1], (const int *)(dtab + o_ent1), t + o_rowoff, img_total, csp, (int)ents[1].size());
             else if (pairable)
                 hipLaunchKernelGGL(fbr_regressor_groups2_kernel, dim3((unsigned)std::min<long>(cs, (long)m->num_cus * 8)), dim3(256), lds, cst, m->dm, cs,
                                    recs, d.dq + s0 * hm.n, d.sign ? d.sign + s0 * hm.n : nullptr,
