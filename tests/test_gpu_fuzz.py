@@ -1,0 +1,96 @@
+"""Randomised parity sweep of the hot path ("cover the edge cases"): random kinematic trees (revolute / prismatic / fixed
+joints, any branching), every base / friction / gravity-only mode, random batch lengths (odd, shorter than a tile pair, several chunks),
+0 ... 3 right-hand sides, row weights with masked rows, and the three column-reduction modes drawn per case -- materialised regressor,
+fused Gram (twice: bitwise repeatable), grouped Gram, TSQR and prediction against the CPU oracle.
+
+FBR_FUZZ_CASES (default 24) and FBR_FUZZ_SEED (default 2025) size the sweep: `FBR_FUZZ_CASES=400 pytest tests/test_gpu_fuzz.py -m gpu`
+is the long run; a failing case prints the parameters that reproduce it."""
+import os
+
+import numpy as np
+import pytest
+
+from common import random_states, random_topology
+
+pytestmark = pytest.mark.gpu
+
+CASES = int(os.environ.get("FBR_FUZZ_CASES", "24"))
+SEED = int(os.environ.get("FBR_FUZZ_SEED", "2025"))
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _draw(case):
+    rng = np.random.default_rng([SEED, case])
+    p = dict(case=case, L=int(rng.integers(2, 46)), floating=int(rng.random() < 0.5), fric=int(rng.random() < 0.4), fric_sym=int(rng.random() < 0.5),
+             grav=int(rng.random() < 0.1), p_fixed=float(rng.choice([0.0, 0.2, 0.5])), p_prism=float(rng.choice([0.0, 0.0, 0.3])),
+             branch=float(rng.choice([0.0, 0.3, 0.7, 1.0])), S=int(rng.choice([1, 2, 3, 7, 64, 129, 256, 500, 777])), k=int(rng.integers(0, 4)),
+             weights=int(rng.integers(0, 3)), mode=str(rng.choice(["default", "reduced", "allcols"])), chunk=int(rng.choice([0, 0, 64, 200])),
+             groups=int(rng.random() < 0.5))
+    return p, rng
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_random_tree_against_the_oracle(case):
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    p, rng = _draw(case)
+    t = random_topology(rng, p["L"], p_fixed=p["p_fixed"], branchiness=p["branch"], p_prismatic=p["p_prism"])
+    if t.num_dofs == 0 or t.num_dofs + (6 if p["floating"] else 0) > 60:
+        pytest.skip("row count outside the fused kernels")
+    if p["grav"] and p["fric"]:
+        p["fric"] = 0
+    om = OracleModel(t, floating=bool(p["floating"]), fric=bool(p["fric"]), fric_sym=bool(p["fric_sym"]), grav_only=bool(p["grav"]))
+    S, k = p["S"], p["k"]
+    st = random_states(t, S, rng, p["floating"])
+    sign = np.tanh(st["dq"] / 0.02)
+    st["sign"] = sign
+    Yo = om.regressor(st, sign)
+    rows = om.rows
+    rhs = rng.standard_normal((S * rows, k)) if k else None
+    w = None
+    if p["weights"]:
+        w = 0.5 + rng.random(S * rows)
+        if p["weights"] == 2:  # masked rows (weight 0): a whole regressor row for every sample, and scattered ones
+            w.reshape(S, rows)[:, int(rng.integers(0, rows))] = 0.0
+            w[rng.random(S * rows) < 0.1] = 0.0
+    opts = {"default": {}, "reduced": {"reduce_min_work": 0, "tsqr_group_min_samples": 1}, "allcols": {"link_merge": 0}}[p["mode"]]
+    if p["chunk"]:
+        opts = dict(opts, chunk_samples=p["chunk"])
+    if p["groups"] and p["mode"] != "reduced":
+        opts = dict(opts, tsqr_group_min_samples=1)
+    eng = Engine(t, floating=bool(p["floating"]), friction=bool(p["fric"]), friction_symmetric=bool(p["fric_sym"]), gravity_only=bool(p["grav"]),
+                 options=opts)
+    why = f"reproduce: FBR_FUZZ_SEED={SEED} case {case}: {p}"
+    try:
+        A = Yo if rhs is None else np.hstack([Yo, rhs])
+        if w is not None:
+            A = A * w[:, None]
+        Go = A.T @ A
+        gn = max(np.linalg.norm(Go), 1e-300)
+        Y = eng.regressor(st)
+        assert Y.shape == Yo.shape and np.abs(Y - Yo).max() <= 1e-11 * max(1.0, np.abs(Yo).max()), why
+        G = eng.gram(st, rhs=rhs, w=w)
+        assert np.linalg.norm(G - Go) <= 1e-11 * gn, (why, _rel(G, Go))
+        assert np.array_equal(G, G.T), why
+        assert np.array_equal(G, eng.gram(st, rhs=rhs, w=w)), why  # deterministic to the bit
+        R = eng.tsqr(st, rhs=rhs, w=w)
+        assert np.all(np.tril(R, -1) == 0), why
+        assert np.linalg.norm(R.T @ R - Go) <= 1e-11 * gn, (why, _rel(R.T @ R, Go))
+        assert np.array_equal(R, eng.tsqr(st, rhs=rhs, w=w)), why
+        for ng in (2, 3):
+            if S % ng == 0 and S >= ng:
+                Gg = eng.gram_grouped(st, ng, rhs=rhs, w=w)
+                h = S // ng * rows
+                for g in range(ng):
+                    Ag = A[g * h:(g + 1) * h]
+                    assert np.linalg.norm(Gg[g] - Ag.T @ Ag) <= 1e-11 * gn, (why, "group", g, ng)
+        x = rng.standard_normal(om.P)
+        tau = eng.predict(st, x)
+        ref = (Yo @ x).reshape(S, rows)
+        assert np.abs(tau - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), why
+    finally:
+        eng.close()
