@@ -899,7 +899,9 @@ static int tsqr_via_red(fbr_model *m, int which, const fbr_states *st, const int
     {
         ProfScope ps(m, FBR_PROF_TREE);
         bool done_wide = false;
-        if (!sh.narrow && sh.n / 16 > FBR_TSQR_NARROW_MAX_TILES && !m->opt.tsqr_tree_one_wg) {  // (the kernels whose merge level takes dense partner rows)
+        // (the kernels whose merge level takes dense partner rows; a working factor has room for sh.n of them: a column subset narrower
+        // than the reduced column set -- Pra > Pa -- takes the row path below)
+        if (!sh.narrow && sh.n / 16 > FBR_TSQR_NARROW_MAX_TILES && !m->opt.tsqr_tree_one_wg && Pra <= sh.n) {
             if ((rc = tsqr_begin(m, wk, m->stream, Pa, Rin_dev, m->num_cus, 2L * sh.mb, m->tsqr_err))) return fail(rc, "tsqr begin");
             if (wk.NW == 2) {
                 if ((rc = launch_expand_rows(m, which, k, Pra, Rred, wk.Rw + (size_t)wk.n * wk.ld, wk.ld, dcolmap, Pa))) return rc;

@@ -94,3 +94,96 @@ def test_random_tree_against_the_oracle(case):
         assert np.abs(tau - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), why
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("case", range(max(CASES // 2, 1)))
+def test_random_tree_other_entry_points(case):
+    """The same draw of trees and modes through the remaining entry points: column subsets of the factorisation (`fbr_tsqr_cols`, with a
+    streamed second half), inverse dynamics, finite-difference scores, contact torques, and submissions (bitwise the blocking results)."""
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    p, rng = _draw(10_000 + case)
+    t = random_topology(rng, p["L"], p_fixed=p["p_fixed"], branchiness=p["branch"], p_prismatic=p["p_prism"])
+    if t.num_dofs == 0 or t.num_dofs + (6 if p["floating"] else 0) > 60:
+        pytest.skip("row count outside the fused kernels")
+    if p["grav"] and p["fric"]:
+        p["fric"] = 0
+    om = OracleModel(t, floating=bool(p["floating"]), fric=bool(p["fric"]), fric_sym=bool(p["fric_sym"]), grav_only=bool(p["grav"]))
+    S, k = max(p["S"], 2), max(p["k"], 1) if p["k"] < 3 else 2
+    st = random_states(t, S, rng, p["floating"])
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    Yo = om.regressor(st, st["sign"])
+    rows, P = om.rows, om.P
+    rhs = rng.standard_normal((S * rows, k))
+    w = 0.5 + rng.random(S * rows) if p["weights"] else None
+    opts = {"default": {}, "reduced": {"reduce_min_work": 0, "tsqr_group_min_samples": 1}, "allcols": {"link_merge": 0}}[p["mode"]]
+    if p["chunk"]:
+        opts = dict(opts, chunk_samples=p["chunk"])
+    eng = Engine(t, floating=bool(p["floating"]), friction=bool(p["fric"]), friction_symmetric=bool(p["fric_sym"]), gravity_only=bool(p["grav"]),
+                 options=opts)
+    why = f"reproduce: FBR_FUZZ_SEED={SEED} case {10_000 + case}: {p}"
+    try:
+        A = np.hstack([Yo, rhs]) * (1.0 if w is None else w[:, None])
+        # a random subset of the columns (in increasing order, as Model.independent_cols is), whole and streamed in two halves
+        ncols = int(rng.integers(1, P + 1))
+        cols = np.sort(rng.choice(P, ncols, replace=False))
+        sel = list(cols) + [P + i for i in range(k)]
+        Gs = A[:, sel].T @ A[:, sel]
+        gn = max(np.linalg.norm(Gs), 1e-300)
+        Rc = eng.tsqr(st, rhs=rhs, w=w, cols=cols)
+        assert Rc.shape == (ncols + k, ncols + k) and np.all(np.tril(Rc, -1) == 0), why
+        assert np.linalg.norm(Rc.T @ Rc - Gs) <= 1e-11 * gn, (why, "cols", ncols)
+        h = S // 2
+        a = {kk: v[:h] for kk, v in st.items()}
+        b = {kk: v[h:] for kk, v in st.items()}
+        wa, wb = (None, None) if w is None else (w[: h * rows], w[h * rows:])
+        R2 = eng.tsqr(b, rhs=rhs[h * rows:], w=wb, cols=cols, R_in=eng.tsqr(a, rhs=rhs[: h * rows], w=wa, cols=cols))
+        assert np.linalg.norm(R2.T @ R2 - Gs) <= 1e-11 * gn, (why, "streamed cols")
+        G2 = eng.gram(b, rhs=rhs[h * rows:], w=wb, out=eng.gram(a, rhs=rhs[: h * rows], w=wa), accumulate=True)
+        assert np.linalg.norm(G2 - A.T @ A) <= 1e-11 * np.linalg.norm(A.T @ A), (why, "accumulated gram")
+        # inverse dynamics with the friction model
+        nfric = P - (4 if p["grav"] else 10) * t.num_links
+        x_std = np.concatenate([t.x_std(), rng.random(max(nfric, 0) + 4 * t.num_dofs)])
+        tau = eng.inverse_dynamics(st, x_std)
+        tau_o = om.inverse_dynamics(st, x_std, st["sign"])
+        assert np.abs(tau - tau_o).max() <= 1e-11 * max(np.abs(tau_o).max(), 1.0), (why, "inverse dynamics")
+        # contact torques at the last link
+        wr = rng.standard_normal((S, 6))
+        ct = eng.contact_torques(st, t.link_names[-1], wr)
+        ct_o = om.contact_torques(st, t.link_names[-1], wr)
+        assert np.abs(ct - ct_o).max() <= 1e-11 * max(np.abs(ct_o).max(), 1.0), (why, "contact")
+        # finite-difference scores on a few samples
+        Sf = min(S, 5)
+        sf = {kk: v[:Sf] for kk, v in st.items()}
+        W = rng.standard_normal((Sf * rows, P))
+        eps = 1e-6
+        sc = eng.fd_scores(sf, W, eps)
+        n = t.num_dofs
+        Wb = W.reshape(Sf, rows, P)
+        ref = np.empty_like(sc)
+        ref[:, 0] = np.einsum("src,src->s", Wb, Yo[: Sf * rows].reshape(Sf, rows, P))
+        for kind, key in enumerate(("q", "dq", "ddq")):
+            for d in range(n):
+                sp = {kk: v.copy() for kk, v in sf.items()}
+                sp[key][:, d] += eps
+                ref[:, 1 + kind * n + d] = np.einsum("src,src->s", Wb, om.regressor(sp, sf["sign"]).reshape(Sf, rows, P))
+        assert np.abs(sc - ref).max() <= 1e-11 * max(np.abs(ref).max(), 1.0), (why, "fd scores")
+        # submissions (device-resident operands): two in flight, bitwise the blocking results
+        import torch
+
+        dev = torch.device("cuda", 0)
+        dv = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+        sd = {kk: dv(v) for kk, v in st.items()}
+        Gb, Rb = eng.gram(sd, rhs=dv(rhs), w=dv(w)), eng.tsqr(sd, rhs=dv(rhs), w=dv(w))
+        assert np.array_equal(Gb.cpu().numpy(), eng.gram(st, rhs=rhs, w=w)), (why, "device vs host operands")
+        Gsub, Rsub = torch.zeros_like(Gb), torch.zeros_like(Rb)
+        rd, wd = dv(rhs), dv(w)
+        t1 = eng.gram_submit(sd, Gsub, rhs=rd, w=wd)
+        t2 = eng.tsqr_submit(sd, Rsub, rhs=rd, w=wd)
+        eng.wait(t1)
+        eng.wait(t2)
+        torch.cuda.synchronize()
+        assert torch.equal(Gsub, Gb) and torch.equal(Rsub, Rb), (why, "submissions")
+    finally:
+        eng.close()

@@ -232,6 +232,14 @@ def test_column_subset_factor_through_the_regrouped_model():
     Ro = torch.zeros_like(Rb)
     eng.wait(eng.tsqr_submit(dev, Ro, rhs=drhs, cols=ic))
     assert torch.equal(Ro, Rb)
+    # a subset NARROWER than the regrouped column set (180 of 214 augmented columns: the expanded rows R_red E[:, cols] are more than a working
+    # factor of the subset holds -- they are folded as rows, not as a merge partner; a randomised sweep found the overflow) and a WIDER,
+    # rank-deficient one (300 columns)
+    for sub in (ic[:180], np.sort(rng.choice(om.P, 300, replace=False)).astype(np.int32)):
+        A = np.hstack([Y[:, sub], rhs])
+        assert eng.tsqr_work_info(S, k=1, cols=sub) != (eng.set_option("link_merge", 0), eng.tsqr_work_info(S, k=1, cols=sub), eng.set_option("link_merge", 1))[1]
+        Rn = eng.tsqr(st, rhs=rhs, cols=sub)
+        assert np.all(np.tril(Rn, -1) == 0) and _rel(Rn.T @ Rn, A.T @ A) <= 1e-11, len(sub)
     # narrow subset / masked joint rows: the direct path (same answers)
     few = ic[:60]
     A = np.hstack([Y[:, few], rhs])
