@@ -29,7 +29,39 @@ def _draw(case):
              branch=float(rng.choice([0.0, 0.3, 0.7, 1.0])), S=int(rng.choice([1, 2, 3, 7, 64, 129, 256, 500, 777])), k=int(rng.integers(0, 4)),
              weights=int(rng.integers(0, 3)), mode=str(rng.choice(["default", "reduced", "allcols"])), chunk=int(rng.choice([0, 0, 64, 200])),
              groups=int(rng.random() < 0.5))
+    # (second generation of the sweep, drawn after the first so that the earlier cases stay what they were)
+    if rng.random() < 0.25:
+        p["S"] = int(rng.choice([1024, 1536, 2053]))
+    p["stribeck"] = float(rng.choice([0.0, 0.0, 0.05])) if p["fric"] else 0.0
+    if rng.random() < 0.15:
+        p["weights"] = int(rng.choice([3, 4]))  # 3: base-wrench rows only (every joint row masked), 4: joint rows only
+    p["grouped_min"] = int(rng.choice([512, 1]))
     return p, rng
+
+
+def _weights(p, rng, S, rows, fb):
+    if not p["weights"]:
+        return None
+    w = 0.5 + rng.random(S * rows)
+    wr = w.reshape(S, rows)
+    if p["weights"] == 2:  # masked rows (weight 0): a whole regressor row for every sample, and scattered ones
+        wr[:, int(rng.integers(0, rows))] = 0.0
+        w[rng.random(S * rows) < 0.1] = 0.0
+    elif p["weights"] == 3 and fb:
+        wr[:, fb:] = 0.0
+    elif p["weights"] == 4 and fb:
+        wr[:, :fb] = 0.0
+    return w
+
+
+def _options(p):
+    opts = {"default": {}, "reduced": {"reduce_min_work": 0, "tsqr_group_min_samples": 1, "reduce_grouped_min_samples": p["grouped_min"]},
+            "allcols": {"link_merge": 0}}[p["mode"]]
+    if p["chunk"]:
+        opts = dict(opts, chunk_samples=p["chunk"])
+    if p["groups"] and p["mode"] != "reduced":
+        opts = dict(opts, tsqr_group_min_samples=1)
+    return opts
 
 
 @pytest.mark.parametrize("case", range(CASES))
@@ -43,7 +75,7 @@ def test_random_tree_against_the_oracle(case):
         pytest.skip("row count outside the fused kernels")
     if p["grav"] and p["fric"]:
         p["fric"] = 0
-    om = OracleModel(t, floating=bool(p["floating"]), fric=bool(p["fric"]), fric_sym=bool(p["fric_sym"]), grav_only=bool(p["grav"]))
+    om = OracleModel(t, floating=bool(p["floating"]), fric=bool(p["fric"]), fric_sym=bool(p["fric_sym"]), grav_only=bool(p["grav"]), stribeck=p["stribeck"])
     S, k = p["S"], p["k"]
     st = random_states(t, S, rng, p["floating"])
     sign = np.tanh(st["dq"] / 0.02)
@@ -51,19 +83,10 @@ def test_random_tree_against_the_oracle(case):
     Yo = om.regressor(st, sign)
     rows = om.rows
     rhs = rng.standard_normal((S * rows, k)) if k else None
-    w = None
-    if p["weights"]:
-        w = 0.5 + rng.random(S * rows)
-        if p["weights"] == 2:  # masked rows (weight 0): a whole regressor row for every sample, and scattered ones
-            w.reshape(S, rows)[:, int(rng.integers(0, rows))] = 0.0
-            w[rng.random(S * rows) < 0.1] = 0.0
-    opts = {"default": {}, "reduced": {"reduce_min_work": 0, "tsqr_group_min_samples": 1}, "allcols": {"link_merge": 0}}[p["mode"]]
-    if p["chunk"]:
-        opts = dict(opts, chunk_samples=p["chunk"])
-    if p["groups"] and p["mode"] != "reduced":
-        opts = dict(opts, tsqr_group_min_samples=1)
+    w = _weights(p, rng, S, rows, 6 if p["floating"] else 0)
+    opts = _options(p)
     eng = Engine(t, floating=bool(p["floating"]), friction=bool(p["fric"]), friction_symmetric=bool(p["fric_sym"]), gravity_only=bool(p["grav"]),
-                 options=opts)
+                 stribeck_velocity=p["stribeck"], options=opts)
     why = f"reproduce: FBR_FUZZ_SEED={SEED} case {case}: {p}"
     try:
         A = Yo if rhs is None else np.hstack([Yo, rhs])
@@ -109,19 +132,17 @@ def test_random_tree_other_entry_points(case):
         pytest.skip("row count outside the fused kernels")
     if p["grav"] and p["fric"]:
         p["fric"] = 0
-    om = OracleModel(t, floating=bool(p["floating"]), fric=bool(p["fric"]), fric_sym=bool(p["fric_sym"]), grav_only=bool(p["grav"]))
+    om = OracleModel(t, floating=bool(p["floating"]), fric=bool(p["fric"]), fric_sym=bool(p["fric_sym"]), grav_only=bool(p["grav"]), stribeck=p["stribeck"])
     S, k = max(p["S"], 2), max(p["k"], 1) if p["k"] < 3 else 2
     st = random_states(t, S, rng, p["floating"])
     st["sign"] = np.tanh(st["dq"] / 0.02)
     Yo = om.regressor(st, st["sign"])
     rows, P = om.rows, om.P
     rhs = rng.standard_normal((S * rows, k))
-    w = 0.5 + rng.random(S * rows) if p["weights"] else None
-    opts = {"default": {}, "reduced": {"reduce_min_work": 0, "tsqr_group_min_samples": 1}, "allcols": {"link_merge": 0}}[p["mode"]]
-    if p["chunk"]:
-        opts = dict(opts, chunk_samples=p["chunk"])
+    w = _weights(p, rng, S, rows, 6 if p["floating"] else 0)
+    opts = _options(p)
     eng = Engine(t, floating=bool(p["floating"]), friction=bool(p["fric"]), friction_symmetric=bool(p["fric_sym"]), gravity_only=bool(p["grav"]),
-                 options=opts)
+                 stribeck_velocity=p["stribeck"], options=opts)
     why = f"reproduce: FBR_FUZZ_SEED={SEED} case {10_000 + case}: {p}"
     try:
         A = np.hstack([Yo, rhs]) * (1.0 if w is None else w[:, None])
@@ -145,8 +166,9 @@ def test_random_tree_other_entry_points(case):
         # inverse dynamics with the friction model
         nfric = P - (4 if p["grav"] else 10) * t.num_links
         x_std = np.concatenate([t.x_std(), rng.random(max(nfric, 0) + 4 * t.num_dofs)])
-        tau = eng.inverse_dynamics(st, x_std)
-        tau_o = om.inverse_dynamics(st, x_std, st["sign"])
+        vel_sign = st["dq"] * 0.9 if p["stribeck"] > 0 else None
+        tau = eng.inverse_dynamics(st, x_std, vel_sign=vel_sign)
+        tau_o = om.inverse_dynamics(st, x_std, st["sign"], vel_sign)
         assert np.abs(tau - tau_o).max() <= 1e-11 * max(np.abs(tau_o).max(), 1.0), (why, "inverse dynamics")
         # contact torques at the last link
         wr = rng.standard_normal((S, 6))
