@@ -236,7 +236,7 @@ struct FbrHostModel {
         }
         cols = (int)coldesc.size();
     }
-    int rec_size() const { return 21 * L + 6 * n; }
+    int rec_size() const { return FBR_LINK_REC * L + FBR_DOF_REC * n; }
     // standard-vector index of the first friction parameter (model.py:164-168)
     int friction_start() const { return grav_only ? 4 * L : 10 * L; }
 };
