@@ -110,7 +110,7 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
     DevModel &dm = m->dm;
     memset(&dm, 0, sizeof(dm));
     dm.L = hm.L; dm.n = hm.n; dm.fb = hm.fb; dm.rows = hm.rows; dm.cols = hm.cols; dm.cpl = hm.cpl;
-    dm.floating = hm.floating; dm.rec = hm.rec_size(); dm.soff = hm.dof_off(); m->kin_stream = hm.parents_first(); dm.maxd = std::max(hm.maxdepth, 1);
+    dm.floating = hm.floating; dm.rec = hm.rec_size(); dm.maxd = std::max(hm.maxdepth, 1);
     dm.nw = std::max(1, (hm.n + 31) / 32);
     dm.fric = hm.fric; dm.grav_only = hm.grav_only; dm.fstart = hm.friction_start();
     for (int i = 0; i < 3; i++) dm.g[i] = hm.gravity[i];
@@ -447,12 +447,6 @@ int run_kin(fbr_model *m, const DevStates &d, long s0, long cs, hipStream_t st, 
     const int threads = 256;
     const int blocks = (int)((cs + threads - 1) / threads);
     ProfScope ps(m, FBR_PROF_KIN, st);
-    if (m->kin_stream && m->opt.kin_stream != 0 && cs > 0) {  // links numbered parents first: the records leave as whole lines
-        hipLaunchKernelGGL(fbr_kin_stream_kernel, dim3((unsigned)((cs + 63) / 64)), dim3(64), 0, st, m->dm, cs, d.q + s0 * hm.n, d.dq + s0 * hm.n, d.ddq + s0 * hm.n,
-                           d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr, d.rpy ? d.rpy + s0 * 3 : nullptr, recbuf->as<double>());
-        HIPCHK(hipGetLastError());
-        return FBR_OK;
-    }
     // (one instance, no register cap: the 96-VGPR instance that once ran beside the Gram kernel spilled 41 registers and, since the column
     // reductions, was the slower one there as well -- kin 6.2 instead of 5.3 ms per 1 M samples: DESIGN.md 10)
     hipLaunchKernelGGL(fbr_kin_kernel<2>, dim3(blocks), dim3(threads), 0, st, m->dm, cs, d.q + s0 * hm.n, d.dq + s0 * hm.n, d.ddq + s0 * hm.n,

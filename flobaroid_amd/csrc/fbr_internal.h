@@ -106,8 +106,7 @@ struct GramHolder {
 };
 
 struct fbr_model {
-    FbrOptions opt;
-    bool kin_stream = false;  // fbr_kin_stream_kernel (links numbered parents first, joints in link order)  // fbr_model_set_option; the reduced models rdm[] share their parent's values
+    FbrOptions opt;  // fbr_model_set_option; the reduced models rdm[] share their parent's values
     FbrHostModel hm;
     DevModel dm;
     int device = 0;

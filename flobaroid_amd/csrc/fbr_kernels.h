@@ -12,7 +12,6 @@
 // ------------------------------------------------------------------------------------------------
 struct DevModel {
     int L, n, fb, rows, cols, cpl, floating, rec, maxd, nw;  // nw = 32-bit words of the ancestor mask
-    int soff;                         // offset of the motion vectors in a sample's record (FbrHostModel::dof_off)
     int fric, grav_only, fstart;
     double g[3];
     double stribeck;
@@ -51,7 +50,7 @@ struct DevGram {
 
 #ifdef FBR_KERNELS_CORE  // kinematics, materialising regressor, finite-difference scores, inverse dynamics, contact (fbr_api.hip)
 // ------------------------------------------------------------------------------------------------
-// K1: link kinematics, one lane per sample, AoS records  rec[s][link records | motion vectors] (FbrHostModel::rec_size)
+// K1: link kinematics, one lane per sample, AoS records  rec[s][21*L + 6*n]
 // ------------------------------------------------------------------------------------------------
 // (256, 5): at most 96 VGPRs (41 spilled), so that a kin wave fits beside the two 173-VGPR Gram waves of a SIMD -- the producer
 // kernels run concurrently with the Gram kernel of the previous chunk; +2.7 % on the fused pass
@@ -110,120 +109,10 @@ __global__ __launch_bounds__(256, WAVES) void fbr_kin_kernel(DevModel m, long S,
             fbr_kin_child(P, rR, rp, ax, m.jtype[l], qv, dqv, ddqv, out, Sv);
         }
         if (d >= 0)
-            for (int i = 0; i < 6; i++) r[m.soff + FBR_DOF_REC * d + i] = Sv[i];
+            for (int i = 0; i < 6; i++) r[FBR_LINK_REC * m.L + FBR_DOF_REC * d + i] = Sv[i];
         for (int i = 0; i < FBR_LINK_REC; i++) r[FBR_LINK_REC * l + i] = out[i];
         for (int i = 0; i < FBR_LINK_REC; i++) P[i] = out[i];
         prev_l = l;
-    }
-}
-
-// K1s: the same records for models whose links are numbered parents first (FbrHostModel::parents_first: every bundled robot, every
-// reduced model), written as WHOLE 128-BYTE LINES.  What bounds K1 is not its arithmetic (0.4 of its 4.0 ms per 1 M samples of a 30-body
-// tree, tools/kin_probe.hip) but its stores: a lane's 8-byte stores at a record's stride, and equally 168-byte runs that start anywhere,
-// leave partially written lines behind (an interleaved layout written in whole lines takes 2.6 ms, the same bytes).  Here the links are
-// walked in index order, so that the record of a sample grows as ONE stream: the 21 doubles of a link are appended to a per-sample
-// carry in the LDS ([64 samples][37]), whole lines leave through a transposed read (each store instruction: four samples x one line),
-// what is left of a line (< 16 doubles) moves to the front of the carry.  The motion vectors are a second stream of the same kind
-// ([64][23]).  One wave per workgroup (30 KB of LDS).  2.7 instead of 4.0 ms, the records are the same to the bit.
-__global__ __launch_bounds__(64) void fbr_kin_stream_kernel(DevModel m, long S, const double *__restrict__ q, const double *__restrict__ dq,
-                                                            const double *__restrict__ ddq, const double *__restrict__ bv,
-                                                            const double *__restrict__ ba, const double *__restrict__ rpy, double *rec)
-{
-    constexpr int LR = 37, SR = 23;  // (odd strides: the lanes' carries start in different banks)
-    __shared__ double ringl[64 * LR], rings[64 * SR];
-    const int lane = threadIdx.x;
-    const long wbase = (long)blockIdx.x * 64;
-    const long s = min(wbase + lane, S - 1);  // (lanes behind the last sample repeat it; their lines are not stored)
-    const double *qs = q + s * m.n, *dqs = dq + s * m.n, *ddqs = ddq + s * m.n;
-    double *rl = ringl + lane * LR, *rsg = rings + lane * SR;
-    for (int i = 0; i < LR; i++) rl[i] = 0.0;  // (the pads of a record are written from here)
-    for (int i = 0; i < SR; i++) rsg[i] = 0.0;
-    const int fs = lane >> 4, ff = lane & 15;  // flush: this lane stores double ff of the lines of samples 4 i + fs
-    double P[FBR_LINK_REC];
-    int cl = 0, cs = 0;           // doubles carried by the two streams (wave-uniform)
-    long pl = 0, ps = m.soff;     // positions of the streams in the record: what has been stored (multiples of 16 doubles)
-    for (int l = 0; l < m.L; l++) {
-        const int par = m.parent[l];
-        double out[FBR_LINK_REC], Sv[6] = {0, 0, 0, 0, 0, 0};
-        int d = -1;
-        if (par < 0) {
-            double v6[6] = {0, 0, 0, 0, 0, 0}, a6[6] = {0, 0, 0, 0, 0, 0}, e3[3] = {0, 0, 0};
-            if (m.floating) {
-                for (int i = 0; i < 6; i++) {
-                    v6[i] = bv[s * 6 + i];
-                    a6[i] = ba[s * 6 + i];
-                }
-                for (int i = 0; i < 3; i++) e3[i] = rpy[s * 3 + i];
-            }
-            fbr_kin_base(m.floating, m.g, v6, a6, e3, out);
-        } else {
-            // a parent that is not the link before: its record has left the carry (two links back at least: 42 - 15 >= 21 doubles stored),
-            // written by other lanes of this wave: read behind their write acknowledgements and past this CU's L1 (an earlier re-read may
-            // have left a line there from before it was written)
-            if (par != l - 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const double *pr = rec + s * (long)m.rec + FBR_LINK_REC * par;
-                for (int i = 0; i < FBR_LINK_REC; i++) P[i] = __hip_atomic_load(pr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            d = m.dof[l];
-            double rR[9], rp[3], ax[3];
-            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
-            for (int i = 0; i < 3; i++) {
-                rp[i] = m.restp[3 * l + i];
-                ax[i] = m.axis[3 * l + i];
-            }
-            double qv = 0, dqv = 0, ddqv = 0;
-            if (d >= 0) {
-                qv = qs[d];
-                dqv = dqs[d];
-                ddqv = ddqs[d];
-            }
-            fbr_kin_child(P, rR, rp, ax, m.jtype[l], qv, dqv, ddqv, out, Sv);
-        }
-        const bool last = l + 1 == m.L;
-        // ---- link stream
-        for (int i = 0; i < FBR_LINK_REC; i++) rl[cl + i] = out[i];
-        asm volatile("" ::: "memory");
-        {
-            const int tot = cl + FBR_LINK_REC, nl = last ? (tot + 15) >> 4 : tot >> 4;  // (the last link takes its partial line along: the pad is this sample's)
-            for (int ln = 0; ln < nl; ln++) {
-                double *gp = rec + (wbase + fs) * (long)m.rec + pl + ff;
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int sm = 4 * i + fs;
-                    const double v = ringl[sm * LR + 16 * ln + ff];
-                    if (wbase + sm < S) gp[(long)(4 * i) * m.rec] = v;
-                }
-                pl += 16;
-            }
-            asm volatile("" ::: "memory");
-            const int sh = 16 * nl;  // the rest of the last line (all of it part of this link's record) moves to the front
-            for (int i = 0; i < FBR_LINK_REC; i++)
-                if (cl + i - sh >= 0) rl[cl + i - sh] = out[i];
-            cl = tot - sh > 0 ? tot - sh : 0;
-        }
-        // ---- motion-vector stream (dof d of a link is the d-th to appear: checked on the host, FbrHostModel::parents_first)
-        if (d >= 0) {
-            for (int i = 0; i < 6; i++) rsg[cs + i] = Sv[i];
-            cs += 6;
-        }
-        asm volatile("" ::: "memory");
-        while (cs >= 16 || (last && cs > 0)) {  // (the last link leaves nothing behind: a whole line and then the partial one)
-            double *gp = rec + (wbase + fs) * (long)m.rec + ps + ff;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int sm = 4 * i + fs;
-                const double v = rings[sm * SR + ff];
-                if (wbase + sm < S) gp[(long)(4 * i) * m.rec] = v;
-            }
-            ps += 16;
-            asm volatile("" ::: "memory");
-            const int rem = cs - 16;
-            for (int i = 0; i < 6; i++)
-                if (i < rem) rsg[i] = rsg[16 + i];
-            cs = rem > 0 ? rem : 0;
-        }
-        for (int i = 0; i < FBR_LINK_REC; i++) P[i] = out[i];
     }
 }
 
@@ -285,7 +174,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_kernel(DevModel m, long S, 
                 for (int d = 0; d < m.n; d++) {
                     const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
                     double v = 0.0;
-                    if (bit) v = fbr_dot6(rs + m.soff + FBR_DOF_REC * d, w6);
+                    if (bit) v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
                     if (!rowfc || co >= (rowfc[m.fb + d] & ~15)) Ys[(m.fb + d) * rl + co] = v;
                 }
             } else {
@@ -347,7 +236,7 @@ __device__ __forceinline__ double fbr_score_column(const DevModel &m, const doub
         for (int r = 0; r < m.fb; r++) acc += Ws[(long)r * m.cols + c] * w6[r];
         for (int d = 0; d < m.n; d++) {
             const unsigned bit = (m.ancmask[cd.y * m.nw + (d >> 5)] >> (d & 31)) & 1u;
-            if (bit) acc += Ws[(long)(m.fb + d) * m.cols + c] * fbr_dot6(rs + m.soff + FBR_DOF_REC * d, w6);
+            if (bit) acc += Ws[(long)(m.fb + d) * m.cols + c] * fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, w6);
         }
     } else {
         const int j = cd.w;
@@ -451,7 +340,7 @@ __global__ __launch_bounds__(256) void fbr_regressor2_kernel(DevModel m, long S,
                         const int d = 32 * wd + b;
                         fbr_d2 v = {0.0, 0.0};
                         if ((mask >> b) & 1u) {
-                            const double *Sd = rs + m.soff + FBR_DOF_REC * d;
+                            const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d;
                             v[0] = fbr_dot6(Sd, wa);
                             v[1] = fbr_dot6(Sd, wb);
                         } else if (rowfc && cout < (rowfc[m.fb + d] & ~15)) {
@@ -566,7 +455,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, l
                 if (kind == 0)
                     v = w6[r];
                 else if (kind == 1)
-                    v = fbr_dot6(rs + m.soff + FBR_DOF_REC * (r - m.fb), w6);
+                    v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
                 else if (kind == 3)
                     v = fv;
                 if (wts) v *= wts[s * m.rows + r];
@@ -695,7 +584,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups_lds_kernel(DevModel 
                 if (kind == 0)
                     v = w6[r];
                 else if (kind == 1)
-                    v = fbr_dot6(rs + m.soff + FBR_DOF_REC * (r - m.fb), w6);
+                    v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
                 else if (kind == 3)
                     v = fv;
                 if (ws) v *= ws[r];
@@ -789,7 +678,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
                         v[0] = wa[r];
                         v[1] = wb[r];
                     } else if (kind == 1) {
-                        const double *Sd = rs + m.soff + FBR_DOF_REC * (r - m.fb);
+                        const double *Sd = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb);
                         v[0] = fbr_dot6(Sd, wa);
                         v[1] = fbr_dot6(Sd, wb);
                     }
@@ -813,7 +702,7 @@ __global__ __launch_bounds__(256) void fbr_regressor_groups2_kernel(DevModel m, 
                     if (kind == 0)
                         v = w6[r];
                     else if (kind == 1)
-                        v = fbr_dot6(rs + m.soff + FBR_DOF_REC * (r - m.fb), w6);
+                        v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * (r - m.fb), w6);
                     if (wts) v *= wts[s * m.rows + r];
                     __builtin_nontemporal_store(v, rowptr[r] + pos);
                 }
@@ -875,7 +764,7 @@ __global__ __launch_bounds__(256) void fbr_id_kernel(DevModel m, long S, const d
                     const int l = m.sub_links[i];
                     for (int c = 0; c < 6; c++) acc[c] += F[6 * l + c];
                 }
-                v = fbr_dot6(rs + m.soff + FBR_DOF_REC * d, acc);
+                v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * d, acc);
                 if (m.fric) {
                     const double dqv = dq[s * m.n + d];
                     const double sg = sign[s * m.n + d];
@@ -932,7 +821,7 @@ __global__ __launch_bounds__(256) void fbr_contact_kernel(DevModel m, long S, co
     for (int j = 0; j < len; j++) {
         const int d = m.pathtab[flink * m.maxd + j];
         double Sv[6];
-        for (int i = 0; i < 6; i++) Sv[i] = r[m.soff + FBR_DOF_REC * d + i];
+        for (int i = 0; i < 6; i++) Sv[i] = r[FBR_LINK_REC * m.L + FBR_DOF_REC * d + i];
         o[m.fb + d] = fbr_dot6(Sv, w6);
     }
 }
@@ -1091,13 +980,13 @@ __global__ __launch_bounds__(256, 7) void fbr_pack_kernel(DevGram g, DevModel m,
                 for (int j = 0; j < len; j++) {
                     const int dd = ptab[d.z * m.maxd + j];
 #if defined(FBR_PACK_TIMING_CHEAPDOT)  // timing-only experiments (results wrong): 1 = one multiply and one LDS read per joint row,
-                    const double *Sx = rs + m.soff + FBR_DOF_REC * dd;  // 2 = one multiply, all six LDS reads kept
+                    const double *Sx = rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd;  // 2 = one multiply, all six LDS reads kept
                     double v = Sx[0] * w6[0];
 #if FBR_PACK_TIMING_CHEAPDOT == 2
                     asm volatile("" ::"v"(Sx[1]), "v"(Sx[2]), "v"(Sx[3]), "v"(Sx[4]), "v"(Sx[5]));
 #endif
 #else
-                    double v = fbr_dot6(rs + m.soff + FBR_DOF_REC * dd, w6);
+                    double v = fbr_dot6(rs + FBR_LINK_REC * m.L + FBR_DOF_REC * dd, w6);
 #endif
                     if (ws) v *= ws[m.fb + dd];
                     img[d.x + ppos[d.z * m.maxd + j] * FBR_TILE] = v;

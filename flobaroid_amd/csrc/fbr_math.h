@@ -21,9 +21,7 @@
 #include <math.h>
 
 // per-link record: R(9) p(3) w(3) dw(3) a(3)
-#ifndef FBR_LINK_REC  // (tools/kin_probe.hip times a padded record)
 #define FBR_LINK_REC 21
-#endif
 #define FBR_OFF_R 0
 #define FBR_OFF_P 9
 #define FBR_OFF_W 12

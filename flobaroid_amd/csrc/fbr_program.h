@@ -236,21 +236,7 @@ struct FbrHostModel {
         }
         cols = (int)coldesc.size();
     }
-    // kinematic record of a sample: the link records [L][FBR_LINK_REC], then -- from a 128-byte boundary on -- the motion vectors [n][6], the
-    // whole a multiple of 128 bytes (fbr_kin_stream_kernel writes whole lines)
-    int dof_off() const { return (FBR_LINK_REC * L + 15) & ~15; }
-    int rec_size() const { return (dof_off() + FBR_DOF_REC * n + 15) & ~15; }
-    // links numbered parents first and joints in the order of their links: the kinematics can walk the links in index order and both
-    // parts of a sample's record grow as streams (fbr_kin_stream_kernel)
-    bool parents_first() const
-    {
-        int k = 0;
-        for (int l = 0; l < L; l++) {
-            if (parent[l] >= l) return false;
-            if (dof[l] >= 0 && dof[l] != k++) return false;
-        }
-        return true;
-    }
+    int rec_size() const { return FBR_LINK_REC * L + FBR_DOF_REC * n; }
     // standard-vector index of the first friction parameter (model.py:164-168)
     int friction_start() const { return grav_only ? 4 * L : 10 * L; }
 };

@@ -296,8 +296,6 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "chunk_samples"              0     > 0: samples per chunk of every pass (0: sized by memory)
  *   "min_chunks"                 4     a short fused pass is still cut into this many chunks
  *   "h2d_chunked"                1     pinned host inputs staged chunk by chunk on a copy stream, overlapped with the kernels
- *   "kin_stream"                 1     kinematic records written as whole 128-byte lines when the links are numbered parents first and
- *                                      the joints in the order of their links (0: the plain one-lane-per-sample stores; same records)
  *   "gram_shape"                 0     fused Gram kernel shape: 0 by model, 1 one workgroup per CU, 2 two per CU
  *   "gram_rhs_tile"              0     1: dense tiles for the rhs columns even for k <= 2 (default: their products come from the packer)
  *   "gram_orient"                1     tile pairs turned so that the row segments fill up

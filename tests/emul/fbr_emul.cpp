@@ -79,7 +79,7 @@ static void kin_sample(const FbrHostModel &hm, const double *q, const double *dq
             int d = hm.dof[l];
             fbr_kin_child(rec + FBR_LINK_REC * hm.parent[l], &hm.restR[9 * l], &hm.restp[3 * l], &hm.axis[3 * l], hm.jtype[l],
                           d >= 0 ? q[d] : 0.0, d >= 0 ? dq[d] : 0.0, d >= 0 ? ddq[d] : 0.0, r,
-                          d >= 0 ? rec + hm.dof_off() + 6 * d : nullptr);
+                          d >= 0 ? rec + FBR_LINK_REC * hm.L + 6 * d : nullptr);
         }
     }
 }
@@ -124,7 +124,7 @@ int emul_regressor(const EmulTopo *t, long S, const double *q, const double *dq,
                 fbr_unit_wrench(&rec[FBR_LINK_REC * cd.link], cd.pidx, w6);
                 for (int r = 0; r < hm.fb; r++) Ys[(size_t)r * hm.cols + c] = w6[r];
                 for (int d : hm.path[cd.link])
-                    Ys[(size_t)(hm.fb + d) * hm.cols + c] = fbr_dot6(&rec[hm.dof_off() + 6 * d], w6);
+                    Ys[(size_t)(hm.fb + d) * hm.cols + c] = fbr_dot6(&rec[FBR_LINK_REC * hm.L + 6 * d], w6);
             } else {
                 int j = cd.joint;
                 Ys[(size_t)(hm.fb + j) * hm.cols + c] =
@@ -160,7 +160,7 @@ int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const 
             }
             fbr_link_wrench(&rec[FBR_LINK_REC * l], pi, &F[6 * l]);
             for (int r = 0; r < hm.fb; r++) ts[r] += F[6 * l + r];
-            for (int d : hm.path[l]) ts[hm.fb + d] += fbr_dot6(&rec[hm.dof_off() + 6 * d], &F[6 * l]);
+            for (int d : hm.path[l]) ts[hm.fb + d] += fbr_dot6(&rec[FBR_LINK_REC * hm.L + 6 * d], &F[6 * l]);
         }
         if (hm.fric) {
             const int n = hm.n;
@@ -355,7 +355,7 @@ int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, cons
                 if (hm.fb && !odd && !partner) img[it.off + 6 * FBR_TILE] = img[it.off + 7 * FBR_TILE] = 0.0;
                 int j = 0;
                 for (int d : hm.path[it.a]) {
-                    img[it.off + hm.ppos[it.a][j] * FBR_TILE] = fbr_dot6(&rec[hm.dof_off() + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
+                    img[it.off + hm.ppos[it.a][j] * FBR_TILE] = fbr_dot6(&rec[FBR_LINK_REC * hm.L + 6 * d], w6) * (ws ? ws[hm.fb + d] : 1.0);
                     note(img[it.off + hm.ppos[it.a][j] * FBR_TILE], hm.fb + d);
                     j++;
                 }
