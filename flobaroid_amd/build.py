@@ -46,12 +46,25 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def _lib_digest() -> str | None:
+    try:
+        with open(OUT, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def built_hash() -> str | None:
+    """Source hash the library in the tree was built from -- None when the stamp does not belong to THIS binary (the stamp carries the
+    binary's own digest: a stamp restored by a checkout beside a library built from other sources must not pass for up to date)."""
     try:
         with open(STAMP) as fh:
-            return json.load(fh).get("source_hash")
+            st = json.load(fh)
     except (OSError, ValueError):
         return None
+    if st.get("lib_sha256") != _lib_digest():
+        return None
+    return st.get("source_hash")
 
 
 def needs_build() -> bool:
@@ -85,7 +98,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     subprocess.check_call(cmd, cwd=CSRC)
     last_build = {"compiled": True, "source_hash": want, "seconds": round(time.time() - t0, 1), "units": len(SOURCES)}
     with open(STAMP, "w") as fh:
-        json.dump(last_build, fh)
+        json.dump(dict(last_build, lib_sha256=_lib_digest()), fh)
     return OUT
 
 
