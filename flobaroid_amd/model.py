@@ -455,6 +455,17 @@ class Model:
                 f = np.load(fn)
                 if "producer" not in f:
                     foreign = foreign or fn == regr_filename
+                    # opt['useReferenceRegressorCache'] = 1: a cache the reference itself wrote is adopted when it passes the
+                    # reference's own validity check (model.py:663-671) -- its Gram, its pivots, hence ITS choice among tied pivots and its
+                    # base-parameter basis; the caller vouches for the serialisation (links and DOFs in iDynTree's traversal order, which
+                    # is also ours) and for stribeckVelocity, which that check does not look at
+                    if fn == regr_filename and opt.get("useReferenceRegressorCache", 0):
+                        R, Q, RQ, PQ = f["R"], f["Q"], f["RQ"], f["PQ"]
+                        if not (f["n"] != n_samples or f["fb"] != fb or R.shape[0] != self.num_identified_params
+                                or opt["identifyGravityParamsOnly"] != f["grav_only"] or f["fric"] != opt["identifyFrictionSimultaneously"]
+                                or f["fric_sym"] != opt["identifySymmetricVelFriction"]):
+                            generate_new = False
+                            break
                     continue
                 R, Q, RQ, PQ = f["R"], f["Q"], f["RQ"], f["PQ"]
                 if not (f["n"] != n_samples or f["fb"] != fb or R.shape[0] != self.num_identified_params

@@ -308,6 +308,56 @@ def test_random_regressor_matches_the_reference_logic_outputs(tag, tmp_path):
     assert int(cache["n"]) == int(z[tag + "_cache_n"]) and int(cache["fb"]) == int(z[tag + "_cache_fb"]) and int(cache["fric"]) == int(z[tag + "_cache_fric"])
 
 
+@pytest.mark.parametrize("tag", ["rrA", "rrW"])
+def test_reference_written_cache_is_adopted_on_request(tag, tmp_path):
+    """A `.regressor.npz` written by the REFERENCE (its keys, no producer tag) is not trusted by default -- its validity check ignores the
+    serialisation -- and never overwritten (ours goes to `.fbr.npz` beside it).  With opt['useReferenceRegressorCache'] = 1 it is adopted
+    when it passes the reference's own check: the reference's Gram, ITS pivot order (LAPACK's choice among the tied pivots) and therefore
+    its independent columns -- the basis of an existing installation -- instead of the deterministic tie rule's."""
+    import json
+
+    from flobaroid_amd.model import Model, pivoted_qr
+
+    z = _Golden()
+    meta = json.loads(str(z[tag + "_meta"]))
+    if tag + "_R" not in z.files:
+        pytest.skip("the fixture holds the reference's Gram as a triangle only")
+    Rw, ref_PQ = z[tag + "_R"], z[tag + "_PQ"]
+    topo = load_topo(meta["robot"])
+    path = str(tmp_path / (meta["robot"] + ".topology.json"))
+    topo.save_json(path)
+    Qr, RQr, PQr = pivoted_qr(Rw, 0.0)  # (the reference's own call on its own Gram: scipy.linalg.qr(R, pivoting=True), model.py:809)
+    assert np.array_equal(PQr, ref_PQ)
+    opt0 = dict(meta["opt"], startOffset=0, estimateWith="std", randomSamples=meta["n_samples"], minTol=1e-4, skipSamples=0, useAPriori=0,
+                simulateTorques=0, useStructuralRegressor=1, filterRegressor=0, showTiming=0, selectBlocksFromMeasurements=0)
+    ref_cache = path + ".regressor.npz"
+
+    def write_reference_cache():
+        np.savez(ref_cache, R=Rw, Q=Qr, RQ=RQr, PQ=PQr, n=meta["n_samples"], fb=opt0["floatingBase"], grav_only=opt0["identifyGravityParamsOnly"],
+                 fric=opt0["identifyFrictionSimultaneously"], fric_sym=opt0["identifySymmetricVelFriction"])
+
+    write_reference_cache()
+    before = open(ref_cache, "rb").read()
+    # default: not trusted, not touched
+    model = Model(dict(opt0), path, regressor_init=False)
+    np.random.seed(meta["seed"])
+    R, Q, RQ, PQ = model.getRandomRegressor(meta["n_samples"])
+    assert not np.array_equal(R, Rw) and la.norm(R - Rw) <= 1e-11 * la.norm(Rw)   # generated here (the GPU's summation order)
+    assert open(ref_cache, "rb").read() == before and os.path.exists(path + ".regressor.fbr.npz")
+    # on request: the reference's arrays, bit for bit
+    model = Model(dict(opt0, useReferenceRegressorCache=1), path, regressor_init=False)
+    R, Q, RQ, PQ = model.getRandomRegressor(meta["n_samples"])
+    assert np.array_equal(R, Rw) and np.array_equal(PQ, ref_PQ) and np.array_equal(RQ, RQr)
+    model.computeRegressorLinDepsQR()
+    r = model.num_base_params
+    assert np.array_equal(np.asarray(model.independent_cols), ref_PQ[:r])
+    # ... but only when it passes the reference's check (another sample count: regenerated)
+    model = Model(dict(opt0, useReferenceRegressorCache=1, randomSamples=meta["n_samples"] + 1), path, regressor_init=False)
+    np.random.seed(meta["seed"])
+    R2 = model.getRandomRegressor(meta["n_samples"] + 1)[0]
+    assert not np.array_equal(R2, Rw) and open(ref_cache, "rb").read() == before
+
+
 def test_walkman_measurements_in_the_reference_joint_order_need_no_regressor_file(tmp_path):
     """VERDICT r2 item 1.  A WALK-MAN measurement file recorded for the reference has its positions / velocities / torques columns
     in iDynTree's DOF order (model.py:388-394) = the list of model/walkman_regressor.xml (tests/golden/reference_joint_orders.json).
