@@ -209,3 +209,49 @@ def test_random_tree_other_entry_points(case):
         assert torch.equal(Gsub, Gb) and torch.equal(Rsub, Rb), (why, "submissions")
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("case", range(max(CASES // 6, 2)))
+def test_random_tree_at_the_sizes_where_the_library_switches_paths(case):
+    """Default options only, batches long enough that the library itself takes the column reductions (`reduce_min_work`), the row groups of
+    the TSQR (`tsqr_group_min_samples`) and several chunks: what a user gets on a robot that is none of the bundled ones.  Gram and
+    R^T R against the oracle's Gram accumulated in slices; the fused pass and the factorisation repeat to the bit."""
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng([SEED, 20_000 + case])
+    L = int(rng.integers(12, 46))
+    floating = int(rng.random() < 0.6)
+    t = random_topology(rng, L, p_fixed=float(rng.choice([0.0, 0.3, 0.5])), branchiness=float(rng.choice([0.2, 0.5, 0.8])),
+                        p_prismatic=float(rng.choice([0.0, 0.2])))
+    if t.num_dofs == 0 or t.num_dofs + (6 if floating else 0) > 60:
+        pytest.skip("row count outside the fused kernels")
+    fric = int(rng.random() < 0.3)
+    om = OracleModel(t, floating=bool(floating), fric=bool(fric), fric_sym=True)
+    S = int(rng.choice([26_000, 31_111, 48_000]))
+    k = int(rng.integers(1, 3))
+    st = random_states(t, S, rng, floating)
+    st["sign"] = np.tanh(st["dq"] / 0.02)
+    rows, P = om.rows, om.P
+    rhs = rng.standard_normal((S * rows, k))
+    w = 0.5 + rng.random(S * rows) if rng.random() < 0.4 else None
+    Go = np.zeros((P + k, P + k))
+    for a in range(0, S, 4000):
+        b = min(S, a + 4000)
+        A = np.hstack([om.regressor({kk: v[a:b] for kk, v in st.items()}, st["sign"][a:b]), rhs[a * rows:b * rows]])
+        if w is not None:
+            A *= w[a * rows:b * rows, None]
+        Go += A.T @ A
+    eng = Engine(t, floating=bool(floating), friction=bool(fric), friction_symmetric=True)
+    why = f"reproduce: FBR_FUZZ_SEED={SEED} case {20_000 + case}: L={L} floating={floating} fric={fric} S={S} k={k} weights={w is not None}"
+    try:
+        info = eng.link_merge_info(S)
+        gn = np.linalg.norm(Go)
+        G = eng.gram(st, rhs=rhs, w=w)
+        assert np.linalg.norm(G - Go) <= 1e-11 * gn, (why, info, _rel(G, Go))
+        assert np.array_equal(G, eng.gram(st, rhs=rhs, w=w)), why
+        R = eng.tsqr(st, rhs=rhs, w=w)
+        assert np.all(np.tril(R, -1) == 0) and np.linalg.norm(R.T @ R - Go) <= 1e-11 * gn, (why, info, _rel(R.T @ R, Go))
+        assert np.array_equal(R, eng.tsqr(st, rhs=rhs, w=w)), why
+    finally:
+        eng.close()
