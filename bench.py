@@ -60,7 +60,16 @@ def parse_args(argv=None):
     ap.add_argument("--engine", default=None,
                     help="module:factory returning an Engine-like object (tests inject a CPU stand-in to exercise the launch / "
                          "sharding / reduction logic without a GPU); default: flobaroid_amd._lib.Engine (HIP, fails without a device)")
-    return ap.parse_args(argv)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="option of every model handle the bench creates (fbr_model_set_option, include/fbr.h); experiments only -- the line records them")
+    args = ap.parse_args(argv)
+    if args.opt:
+        from flobaroid_amd import _lib
+
+        for kv in args.opt:
+            key, _, val = kv.partition("=")
+            _lib.DEFAULT_OPTIONS[key.strip()] = float(val)
+    return args
 
 
 def _free_port() -> int:
@@ -531,6 +540,7 @@ def run_rank(args) -> int:
         # run on the same workload with pinned host inputs staged chunk by chunk on a copy stream (the two differ by run-to-run noise: the
         # 1.1 GB per step cross PCIe behind the kernels).
         "value_resident": value,
+        "engine_options": dict(getattr(__import__("flobaroid_amd._lib", fromlist=["DEFAULT_OPTIONS"]), "DEFAULT_OPTIONS", {})),
         "value_definition": "samples per second of the whole job with states and tau resident in HBM (bench contract); value_incl_h2d = the same "
                             "pass fed from pinned host memory (SURVEY 8(d) wording), reported beside it",
         # all world sizes reduce the same 1 M samples: these must agree (to rounding) between the N = 1, 2, 4, 8 lines
