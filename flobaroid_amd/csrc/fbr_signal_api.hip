@@ -50,29 +50,22 @@ extern "C" int fbr_filtfilt(fbr_model *m, const double *b, const double *a, int3
             f.zi[k] = asum * f.zi[0] - csum;
         }
     }
-    {  // M^LB of z' = M z + g x (y = z_0 + b_0 x): M[i][0] = -a[i+1], M[i][i+1] = 1
-        std::vector<double> M((size_t)p * p, 0.0), R((size_t)p * p, 0.0), Tm((size_t)p * p);
-        for (int i = 0; i < p; i++) {
-            M[(size_t)i * p] = -f.a[i + 1];
-            if (i + 1 < p) M[(size_t)i * p + i + 1] += 1.0;
-            R[(size_t)i * p + i] = 1.0;
+    {  // M^LB of z' = M z + g x (y = z_0 + b_0 x; M[i][0] = -a[i+1], M[i][i+1] = 1): column j = the zero-input recurrence run LB steps
+       // from e_j, i.e. the filter's own arithmetic.  NOT by repeated squaring: the companion matrix of a low cut-off is far from normal
+       // (poles clustered at z = 1: |M^k| grows like k^(p-1) before it decays), the rounding errors of the squarings are relative to
+       // those intermediate norms and do not decay with them -- order 5 at 0.016 of Nyquist (filterLowPass1 = [8 Hz, 5] on a 1 kHz
+       // recording) gave an M^LB with entries far above 1 and NaN / 1e190 outputs from the second block on (found by the randomised
+       // sweep); in the recurrence the errors made at the peak are carried by the same decaying dynamics.
+        for (int j = 0; j < p; j++) {
+            std::vector<double> z((size_t)p, 0.0);
+            z[(size_t)j] = 1.0;
+            for (long t = 0; t < FBR_SIG_LB; t++) {
+                const double y = z[0];
+                for (int i = 0; i + 1 < p; i++) z[(size_t)i] = z[(size_t)i + 1] - y * f.a[i + 1];
+                z[(size_t)p - 1] = -y * f.a[p];
+            }
+            for (int i = 0; i < p; i++) f.Mp[i * p + j] = z[(size_t)i];
         }
-        auto mul = [&](std::vector<double> &A, const std::vector<double> &B) {  // A = A * B
-            for (int i = 0; i < p; i++)
-                for (int j = 0; j < p; j++) {
-                    double acc = 0.0;
-                    for (int k = 0; k < p; k++) acc += A[(size_t)i * p + k] * B[(size_t)k * p + j];
-                    Tm[(size_t)i * p + j] = acc;
-                }
-            A = Tm;
-        };
-        for (long e = FBR_SIG_LB; e > 0; e >>= 1) {
-            if (e & 1) mul(R, M);
-            std::vector<double> M2 = M;
-            mul(M2, M);
-            M = M2;
-        }
-        for (int i = 0; i < p * p; i++) f.Mp[i] = R[i];
     }
     int rc;
     double *dX = nullptr;

@@ -255,3 +255,47 @@ def test_random_tree_at_the_sizes_where_the_library_switches_paths(case):
         assert np.array_equal(R, eng.tsqr(st, rhs=rhs, w=w)), why
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("case", range(max(CASES // 2, 1)))
+def test_random_signals_through_the_preprocessing_kernels(case):
+    """N2 (`Data.preprocess` on the device): fbr_filtfilt / fbr_medfilt / fbr_central_diff on random lengths (around the 2048-sample blocks
+    of the state scan), channel counts, filter orders and cut-offs, kernel widths and time grids against SciPy / the host version."""
+    import scipy.signal as sig
+
+    from common import load_topo
+    from flobaroid_amd._lib import Engine
+    from flobaroid_amd.data import Data
+
+    rng = np.random.default_rng([SEED, 30_000 + case])
+    eng = Engine(load_topo("threeLinks"))
+    try:
+        order = int(rng.integers(1, 9))
+        fc = float(rng.uniform(0.01, 0.45))
+        S = int(rng.choice([3 * (order + 1) + 1, 64, 2047, 2048, 2049, 4097, int(rng.integers(50, 20000))]))
+        C = int(rng.integers(1, 40))
+        X = np.cumsum(rng.standard_normal((S, C)), axis=0) * 0.1 + 3.0 * rng.standard_normal(C)
+        why = f"reproduce: FBR_FUZZ_SEED={SEED} case {30_000 + case}: order={order} fc={fc:.4f} S={S} C={C}"
+        b, a = sig.butter(order, fc)
+        # (b, a) of a high-order, low cut-off Butterworth is an ill-conditioned description of the filter (sum a ~ prod (1 - pole) against
+        # coefficients of order 2^order): SciPy's own result moves with the rounding of its start states (a linear solve there, the
+        # closed form here) by about eps * cond -- the comparison allows that much and skips what no double-precision run defines
+        cond = float(np.abs(a).sum() / abs(a.sum()))
+        if S > 3 * (order + 1) and cond < 1e10:
+            want = sig.filtfilt(b, a, X, axis=0)
+            got = eng.filtfilt(b, a, X.copy())
+            assert np.all(np.isfinite(got)), why
+            assert np.abs(got - want).max() <= max(1e-10, 1e-14 * cond) * max(np.abs(want).max(), 1.0), (why, cond)
+            nc = int(rng.integers(1, C + 1))
+            Y = X.copy()
+            eng.filtfilt(b, a, Y, ncols=nc)
+            assert np.array_equal(Y[:, :nc], got[:, :nc]) and np.array_equal(Y[:, nc:], X[:, nc:]), why
+        k = int(rng.choice([1, 3, 5, 7, 9, 11]))
+        assert np.array_equal(eng.medfilt(k, X.copy()), sig.medfilt(X, (k, 1))), (why, k)
+        if S >= 3:
+            T = np.cumsum(rng.uniform(0.001, 0.02) + 1e-4 * rng.random(S))
+            want = Data._central_diff(X, T)
+            got = eng.central_diff(X, T)
+            assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), why
+    finally:
+        eng.close()

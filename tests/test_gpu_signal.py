@@ -44,6 +44,27 @@ def test_filtfilt_matches_scipy(S, order, fc):
     assert np.array_equal(Xd.cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("order,fc_hz,fs", [(5, 8.0, 1000.0), (5, 6.0, 1000.0), (4, 3.0, 500.0)])
+def test_filtfilt_low_cutoffs_of_fast_recordings(order, fc_hz, fs):
+    """The reference's own filter settings (configs/*.yaml: filterLowPass1 / 2 / 3 = [8 Hz, 5], [6 Hz, 5], [3 Hz, 4]) on a recording sampled
+    at 0.5 ... 1 kHz: cut-offs of 0.012 ... 0.016 of Nyquist.  The state transition over a block of the scan used to be formed by repeated
+    squaring of the companion matrix, which is meaningless there (entries far above 1: NaN / 1e190 from the second block on; found by the
+    randomised sweep of tests/test_gpu_fuzz.py) -- it is the filter's own zero-input recurrence now.  Tolerance: eps x the conditioning
+    of the (b, a) form, which is what SciPy's own result moves by."""
+    import scipy.signal as sig
+
+    eng = _engine()
+    rng = np.random.default_rng(int(fc_hz * 10) + order)
+    S = 3 * 2048 + 77
+    X = np.cumsum(rng.standard_normal((S, 5)), axis=0) * 0.05 + rng.standard_normal(5)
+    b, a = sig.butter(order, fc_hz / (fs / 2))
+    cond = float(np.abs(a).sum() / abs(a.sum()))
+    want = sig.filtfilt(b, a, X, axis=0)
+    got = eng.filtfilt(b, a, X.copy())
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - want).max() <= max(1e-10, 1e-14 * cond) * np.abs(want).max(), cond
+
+
 def test_filtfilt_rejects_short_signals_like_scipy():
     import scipy.signal as sig
 
