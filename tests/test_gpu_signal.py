@@ -132,3 +132,34 @@ def test_preprocess_large_file_device_equals_host():
         res.append((Q, V, Vdot, Tau))
     for name, h, d in zip(("Q", "V", "Vdot", "Tau"), res[0], res[1]):
         assert np.abs(h - d).max() <= 1e-9 * max(1.0, np.abs(h).max()), name
+
+
+@pytest.mark.parametrize("Fs,S,seed", [(100.0, 5_000, 1), (500.0, 20_011, 2), (1000.0, 30_000, 3), (2000.0, 40_001, 4)])
+def test_preprocess_at_other_sampling_rates_device_equals_host(Fs, S, seed):
+    """The same pipeline at 0.1 ... 2 kHz with the reference's filter settings (cut-offs down to 0.003 of Nyquist): device == host SciPy to
+    eps x the conditioning of the filters; finite everywhere."""
+    import scipy.signal as sig
+
+    from flobaroid_amd.data import Data
+
+    rng = np.random.default_rng(seed)
+    n = 7
+    T = np.arange(S) / Fs
+    Q0 = np.sin(T[:, None] * (0.3 + 0.1 * np.arange(n))) + 0.01 * rng.standard_normal((S, n))
+    Tau0 = 5 * np.cos(T[:, None] * (0.2 + 0.05 * np.arange(n))) + 0.3 * rng.standard_normal((S, n))
+    opt = {"filterMedianSize": 11, "useDeg": 0, "num_dofs": n, "filterLowPass1": [8.0, 5], "filterLowPass2": [6.0, 5], "filterLowPass3": [3.0, 4],
+           "waitForZeroAcc": 0, "zeroAccThresh": 0.1}
+    cond = 1.0
+    for fc, order in (opt["filterLowPass1"], opt["filterLowPass2"], opt["filterLowPass3"]):
+        a = sig.butter(order, fc / (Fs / 2))[1]
+        cond = max(cond, float(np.abs(a).sum() / abs(a.sum())))
+    res = []
+    for engine in (None, _engine()):
+        Q, V, Vdot, Tau = Q0.copy(), np.zeros((S, n)), np.zeros((S, n)), Tau0.copy()
+        Data(opt).preprocess(Q, V, Vdot, Tau, T, Fs, engine=engine)
+        res.append((Q, V, Vdot, Tau))
+    for name, h, d in zip(("Q", "V", "Vdot", "Tau"), res[0], res[1]):
+        assert np.all(np.isfinite(d)), name
+        # (velocities and accelerations are differences of filtered positions: the filters' disagreement is divided by the time step)
+        scale = max(1.0, np.abs(h).max())
+        assert np.abs(h - d).max() <= max(1e-9, 1e-13 * cond) * scale * (1.0 if name in ("Q", "Tau") else Fs), (name, cond, np.abs(h - d).max())
