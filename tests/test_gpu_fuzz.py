@@ -3,6 +3,8 @@ joints, any branching), every base / friction / gravity-only mode, random batch 
 0 ... 3 right-hand sides, row weights with masked rows, and the three column-reduction modes drawn per case -- materialised regressor,
 fused Gram (twice: bitwise repeatable), grouped Gram, TSQR and prediction against the CPU oracle.
 
+Further down: the preprocessing kernels against SciPy, the Fourier-series state generator against its NumPy form, factor merges.
+
 FBR_FUZZ_CASES (default 24) and FBR_FUZZ_SEED (default 2025) size the sweep: `FBR_FUZZ_CASES=400 pytest tests/test_gpu_fuzz.py -m gpu`
 is the long run; a failing case prints the parameters that reproduce it."""
 import os
@@ -297,5 +299,71 @@ def test_random_signals_through_the_preprocessing_kernels(case):
             want = Data._central_diff(X, T)
             got = eng.central_diff(X, T)
             assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), why
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("case", range(max(CASES // 3, 1)))
+def test_random_fourier_candidates_and_factor_merges(case):
+    """fbr_fourier_states (classic and bounded generators: trajectoryGenerator.py:411-510 written out in NumPy) on random candidate counts,
+    lengths, harmonics and rates, host and device outputs; fbr_tsqr_merge of random triangular factors of every width, some rank
+    deficient, against the Gram of the stacked pair."""
+    from flobaroid_amd._lib import Engine
+
+    rng = np.random.default_rng([SEED, 40_000 + case])
+    t = random_topology(rng, int(rng.integers(2, 30)), p_fixed=0.2, branchiness=0.5)
+    if t.num_dofs == 0:
+        pytest.skip("no joint")
+    eng = Engine(t)
+    try:
+        n = t.num_dofs
+        C, T, nh = int(rng.integers(1, 9)), int(rng.choice([1, 2, 37, 256, 1000])), int(rng.integers(1, 7))
+        freq = float(rng.choice([50.0, 200.0, 1000.0]))
+        wf = rng.uniform(0.3, 3.0, C)
+        a, b = rng.standard_normal((C, n, nh)), rng.standard_normal((C, n, nh))
+        qo = rng.standard_normal((C, n))
+        bounded = bool(rng.random() < 0.5)
+        qr = rng.uniform(0.1, 1.5, (C, n)) if bounded else None
+        why = f"reproduce: FBR_FUZZ_SEED={SEED} case {40_000 + case}: C={C} T={T} nh={nh} freq={freq} bounded={bounded} n={n}"
+        ts = np.arange(T) / freq
+        l = np.arange(1, nh + 1)
+        want = {k: np.empty((C * T, n)) for k in ("q", "dq", "ddq")}
+        for c in range(C):
+            wl = wf[c] * l                                              # (nh,)
+            ang = ts[:, None] * wl[None, :]                             # (T, nh)
+            sn, cs = np.sin(ang), np.cos(ang)
+            if not bounded:
+                q = sn @ (a[c] / wl).T - cs @ (b[c] / wl).T + qo[c]
+                dq = cs @ a[c].T + sn @ b[c].T
+                ddq = -sn @ (a[c] * wl).T + cs @ (b[c] * wl).T
+            else:
+                raw = cs @ b[c].T + sn @ a[c].T
+                rd = cs @ (a[c] * wl).T - sn @ (b[c] * wl).T
+                rdd = -sn @ (a[c] * wl * wl).T - cs @ (b[c] * wl * wl).T
+                th = np.tanh(raw)
+                s2 = 1.0 - th * th
+                q = qo[c] + qr[c] * th
+                dq = qr[c] * s2 * rd
+                ddq = qr[c] * (s2 * rdd - 2.0 * th * s2 * rd * rd)
+            for k, v in (("q", q), ("dq", dq), ("ddq", ddq)):
+                want[k][c * T:(c + 1) * T] = v
+        got_h = eng.fourier_states(wf, a, b, qo, T, freq, q_range=qr, device=False)
+        got_d = eng.fourier_states(wf, a, b, qo, T, freq, q_range=qr, device=True)
+        for k in ("q", "dq", "ddq"):
+            scale = max(1.0, np.abs(want[k]).max())
+            assert np.abs(got_h[k] - want[k]).max() <= 1e-11 * scale, (why, k)
+            assert np.array_equal(got_d[k].cpu().numpy(), got_h[k]), (why, k, "device == host")
+        # factor merges
+        nn = int(rng.integers(1, 700))
+        R1, R2 = np.triu(rng.standard_normal((nn, nn))), np.triu(rng.standard_normal((nn, nn)))
+        if rng.random() < 0.4:  # a few dependent / zero columns
+            for j in rng.integers(0, nn, size=max(1, nn // 10)):
+                R1[:, j] = 0.0
+                R2[:, j] = 0.0 if rng.random() < 0.5 else R2[:, j]
+        Rm = eng.tsqr_merge(R1, R2)
+        G = R1.T @ R1 + R2.T @ R2
+        assert np.all(np.tril(Rm, -1) == 0) and np.all(np.isfinite(Rm)), (why, nn)
+        assert np.linalg.norm(Rm.T @ Rm - G) <= 1e-11 * max(np.linalg.norm(G), 1e-300), (why, nn, _rel(Rm.T @ Rm, G))
+        assert np.array_equal(Rm, eng.tsqr_merge(R1, R2)), (why, nn)
     finally:
         eng.close()
