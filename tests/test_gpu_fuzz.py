@@ -367,3 +367,69 @@ def test_random_fourier_candidates_and_factor_merges(case):
         assert np.array_equal(Rm, eng.tsqr_merge(R1, R2)), (why, nn)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("case", range(max(CASES // 4, 1)))
+def test_random_robot_through_the_class_level_pipeline(case, tmp_path):
+    """The host layer on robots that are none of the bundled ones: random tree (mixed joint types) -> topology file -> Model (structural
+    Gram on the device, pivoted QR, base projection) -> Data -> computeRegressors -> identification from the TSQR factor, against the same
+    pipeline on the oracle's materialised regressor: same independent columns, base parameters equal to NumPy's lstsq on YBase, the
+    noise-free torques reproduced, K x_true recovered."""
+    import numpy.linalg as la
+
+    from flobaroid_amd import estimation as est
+    from flobaroid_amd.data import Data
+    from flobaroid_amd.model import Model, pivoted_qr
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng([SEED, 50_000 + case])
+    L = int(rng.integers(3, 16))
+    floating = int(rng.random() < 0.5)
+    t = random_topology(rng, L, p_fixed=float(rng.choice([0.0, 0.3])), branchiness=float(rng.choice([0.0, 0.5, 1.0])), p_prismatic=float(rng.choice([0.0, 0.3])))
+    if t.num_dofs == 0:
+        pytest.skip("no joint")
+    t.limits = {j: {"lower": -2.0, "upper": 2.0, "velocity": 3.0, "torque": 100.0} for j in t.dof_names}
+    path = str(tmp_path / "random.topology.json")
+    t.save_json(path)
+    mode = str(rng.choice(["default", "reduced", "allcols"]))
+    eo = {"default": {}, "reduced": {"reduce_min_work": 0, "tsqr_group_min_samples": 1}, "allcols": {"link_merge": 0}}[mode]
+    opt = dict(floatingBase=floating, identifyFrictionSimultaneously=0, identifySymmetricVelFriction=1, identifyGravityParamsOnly=0,
+               simulateTorques=0, useAPriori=0, useStructuralRegressor=1, skipSamples=0, startOffset=0, verbose=0, showTiming=0,
+               filterRegressor=0, estimateWith="std", randomSamples=1500, minTol=1e-6, selectBlocksFromMeasurements=0, engineOptions=eo)
+    why = f"reproduce: FBR_FUZZ_SEED={SEED} case {50_000 + case}: L={L} floating={floating} mode={mode} n={t.num_dofs}"
+    np.random.seed(int(rng.integers(1 << 30)))
+    state = np.random.get_state()
+    model = Model(opt, path)
+    om = OracleModel(t, floating=bool(floating))
+    # the CPU path's structural Gram on the same random states
+    np.random.set_state(state)
+    st_r = model._random_states(1500)
+    Yr = om.regressor(st_r)
+    Q, R, P = pivoted_qr(Yr.T @ Yr)
+    r = int(np.count_nonzero(np.abs(np.diag(R)) > opt["minTol"]))
+    dg = np.abs(np.diag(R))
+    if r < len(dg) and r > 0 and dg[r - 1] < 1e3 * opt["minTol"]:
+        pytest.skip("a pivot within three decades of minTol: the rank is a matter of rounding")
+    assert model.num_base_params == r, why
+    assert np.array_equal(np.sort(np.asarray(model.independent_cols)), np.sort(P[:r])), why
+    # identification on noise-free data
+    S = 600
+    st = random_states(t, S, rng, floating, use_limits=True)
+    x_true = t.x_std()
+    tau = om.inverse_dynamics(st, x_true)
+    meas = {"positions": st["q"], "velocities": st["dq"], "accelerations": st["ddq"], "torques": tau[:, 6:] if floating else tau, "times": np.arange(S) / 200.0}
+    if floating:
+        meas.update(base_velocity=st["base_vel"], base_acceleration=st["base_acc"], base_rpy=st["rpy"])
+    data = Data(opt)
+    data.init_from_data(meas)
+    model.computeRegressors(data)
+    Yo = om.regressor(st)
+    assert np.abs(np.asarray(model.YStd) - Yo).max() <= 1e-11 * max(1.0, np.abs(Yo).max()), why
+    ic = np.asarray(model.independent_cols)
+    xb_ref = la.lstsq(Yo[:, ic], model.tau, rcond=None)[0]
+    R_aug = model.engine.tsqr(model._states, rhs=np.stack((model.tau, model.contactForcesSum), axis=1))
+    xB, Rb, s = est.identify_base_parameters(R_aug, model.independent_cols, model.num_identified_params, Yo.shape[0])
+    assert la.norm(xB - xb_ref) <= 1e-7 * max(la.norm(xb_ref), 1e-300), (why, la.norm(xB - xb_ref) / la.norm(xb_ref))
+    assert la.norm(Yo[:, ic] @ xB - model.tau) <= 1e-8 * la.norm(model.tau), why          # noise-free: the torques are reproduced
+    xb_true = model.K @ x_true[model.identified_params]
+    assert la.norm(xB - xb_true) <= 1e-5 * max(la.norm(xb_true), 1e-300), (why, la.norm(xB - xb_true) / la.norm(xb_true))
