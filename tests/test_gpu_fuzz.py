@@ -433,3 +433,31 @@ def test_random_robot_through_the_class_level_pipeline(case, tmp_path):
     assert la.norm(Yo[:, ic] @ xB - model.tau) <= 1e-8 * la.norm(model.tau), why          # noise-free: the torques are reproduced
     xb_true = model.K @ x_true[model.identified_params]
     assert la.norm(xB - xb_true) <= 1e-5 * max(la.norm(xb_true), 1e-300), (why, la.norm(xB - xb_true) / la.norm(xb_true))
+
+
+@pytest.mark.parametrize("opts", [{}, {"reduce_min_work": 0, "tsqr_group_min_samples": 1}], ids=["default", "reduced"])
+def test_non_finite_inputs_come_back_and_leave_the_handle_usable(opts):
+    """A NaN, an Inf or an overflowing value in the states of one sample: every call returns (non-finite results, no wait that never ends in
+    the flag protocols of the factorisation) and the next call on clean inputs is right."""
+    from common import load_topo
+    from flobaroid_amd._lib import Engine
+
+    t = load_topo("walkman_apriori")
+    rng = np.random.default_rng(0)
+    S = 3000
+    eng = Engine(t, floating=True, options=opts)
+    try:
+        st = random_states(t, S, rng, True)
+        rhs = rng.standard_normal((S * 35, 1))
+        G0 = eng.gram(st, rhs=rhs)
+        for bad in (np.nan, np.inf, 1e300):
+            s2 = {k: v.copy() for k, v in st.items()}
+            s2["ddq"][S // 2, 3] = bad
+            s2["q"][7, 0] = bad if np.isfinite(bad) else 1e18
+            G = eng.gram(s2, rhs=rhs)
+            R = eng.tsqr(s2, rhs=rhs)
+            eng.predict(s2, rng.standard_normal(480))
+            assert not np.isfinite(G).all() and not np.isfinite(R).all()
+            assert np.array_equal(eng.gram(st, rhs=rhs), G0)
+    finally:
+        eng.close()
