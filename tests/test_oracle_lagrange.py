@@ -83,7 +83,7 @@ def _lagrange_regressor(t, gravity=(0.0, 0.0, -9.81)):
 
 
 _SLOW = pytest.mark.skipif(not __import__("os").environ.get("FBR_SLOW_TESTS"), reason="minutes of symbolic differentiation: FBR_SLOW_TESTS=1 (run and green "
-                           "when the test was written: 5 fixed-base cases in 46 s, 3 floating-base cases in 311 s)")
+                           "when the test was written: 5 fixed-base cases in 46 s, 3 floating-base cases in 311 s, the fourth contact case in 69 s)")
 
 
 @pytest.mark.parametrize("seed,L,p_fixed,branch,p_prism", [(1, 3, 0.0, 0.0, 0.0), pytest.param(2, 4, 0.0, 0.5, 0.0, marks=_SLOW), (3, 4, 0.25, 0.5, 0.4),
@@ -220,3 +220,72 @@ def test_oracle_floating_base_rows_are_the_mixed_generalised_forces(seed, L, p_f
         scale = max(1.0, np.abs(Ys).max())
         err = np.abs(Yo[s] - Ys)
         assert err.max() <= 1e-9 * scale, (seed, s, "base rows" if err[:6].max() == err.max() else "joint rows", err.max())
+
+
+@pytest.mark.parametrize("seed,L,floating,p_prism", [(21, 4, 0, 0.0), (22, 4, 0, 0.5), (23, 3, 1, 0.0), pytest.param(24, 4, 1, 0.4, marks=_SLOW)])
+def test_oracle_contact_torques_are_the_virtual_work_of_the_wrench(seed, L, floating, p_prism):
+    """A4 (J^T w, model.py:535-549) from the principle of virtual work: a wrench (f, n) in world axes at the origin of a frame fixed to a
+    link does the work f . dp + n . dtheta on a virtual displacement; with p(x), w = J_w(x) dx/dt derived symbolically from the
+    kinematics, the generalised forces are (dp/dx)^T f + J_w^T n -- for a floating base in the true coordinates (position,
+    roll-pitch-yaw), the moment rows mapped to world axes by E^-T as in the regressor test above."""
+    from scipy.spatial.transform import Rotation
+
+    from oracle.oracle import OracleModel
+
+    rng = np.random.default_rng(3000 + seed)
+    t = random_topology(rng, L, p_fixed=0.2, branchiness=0.5, p_prismatic=p_prism)
+    if t.num_dofs == 0:
+        pytest.skip("no joint")
+    n = t.num_dofs
+    fl = L - 1
+    fR, fp = Rotation.random(random_state=seed).as_matrix(), 0.3 * rng.standard_normal(3)
+    t.frames = {"tool": {"link": fl, "R": fR, "p": fp}}
+    pb = sp.symbols("pb0:3", real=True)
+    ph = sp.symbols("ph0:3", real=True)
+    q = sp.symbols("q0:%d" % n, real=True)
+    x = (list(pb) + list(ph) if floating else []) + list(q)
+    dx = list(sp.symbols("dx0:%d" % len(x), real=True))
+    r_, p_, y_ = ph
+    Rz = sp.Matrix([[sp.cos(y_), -sp.sin(y_), 0], [sp.sin(y_), sp.cos(y_), 0], [0, 0, 1]])
+    Ry = sp.Matrix([[sp.cos(p_), 0, sp.sin(p_)], [0, 1, 0], [-sp.sin(p_), 0, sp.cos(p_)]])
+    Rx = sp.Matrix([[1, 0, 0], [0, sp.cos(r_), -sp.sin(r_)], [0, sp.sin(r_), sp.cos(r_)]])
+    R, p = [None] * L, [None] * L
+    for l in range(L):
+        par = t.parent[l]
+        if par < 0:
+            R[l], p[l] = ((Rz * Ry * Rx).T, sp.Matrix(pb)) if floating else (sp.eye(3), sp.zeros(3, 1))
+            continue
+        rest_R = sp.Matrix(np.asarray(t.rest_R[l], dtype=float))
+        rest_p = sp.Matrix(np.asarray(t.rest_p[l], dtype=float))
+        ax = [float(a) for a in t.axis[l]]
+        d = t.dof_index[l]
+        if t.joint_type[l] == 1:
+            R[l], p[l] = R[par] * rest_R * _rodrigues(ax, q[d]), p[par] + R[par] * rest_p
+        elif t.joint_type[l] == 2:
+            R[l], p[l] = R[par] * rest_R, p[par] + R[par] * (rest_p + rest_R * sp.Matrix(ax) * q[d])
+        else:
+            R[l], p[l] = R[par] * rest_R, p[par] + R[par] * rest_p
+    pf = p[fl] + R[fl] * sp.Matrix(fp)
+    N = len(x)
+    W = R[fl].applyfunc(lambda e: sum(sp.diff(e, x[k]) * dx[k] for k in range(N))) * R[fl].T
+    w = sp.Matrix([W[2, 1], W[0, 2], W[1, 0]])
+    Jp, Jw = pf.jacobian(sp.Matrix(x)), w.jacobian(sp.Matrix(dx))
+    fJ = sp.lambdify([x], [Jp, Jw], modules="numpy")
+    if floating:
+        Wb = R[0].applyfunc(lambda e: sum(sp.diff(e, ph[k]) * dx[3 + k] for k in range(3))) * R[0].T
+        E = sp.Matrix([Wb[2, 1], Wb[0, 2], Wb[1, 0]]).jacobian(sp.Matrix(dx[3:6]))
+        fE = sp.lambdify([ph], E, modules="numpy")
+    om = OracleModel(t, floating=bool(floating))
+    S = 6
+    st = random_states(t, S, rng, floating)
+    if floating:
+        st["rpy"] = rng.uniform(-1.2, 1.2, (S, 3))
+    wr = rng.standard_normal((S, 6))
+    got = om.contact_torques(st, "tool", wr)
+    for s in range(S):
+        xv = ([0.0, 0.0, 0.0] + list(st["rpy"][s]) if floating else []) + list(st["q"][s])
+        Jpv, Jwv = (np.asarray(m_, dtype=float) for m_ in fJ(xv))
+        Q = Jpv.T @ wr[s, :3] + Jwv.T @ wr[s, 3:]
+        if floating:
+            Q[3:6] = np.linalg.solve(np.asarray(fE(list(st["rpy"][s])), dtype=float).T, Q[3:6])
+        assert np.abs(got[s] - Q).max() <= 1e-11 * max(1.0, np.abs(Q).max()), (seed, s, np.abs(got[s] - Q).max())
