@@ -265,6 +265,35 @@ template <int PF> __global__ __launch_bounds__(64) void kin_stream(DevModel m, l
     }
 }
 
+// The consumer side of an interleaved record layout: what every per-sample consumer (the tile-image packer, the regressor writers) does
+// first -- one workgroup per sample copies the sample's record into the LDS -- (0) from contiguous records, (1) from records interleaved
+// over 16 samples ([s / 16][field][s % 16]: 8 bytes per 128-byte line, the sixteen consumers of a tile spread over all XCDs by their
+// block index), (2) the same with the sixteen samples of a tile dealt to workgroups of ONE XCD (block index mod 8), so that the tile's
+// lines are fetched into one L2 only.
+template <int MODE> __global__ __launch_bounds__(256) void consume_kernel(long S, int recsz, const double *__restrict__ rec, double *__restrict__ out)
+{
+    extern __shared__ double rs[];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    const long nb = gridDim.x;
+    for (long k = 0;; k++) {
+        long s;
+        if (MODE == 2) {
+            const long xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) + k * (nb >> 3);
+            s = ((slot >> 4) * 8 + xcd) * 16 + (slot & 15);
+        } else {
+            s = blockIdx.x + k * nb;
+        }
+        if (s >= S) break;
+        __syncthreads();
+        for (int i = tid; i < recsz; i += 256)
+            rs[i] = MODE == 0 ? rec[s * (long)recsz + i] : rec[(s & ~15L) * (long)recsz + (long)i * 16 + (s & 15)];
+        __syncthreads();
+        acc += rs[(tid * 3) % recsz] + rs[(tid * 7 + 1) % recsz];
+    }
+    out[(long)blockIdx.x * 256 + tid] = acc;
+}
+
 template <typename T> static T *up(const std::vector<T> &v)
 {
     T *d;
@@ -414,5 +443,29 @@ int main()
     run<64, 2>("states joint-major (coalesced loads)", m, S, st, rec, chk);
     run<32 + 16 + 64, 2>("both", m, S, st, rec, chk);
     run<32 + 16 + 64, 3>("both, 3 workgroups per CU asked for", m, S, st, rec, chk);
+    {
+        const int grid = 256 * 24;
+        double *out;
+        hipMalloc(&out, (size_t)grid * 256 * 8);
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        const char *names[3] = {"contiguous records", "interleaved by 16 samples, consumers dealt by block index", "interleaved by 16 samples, a tile's consumers on one XCD"};
+        for (int mode = 0; mode < 3; mode++) {
+            float best = 1e9f;
+            for (int it = 0; it < 4; it++) {
+                hipEventRecord(a, 0);
+                if (mode == 0) hipLaunchKernelGGL(consume_kernel<0>, dim3(grid), dim3(256), m.rec * 8, 0, S, m.rec, rec, out);
+                if (mode == 1) hipLaunchKernelGGL(consume_kernel<1>, dim3(grid), dim3(256), m.rec * 8, 0, S, m.rec, rec, out);
+                if (mode == 2) hipLaunchKernelGGL(consume_kernel<2>, dim3(grid), dim3(256), m.rec * 8, 0, S, m.rec, rec, out);
+                hipEventRecord(b, 0);
+                hipEventSynchronize(b);
+                float ms;
+                hipEventElapsedTime(&ms, a, b);
+                if (it) best = ms < best ? ms : best;
+            }
+            printf("consumer-side stage copy of 1 M records (one workgroup per sample), %-58s %7.3f ms\n", names[mode], best);
+        }
+    }
     return 0;
 }
