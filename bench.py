@@ -841,6 +841,7 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
             out["cpu_baseline_all_cores"] = {"error": repr(e)}
         try:
             bc, _, _ = cpu_phases_bc_and_parity(eng, topo)
+            out["parity"] = bc.pop("parity", None)  # (top level: GPU vs CPU path on the same inputs, the SDP statement)
             out["cpu_baseline_phases"] = bc
         except Exception as e:
             out["cpu_baseline_phases"] = {"error": repr(e)}
