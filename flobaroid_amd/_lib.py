@@ -144,6 +144,7 @@ _SIGNATURES = {
 # Options every new Engine starts with (``fbr_model_set_option``, include/fbr.h lists the keys), on top of the library's defaults and below
 # the ``options`` argument of the constructor.  A plain Python dict: the library itself never reads the process environment.  The test
 # suite uses it to run whole modules with the column reductions forced / switched off (tests/conftest.py: reduction_mode).
+FBR_VERSION = 101  # include/fbr.h FBR_VERSION: the C-ABI these ctypes signatures describe
 DEFAULT_OPTIONS: dict = {}
 
 
@@ -169,6 +170,10 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    got = int(lib.fbr_version())
+    if got != FBR_VERSION:
+        raise FbrError(f"{LIB_PATH} reports C-ABI version {got}, this binding was written for {FBR_VERSION} (include/fbr.h FBR_VERSION): "
+                       "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'` -- signatures have changed between the two")
     _lib = lib
     return lib
 

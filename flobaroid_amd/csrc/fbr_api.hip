@@ -8,7 +8,9 @@
 thread_local std::string g_fbr_err;
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int fbr_version(void) { return 100; }
+// 101 (round 6): fbr_topology.joint_type, the num_samples argument of fbr_gram_program_info / fbr_model_link_merge_info (both added in
+// round 5 under 100), option "fused_id".  flobaroid_amd/_lib.py refuses a library of another version than the header it was written for.
+extern "C" int fbr_version(void) { return FBR_VERSION; }
 
 // The HIP runtime does not survive fork(): a child that inherits an initialised runtime hangs or fails in its first call.  The
 // reference's multi-process users build one Model per worker AFTER the fork (analyticalGradient.py:188-210); this records the process
@@ -155,6 +157,16 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
     if ((rc = upload(m->tables, sub_begin, &dm.sub_begin))) return rc;
     if ((rc = upload(m->tables, sub_links, &dm.sub_links))) return rc;
     if ((rc = upload(m->tables, dof_link, &dm.dof_link))) return rc;
+    if (hm.maxdepth <= FBR_KINID_MAXD) {
+        try {
+            fbr_kinid_build(hm, m->kinid);
+        } catch (const std::exception &e) {
+            set_err(std::string("internal: ") + e.what());
+            return FBR_E_INVALID;
+        }
+        if ((rc = upload(m->tables, m->kinid.steps, &m->kinid_steps))) return rc;
+        if ((rc = upload(m->tables, m->kinid.endflush, &m->kinid_endflush))) return rc;
+    }
     if (allow_merge) {  // (always built; the options "link_merge" / "regroup" decide per call whether they are used)
         if ((rc = build_reduction(m.get(), t, 0))) return rc;
         if ((rc = build_reduction(m.get(), t, 1))) return rc;
@@ -575,6 +587,39 @@ static int run_id(fbr_model *m, const fbr_states *st, const double *x, int nx, c
     if (out_mem == FBR_HOST) {
         if ((rc = m->out_tmp.ensure((size_t)S * hm.rows * sizeof(double)))) return rc;
         dst = m->out_tmp.as<double>();
+    }
+    if (m->opt.fused_id != 0 && m->kinid.nsteps > 0) {
+        // one kernel, one lane per sample: the link records stay in registers, branch-point records in a per-wave scratch (fbr_kinid.h)
+        DevKinId kp;
+        kp.nsteps = m->kinid.nsteps;
+        kp.maxlvl = m->kinid.maxlvl;
+        kp.nslots = m->kinid.nslots;
+        kp.ldn = std::max(hm.n, 1) | 1;
+        kp.steps = m->kinid_steps;
+        kp.endflush = m->kinid_endflush;
+        const size_t lds = (size_t)3 * 64 * kp.ldn * sizeof(double);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 << 10) / std::max<size_t>(lds, 1)));
+        const long nblk = (S + 63) / 64;
+        const int blocks = (int)std::min<long>(nblk, (long)m->num_cus * per_cu);
+        if ((rc = m->kinid_scratch.ensure((size_t)blocks * std::max(kp.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
+        ProfScope ps(m, FBR_PROF_ID);
+#define FBR_KINID_LAUNCH(D)                                                                                                              \
+    do {                                                                                                                                 \
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_kinid_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL(fbr_kinid_kernel<D>, dim3(blocks), dim3(64), lds, m->stream, m->dm, kp, S, d.q, d.dq, d.ddq, d.bv, d.ba, d.rpy, \
+                           d.sign, dvs, m->st_x.as<double>(), mode, dst, m->kinid_scratch.as<double>());                                 \
+    } while (0)
+        if (kp.maxlvl <= 4)
+            FBR_KINID_LAUNCH(4);
+        else if (kp.maxlvl <= 8)
+            FBR_KINID_LAUNCH(8);
+        else if (kp.maxlvl <= 12)
+            FBR_KINID_LAUNCH(12);
+        else
+            FBR_KINID_LAUNCH(FBR_KINID_MAXD);
+#undef FBR_KINID_LAUNCH
+        HIPCHK(hipGetLastError());
+        return finish_output(m, dst, tau_out, (size_t)S * hm.rows, out_mem);
     }
     const int waves = 4;
     const size_t lds = (size_t)waves * (hm.rec_size() + 6 * hm.L) * sizeof(double);

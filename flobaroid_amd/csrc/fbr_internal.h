@@ -18,6 +18,7 @@
 #include "../../include/fbr.h"
 #include "fbr_options.h"
 #include "fbr_kernels.h"
+#include "fbr_kinid.h"
 #include "fbr_tsqr_work.h"
 
 extern thread_local std::string g_fbr_err;
@@ -132,6 +133,9 @@ struct fbr_model {
     DevBuf st_chunk[2];       // per-chunk staging of pinned host inputs (fused Gram pass), double buffered with the tile images
     DevBuf fd[7];             // expanded states of the finite-difference sweep (q, dq, ddq, base_vel, base_acc, rpy, sign)
     DevBuf row_flags;         // active_rows(): per regressor row, does any sample weight it
+    FbrKinIdProgram kinid;    // program of the fused kinematics + torque kernel (fbr_kinid.h); nsteps == 0: not available for this tree
+    const int *kinid_steps = nullptr, *kinid_endflush = nullptr;
+    DevBuf kinid_scratch;     // branch-point records of the waves in flight
     DevBuf fd_tab, fd_part;   // sub-tree column lists of every joint [n + 1 | entries] (built on first use), baseline partial sums [S][n]
     int fd_tab_entries = -1;
     FbrTsqrWork tsqr;

@@ -1,0 +1,279 @@
+// fbr_kinid.h -- kinematics + inverse dynamics / prediction FUSED, one lane per sample, the link records never leave the registers.
+//
+// Replaces the pair fbr_kin_kernel (one lane per sample, 9.5 KB of records written per WALK-MAN sample in partially filled lines) +
+// fbr_id_kernel (one wave per sample, the records read back) on the calls that need torques only: fbr_predict (A9, identifier.py:135-141),
+// fbr_inverse_dynamics_batch (A3, identification/model.py:239-331, and the simulated base wrench of every floating-base pass,
+// model.py:398-413).  The round-5 review priced the pair at 18.9 KB per sample staged through HBM for 1.1 KB of algorithmic I/O.
+//
+// Formulation (base-frame composite): with F_l = W_l pi_l the wrench of link l in frame A and S_d the motion vector of
+// joint d in A,   base rows = sum_l F_l,   tau_d = S_d . sum_{l below d} F_l.   The links are walked parents first (FbrHostModel::order,
+// a depth-first order); every lane carries
+//   * the record of the link before (the parent of a chain's next link) in registers,
+//   * a STACK of the ancestor joints' motion vectors and torque accumulators, indexed by the joint's depth on the path (<= MAXD levels):
+//     F_l is added to every ancestor's accumulator when it is formed; a level is written out when another joint takes it,
+//   * the records of branch points (links with a child that is not walked right after them) in a per-wave scratch, lanes interleaved
+//     (512-byte coalesced lines; 2 records per WALK-MAN sample).
+// All lanes of a wave walk the same link at the same time, so every index into the stacks is wave-uniform: the stacks live in
+// registers behind scalar branches, never in scratch memory.  The states of a wave's 64 samples are staged through the LDS with
+// coalesced loads (a lane reading q[s][d] straight from the row-major arrays touches 64 lines per instruction: 16 x the bytes).
+//
+// The program (steps, flush lists, slots) is built on the host by fbr_kinid_build -- HIP-free, so that tests/emul runs the same
+// program and the same lane body (fbr_kinid_lane) on the CPU (checked there against the CPU restatement of the reference).
+#pragma once
+#include <vector>
+
+#include "fbr_math.h"
+#include "fbr_program.h"
+
+#define FBR_KINID_STEP 8  // ints per step: link, psrc, psave, jtype, dof, level, depth, flushdof
+#define FBR_KINID_MAXD 24 // deepest joint path the register-stack instances cover (deeper trees keep the two-kernel path)
+
+struct FbrKinIdProgram {
+    int nsteps = 0, maxlvl = 0, nslots = 0;
+    std::vector<int> steps;     // [nsteps][FBR_KINID_STEP]
+    std::vector<int> endflush;  // [maxlvl] dof left on level v after the last link (-1: none)
+};
+
+// psrc: -1 base link; 0 the parent is the link of the step before (its record is in registers); 1 + b: the parent's record is in slot b.
+// psave: slot this link's record is saved to (a later link that is not the next step has it as parent), or -1.
+// level: 0-based depth of the link's own joint on its path (-1: fixed joint / base); depth: joints on the link's path (own one included).
+// flushdof: the dof that held `level` until now and is complete (every link below it has been walked), or -1.
+static inline void fbr_kinid_build(const FbrHostModel &hm, FbrKinIdProgram &p)
+{
+    const int L = hm.L;
+    p.nsteps = L;
+    p.steps.assign((size_t)L * FBR_KINID_STEP, -1);
+    std::vector<int> pos(L, 0), lastchild(L, -1);  // step of every link; the last step whose parent it is
+    for (int k = 0; k < L; k++) pos[hm.order[k]] = k;
+    for (int k = 0; k < L; k++) {
+        const int par = hm.parent[hm.order[k]];
+        if (par >= 0) lastchild[par] = std::max(lastchild[par], k);
+    }
+    // slots: a link holds one from its own step to the step of its last child whenever that child is not the very next step
+    std::vector<int> slot(L, -1), holder;  // holder[b]: link that holds slot b, or -1
+    int maxlvl = 0;
+    std::vector<int> lvldof(std::max(hm.maxdepth, 1), -1);
+    for (int k = 0; k < L; k++) {
+        const int l = hm.order[k], par = hm.parent[l];
+        int *st = &p.steps[(size_t)k * FBR_KINID_STEP];
+        for (int &h : holder)
+            if (h >= 0 && lastchild[h] < k) h = -1;  // (its last child has been walked)
+        st[0] = l;
+        st[1] = par < 0 ? -1 : (k > 0 && hm.order[k - 1] == par ? 0 : 1 + slot[par]);
+        if (par >= 0 && st[1] != 0 && (slot[par] < 0 || holder[slot[par]] != par)) throw std::runtime_error("fbr_kinid_build: parent record not held");
+        st[2] = -1;
+        if (lastchild[l] > k + 1) {  // some child comes later than the next step
+            int b = 0;
+            while (b < (int)holder.size() && holder[b] >= 0) b++;
+            if (b == (int)holder.size()) holder.push_back(-1);
+            holder[b] = l;
+            slot[l] = st[2] = b;
+        }
+        st[3] = hm.jtype[l];
+        st[4] = hm.dof[l];
+        const int depth = (int)hm.path[l].size();
+        st[5] = (par >= 0 && hm.dof[l] >= 0) ? depth - 1 : -1;
+        st[6] = depth;
+        st[7] = -1;
+        if (st[5] >= 0) {
+            // the joint that held this level is complete: every link below it has been walked (a link adds to level v only if its
+            // path has more than v joints, i.e. passes through the joint that holds level v at that moment)
+            st[7] = lvldof[st[5]];
+            lvldof[st[5]] = hm.dof[l];
+            maxlvl = std::max(maxlvl, st[5] + 1);
+        }
+    }
+    const int nslots = (int)holder.size();
+    p.nslots = nslots;
+    p.maxlvl = maxlvl;
+    p.endflush.assign(std::max(maxlvl, 1), -1);
+    for (int v = 0; v < maxlvl; v++) p.endflush[v] = lvldof[v];
+}
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define FBR_UNI(x) __builtin_amdgcn_readfirstlane(x)  // the program is the same for every lane: keep it in scalar registers
+#else
+#define FBR_UNI(x) (x)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// One lane = one sample.  StateFn(d, q, dq, ddq): joint state of dof d; BaseFn(bv6, ba6, rpy3); Slot: save(b, i, v) / load(b, i);
+// PiFn(l, pi10): the ten parameters of link l; Emit(row, value): regressor row `row` of this sample (value without friction for joint
+// rows: the caller adds it).  `steps` / `endflush` of FbrKinIdProgram; every table access is wave-uniform.
+// ------------------------------------------------------------------------------------------------
+template <int MAXD, class StateFn, class BaseFn, class SlotSave, class SlotLoad, class PiFn, class EmitFn, class ConstFn>
+FBR_HD void fbr_kinid_lane(int nsteps, int maxlvl, const int *steps, const int *endflush, int floating, const double *g, int fb,
+                           StateFn state, BaseFn basest, SlotSave save, SlotLoad load, PiFn getpi, EmitFn emit, ConstFn consts)
+{
+    double P[FBR_LINK_REC];
+    double Sst[MAXD][6], tac[MAXD];
+    double T[6] = {0, 0, 0, 0, 0, 0};
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < MAXD; j++) {
+        tac[j] = 0.0;
+        for (int i = 0; i < 6; i++) Sst[j][i] = 0.0;
+    }
+    for (int k = 0; k < nsteps; k++) {
+        const int *st = steps + k * FBR_KINID_STEP;
+        const int l = FBR_UNI(st[0]), psrc = FBR_UNI(st[1]), psave = FBR_UNI(st[2]), jt = FBR_UNI(st[3]), d = FBR_UNI(st[4]), lvl = FBR_UNI(st[5]),
+                  depth = FBR_UNI(st[6]), fd = FBR_UNI(st[7]);
+        double out[FBR_LINK_REC], Sv[6] = {0, 0, 0, 0, 0, 0};
+        if (psrc < 0) {
+            double v6[6] = {0, 0, 0, 0, 0, 0}, a6[6] = {0, 0, 0, 0, 0, 0}, e3[3] = {0, 0, 0};
+            if (floating) basest(v6, a6, e3);
+            fbr_kin_base(floating, g, v6, a6, e3, out);
+        } else {
+            if (psrc > 0)
+                for (int i = 0; i < FBR_LINK_REC; i++) P[i] = load(psrc - 1, i);
+            double rR[9], rp[3], ax[3];
+            consts(l, rR, rp, ax);
+            double qv = 0, dqv = 0, ddqv = 0;
+            if (d >= 0) state(d, qv, dqv, ddqv);
+            fbr_kin_child(P, rR, rp, ax, jt, qv, dqv, ddqv, out, Sv);
+        }
+        if (psave >= 0)
+            for (int i = 0; i < FBR_LINK_REC; i++) save(psave, i, out[i]);
+        for (int i = 0; i < FBR_LINK_REC; i++) P[i] = out[i];
+        // the joint takes its level: whoever held it is complete
+        if (lvl >= 0) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int j = 0; j < MAXD; j++)
+                if (j == lvl) {
+                    if (fd >= 0) emit(fb + fd, tac[j]);
+                    tac[j] = 0.0;
+                    for (int i = 0; i < 6; i++) Sst[j][i] = Sv[i];
+                }
+        }
+        double pi[10], F[6];
+        getpi(l, pi);
+        fbr_link_wrench(out, pi, F);
+        for (int i = 0; i < 6; i++) T[i] += F[i];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int j = 0; j < MAXD; j++)
+            if (j < depth) tac[j] += fbr_dot6(Sst[j], F);
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < MAXD; j++)
+        if (j < maxlvl) {
+            const int fd = FBR_UNI(endflush[j]);
+            if (fd >= 0) emit(fb + fd, tac[j]);
+        }
+    for (int r = 0; r < fb; r++) emit(r, T[r]);
+}
+
+#if defined(__HIPCC__) && defined(FBR_KERNELS_CORE)
+struct DevKinId {
+    int nsteps, maxlvl, nslots, ldn;  // ldn: row stride (doubles, odd) of the staged joint states of one sample
+    const int *steps, *endflush;
+};
+
+// mode 0: x = full standard vector (10 per link + friction slots); mode 1: x = identified-parameter vector (cols).
+// grid-stride over blocks of 64 samples; dynamic LDS: 3 x [64][ldn] doubles (q, dq, ddq of the wave's samples).
+// scratch: [gridDim.x][nslots][FBR_LINK_REC][64] doubles.
+template <int MAXD>
+__global__ __launch_bounds__(64) void fbr_kinid_kernel(DevModel m, DevKinId p, long S, const double *__restrict__ q, const double *__restrict__ dq,
+                                                       const double *__restrict__ ddq, const double *__restrict__ bv,
+                                                       const double *__restrict__ ba, const double *__restrict__ rpy,
+                                                       const double *__restrict__ sign, const double *__restrict__ vel_sign,
+                                                       const double *__restrict__ x, int mode, double *__restrict__ tau, double *__restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x, n = m.n, ldn = p.ldn;
+    double *sq = smem, *sdq = sq + 64 * ldn, *sddq = sdq + 64 * ldn;
+    double *scr = scratch + (long)blockIdx.x * p.nslots * FBR_LINK_REC * 64 + lane;
+    const long nblk = (S + 63) >> 6;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long base = blk << 6;
+        const int valid = (int)min(64L, S - base);
+        __syncthreads();  // (the block before has read its states)
+        {
+            // coalesced copy of the block's q / dq / ddq rows into [sample][ldn]
+            const long off = base * n;
+            const int cnt = valid * n;
+            int sr = lane / n, dc = lane - sr * n;
+            const int ds = 64 / n, dd = 64 - ds * n;
+            for (int i = lane; i < cnt; i += 64) {
+                const double a = q[off + i], b = dq[off + i], c = ddq[off + i];
+                sq[sr * ldn + dc] = a;
+                sdq[sr * ldn + dc] = b;
+                sddq[sr * ldn + dc] = c;
+                sr += ds;
+                dc += dd;
+                if (dc >= n) {
+                    dc -= n;
+                    sr++;
+                }
+            }
+        }
+        __syncthreads();
+        const int ls = min(lane, valid - 1);  // lanes behind the last sample repeat it and store nothing
+        const long s = base + ls;
+        const bool live = lane < valid;
+        const double *mysq = sq + ls * ldn, *mysdq = sdq + ls * ldn, *mysddq = sddq + ls * ldn;
+        double *ts = tau + s * m.rows;
+        auto state = [&](int d, double &a, double &b, double &c) {
+            a = mysq[d];
+            b = mysdq[d];
+            c = mysddq[d];
+        };
+        auto basest = [&](double *v6, double *a6, double *e3) {
+            for (int i = 0; i < 6; i++) {
+                v6[i] = bv[s * 6 + i];
+                a6[i] = ba[s * 6 + i];
+            }
+            for (int i = 0; i < 3; i++) e3[i] = rpy[s * 3 + i];
+        };
+        auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
+        auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
+        auto getpi = [&](int l, double *pi) {
+            if (mode == 0) {
+                for (int c = 0; c < 10; c++) pi[c] = x[10 * l + c];
+            } else {
+                for (int c = 0; c < 10; c++) pi[c] = (c < m.cpl) ? x[m.cpl * l + c] : 0.0;
+            }
+        };
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {
+            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+            for (int i = 0; i < 3; i++) {
+                rp[i] = m.restp[3 * l + i];
+                ax[i] = m.axis[3 * l + i];
+            }
+        };
+        auto emit = [&](int r, double v) {
+            if (r >= m.fb && m.fric) {
+                const int d = r - m.fb;
+                const double dqv = mysdq[d];
+                const double sg = sign[s * n + d];
+                if (mode == 0) {
+                    double t = sg * x[m.fstart + d];
+                    if (!m.grav_only) {
+                        t += x[m.fstart + n + d] * dqv;
+                        const int poff = m.fstart + 2 * n;
+                        t += x[poff + d];
+                        if (m.stribeck > 0) {
+                            const double sgn = (sg > 0) - (sg < 0);
+                            t += x[poff + n + d] * exp(-fabs(vel_sign[s * n + d]) / m.stribeck) * sgn;
+                        }
+                    }
+                    v += t;
+                } else {
+                    for (int c = m.cpl * m.L; c < m.cols; c++) {
+                        const int4 cd = m.coldesc[c];
+                        if (cd.w == d) v += x[c] * fbr_friction_value(cd.z, dqv, sg, m.stribeck);
+                    }
+                }
+            }
+            if (live) ts[r] = v;
+        };
+        fbr_kinid_lane<MAXD>(p.nsteps, p.maxlvl, p.steps, p.endflush, m.floating, m.g, m.fb, state, basest, save, load, getpi, emit, consts);
+    }
+}
+#endif

@@ -14,6 +14,8 @@ struct FbrOptions {
     double chunk_samples = 0;               // > 0: samples per chunk (tests force the multi-chunk paths at small sizes); 0: by memory
     double min_chunks = 4;                  // a short fused pass is still cut into this many chunks (the first producer launch is not hidden)
     double h2d_chunked = 1;                 // pinned host inputs are staged chunk by chunk on a copy stream
+    // ---- per-sample entry points
+    double fused_id = 1;                    // fbr_predict / fbr_inverse_dynamics_batch: kinematics + torques in one kernel, no records in HBM (0: two kernels)
     // ---- fused Gram program
     double gram_shape = 0;                  // 0: by model, 1: one workgroup per CU (18 accumulators), 2: two per CU (10)
     double gram_rhs_tile = 0;               // 1: dense rhs tiles even for k <= 2 (default: tau's products come from the pack kernel)
@@ -48,6 +50,7 @@ static inline const FbrOptionKey *fbr_option_keys(int *count)
         {"chunk_samples", &FbrOptions::chunk_samples, false},
         {"min_chunks", &FbrOptions::min_chunks, false},
         {"h2d_chunked", &FbrOptions::h2d_chunked, false},
+        {"fused_id", &FbrOptions::fused_id, false},
         {"gram_shape", &FbrOptions::gram_shape, true},
         {"gram_rhs_tile", &FbrOptions::gram_rhs_tile, true},
         {"gram_orient", &FbrOptions::gram_orient, true},

@@ -3,8 +3,8 @@
 The path shards by trajectory samples (they are independent, identification/model.py:370); the only
 exchange steps are
   * one all-reduce (sum) of the (P+k)^2 fp64 Gram (<= 1.9 MB for WALK-MAN: latency bound, one fused buffer), and
-  * a binary tree over the ranks for the TSQR factor: log2(N) rounds, each a point-to-point send of an R factor
-    over a direct xGMI link followed by ``fbr_tsqr_merge`` on the receiver, then a broadcast of the result.
+  * a binary tree over the ranks for the TSQR factor: log2(N) rounds, each a point-to-point send of an R factor's packed upper
+    triangle over a direct xGMI link followed by ``fbr_tsqr_merge`` on the receiver, then (optionally) a broadcast of the result.
 The same functions run on CPU tensors with the gloo backend (that is how the N > 1 logic is tested without GPUs).
 """
 from __future__ import annotations
@@ -56,10 +56,44 @@ def warm_p2p(device=None, group=None) -> None:
     dist.broadcast(x, src=g(0), group=group)
 
 
-def tsqr_tree(R: torch.Tensor, merge: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], group=None) -> torch.Tensor:
-    """Binary-tree reduction of per-rank triangular factors; every rank returns the global factor.
+_TRIU_CACHE: dict = {}
 
-    ``merge(Ra, Rb)`` must return the R factor of [Ra; Rb] (``Engine.tsqr_merge`` on the GPU)."""
+
+def _triu_index(n: int, device) -> torch.Tensor:
+    """Flat positions of the upper triangle (row-major) of an n x n matrix, cached per (n, device)."""
+    key = (int(n), str(device))
+    idx = _TRIU_CACHE.get(key)
+    if idx is None:
+        iu = torch.triu_indices(n, n, device=device)
+        idx = _TRIU_CACHE[key] = (iu[0] * n + iu[1]).contiguous()
+    return idx
+
+
+def pack_triu(R: torch.Tensor) -> torch.Tensor:
+    """The n (n + 1) / 2 entries of the upper triangle of a square factor, row by row: what travels over a link (0.93 MB
+    instead of 1.86 MB for WALK-MAN's 482 columns)."""
+    n = R.shape[0]
+    return R.reshape(-1).index_select(0, _triu_index(n, R.device))
+
+
+def unpack_triu(packed: torch.Tensor, n: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Inverse of ``pack_triu`` (zeros below the diagonal)."""
+    if out is None:
+        out = torch.zeros((n, n), dtype=packed.dtype, device=packed.device)
+    else:
+        out.zero_()
+    out.view(-1).index_copy_(0, _triu_index(n, packed.device), packed)
+    return out
+
+
+def tsqr_tree(R: torch.Tensor, merge: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], group=None, packed: bool = True,
+              broadcast: bool = True) -> torch.Tensor | None:
+    """Binary-tree reduction of per-rank triangular factors.
+
+    ``merge(Ra, Rb)`` must return the R factor of [Ra; Rb] (``Engine.tsqr_merge`` on the GPU).  ``packed``: square upper-triangular factors
+    travel as their packed upper triangle (half the bytes of every hop and of the broadcast).  ``broadcast=True``: every rank returns the
+    global factor; ``False``: only rank 0 of the group does (the others return None) -- for callers whose consumer (the OLS / SDP inputs)
+    lives on rank 0, the step behind the last merge disappears."""
     if not dist.is_initialized():
         return R
     world = dist.get_world_size(group)
@@ -67,20 +101,37 @@ def tsqr_tree(R: torch.Tensor, merge: Callable[[torch.Tensor, torch.Tensor], tor
     if world == 1:
         return R
     R = R.contiguous()
+    n = R.shape[0]
+    packed = bool(packed) and R.dim() == 2 and R.shape[0] == R.shape[1]
     # rank arithmetic is group-local; send / recv / broadcast take GLOBAL ranks
     g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     step = 1
+    root = True
     while step < world:
         if rank % (2 * step) == 0:
             src = rank + step
             if src < world:
-                other = torch.empty_like(R)
-                dist.recv(other, src=g(src), group=group)
+                if packed:
+                    buf = torch.empty(n * (n + 1) // 2, dtype=R.dtype, device=R.device)
+                    dist.recv(buf, src=g(src), group=group)
+                    other = unpack_triu(buf, n)
+                else:
+                    other = torch.empty_like(R)
+                    dist.recv(other, src=g(src), group=group)
                 R = merge(R, other).contiguous()
         elif rank % (2 * step) == step:
-            dist.send(R, dst=g(rank - step), group=group)
+            dist.send(pack_triu(R) if packed else R, dst=g(rank - step), group=group)
+            root = False
             break
         step *= 2
+    if not broadcast:
+        return R if root else None
+    if packed:
+        buf = pack_triu(R) if root else torch.empty(n * (n + 1) // 2, dtype=R.dtype, device=R.device)
+        dist.broadcast(buf, src=g(0), group=group)
+        return R if root else unpack_triu(buf, n)
+    if not root:
+        R = torch.empty_like(R)  # (never into the caller's own factor)
     dist.broadcast(R, src=g(0), group=group)
     return R
 
@@ -201,8 +252,8 @@ def selfcheck(device=None, merge: Callable[[torch.Tensor, torch.Tensor], torch.T
                 buf = torch.empty(4096, dtype=torch.float64, device=device)
                 dist.recv(buf, src=g(send), group=group)
                 if not torch.equal(buf.cpu(), _edge_payload(recv, send)):
-                    bad = int((buf.cpu() != _edge_payload(recv, send)).sum())
-                    fail(f"payload received over tree edge {send} -> {recv} differs from what rank {send} sends in {bad} of 4096 entries")
+                    ndiff = int((buf.cpu() != _edge_payload(recv, send)).sum())
+                    fail(f"payload received over tree edge {send} -> {recv} differs from what rank {send} sends in {ndiff} of 4096 entries")
         wd.step("status exchange after the tree edges")
         agree("send/recv over the tree edges")
         out["edges_s"] = time.perf_counter() - t0

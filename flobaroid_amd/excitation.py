@@ -114,12 +114,14 @@ def candidate_states(engine, candidates: list, T: int, freq: float, device: bool
 
 
 def candidate_dopt_from_coefficients(engine, candidates: list, T: int, freq: float, independent_cols, dopt_regularization: float = 1e-4,
-                                     YtY_prior=None) -> np.ndarray:
+                                     YtY_prior=None, friction_sign_threshold: float = 0.02) -> np.ndarray:
     """D-optimality of every candidate without its samples ever leaving the device: Fourier coefficients -> states (``fbr_fourier_states``)
-    -> one Gram per candidate (``fbr_gram_grouped``) -> eigenvalues on the host (trajectoryOptimizer.py:240-272 per candidate)."""
+    -> one Gram per candidate (``fbr_gram_grouped``) -> eigenvalues on the host (trajectoryOptimizer.py:240-272 per candidate).
+    ``friction_sign_threshold``: the Coulomb column is tanh(dq / threshold) -- callers with an option dict pass
+    ``opt.get('frictionSignThreshold', 0.02)`` (helpers.py getFrictionSignSeries, model.py:757), the value ``Model`` uses on the host path."""
     st = candidate_states(engine, candidates, T, freq, device=True)
     if engine.friction:
         import torch
 
-        st["sign"] = torch.tanh(st["dq"] / 0.02)
+        st["sign"] = torch.tanh(st["dq"] / float(friction_sign_threshold))
     return candidate_dopt(engine, st, len(candidates), independent_cols, dopt_regularization, YtY_prior=YtY_prior)

@@ -81,6 +81,10 @@ typedef struct {
 } fbr_states;
 
 /* ---- library / device ------------------------------------------------------------------------- */
+/* Version of THIS header.  fbr_version() returns the value the loaded library was built with: a caller compares the two before its first
+ * call (flobaroid_amd/_lib.py load_library refuses a mismatch), because the C-ABI has grown in place -- 101: fbr_topology.joint_type,
+ * the num_samples argument of fbr_gram_program_info / fbr_model_link_merge_info, option "fused_id". */
+#define FBR_VERSION 101
 int fbr_version(void);
 int fbr_device_count(void);        /* number of visible HIP devices (0 if none / no runtime) */
 const char *fbr_last_error(void);  /* thread-local message of the last failing call */
@@ -296,6 +300,8 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "chunk_samples"              0     > 0: samples per chunk of every pass (0: sized by memory)
  *   "min_chunks"                 4     a short fused pass is still cut into this many chunks
  *   "h2d_chunked"                1     pinned host inputs staged chunk by chunk on a copy stream, overlapped with the kernels
+ *   "fused_id"                   1     fbr_predict / fbr_inverse_dynamics_batch run kinematics and torques in ONE kernel, the link records
+ *                                      stay in registers (0: kinematics kernel + torque kernel with the records staged through HBM)
  *   "gram_shape"                 0     fused Gram kernel shape: 0 by model, 1 one workgroup per CU, 2 two per CU
  *   "gram_rhs_tile"              0     1: dense tiles for the rhs columns even for k <= 2 (default: their products come from the packer)
  *   "gram_orient"                1     tile pairs turned so that the row segments fill up

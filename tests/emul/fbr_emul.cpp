@@ -4,12 +4,14 @@
 // kernels' indexing (records, packed tile image, pair slots, MFMA lane mapping), so table / index bugs
 // show up in the CPU test-suite instead of costing a GPU round trip.  Nothing here is shipped or used
 // by the product path.
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "../../flobaroid_amd/csrc/fbr_math.h"
 #include "../../flobaroid_amd/csrc/fbr_program.h"
 #include "../../flobaroid_amd/csrc/fbr_reduce.h"
+#include "../../flobaroid_amd/csrc/fbr_kinid.h"
 
 extern "C" {
 
@@ -188,6 +190,88 @@ int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const 
                 }
             }
         }
+    }
+    return 0;
+}
+
+// mirrors fbr_kinid_kernel (csrc/fbr_kinid.h): the SAME host-built step program and the SAME lane body as the device kernel, one "lane"
+// per sample, branch-point records in slots, torques written when their level of the joint stack is taken again.  info (optional, 3):
+// nsteps, maxlvl, nslots of the program.  Returns -1 when the tree is deeper than the kernel instances cover.
+int emul_kinid(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
+               const double *rpy, const double *sign, const double *vel_sign, const double *x, int mode, double *tau, int *info)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    if (hm.maxdepth > FBR_KINID_MAXD) return -1;
+    FbrKinIdProgram p;
+    fbr_kinid_build(hm, p);
+    if (info) {
+        info[0] = p.nsteps;
+        info[1] = p.maxlvl;
+        info[2] = p.nslots;
+    }
+    const int n = hm.n;
+    std::vector<double> slots((size_t)std::max(p.nslots, 1) * FBR_LINK_REC);
+    for (long s = 0; s < S; s++) {
+        double *ts = tau + (size_t)s * hm.rows;
+        for (int r = 0; r < hm.rows; r++) ts[r] = std::nan("");  // every row must be written exactly once
+        std::vector<int> written(hm.rows, 0);
+        for (auto &v : slots) v = std::nan("");
+        auto state = [&](int d, double &a, double &b, double &c) {
+            a = q[s * n + d];
+            b = dq[s * n + d];
+            c = ddq[s * n + d];
+        };
+        auto basest = [&](double *v6, double *a6, double *e3) {
+            for (int i = 0; i < 6; i++) {
+                v6[i] = bv[6 * s + i];
+                a6[i] = ba[6 * s + i];
+            }
+            for (int i = 0; i < 3; i++) e3[i] = rpy[3 * s + i];
+        };
+        auto save = [&](int b, int i, double v) { slots[(size_t)b * FBR_LINK_REC + i] = v; };
+        auto load = [&](int b, int i) { return slots[(size_t)b * FBR_LINK_REC + i]; };
+        auto getpi = [&](int l, double *pi) {
+            for (int c = 0; c < 10; c++) pi[c] = mode == 0 ? x[10 * l + c] : (c < hm.cpl ? x[hm.cpl * l + c] : 0.0);
+        };
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {
+            for (int i = 0; i < 9; i++) rR[i] = hm.restR[9 * l + i];
+            for (int i = 0; i < 3; i++) {
+                rp[i] = hm.restp[3 * l + i];
+                ax[i] = hm.axis[3 * l + i];
+            }
+        };
+        auto emit = [&](int r, double v) {
+            if (r >= hm.fb && hm.fric) {
+                const int d = r - hm.fb;
+                const double dqv = dq[s * n + d], sg = sign[s * n + d];
+                if (mode == 0) {
+                    const int f0 = hm.friction_start();
+                    double tt = sg * x[f0 + d];
+                    if (!hm.grav_only) {
+                        tt += x[f0 + n + d] * dqv;
+                        const int poff = f0 + 2 * n;
+                        tt += x[poff + d];
+                        if (hm.stribeck > 0) {
+                            const double sgn = (sg > 0) - (sg < 0);
+                            tt += x[poff + n + d] * exp(-fabs(vel_sign[s * n + d]) / hm.stribeck) * sgn;
+                        }
+                    }
+                    v += tt;
+                } else {
+                    for (int c = hm.cpl * hm.L; c < hm.cols; c++) {
+                        const FbrCol &cd = hm.coldesc[c];
+                        if (cd.joint == d) v += x[c] * fbr_friction_value(cd.pidx, dqv, sg, hm.stribeck);
+                    }
+                }
+            }
+            written[r]++;
+            ts[r] = v;
+        };
+        fbr_kinid_lane<FBR_KINID_MAXD>(p.nsteps, p.maxlvl, p.steps.data(), p.endflush.data(), hm.floating, hm.gravity, hm.fb, state, basest, save,
+                                       load, getpi, emit, consts);
+        for (int r = 0; r < hm.rows; r++)
+            if (written[r] != 1) return -2 - r;  // a row written twice or never: a bug of the flush lists
     }
     return 0;
 }

@@ -26,7 +26,7 @@ class EmulTopo(ctypes.Structure):
 def lib():
     global _lib
     if _lib is None:
-        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h"), os.path.join(_CSRC, "fbr_reduce.h")]
+        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h"), os.path.join(_CSRC, "fbr_reduce.h"), os.path.join(_CSRC, "fbr_kinid.h")]
         if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
             os.makedirs(os.path.dirname(_OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _OUT, _SRC])
@@ -115,6 +115,21 @@ class Emul:
         lib().emul_id(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
                       _d(vel_sign), _d(x), int(mode), _d(tau))
         return tau
+
+    def fused_inverse_dynamics(self, st, x, sign=None, vel_sign=None, mode=0):
+        """(tau, (nsteps, maxlvl, nslots)) from the emulation of fbr_kinid_kernel (csrc/fbr_kinid.h): the device kernel's own step program
+        and lane body, one lane per sample.  Raises if a regressor row is written twice or never."""
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        sign = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+        vel_sign = None if vel_sign is None else np.ascontiguousarray(vel_sign, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        tau = np.zeros((S, self.rows))
+        info = (ctypes.c_int * 3)()
+        rc = lib().emul_kinid(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
+                              _d(vel_sign), _d(x), int(mode), _d(tau), info)
+        if rc != 0:
+            raise RuntimeError(f"emul_kinid: rc {rc}" + (f" (row {-2 - rc} not written exactly once)" if rc <= -2 else " (tree too deep)"))
+        return tau, tuple(info)
 
     def program_info(self, k):
         NT, npairs, T, img, items = (ctypes.c_int() for _ in range(5))

@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from common import ROOT
 from flobaroid_amd.dist import shard_range
@@ -39,6 +40,27 @@ if os.environ.get("FBR_TEST_BAD_MERGE"):   # a merge that returns a wrong factor
         print("BAD MERGE NOT DETECTED"); sys.exit(5)
     except RuntimeError as e:
         assert "tsqr_tree" in str(e) and "self-check failed" in str(e), str(e)
+if os.environ.get("FBR_TEST_BAD_EDGE"):   # a payload corrupted on a tree edge: the receiver names the edge, every other rank learns that a peer failed
+    import flobaroid_amd.dist as D
+    orig = D._edge_payload
+    if rank == 1:   # (rank 1 sends to rank 0 on the first level; only the sender's copy is wrong)
+        D._edge_payload = lambda r, s, n=4096: orig(r, s, n) + (torch.arange(n) == 7).to(torch.float64)
+    try:
+        selfcheck(timeout=60.0)
+        print("BAD EDGE NOT DETECTED"); sys.exit(6)
+    except RuntimeError as e:
+        if rank == 0:
+            assert "tree edge 1 -> 0 differs from what rank 1 sends in 1 of 4096" in str(e), str(e)
+        else:
+            assert "other rank(s) reported a failure in step 'send/recv over the tree edges'" in str(e), str(e)
+    D._edge_payload = orig
+# packed triangles (the default) and dense squares give the same factor; without the broadcast only the root has it
+Rt = torch.triu(torch.randn((9, 9), dtype=torch.float64, generator=torch.Generator().manual_seed(3 + rank)))
+qr = lambda a, b: torch.from_numpy(np.linalg.qr(np.vstack([a.numpy(), b.numpy()]), mode="r"))
+Rp, Rd = tsqr_tree(Rt, qr), tsqr_tree(Rt, qr, packed=False)
+assert torch.equal(Rp, Rd) and bool((torch.tril(Rp, -1) == 0).all())
+Rn = tsqr_tree(Rt, qr, broadcast=False)
+assert (Rn is not None and torch.equal(Rn, Rp)) if rank == 0 else Rn is None
 assert len(_tree_edges(world)) == world - 1 and sorted(s for _, s in _tree_edges(world)) == list(range(1, world))
 t = load_topo("kuka_lwr4")
 om = OracleModel(t)
@@ -89,7 +111,7 @@ def test_two_rank_gloo(tmp_path):
     procs = []
     for world in (2, 3):
         for r in range(world):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world), FBR_TEST_BAD_MERGE="1")
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world), FBR_TEST_BAD_MERGE="1", FBR_TEST_BAD_EDGE="1")
             procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=240)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
@@ -158,6 +180,7 @@ def test_bench_refuses_a_mislabelled_world():
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
 
 
+@pytest.mark.timeout(1800)   # (8 ranks on the build container's cores: the subprocess has its own 900 s limit, below pytest's)
 def test_bench_gpus_8_dry_run_over_gloo():
     """The world size the driver's scaling run uses, before the first real node sees it: ``bench.py --gpus 8`` over gloo with the CPU
     stand-in -- eight ranks spawned by the bench itself, the self-check over every one of the 7 edges of the depth-3 rank tree,

@@ -220,3 +220,54 @@ def test_rhs_moments_of_a_tile_without_rows(request):
         request.addfinalizer(lambda: emul_lib.lib().emul_set_gram_shape(0))
         G = em.gram(st, rhs)
         assert np.linalg.norm(G - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A), shape
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=cfg_id)
+def test_fused_kinematics_and_torques_program(cfg):
+    """csrc/fbr_kinid.h on the CPU: the device kernel's own step program (slots of the branch-point records, levels of the joint stack,
+    flush lists) and its own lane body against the oracle -- every torque row written exactly once, both parameter layouts."""
+    t, om, em, st, sign, rng = _setup(cfg, 25, 3)
+    x = np.concatenate([t.x_std(), rng.random(om.P + 4 * t.num_dofs)])
+    tau = om.inverse_dynamics(st, x, sign, 0.9 * st["dq"])
+    tf, (nsteps, maxlvl, nslots) = em.fused_inverse_dynamics(st, x, sign, 0.9 * st["dq"])
+    assert nsteps == t.num_links and maxlvl >= 1
+    assert np.abs(tau - tf).max() <= 1e-13 * np.abs(tau).max()
+    Y = om.regressor(st, sign)
+    xi = rng.standard_normal(om.P)
+    tp, _ = em.fused_inverse_dynamics(st, xi, sign, mode=1)
+    assert np.abs(tp.reshape(-1) - Y @ xi).max() <= 1e-12 * np.abs(Y @ xi).max()
+
+
+def test_fused_program_of_walkman_needs_two_slots():
+    """The per-wave scratch of the fused kernel: WALK-MAN's branch points (waist: legs + torso, torso: arms + neck) nest two deep."""
+    t = load_topo("walkman_apriori")
+    em = Emul(t, floating=True)
+    st = random_states(t, 2, np.random.default_rng(0), True)
+    _, (nsteps, maxlvl, nslots) = em.fused_inverse_dynamics(st, t.x_std())
+    assert (nsteps, maxlvl) == (48, 10) and nslots <= 4
+    red, _E = em.reduction(0)   # the link-merged robot fbr_predict runs on
+    _, (ns2, ml2, sl2) = red.fused_inverse_dynamics(st, np.zeros(10 * red.num_links))
+    assert (ns2, ml2) == (30, 10) and sl2 <= 3
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_program_on_random_trees(seed):
+    """Random trees with fixed / revolute / prismatic joints, bushy and chain-like, fixed and floating base, friction layouts."""
+    rng = np.random.default_rng(500 + seed)
+    L = int(rng.integers(2, 26))
+    t = random_topology(rng, L, p_fixed=float(rng.choice([0.0, 0.2, 0.5])), branchiness=float(rng.choice([0.0, 0.3, 0.7, 1.0])),
+                        p_prismatic=float(rng.choice([0.0, 0.3])))
+    fl, fr, sym = bool(seed & 1), bool(seed & 2), bool(seed & 4)
+    strb = 0.1 if (fr and seed % 3 == 0) else 0.0
+    om = OracleModel(t, floating=fl, fric=fr, fric_sym=sym, stribeck=strb)
+    em = Emul(t, floating=fl, fric=fr, fric_sym=sym, stribeck=strb)
+    st = random_states(t, 7, rng, fl)
+    sign = np.tanh(st["dq"] / 0.02) if t.num_dofs else np.zeros((7, 0))
+    x = np.concatenate([t.x_std(), rng.random(om.P + 4 * t.num_dofs)])
+    tau = om.inverse_dynamics(st, x, sign, 0.9 * st["dq"])
+    tf, info = em.fused_inverse_dynamics(st, x, sign, 0.9 * st["dq"])
+    assert np.abs(tau - tf).max() <= 1e-12 * max(np.abs(tau).max(), 1e-300), info
+    Y = om.regressor(st, sign)
+    xi = rng.standard_normal(om.P)
+    tp, _ = em.fused_inverse_dynamics(st, xi, sign, mode=1)
+    assert np.abs(tp.reshape(-1) - Y @ xi).max() <= 1e-11 * max(np.abs(Y @ xi).max(), 1e-300)

@@ -173,5 +173,8 @@ def test_random_trees_against_the_oracle(seed):
         sys.path.insert(0, os.path.join(root, "tools"))
     from stress_gpu import run_case
 
-    for desc, e_gram, e_tsqr in run_case(seed):
+    cases = run_case(seed)
+    for desc, e_gram, e_tsqr, _info in cases:
         assert e_gram < 1e-11 and e_tsqr < 1e-9, desc
+    # the two variants of a case are the two compiled shapes of the Gram kernel (options of the handle, asserted inside run_case)
+    assert len(cases) in (0, 2)

@@ -24,7 +24,8 @@ def test_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libfbr.so does not export {n}"
     assert set(_lib._SIGNATURES) == set(names)
-    assert lib.fbr_version() >= 100
+    hdr = open(os.path.join(ROOT, "include", "fbr.h")).read()
+    assert lib.fbr_version() == _lib.FBR_VERSION == int(re.search(r"#define FBR_VERSION (\d+)", hdr).group(1))
 
 
 def test_fails_loudly_without_device():

@@ -1,9 +1,12 @@
-"""Fused Gram rate of one batch of S WALK-MAN samples (device resident) -- run once per FBR_MIN_CHUNKS / FBR_CHUNK_SAMPLES value."""
+"""Fused Gram rate of one batch of S WALK-MAN samples (device resident) -- run once per FBR_OPT_MIN_CHUNKS / FBR_OPT_CHUNK_SAMPLES value
+(engine options "min_chunks" / "chunk_samples" through tools/_opts.py; the library reads no environment)."""
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import synth_states
 from flobaroid_amd._lib import Engine
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _opts  # noqa: F401,E402  (FBR_OPT_<KEY>=value -> engine options)
 from flobaroid_amd.topology import Topology
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
 topo = Topology.load(os.path.join(ROOT, "flobaroid_amd/robots/walkman_apriori.topology.json"))
@@ -22,4 +25,4 @@ for _ in range(K):
     eng.gram(st, rhs=rhs, out=G)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(f"S={S} FBR_MIN_CHUNKS={os.environ.get('FBR_MIN_CHUNKS')} FBR_CHUNK_SAMPLES={os.environ.get('FBR_CHUNK_SAMPLES')} ms={dt*1e3:.3f} Msamples/s={S/dt/1e6:.3f}")
+print(f"S={S} min_chunks={eng.get_option('min_chunks')} chunk_samples={eng.get_option('chunk_samples')} ms={dt*1e3:.3f} Msamples/s={S/dt/1e6:.3f}")

@@ -30,12 +30,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "flobaroid_amd/robots/*.topology
         st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
         for fr, sym in [(0, 1), (1, 1), (1, 0)]:
             line = f"{name:24s} floating={int(floating)} friction={fr} sym={sym}:"
-            for shape in ("two", "one", ""):
-                if shape:
-                    os.environ["FBR_GRAM_SHAPE"] = shape
-                else:
-                    os.environ.pop("FBR_GRAM_SHAPE", None)
-                eng = Engine(topo, floating=floating, friction=bool(fr), friction_symmetric=bool(sym))
+            for shape, code in (("two", 2), ("one", 1), ("", 0)):   # engine option "gram_shape"
+                eng = Engine(topo, floating=floating, friction=bool(fr), friction_symmetric=bool(sym), options={"gram_shape": code})
                 rhs = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
                 eng.gram(st, rhs=rhs)
                 torch.cuda.synchronize()

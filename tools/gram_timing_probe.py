@@ -1,8 +1,8 @@
-"""Per-part phase cycles of the streaming Gram kernel (FBR_GRAM_TIMING=1 diagnostic instantiation), WALK-MAN floating base.
+"""Per-part phase cycles of the streaming Gram kernel (engine option "gram_timing": the diagnostic instantiation), WALK-MAN floating base.
 
     gpurun -- 'python tools/gram_timing_probe.py [fixed] [friction] [asym] > gpurun_out/gram_timing.txt 2>&1'
 
-FBR_GRAM_SHAPE=one|two forces a kernel shape.  tools/fit_gram_cost.py fits the part cost model (FbrGramConfig) to this output."""
+FBR_OPT_GRAM_SHAPE=1|2 (tools/_opts.py -> engine option "gram_shape") forces a kernel shape.  tools/fit_gram_cost.py fits the part cost model (FbrGramConfig) to this output."""
 import os
 import sys
 
@@ -29,7 +29,7 @@ st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.ite
 rhs = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
 eng.gram(st, rhs=rhs)
 torch.cuda.synchronize()
-print(f"=== floating={int(floating)} friction={int(fric)} sym={int(sym)} shape={os.environ.get('FBR_GRAM_SHAPE', 'auto')} {eng.gram_program_info(1)}", file=sys.stderr, flush=True)
-os.environ["FBR_GRAM_TIMING"] = "1"
+print(f"=== floating={int(floating)} friction={int(fric)} sym={int(sym)} shape={eng.get_option('gram_shape'):.0f} {eng.gram_program_info(1)}", file=sys.stderr, flush=True)
+eng.set_option("gram_timing", 1)
 eng.gram(st, rhs=rhs)
 torch.cuda.synchronize()

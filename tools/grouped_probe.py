@@ -14,8 +14,7 @@ for ng, per in ((64, 2000), (16, 8000), (256, 512)):
     st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth_states(topo, S, 1, True)[0].items()}
     res = {}
     for mode in ("reduced", "plain", "reduced"):
-        if mode == "plain": os.environ["FBR_NO_GROUPED_REDUCTION"] = "1"
-        else: os.environ.pop("FBR_NO_GROUPED_REDUCTION", None)
+        eng.set_option("reduce_grouped_min_samples", 1e18 if mode == "plain" else 512)   # (groups below the threshold run over all columns)
         for _ in range(5): G = eng.gram_grouped(st, ng)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): G = eng.gram_grouped(st, ng)

@@ -18,11 +18,8 @@ for k in (1, 0, 3):
     for wt in (None, w):
         res = {}
         for mode in ("merged", "plain") + (("nore",) if os.environ.get("PROBE_NOREGROUP") else ()):
-            os.environ.pop("FBR_NO_LINK_MERGE", None); os.environ.pop("FBR_NO_REGROUP", None)
-            if mode == "plain":
-                os.environ["FBR_NO_LINK_MERGE"] = "1"
-            elif mode == "nore":
-                os.environ["FBR_NO_REGROUP"] = "1"
+            eng.set_option("link_merge", 0 if mode == "plain" else 1)   # options of the handle (the library reads no environment)
+            eng.set_option("regroup", 0 if mode == "nore" else 1)
             G = eng.gram(st, rhs=rhs, w=wt)
             R = eng.tsqr(st, rhs=rhs, w=wt)
             torch.cuda.synchronize()
@@ -41,4 +38,4 @@ for k in (1, 0, 3):
             print(f"   merged only: gram {res['nore'][2]*1e3:.2f} ms tsqr {res['nore'][3]*1e3:.2f} ms")
         print(f"k={k} weights={wt is not None} S={S}: gram {tgm*1e3:.2f} vs {tgp*1e3:.2f} ms, relerr {eg:.2e} asym {asym:.1e} repeat {sg} | "
               f"tsqr {trm*1e3:.2f} vs {trp*1e3:.2f} ms, RtR-G merged {er:.2e} plain {erp:.2e} lower {low:.1e} repeat {sr}", flush=True)
-os.environ.pop("FBR_NO_LINK_MERGE", None); os.environ.pop("FBR_NO_REGROUP", None)
+eng.set_option("link_merge", 1); eng.set_option("regroup", 1)

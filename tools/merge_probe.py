@@ -13,8 +13,7 @@ for n in (481, 214, 92):
     Rb = torch.triu(torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g))
     res = {}
     for var in ("pipelined", "one_wg"):
-        if var == "one_wg":
-            os.environ["FBR_TSQR_TREE_ONE_WG"] = "1"
+        eng.set_option("tsqr_tree_one_wg", 1 if var == "one_wg" else 0)
         R = eng.tsqr_merge(Ra, Rb)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -22,7 +21,6 @@ for n in (481, 214, 92):
             R = eng.tsqr_merge(Ra, Rb)
         torch.cuda.synchronize()
         res[var] = ((time.perf_counter() - t0) / 20 * 1e3, R.clone())
-        os.environ.pop("FBR_TSQR_TREE_ONE_WG", None)
     G = Ra.T @ Ra + Rb.T @ Rb
     Rp = res["pipelined"][1]
     print(f"n={n}: pipelined {res['pipelined'][0]:.3f} ms, one workgroup {res['one_wg'][0]:.3f} ms, bitwise equal {bool(torch.equal(Rp, res['one_wg'][1]))}, "

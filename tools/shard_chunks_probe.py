@@ -1,9 +1,12 @@
-"""Fused pass of one rank's shard (125 k WALK-MAN samples) for the chunk count given by FBR_MIN_CHUNKS (read once per process)."""
+"""Fused pass of one rank's shard (125 k WALK-MAN samples) for the chunk count given by the engine option "min_chunks"
+(FBR_OPT_MIN_CHUNKS=.. through tools/_opts.py)."""
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import synth_states
 from flobaroid_amd._lib import Engine
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _opts  # noqa: F401,E402
 from flobaroid_amd.topology import Topology
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
 dev = torch.device("cuda", 0)
@@ -23,4 +26,4 @@ for rep in range(3):
         if pend is not None: eng.wait(pend)
         pend = tk
     eng.wait(pend); torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 40)
-print(f"FBR_MIN_CHUNKS={os.environ.get('FBR_MIN_CHUNKS', 'default')} S={S}: {best*1e3:.3f} ms per pass = {S/best/1e6:.1f} M samples/s", flush=True)
+print(f"min_chunks={eng.get_option('min_chunks')} S={S}: {best*1e3:.3f} ms per pass = {S/best/1e6:.1f} M samples/s", flush=True)

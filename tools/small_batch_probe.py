@@ -8,9 +8,8 @@ ROOT="/root/repo"
 dev = torch.device("cuda", 0)
 for name, fl, S in (("kuka_lwr4", False, 50000), ("walkman_apriori", True, 125000)):
     topo = Topology.load(os.path.join(ROOT, f"flobaroid_amd/robots/{name}.topology.json"))
-    for env in ({"FBR_GRAM_RHS_TILE": "1"}, {}, {"FBR_GRAM_RHS_TILE": "1"}, {}, {"FBR_NO_LINK_MERGE": "1", "FBR_GRAM_RHS_TILE": "1"}, {}):
-        for k_, v in env.items(): os.environ[k_] = v
-        eng = Engine(topo, floating=fl)
+    for env in ({"gram_rhs_tile": 1}, {}, {"gram_rhs_tile": 1}, {}, {"link_merge": 0, "gram_rhs_tile": 1}, {}):   # engine options of the variant
+        eng = Engine(topo, floating=fl, options=env)
         eng.use_torch_stream()
         st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth_states(topo, S, 1, fl)[0].items()}
         rhs = torch.randn((S * eng.rows, 1), dtype=torch.float64, device=dev)
@@ -32,4 +31,3 @@ for name, fl, S in (("kuka_lwr4", False, 50000), ("walkman_apriori", True, 12500
         eng.wait(pend); torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / 20
         print(name, S, env, f"blocking {dt*1e3:.3f} ms  pipelined {dtp*1e3:.3f} ms = {S/dtp/1e6:.1f} M/s", eng.link_merge_info()["reduced_cols"], eng.gram_program_info(1), flush=True)
         eng.close()
-        for k_ in env: os.environ.pop(k_, None)

@@ -2,13 +2,12 @@
 oracle (gpurun -- python tools/stress_gpu.py).  Prints one line per case and the number of failures.  run_case(seed) is also what
 tests/test_gpu_determinism.py runs, one seed per parametrised case."""
 import os, sys, numpy as np
-os.environ.setdefault("FBR_REDUCE_ALWAYS", "1")  # (the random cases are small: the reduced paths are what is stressed)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 
 def run_case(seed):
-    """[(description, relative Gram error, relative TSQR error)] for both kernel shapes of one random case (empty: the draw is skipped)."""
+    """[(description, relative Gram error, relative TSQR error, program info)] for both kernel shapes of one random case (empty: the draw is skipped)."""
     from common import random_topology, random_states
     from flobaroid_amd._lib import Engine
     from oracle.oracle import OracleModel
@@ -32,24 +31,20 @@ def run_case(seed):
     if w is not None: A = A * w[:, None]
     Go = A.T @ A
     out = []
-    prev = os.environ.get("FBR_GRAM_SHAPE")
-    try:
-        for shape in ("two", "one"):
-            os.environ["FBR_GRAM_SHAPE"] = shape
-            eng = Engine(t, floating=bool(fl), friction=bool(fr), friction_symmetric=bool(sym), gravity_only=bool(grav), stribeck_velocity=strb)
-            G = eng.gram(st, rhs=rhs, w=w)
-            err = np.linalg.norm(G - Go) / max(np.linalg.norm(Go), 1e-300)
-            info = eng.gram_program_info(k)
-            R = eng.tsqr(st, rhs=rhs, w=w) if shape == "two" and eng.cols + k <= 768 else None  # (FBR_TSQR_MAXN)
-            e2 = np.linalg.norm(R.T @ R - Go) / max(np.linalg.norm(Go), 1e-300) if R is not None else 0
-            out.append((f"seed {seed} L={L} n={t.num_dofs} fl={fl} fr={fr}{'s' if sym else 'a'} g={grav} st={strb} k={k} S={S} w={w is not None} {shape}: "
-                        f"parts {info['parts']} gram {err:.1e} tsqr {e2:.1e}", err, e2))
-            eng.close()
-    finally:
-        if prev is None:
-            os.environ.pop("FBR_GRAM_SHAPE", None)
-        else:
-            os.environ["FBR_GRAM_SHAPE"] = prev
+    # the variants are options of the model handle (the library reads no environment): both compiled shapes of the Gram kernel, the
+    # column reductions forced (the random cases are small: the reduced paths are what is stressed), the row-group TSQR from 1 sample on
+    for shape, code in (("two", 2), ("one", 1)):
+        eng = Engine(t, floating=bool(fl), friction=bool(fr), friction_symmetric=bool(sym), gravity_only=bool(grav), stribeck_velocity=strb,
+                     options={"gram_shape": code, "reduce_min_work": 0, "tsqr_group_min_samples": 1})
+        assert eng.get_option("gram_shape") == code and eng.get_option("reduce_min_work") == 0
+        G = eng.gram(st, rhs=rhs, w=w)
+        err = np.linalg.norm(G - Go) / max(np.linalg.norm(Go), 1e-300)
+        info = eng.gram_program_info(k, S)
+        R = eng.tsqr(st, rhs=rhs, w=w) if shape == "two" and eng.cols + k <= 768 else None  # (the TSQR kernels' column limit)
+        e2 = np.linalg.norm(R.T @ R - Go) / max(np.linalg.norm(Go), 1e-300) if R is not None else 0
+        out.append((f"seed {seed} L={L} n={t.num_dofs} fl={fl} fr={fr}{'s' if sym else 'a'} g={grav} st={strb} k={k} S={S} w={w is not None} {shape}: "
+                    f"parts {info['parts']} gram {err:.1e} tsqr {e2:.1e}", err, e2, info))
+        eng.close()
     return out
 
 
@@ -57,7 +52,7 @@ if __name__ == "__main__":
     bad = 0
     first = int(os.environ.get("FBR_STRESS_FIRST", 0))
     for seed in range(first, first + int(os.environ.get("FBR_STRESS_SEEDS", 40))):
-        for desc, err, e2 in run_case(seed):
+        for desc, err, e2, _info in run_case(seed):
             flag = "" if err < 1e-11 and e2 < 1e-9 else "  <-- BAD"
             bad += bool(flag)
             print(desc + flag, flush=True)

@@ -1,5 +1,5 @@
-"""A/B of TSQR kernel-shape switches inside one process (the switches are environment variables read per call):
-python tools/tsqr_ab.py [S] [VAR=val,VAR2=val2 ...]   -- each argument after S is one variant (comma-separated settings, '-' = defaults).
+"""A/B of TSQR kernel-shape switches inside one process (the switches are options of the model handle, include/fbr.h):
+python tools/tsqr_ab.py [S] [option=val,option2=val2 ...]   -- each argument after S is one variant (comma-separated settings, '-' = defaults).
 Prints wall time, per-class device time and ||R^T R - G|| / ||G|| against the fused Gram of the same samples."""
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,8 +21,9 @@ gn = float(torch.linalg.norm(G))
 Rfirst = None
 for var in variants:
     sets = [] if var == "-" else [kv.split("=") for kv in var.split(",")]
+    saved = {k: eng.get_option(k) for k, _ in sets}
     for k, v in sets:
-        os.environ[k] = v
+        eng.set_option(k, float(v))
     R = eng.tsqr(st, rhs=rhs)
     err = float(torch.linalg.norm(R.T @ R - G)) / gn
     torch.cuda.synchronize()
@@ -58,5 +59,5 @@ for var in variants:
     print(f"pipelined {dtp*1e3:8.2f} ms ({wi['flop']/dtp/1e12/78.6:.3f}) |", end=" ")
     print(f"{var:40s} S={S} {dt*1e3:8.2f} ms  executed {wi['flop']/dt/1e12:6.2f} TF ({wi['flop']/dt/1e12/78.6:.3f})  relerr {err:.2e} repeat-bitwise {same} bitwise-equal-to-first-variant {same_as_first} |",
           {k: round(v[0] / reps, 2) for k, v in pr.items() if v[1]}, flush=True)
-    for k, v in sets:
-        del os.environ[k]
+    for k, v in saved.items():
+        eng.set_option(k, v)

@@ -13,5 +13,5 @@ dev = torch.device("cuda", 0)
 st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in st_np.items()}
 rhs = torch.randn((S * eng.rows, 2), dtype=torch.float64, device=dev)
 eng.tsqr(st, rhs=rhs)
-os.environ["FBR_TSQR_TIMING"] = "1"
+eng.set_option("tsqr_timing", 1)
 eng.tsqr(st, rhs=rhs)
