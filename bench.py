@@ -193,41 +193,56 @@ def cpu_baseline(topo, budget_s=12.0):
             "sample": f"{done} WALK-MAN floating-base samples: oracle regressor + RNEA (C, 1 thread) + NumPy A^T A (1 BLAS thread), {dt:.1f} s"}
 
 
-def cpu_baseline_all_cores(topo, budget_s=8.0):
-    """The same port on every host core: one Python thread per core, each running the C oracle (ctypes releases the GIL)
-    and its own 1-thread NumPy A^T A on private sample blocks ("1 thread, then all host cores")."""
-    import concurrent.futures as cf
-
+def cpu_baseline_all_cores(topo, one_thread_rate=None, budget_s=10.0):
+    """The same port on every host core, ONE process: the reference's loop body (regressor + simulated torques of a sample, stacked) dealt
+    to OpenMP threads inside the C oracle (``orc_stack_block_omp``: straight into the augmented block, nothing allocated per block), then
+    A^T A of the whole block with one threaded BLAS call (``dsyrk``: the symmetric half, as NumPy's ``A.T @ A`` does).  SURVEY 8(d):
+    "1 thread, then all host cores with OpenMP".  Reports both phases, the threads, and the parallel efficiency against the one-thread
+    figure of ``cpu_baseline`` -- with what bounds it."""
     from oracle.oracle import OracleModel
-    from threadpoolctl import threadpool_limits
+    from scipy.linalg.blas import dsyrk
+    from threadpoolctl import threadpool_info, threadpool_limits
 
     cores = os.cpu_count() or 1
+    om = OracleModel(topo, floating=True)
     x = topo.x_std()
-    block = 256
+    block = max(512, min(16384, 64 * cores))
     st = _np_states(topo, block, 4321)
-    oms = [OracleModel(topo, floating=True) for _ in range(cores)]
-    t_end = time.perf_counter() + budget_s
-
-    def work(i):
-        om = oms[i]
-        G = np.zeros((om.P + 1, om.P + 1))
-        done = 0
-        while time.perf_counter() < t_end:
-            Y = om.regressor(st)
-            tau = om.inverse_dynamics(st, x).reshape(-1, 1)
-            Ya = np.hstack([Y, tau])
-            G += Ya.T @ Ya
-            done += block
-        return done
-
-    with threadpool_limits(limits=1):
+    A = np.empty((block * om.rows, om.P + 1))
+    G = np.zeros((om.P + 1, om.P + 1))
+    om.stack_block(st, x, out=A, threads=cores)  # (page in the block, start the OpenMP team)
+    t_stack = t_syrk = 0.0
+    done = 0
+    thr = 1
+    with threadpool_limits(limits=cores):
         t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(cores) as ex:
-            res = list(ex.map(work, range(cores)))
+        while True:
+            t1 = time.perf_counter()
+            _, thr = om.stack_block(st, x, out=A, threads=cores)
+            t2 = time.perf_counter()
+            G += dsyrk(1.0, A, trans=1, lower=0)   # upper triangle of A^T A (A is C-contiguous: trans on the Fortran view is handled by SciPy)
+            t3 = time.perf_counter()
+            t_stack += t2 - t1
+            t_syrk += t3 - t2
+            done += block
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
-    done = sum(res)
-    return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{done} WALK-MAN floating-base samples over {cores} threads (C oracle + 1-thread NumPy A^T A each), {dt:.1f} s"}
+    blas = [f"{d.get('internal_api')} {d.get('version')} x{d.get('num_threads')}" for d in threadpool_info() if d.get("user_api") == "blas"]
+    rate = done / dt
+    out = {"value": rate, "unit": "samples/s", "cores": cores, "omp_threads": thr, "kind": "port", "seconds": dt,
+           "phase_seconds": {"regressor_and_rnea_openmp": t_stack, "AtA_threaded_blas_syrk": t_syrk},
+           "phase_rates_samples_per_s": {"regressor_and_rnea_openmp": done / max(t_stack, 1e-12), "AtA_threaded_blas_syrk": done / max(t_syrk, 1e-12)},
+           "syrk_GFLOP_per_s": done * om.rows * (om.P + 1) * (om.P + 2) / max(t_syrk, 1e-12) / 1e9, "blas": blas,
+           "sample": f"{done} WALK-MAN floating-base samples in blocks of {block}: C oracle regressor + RNEA over {thr} OpenMP threads into [Y|tau], "
+                     f"then one threaded dsyrk per block, {dt:.1f} s"}
+    if one_thread_rate:
+        out["speedup_vs_one_thread"] = rate / one_thread_rate
+        out["parallel_efficiency"] = rate / one_thread_rate / cores
+        bound = "the threaded BLAS A^T A (fp64 peak of the host)" if t_syrk > t_stack else "the per-sample regressor loop (memory bandwidth of writing the 134 KB block per sample)"
+        out["bound_by"] = (f"{bound}: {t_syrk / dt:.0%} of the time in dsyrk, {t_stack / dt:.0%} in the OpenMP loop; hardware threads are SMT siblings "
+                           f"({cores} threads on about {cores // 2} cores): the efficiency is quoted per thread")
+    return out
 
 
 def cpu_phases_bc_and_parity(eng, topo, Sc=4000):
@@ -300,18 +315,44 @@ def cpu_phases_bc_and_parity(eng, topo, Sc=4000):
     Rr, Pr = pivoted_qr(R_struct)[1:]
     dr, dl = np.abs(np.diag(Rr)), np.abs(np.diag(RQ))
     differ = np.flatnonzero(Pr[:r] != PQ[:r])
+    # the same audit with the tie rule OFF (opt['pivotTieTolerance'] = 0: LAPACK's own last-bit tie breaking) on the GPU Gram, against
+    # scipy.linalg.qr on the CPU oracle's Gram of the same states: what differs THEN is the summation order of two implementations of the
+    # same sum (coin flips no implementation can reproduce); what the rule adds on top is the difference to the figure above
+    st_s = _np_states(topo, 10000, 99)
+    om_s = OracleModel(topo, floating=True)
+    G_cpu = np.zeros_like(R_struct)
+    for i0 in range(0, 10000, 500):   # the reference's raw sum over the samples (model.py:803-806), block by block
+        Yb = om_s.regressor({k_: v[i0:i0 + 500] for k_, v in st_s.items()})
+        G_cpu += Yb.T @ Yb
+    P0 = pivoted_qr(R_struct, tie_eps=0.0)[2]
+    Pc = sla.qr(G_cpu, pivoting=True, mode="economic")[2]
+    Rc = sla.qr(G_cpu, pivoting=True, mode="economic")[1]
+    rc_ = int(np.count_nonzero(np.abs(np.diag(Rc)) > 0.005))
+    set0, setc, setr = set(P0[:r].tolist()), set(Pc[:rc_].tolist()), set(Pr[:r].tolist())
     try:
         import cvxpy  # noqa: F401
-        sdp_state = "cvxpy importable here, but the bench does not run the solve (tests/test_gpu_endtoend.py compares its inputs)"
+        sdp_state = ("cvxpy importable here: `python tools/pin_sdp.py --robot walkman --samples 20000 --write` runs the reference's own "
+                     "SDP.identifyFeasibleStandardParameters on the CPU path and on this path's TSQR factor and checks xStd at 1e-6")
     except Exception:
-        sdp_state = ("NOT executed: cvxpy / CLARABEL are not installed on the build or the GPU image (no network), so "
-                     "SDP.identifyFeasibleStandardParameters (sdp.py:450-604) has never consumed this path's output; what is compared instead are "
-                     "its inputs R1, rho1, rho2_norm_sqr, R1 K, the observability weights and the CAD-regularisation rows (tests/test_gpu_endtoend.py)")
+        sdp_state = ("NOT executed with a conic solver: cvxpy / CLARABEL are not installed on the build or the GPU image (no network).  tools/pin_sdp.py "
+                     "runs the reference's own, unmodified SDP.identifyFeasibleStandardParameters (sdp.py:450-604) twice -- its own la.qr(YBase) on the CPU "
+                     "path, the TSQR factor of this path through estimation.sdp_inputs -- and compares xStd at 1e-6 wherever cvxpy exists; here its plumbing "
+                     "runs with tests/stub_cvxpy.py (affine expressions exact, LMIs ignored): tests/test_pin_sdp.py, 2e-13 (KUKA) / 1e-14 (WALK-MAN) "
+                     "between the two routes; its inputs R1, rho1, rho2_norm_sqr, R1 K, observability weights, CAD rows: tests/test_gpu_endtoend.py")
     out["parity"] = {"sdp_solve": sdp_state, "samples": Sc, "xstd_rel_fro_err_gpu_vs_cpu": float(la.norm(xstd_gpu - xstd_cpu) / la.norm(xstd_cpu)),
                      "xbase_rel_err": float(la.norm(xb_gpu - xb_cpu) / la.norm(xb_cpu)), "bar": 1e-6, "num_base_params": r,
                      "pivot_rule_vs_lapack": {"rank_rule": int(np.count_nonzero(dr > 0.005)), "positions_differing": int(len(differ)),
                                               "largest_rel_gap_at_those": float(max([abs(dr[i] - dl[i]) / dl[i] for i in differ], default=0.0)),
                                               "index_set_columns_differing": int(len(set(Pr[:r].tolist()) - set(PQ[:r].tolist()))),
+                                              "index_set_equal_with_pivotTieTolerance_0": bool(set0 == setc),
+                                              "with_pivotTieTolerance_0": {
+                                                  "gpu_gram_vs_cpu_oracle_gram_lapack_order_columns_differing": int(len(set0 - setc)),
+                                                  "gram_rel_diff_gpu_vs_cpu": float(la.norm(R_struct - G_cpu) / la.norm(G_cpu)),
+                                                  "tie_rule_on_gpu_gram_vs_cpu_gram_columns_differing": int(len(setr - set(pivoted_qr(G_cpu)[2][:rc_].tolist()))),
+                                                  "meaning": "rule off: columns by which two implementations of the same Gram sum (GPU reduction order vs the CPU "
+                                                             "oracle's sample loop) disagree through LAPACK's last-bit tie breaking -- coin flips between exactly "
+                                                             "tied columns that no implementation reproduces; rule on (the default): the same comparison is exact "
+                                                             "(0 columns), which is what the rule is for"},
                                               "note": "every differing position is an exact tie (gap at rounding level); "
                                                       "tests/test_gpu_model.py rrW audits the same against the reference run's own order"}}
     return out, ic, K
@@ -712,7 +753,125 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
             "kernel_ms_per_call": {k_: v[0] / 5 for k_, v in prs.items() if v[1]},
             "tree_share_of_call": (prs["tree"][0] / 5) / (dsh * 1e3) if prs.get("tree", (0, 0))[1] else None,
         }
-        del sts, rhss
+        # ---- the rank tree that follows the shard at 8 GPUs, timed on this one device: three chained fbr_tsqr_merge (the levels of the
+        # binary tree on rank 0's critical path) with the packed-triangle traffic of every hop (pack on the sender, a device copy standing
+        # in for the xGMI transfer of 0.93 MB, unpack on the receiver: flobaroid_amd/dist.py tsqr_tree) -- so that the line carries the
+        # FULL predicted 8-GPU TSQR time (shard + tree), not only the shard
+        from flobaroid_amd.dist import pack_triu, unpack_triu
+
+        Rsh = eng.tsqr(sts, rhs=rhss)
+        partners = [Rsh.clone() for _ in range(3)]
+        hop = torch.empty(((P + 1) * (P + 2)) // 2, dtype=torch.float64, device=dev)
+
+        def rank_tree_once():
+            Rt = Rsh
+            for lvl in range(3):
+                hop.copy_(pack_triu(partners[lvl]))          # sender: pack; the copy stands in for the link
+                Rt = eng.tsqr_merge(Rt, unpack_triu(hop, P + 1))
+            return Rt
+
+        Rt = rank_tree_once()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            rank_tree_once()
+        sync()
+        d_tree = (time.perf_counter() - t0) / 10
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            eng.tsqr_merge(Rsh, partners[0])
+        sync()
+        d_merge = (time.perf_counter() - t0) / 10
+        # four stacked copies of the same factor: R^T R = 4 R_sh^T R_sh
+        err_tree = float((torch.linalg.norm(Rt.T @ Rt - 4.0 * (Rsh.T @ Rsh)) / torch.linalg.norm(4.0 * (Rsh.T @ Rsh))).item())
+        xgmi_s = 3 * hop.numel() * 8 / 153e9   # three hops of the packed triangle at one link's 153 GB/s (MI355X_MICROARCH.md)
+        out["rank_tree"] = {"levels": 3, "seconds_three_merges_with_pack_unpack": d_tree, "one_merge_seconds": d_merge,
+                            "packed_triangle_bytes_per_hop": hop.numel() * 8, "dense_square_bytes_per_hop": (P + 1) ** 2 * 8,
+                            "xgmi_wire_seconds_three_hops_at_153_GB_per_s": xgmi_s, "relerr_RtR": err_tree,
+                            "predicted_8_gpu_tsqr_seconds": dsh + d_tree + xgmi_s,
+                            "predicted_scaling_at_8_gpus_shard_plus_tree": dt / (dsh + d_tree + xgmi_s),
+                            "note": "N = 1 prediction: one rank's shard (tsqr_shard.seconds) + the three merge levels on rank 0's critical path + "
+                                    "wire time of the packed triangles; no broadcast (dist.tsqr_tree(broadcast=False): the consumer of R lives on rank 0)"}
+        out["tsqr_shard"]["scaling_ceiling_at_8_gpus_with_rank_tree"] = out["rank_tree"]["predicted_scaling_at_8_gpus_shard_plus_tree"]
+        # ---- the fused Gram pass of the same shard: blocking and two in flight, against one eighth of the timed 1 M step
+        Gsh = [torch.zeros((P + 1, P + 1), dtype=torch.float64, device=dev) for _ in range(2)]
+        for _ in range(3):
+            eng.gram(sts, rhs=rhss, out=Gsh[0])
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.gram(sts, rhs=rhss, out=Gsh[0])
+        sync()
+        g_blk = (time.perf_counter() - t0) / 20
+        eng.wait(eng.gram_submit(sts, Gsh[0], rhs=rhss))
+        sync()
+        t0 = time.perf_counter()
+        pend = None
+        for i in range(40):
+            tk = eng.gram_submit(sts, Gsh[i & 1], rhs=rhss)
+            if pend is not None:
+                eng.wait(pend)
+            pend = tk
+        eng.wait(pend)
+        sync()
+        g_pip = (time.perf_counter() - t0) / 40
+        eighth = out["ms_per_step"] * 1e-3 / 8
+        out["gram_shard"] = {"samples": Ssh, "blocking_seconds": g_blk, "pipelined_seconds": g_pip, "one_eighth_of_the_1M_step_seconds": eighth,
+                             "blocking_ratio_to_one_eighth": g_blk / eighth, "pipelined_ratio_to_one_eighth": g_pip / eighth,
+                             "scaling_ceiling_at_8_gpus_pipelined": 8.0 / (g_pip / eighth), "scaling_ceiling_at_8_gpus_blocking": 8.0 / (g_blk / eighth),
+                             "allreduce_note": "the (P+1)^2 fp64 Gram (1.86 MB) is all-reduced asynchronously beside the next step's kernels (per_rank_allreduce_wait_ms_per_step)"}
+        del sts, rhss, partners
+
+    # ---- A3 inside the step (N = 1): the reference's floating-base loop simulates every sample (model.py:398-413) to obtain the base-wrench
+    # rows of tau when only joint torques are measured; its own timers split simulate / regressor (model.py:626-628).  The same timed step
+    # with fbr_inverse_dynamics_batch INSIDE the region (a second handle on its own stream: its blocking call does not drain the two Gram
+    # submissions in flight), the six base rows copied into tau, then the fused pass.
+    if world == 1 and on_gpu and hasattr(eng, "gram_submit"):
+        eng2 = make_engine(args, topo, True, dev.index or 0)
+        xstd = topo.x_std()
+        sim = torch.empty((S, rows), dtype=torch.float64, device=dev)
+        rhs_sim = [rhs.clone(), rhs.clone()]
+        Gv = [torch.zeros((P + 1, P + 1), dtype=torch.float64, device=dev) for _ in range(2)]
+        t_sim = [0.0]
+
+        def sim_step(i, pend):
+            b = i & 1
+            t_ = time.perf_counter()
+            eng2.inverse_dynamics(st, xstd, out=sim)                 # A3: every sample, a-priori parameters (blocking on eng2's stream)
+            t_sim[0] += time.perf_counter() - t_
+            rhs_sim[b].view(S, rows)[:, :6].copy_(sim[:, :6])        # base-wrench rows of tau := simulated (model.py:412-413)
+            tk = eng.gram_submit(st, Gv[b], rhs=rhs_sim[b])
+            if pend is not None:
+                eng.wait(pend)
+            return tk
+
+        pend = None
+        for i in range(3):
+            pend = sim_step(i, pend)
+        eng.wait(pend)
+        sync()
+        t_sim[0] = 0.0
+        ks = max(4, args.steps // 2)
+        t0 = time.perf_counter()
+        pend = None
+        for i in range(ks):
+            pend = sim_step(i, pend)
+        eng.wait(pend)
+        sync()
+        d_sim = (time.perf_counter() - t0) / ks
+        # the rows of tau the simulation overwrites ARE the simulated ones in this data set (tau = ID + noise): the Gram must agree with the
+        # timed steps' up to the noise of those six rows; checked on the noise-free part: [Y]^T[Y] block is identical
+        same = float((torch.linalg.norm(Gv[(ks - 1) & 1][:P, :P] - G_sharded[:P, :P]) / torch.linalg.norm(G_sharded[:P, :P])).item())
+        out["value_incl_simulate"] = S_total / d_sim
+        out["simulate_in_step"] = {"ms_per_step": d_sim * 1e3, "steps": ks, "simulate_ms_per_step_host_clock": t_sim[0] / ks * 1e3,
+                                   "regressor_and_gram_ms_per_step": (d_sim - t_sim[0] / ks) * 1e3, "ms_per_step_without_simulate": out["ms_per_step"],
+                                   "relerr_YtY_block_vs_timed_steps": same,
+                                   "what": "per step: fbr_inverse_dynamics_batch of all samples (A3, model.py:398-413; fused kinematics + RNEA kernel) -> the 6 "
+                                           "base-wrench rows of tau replaced by the simulated ones -> fused regressor -> Gram pass (two submissions in flight); "
+                                           "the split mirrors the reference's own two timers (model.py:626-628)"}
+        eng2.close()
+        del sim, rhs_sim, Gv
 
     # ---- weak scaling: 1 M samples PER GPU (N = 1: identical to the timed steps)
     if world > 1:
@@ -836,7 +995,7 @@ def secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_di
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo)
         try:
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(topo)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(topo, out["cpu_baseline"]["value"])
         except Exception as e:  # secondary figure: never lose the bench line over it
             out["cpu_baseline_all_cores"] = {"error": repr(e)}
         try:
@@ -881,14 +1040,22 @@ def predict_leg(eng, topo, st, dev):
     tau = torch.empty((S, rows), dtype=torch.float64, device=dev)
     dt, kms = _profiled(eng, lambda: eng.predict(st, x, out=tau))
     alg = 8.0 * (3 * n + 15 + rows)
-    staged = 8.0 * (21 * topo.num_links + 6 * n) * 2  # kinematic records written by fbr_kin_kernel, read by fbr_id_kernel
+    fused = hasattr(eng, "get_option") and eng.get_option("fused_id") != 0
+    if fused:
+        # fbr_kinid_kernel (round 6): no records in HBM; what is staged are the branch-point records of the link-merged tree, written once and
+        # read once per later child, lanes interleaved in a per-wave scratch (WALK-MAN: 2 saves + 4 loads of 21 doubles per sample)
+        staged = 8.0 * 21 * 6
+        kern, note = "fbr_kinid_kernel", ("one lane per sample, link records in registers, joint stack behind scalar branches (csrc/fbr_kinid.h); compute / "
+                                           "latency bound at one wave per SIMD (342 VGPRs); round 5's two-kernel path staged 18.9 KB per sample")
+    else:
+        staged = 8.0 * (21 * topo.num_links + 6 * n) * 2  # kinematic records written by fbr_kin_kernel, read by fbr_id_kernel
+        kern, note = "fbr_kin_kernel + fbr_id_kernel", "one lane (kinematics) / one wave (torques) per sample, records staged through HBM"
     kernel_s = sum(kms.values()) * 1e-3
     return {"entry_point": "fbr_predict", "samples": S, "seconds": dt, "samples_per_s": S / dt, "kernel_ms_per_call": kms,
-            "roofline": {"bound": "hbm", "kernel": "fbr_kin_kernel + fbr_id_kernel", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+            "roofline": {"bound": "hbm", "kernel": kern, "unit": "GB/s", "peak": PEAK_HBM_GBS,
                          "algorithmic_bytes_per_sample": alg, "achieved": alg * S / kernel_s / 1e9, "frac": alg * S / kernel_s / 1e9 / PEAK_HBM_GBS,
                          "staged_bytes_per_sample": staged, "achieved_incl_staging_GB_per_s": (alg + staged) * S / kernel_s / 1e9,
-                         "note": "one lane (kinematics) / one wave (torques) per sample: latency-bound far below the HBM roofline; the records "
-                                 "staged between the two kernels are an order of magnitude more bytes than the algorithmic I/O"}}
+                         "note": note}}
 
 
 def fd_scores_leg(eng, topo, st, dev, S=4096):
@@ -906,11 +1073,12 @@ def fd_scores_leg(eng, topo, st, dev, S=4096):
     kernel_s = sum(kms.values()) * 1e-3
     return {"entry_point": "fbr_fd_scores", "samples": S, "regressor_evaluations_per_sample": 1 + 3 * n, "seconds": dt,
             "evaluations_per_s": evals / dt, "samples_per_s": S / dt, "kernel_ms_per_call": kms,
-            "roofline": {"bound": "hbm", "kernel": "fbr_fd_expand_kernel + fbr_kin_kernel + fbr_score_kernel", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fbr_kinfd_kernel (one lane per evaluation, nothing staged; option fused_id = 0: fbr_fd_expand_kernel + "
+                                                   "fbr_kin_kernel + fbr_score_kernel)", "unit": "GB/s", "peak": PEAK_HBM_GBS,
                          "algorithmic_bytes_per_sample": alg, "achieved": alg * S / kernel_s / 1e9, "frac": alg * S / kernel_s / 1e9 / PEAK_HBM_GBS,
                          "regressor_entries_evaluated_per_s": evals * rows * P / dt,
-                         "note": "88 regressor blocks of 35 x 480 are evaluated per sample against ONE block of weights read: compute / latency "
-                                 "bound (sub-tree restricted evaluation); the HBM figure is its algorithmic floor"}}
+                         "note": "88 regressor blocks of 35 x 480 are evaluated per sample against ONE block of weights read: compute bound; the HBM "
+                                 "figure is its algorithmic floor (the weight blocks)"}}
 
 
 def other_configs(args, dev, eng4, topo4, st4, rhs4):

@@ -534,6 +534,47 @@ extern "C" int fbr_regressor_batch(fbr_model *m, const fbr_states *st, double *Y
     return FBR_OK;
 }
 
+// Fused kinematics + torques (csrc/fbr_kinid.h): one kernel, one lane per sample, the link records stay in registers, branch-point
+// records in a per-wave scratch.  mode 0 / 1: x = parameters (device); mode 2: x = [S][6] contact wrenches at frame (flink, fp).
+static void kinid_params(const fbr_model *m, DevKinId *kp)
+{
+    kp->nsteps = m->kinid.nsteps;
+    kp->maxlvl = m->kinid.maxlvl;
+    kp->nslots = m->kinid.nslots;
+    kp->ldn = std::max(m->hm.n, 1) | 1;
+    kp->steps = m->kinid_steps;
+    kp->endflush = m->kinid_endflush;
+}
+static int launch_kinid(fbr_model *m, const DevStates &d, long S, const double *dvs, const double *x, int mode, double *dst, int flink, const double *fp)
+{
+    DevKinId kp;
+    kinid_params(m, &kp);
+    const size_t lds = (size_t)3 * 64 * kp.ldn * sizeof(double);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 << 10) / std::max<size_t>(lds, 1)));
+    const long nblk = (S + 63) / 64;
+    const int blocks = (int)std::min<long>(nblk, (long)m->num_cus * per_cu);
+    if (int rc = m->kinid_scratch.ensure((size_t)blocks * std::max(kp.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double))) return rc;
+    const double f0 = fp ? fp[0] : 0.0, f1 = fp ? fp[1] : 0.0, f2 = fp ? fp[2] : 0.0;
+    ProfScope ps(m, FBR_PROF_ID);
+#define FBR_KINID_LAUNCH(D)                                                                                                              \
+    do {                                                                                                                                 \
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_kinid_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+        hipLaunchKernelGGL(fbr_kinid_kernel<D>, dim3(blocks), dim3(64), lds, m->stream, m->dm, kp, S, d.q, d.dq, d.ddq, d.bv, d.ba, d.rpy, \
+                           d.sign, dvs, x, mode, dst, m->kinid_scratch.as<double>(), flink, f0, f1, f2);                                 \
+    } while (0)
+    if (kp.maxlvl <= 4)
+        FBR_KINID_LAUNCH(4);
+    else if (kp.maxlvl <= 8)
+        FBR_KINID_LAUNCH(8);
+    else if (kp.maxlvl <= 12)
+        FBR_KINID_LAUNCH(12);
+    else
+        FBR_KINID_LAUNCH(FBR_KINID_MAXD);
+#undef FBR_KINID_LAUNCH
+    HIPCHK(hipGetLastError());
+    return FBR_OK;
+}
+
 static int run_id(fbr_model *m, const fbr_states *st, const double *x, int nx, const double *vel_sign, int mode,
                   double *tau_out, int32_t out_mem)
 {
@@ -589,36 +630,7 @@ static int run_id(fbr_model *m, const fbr_states *st, const double *x, int nx, c
         dst = m->out_tmp.as<double>();
     }
     if (m->opt.fused_id != 0 && m->kinid.nsteps > 0) {
-        // one kernel, one lane per sample: the link records stay in registers, branch-point records in a per-wave scratch (fbr_kinid.h)
-        DevKinId kp;
-        kp.nsteps = m->kinid.nsteps;
-        kp.maxlvl = m->kinid.maxlvl;
-        kp.nslots = m->kinid.nslots;
-        kp.ldn = std::max(hm.n, 1) | 1;
-        kp.steps = m->kinid_steps;
-        kp.endflush = m->kinid_endflush;
-        const size_t lds = (size_t)3 * 64 * kp.ldn * sizeof(double);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 << 10) / std::max<size_t>(lds, 1)));
-        const long nblk = (S + 63) / 64;
-        const int blocks = (int)std::min<long>(nblk, (long)m->num_cus * per_cu);
-        if ((rc = m->kinid_scratch.ensure((size_t)blocks * std::max(kp.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
-        ProfScope ps(m, FBR_PROF_ID);
-#define FBR_KINID_LAUNCH(D)                                                                                                              \
-    do {                                                                                                                                 \
-        HIPCHK(hipFuncSetAttribute((const void *)fbr_kinid_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-        hipLaunchKernelGGL(fbr_kinid_kernel<D>, dim3(blocks), dim3(64), lds, m->stream, m->dm, kp, S, d.q, d.dq, d.ddq, d.bv, d.ba, d.rpy, \
-                           d.sign, dvs, m->st_x.as<double>(), mode, dst, m->kinid_scratch.as<double>());                                 \
-    } while (0)
-        if (kp.maxlvl <= 4)
-            FBR_KINID_LAUNCH(4);
-        else if (kp.maxlvl <= 8)
-            FBR_KINID_LAUNCH(8);
-        else if (kp.maxlvl <= 12)
-            FBR_KINID_LAUNCH(12);
-        else
-            FBR_KINID_LAUNCH(FBR_KINID_MAXD);
-#undef FBR_KINID_LAUNCH
-        HIPCHK(hipGetLastError());
+        if ((rc = launch_kinid(m, d, S, dvs, m->st_x.as<double>(), mode, dst, 0, nullptr))) return rc;
         return finish_output(m, dst, tau_out, (size_t)S * hm.rows, out_mem);
     }
     const int waves = 4;
@@ -692,6 +704,10 @@ extern "C" int fbr_contact_torques(fbr_model *m, const fbr_states *st, int32_t l
     if (out_mem == FBR_HOST) {
         if ((rc = m->out_tmp.ensure((size_t)S * hm.rows * sizeof(double)))) return rc;
         dst = m->out_tmp.as<double>();
+    }
+    if (m->opt.fused_id != 0 && m->kinid.nsteps > 0) {  // the same fused kernel: only the frame's link carries a wrench (fbr_kinid.h, mode 2)
+        if ((rc = launch_kinid(m, d, S, nullptr, dw, 2, dst, link, frame_p))) return rc;
+        return finish_output(m, dst, out, (size_t)S * hm.rows, out_mem);
     }
     const long ch = chunk_size(m, S);
     for (long s0 = 0; s0 < S; s0 += ch) {
@@ -780,7 +796,30 @@ extern "C" int fbr_fd_scores(fbr_model *m, const fbr_states *st, const double *W
         if ((rc = m->g_tmp.ensure((size_t)S * nper * sizeof(double)))) return rc;
         dout = m->g_tmp.as<double>();
     }
-    if (S > 0) {
+    if (S > 0 && m->opt.fused_id != 0 && m->kinid.nsteps > 0 && !hm.masked) {
+        // one lane per evaluation, nothing staged (fbr_kinfd_kernel, fbr_kinid.h)
+        DevKinId kp;
+        kinid_params(m, &kp);
+        const long nblk = (S * nper + 63) / 64;
+        const int blocks = (int)std::min<long>(nblk, (long)m->num_cus * 8);
+        if ((rc = m->kinid_scratch.ensure((size_t)blocks * std::max(kp.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
+        {
+            ProfScope ps(m, FBR_PROF_REGRESSOR);
+#define FBR_KINFD_LAUNCH(D)                                                                                                               \
+    hipLaunchKernelGGL(fbr_kinfd_kernel<D>, dim3(blocks), dim3(64), 0, m->stream, m->dm, kp, S, nper, eps, d.q, d.dq, d.ddq, d.bv, d.ba, d.rpy, \
+                       d.sign, dW, dout, m->kinid_scratch.as<double>())
+            if (kp.maxlvl <= 4)
+                FBR_KINFD_LAUNCH(4);
+            else if (kp.maxlvl <= 8)
+                FBR_KINFD_LAUNCH(8);
+            else if (kp.maxlvl <= 12)
+                FBR_KINFD_LAUNCH(12);
+            else
+                FBR_KINFD_LAUNCH(FBR_KINID_MAXD);
+#undef FBR_KINFD_LAUNCH
+        }
+        HIPCHK(hipGetLastError());
+    } else if (S > 0) {
         // columns that a perturbation of joint d can change: the inertial columns of the links below d and d's own friction columns
         if (m->fd_tab_entries < 0) {
             std::vector<int> tab(n + 1, 0), ent;

@@ -97,22 +97,27 @@ static inline void fbr_kinid_build(const FbrHostModel &hm, FbrKinIdProgram &p)
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// One lane = one sample.  StateFn(d, q, dq, ddq): joint state of dof d; BaseFn(bv6, ba6, rpy3); Slot: save(b, i, v) / load(b, i);
-// PiFn(l, pi10): the ten parameters of link l; Emit(row, value): regressor row `row` of this sample (value without friction for joint
-// rows: the caller adds it).  `steps` / `endflush` of FbrKinIdProgram; every table access is wave-uniform.
+// One lane = one sample (or one perturbed evaluation of a sample).  StateFn(d, q, dq, ddq): joint state of dof d; BaseFn(bv6, ba6, rpy3);
+// save(b, i, v) / load(b, i): slot b of the branch-point records; ConstFn(l, restR, restp, axis);
+// LinkFn(l, depth, rec, Sst, lvd, F): called once per link with its record, the motion vectors Sst[0 .. depth) and dofs lvd[0 .. depth) of
+// the joints on its path; with ACC it returns the link's wrench F (frame A), which the lane adds to the base rows and to every ancestor
+// joint's torque; Emit(row, value): regressor row `row` of this sample (ACC only; joint rows without friction: the caller adds it).
+// `steps` / `endflush` of FbrKinIdProgram; every table access is wave-uniform.
 // ------------------------------------------------------------------------------------------------
-template <int MAXD, class StateFn, class BaseFn, class SlotSave, class SlotLoad, class PiFn, class EmitFn, class ConstFn>
+template <int MAXD, bool ACC, class StateFn, class BaseFn, class SlotSave, class SlotLoad, class LinkFn, class EmitFn, class ConstFn>
 FBR_HD void fbr_kinid_lane(int nsteps, int maxlvl, const int *steps, const int *endflush, int floating, const double *g, int fb,
-                           StateFn state, BaseFn basest, SlotSave save, SlotLoad load, PiFn getpi, EmitFn emit, ConstFn consts)
+                           StateFn state, BaseFn basest, SlotSave save, SlotLoad load, LinkFn link, EmitFn emit, ConstFn consts)
 {
     double P[FBR_LINK_REC];
     double Sst[MAXD][6], tac[MAXD];
+    int lvd[MAXD];
     double T[6] = {0, 0, 0, 0, 0, 0};
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 0; j < MAXD; j++) {
         tac[j] = 0.0;
+        lvd[j] = 0;
         for (int i = 0; i < 6; i++) Sst[j][i] = 0.0;
     }
     for (int k = 0; k < nsteps; k++) {
@@ -143,30 +148,59 @@ FBR_HD void fbr_kinid_lane(int nsteps, int maxlvl, const int *steps, const int *
 #endif
             for (int j = 0; j < MAXD; j++)
                 if (j == lvl) {
-                    if (fd >= 0) emit(fb + fd, tac[j]);
+                    if (ACC && fd >= 0) emit(fb + fd, tac[j]);
                     tac[j] = 0.0;
+                    lvd[j] = d;
                     for (int i = 0; i < 6; i++) Sst[j][i] = Sv[i];
                 }
         }
-        double pi[10], F[6];
-        getpi(l, pi);
-        fbr_link_wrench(out, pi, F);
-        for (int i = 0; i < 6; i++) T[i] += F[i];
+        double F[6] = {0, 0, 0, 0, 0, 0};
+        link(l, depth, out, Sst, lvd, F);
+        if (ACC) {
+            for (int i = 0; i < 6; i++) T[i] += F[i];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int j = 0; j < MAXD; j++)
+                if (j < depth) tac[j] += fbr_dot6(Sst[j], F);
+        }
+    }
+    if (ACC) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int j = 0; j < MAXD; j++)
-            if (j < depth) tac[j] += fbr_dot6(Sst[j], F);
+            if (j < maxlvl) {
+                const int fd = FBR_UNI(endflush[j]);
+                if (fd >= 0) emit(fb + fd, tac[j]);
+            }
+        for (int r = 0; r < fb; r++) emit(r, T[r]);
     }
+}
+
+// Score of one regressor evaluation against a weight block (fbr_fd_scores, analyticalGradient.py:92-185):  the contribution of link l's
+// inertial columns c = cpl l + p,  sum_r W[r][c] Y[r][c]  with Y's base rows = the unit wrench, joint row of path joint j = S_j . unit wrench.
+// Wr(r, c): the weight of regressor row r, column c of this lane's sample.
+template <int MAXD, class WFn>
+FBR_HD double fbr_kinfd_link_score(int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, int cpl, int fb, WFn Wr)
+{
+    double acc = 0.0;
+#if defined(__HIPCC__)
+#pragma unroll  // (the parameter index must be a constant: fbr_unit_wrench indexes small arrays with it)
+#endif
+    for (int p = 0; p < 10; p++)
+        if (p < cpl) {
+            const int c = cpl * l + p;
+            double w6[6];
+            fbr_unit_wrench(rec, p, w6);
+            for (int r = 0; r < fb; r++) acc += Wr(r, c) * w6[r];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int j = 0; j < MAXD; j++)
-        if (j < maxlvl) {
-            const int fd = FBR_UNI(endflush[j]);
-            if (fd >= 0) emit(fb + fd, tac[j]);
+            for (int j = 0; j < MAXD; j++)
+                if (j < depth) acc += Wr(fb + lvd[j], c) * fbr_dot6(Sst[j], w6);
         }
-    for (int r = 0; r < fb; r++) emit(r, T[r]);
+    return acc;
 }
 
 #if defined(__HIPCC__) && defined(FBR_KERNELS_CORE)
@@ -175,7 +209,9 @@ struct DevKinId {
     const int *steps, *endflush;
 };
 
-// mode 0: x = full standard vector (10 per link + friction slots); mode 1: x = identified-parameter vector (cols).
+// mode 0: x = full standard vector (10 per link + friction slots); mode 1: x = identified-parameter vector (cols);
+// mode 2: contact wrench -> generalized force J^T w (fbr_contact_torques, model.py:535-555): x = [S][6] wrenches at the frame
+// (link `flink`, point fpx/y/z in its axes), every other link contributes nothing, no friction.
 // grid-stride over blocks of 64 samples; dynamic LDS: 3 x [64][ldn] doubles (q, dq, ddq of the wave's samples).
 // scratch: [gridDim.x][nslots][FBR_LINK_REC][64] doubles.
 template <int MAXD>
@@ -183,7 +219,8 @@ __global__ __launch_bounds__(64) void fbr_kinid_kernel(DevModel m, DevKinId p, l
                                                        const double *__restrict__ ddq, const double *__restrict__ bv,
                                                        const double *__restrict__ ba, const double *__restrict__ rpy,
                                                        const double *__restrict__ sign, const double *__restrict__ vel_sign,
-                                                       const double *__restrict__ x, int mode, double *__restrict__ tau, double *__restrict__ scratch)
+                                                       const double *__restrict__ x, int mode, double *__restrict__ tau, double *__restrict__ scratch, int flink, double fpx,
+                                                       double fpy, double fpz)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x, n = m.n, ldn = p.ldn;
@@ -233,12 +270,29 @@ __global__ __launch_bounds__(64) void fbr_kinid_kernel(DevModel m, DevKinId p, l
         };
         auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
         auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
-        auto getpi = [&](int l, double *pi) {
+        auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
+            (void)depth; (void)Sst; (void)lvd;
+            if (mode == 2) {
+                if (l != flink) return;
+                const double *w = x + s * 6;
+                const double fp[3] = {fpx, fpy, fpz};
+                double t[3], pf[3], f[3] = {w[0], w[1], w[2]}, pxf[3];
+                fbr_mv(rec + FBR_OFF_R, fp, t);
+                for (int i = 0; i < 3; i++) pf[i] = rec[FBR_OFF_P + i] + t[i];
+                fbr_cross(pf, f, pxf);
+                for (int i = 0; i < 3; i++) {
+                    F[i] = f[i];
+                    F[3 + i] = w[3 + i] + pxf[i];  // the wrench about the base origin (frame A)
+                }
+                return;
+            }
+            double pi[10];
             if (mode == 0) {
                 for (int c = 0; c < 10; c++) pi[c] = x[10 * l + c];
             } else {
                 for (int c = 0; c < 10; c++) pi[c] = (c < m.cpl) ? x[m.cpl * l + c] : 0.0;
             }
+            fbr_link_wrench(rec, pi, F);
         };
         auto consts = [&](int l, double *rR, double *rp, double *ax) {
             for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
@@ -248,7 +302,7 @@ __global__ __launch_bounds__(64) void fbr_kinid_kernel(DevModel m, DevKinId p, l
             }
         };
         auto emit = [&](int r, double v) {
-            if (r >= m.fb && m.fric) {
+            if (r >= m.fb && m.fric && mode != 2) {
                 const int d = r - m.fb;
                 const double dqv = mysdq[d];
                 const double sg = sign[s * n + d];
@@ -273,7 +327,66 @@ __global__ __launch_bounds__(64) void fbr_kinid_kernel(DevModel m, DevKinId p, l
             }
             if (live) ts[r] = v;
         };
-        fbr_kinid_lane<MAXD>(p.nsteps, p.maxlvl, p.steps, p.endflush, m.floating, m.g, m.fb, state, basest, save, load, getpi, emit, consts);
+        fbr_kinid_lane<MAXD, true>(p.nsteps, p.maxlvl, p.steps, p.endflush, m.floating, m.g, m.fb, state, basest, save, load, link, emit, consts);
+    }
+}
+// Finite-difference sweep (analyticalGradient.py:92-185): one lane per EVALUATION e = s (1 + 3 n) + j -- j = 0 the state of
+// sample s itself, 1 + kind n + d the state with +eps on q_d / dq_d / ddq_d -- score[e] = sum_{r,c} W_s[r][c] Y_e[r][c], the regressor
+// never stored, no records, no expanded states in memory.  The lanes of a wave share one or two samples: their weights arrive as
+// broadcast loads.  (The two-kernel path it replaces evaluates a perturbation's sub-tree columns only but stages every evaluation's
+// kinematic records through HBM and the LDS of a whole workgroup: latency bound at 0.01 of its HBM floor.)
+template <int MAXD>
+__global__ __launch_bounds__(64) void fbr_kinfd_kernel(DevModel m, DevKinId p, long S, int nper, double eps, const double *__restrict__ q,
+                                                       const double *__restrict__ dq, const double *__restrict__ ddq, const double *__restrict__ bv,
+                                                       const double *__restrict__ ba, const double *__restrict__ rpy, const double *__restrict__ sign,
+                                                       const double *__restrict__ W, double *__restrict__ out, double *__restrict__ scratch)
+{
+    const int lane = threadIdx.x, n = m.n;
+    double *scr = scratch + (long)blockIdx.x * p.nslots * FBR_LINK_REC * 64 + lane;
+    const long total = S * nper, nblk = (total + 63) >> 6;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long e = min((blk << 6) + lane, total - 1);
+        const bool live = (blk << 6) + lane < total;
+        const long s = e / nper;
+        const int j = (int)(e - s * nper);
+        const int kind = (j == 0) ? -1 : (j - 1) / n, dj = (j == 0) ? -1 : (j - 1) % n;
+        const double *Ws = W + s * (long)m.rows * m.cols;
+        double score = 0.0;
+        auto state = [&](int d, double &a, double &b, double &c) {
+            a = q[s * n + d] + ((kind == 0 && d == dj) ? eps : 0.0);
+            b = dq[s * n + d] + ((kind == 1 && d == dj) ? eps : 0.0);
+            c = ddq[s * n + d] + ((kind == 2 && d == dj) ? eps : 0.0);
+        };
+        auto basest = [&](double *v6, double *a6, double *e3) {
+            for (int i = 0; i < 6; i++) {
+                v6[i] = bv[s * 6 + i];
+                a6[i] = ba[s * 6 + i];
+            }
+            for (int i = 0; i < 3; i++) e3[i] = rpy[s * 3 + i];
+        };
+        auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
+        auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {
+            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+            for (int i = 0; i < 3; i++) {
+                rp[i] = m.restp[3 * l + i];
+                ax[i] = m.axis[3 * l + i];
+            }
+        };
+        auto Wr = [&](int r, int c) { return Ws[(long)r * m.cols + c]; };
+        auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
+            (void)F;
+            score += fbr_kinfd_link_score<MAXD>(l, depth, rec, Sst, lvd, m.cpl, m.fb, Wr);
+        };
+        auto emit = [&](int, double) {};
+        fbr_kinid_lane<MAXD, false>(p.nsteps, p.maxlvl, p.steps, p.endflush, m.floating, m.g, m.fb, state, basest, save, load, link, emit, consts);
+        for (int c = m.cpl * m.L; c < m.cols; c++) {  // friction columns: one entry each
+            const int4 cd = m.coldesc[c];
+            const int jj = cd.w;
+            const double dqv = dq[s * n + jj] + ((kind == 1 && jj == dj) ? eps : 0.0);
+            score += Ws[(long)(m.fb + jj) * m.cols + c] * fbr_friction_value(cd.z, dqv, sign ? sign[s * n + jj] : 0.0, m.stribeck);
+        }
+        if (live) out[e] = score;
     }
 }
 #endif

@@ -972,8 +972,10 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
 }
 
 // level 0: wave g folds blocks g, g + NWV, ... of A into its private Rw[g]
+// SUB = 6 (96-row blocks, round 6): ONE workgroup of four waves per CU, a wave may use all 512 registers of its SIMD lane (288 of them hold
+// the block of a six-tile factor) -- the 36 fixed instructions of a Householder step are amortised over twice the rows of the 48-row shape
 template <int NPT, int SUB>
-__global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, 2) void fbr_tsqr_narrow_level0_kernel(const double *__restrict__ A, long Mpad,
+__global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, (SUB > 3 ? 1 : 2)) void fbr_tsqr_narrow_level0_kernel(const double *__restrict__ A, long Mpad,
                                                                                                  double *__restrict__ Rw, long nblocks, int nwaves,
                                                                                                  const int *__restrict__ rowfc, int orows, long ogroup, long M)
 {
@@ -1116,6 +1118,16 @@ static inline int fbr_tsqr_sub_for(int tpw) { return tpw == 2 ? FBR_TSQR_SUB2 : 
 #define FBR_TSQR_NARROW_SUB_LE6 3  // <= 6 column tiles (left arm, KUKA): 48-row blocks still fit the 256 VGPRs of a wave
 #endif
 static inline int fbr_tsqr_narrow_sub_for(int npt) { return npt <= 6 ? FBR_TSQR_NARROW_SUB_LE6 : 2; }
+#define FBR_TSQR_NARROW_TALL_SUB 6  // level-0 folds of long calls over <= 6 column tiles: 96-row blocks, one wave per SIMD (the trees keep the 48-row kernels)
+#define FBR_TSQR_NARROW_DISPATCH_TALL(NPTV, CALL)      \
+    switch (NPTV) {                                    \
+    case 1: { constexpr int NPT = 1, SUB = FBR_TSQR_NARROW_TALL_SUB; CALL; } break; \
+    case 2: { constexpr int NPT = 2, SUB = FBR_TSQR_NARROW_TALL_SUB; CALL; } break; \
+    case 3: { constexpr int NPT = 3, SUB = FBR_TSQR_NARROW_TALL_SUB; CALL; } break; \
+    case 4: { constexpr int NPT = 4, SUB = FBR_TSQR_NARROW_TALL_SUB; CALL; } break; \
+    case 5: { constexpr int NPT = 5, SUB = FBR_TSQR_NARROW_TALL_SUB; CALL; } break; \
+    default: { constexpr int NPT = 6, SUB = FBR_TSQR_NARROW_TALL_SUB; CALL; } break; \
+    }
 #define FBR_TSQR_NARROW_DISPATCH(NPTV, CALL)           \
     switch (NPTV) {                                    \
     case 1: { constexpr int NPT = 1, SUB = FBR_TSQR_NARROW_SUB_LE6; CALL; } break; \
@@ -1150,14 +1162,18 @@ static inline int fbr_tsqr_shape(int Pa, int num_cus, long rows_hint, FbrTsqrSha
     const int waves = half ? FBR_TSQR_HALF_WAVES : FBR_TSQR_WAVES;
     const int tpw8 = (n / 16 + FBR_TSQR_WAVES - 1) / FBR_TSQR_WAVES;
     const int tpw = narrow ? n / 16 : (dual ? (n / 16 <= 24 ? 6 : 8) : (n / 16 + waves - 1) / waves);
-    const int sub = narrow ? fbr_tsqr_narrow_sub_for(tpw) : (dual ? (tpw == 6 ? FBR_TSQR_SUB6H : FBR_TSQR_SUB8H) : fbr_tsqr_sub_for(tpw));
+    // 96-row blocks at one wave per SIMD for narrow factors of at most 6 tiles, when every wave still gets a few blocks to fold
+    const bool tall = narrow && opts.narrow_tall && tpw <= 6 && rows_hint >= 16L * FBR_TSQR_NARROW_TALL_SUB * 4 * (FBR_TSQR_NARROW_WAVES * (long)num_cus);
+    const int sub = narrow ? (tall ? FBR_TSQR_NARROW_TALL_SUB : fbr_tsqr_narrow_sub_for(tpw)) : (dual ? (tpw == 6 ? FBR_TSQR_SUB6H : FBR_TSQR_SUB8H) : fbr_tsqr_sub_for(tpw));
     const int mb = 16 * sub;
     const long want = (rows_hint + mb - 1) / mb;
-    const long per_cu = narrow ? 2 * FBR_TSQR_NARROW_WAVES : (half ? 2 : 1);  // narrow: private R per WAVE
+    const long per_cu = narrow ? (tall ? 1 : 2) * FBR_TSQR_NARROW_WAVES : (half ? 2 : 1);  // narrow: private R per WAVE
     const int NW = (int)std::max(1L, std::min<long>(per_cu * num_cus, want));
     const int ld = narrow ? n : 16 * waves * tpw;
     // (the RREG shapes share their leading dimension with the eight-wave kernel of the same width: 16 x 4 x 6 = 16 x 8 x 3, 16 x 4 x 8 = 16 x 8 x 4)
-    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow, waves, dual ? tpw8 : tpw, dual ? fbr_tsqr_sub_for(tpw8) : sub, dual ? 16 * fbr_tsqr_sub_for(tpw8) : mb};
+    // (tall narrow shape: the merge trees run the 48-row wave-private kernels)
+    const int tsub = dual ? fbr_tsqr_sub_for(tpw8) : (tall ? fbr_tsqr_narrow_sub_for(tpw) : sub);
+    *out = FbrTsqrShape{n, tpw, sub, mb, NW, ld, narrow, waves, dual ? tpw8 : tpw, tsub, 16 * tsub};
     return 0;
 }
 
@@ -1246,6 +1262,16 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         }
         const int nwaves = (int)std::min<long>(wk.NW, nblocks);
         const int grid = (nwaves + FBR_TSQR_NARROW_WAVES - 1) / FBR_TSQR_NARROW_WAVES;
+        if (wk.sub == FBR_TSQR_NARROW_TALL_SUB) {
+            FBR_TSQR_NARROW_DISPATCH_TALL(wk.tpw, {
+                constexpr size_t lb = FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double);
+                (void)hipFuncSetAttribute((const void *)fbr_tsqr_narrow_level0_kernel<NPT, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64), lb, st, A, Mpad, wk.Rw, nblocks, nwaves,
+                                   ro.first_col, ro.rows, ro.group, M);
+            });
+            TSQR_HIP(hipGetLastError());
+            return 0;
+        }
         FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
                                                             (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, A, Mpad,
                                                             wk.Rw, nblocks, nwaves, ro.first_col, ro.rows, ro.group, M));

@@ -13,6 +13,7 @@ static FbrTsqrOpts topts(const fbr_model *m)
     o.tree_one_wg = m->opt.tsqr_tree_one_wg != 0;
     o.timing = m->opt.tsqr_timing != 0;
     o.short_calls = m->opt.tsqr_short_call_factors != 0;
+    o.narrow_tall = m->opt.tsqr_narrow_tall != 0;
     return o;
 }
 // fbr_tsqr_begin with the model's options

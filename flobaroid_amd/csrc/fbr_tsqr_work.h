@@ -12,6 +12,7 @@ struct FbrTsqrOpts {
     bool tree_one_wg = false;  // merges by one workgroup (bit-identical to the cross-workgroup pipeline, slower)
     bool timing = false;       // diagnostic: cycle counters of the wide level-0 kernel
     bool short_calls = true;   // fewer private factors for calls too short to amortise the merge tree over them
+    bool narrow_tall = true;   // 96-row level-0 blocks at one wave per SIMD for long calls over <= 6 column tiles
 };
 
 struct FbrTsqrWork {

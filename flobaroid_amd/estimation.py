@@ -120,13 +120,16 @@ def observability_weights(R1_K: np.ndarray) -> np.ndarray:
     """Per-parameter CAD-pull weights of ``SDP._observabilityWeights`` (sdp.py:295-315), same expression: with the reduced
     normal matrix M = (R1 K)^T (R1 K) and the ridge eps = 1e-6 * trace(M) / n, obs_std = sqrt(clip(diag((M + eps I)^-1), 0)),
     normalised by the median of its positive entries and clipped to [0.1, 100].  Ordered like the columns of ``R1_K``."""
+    n = R1_K.shape[1]
     M = R1_K.T @ R1_K
-    eps = 1e-6 * float(np.trace(M)) / M.shape[0]
-    cov_diag = np.clip(np.diag(la.inv(M + eps * np.eye(M.shape[0]))), 0.0, None)
-    obs_std = np.sqrt(cov_diag)
-    positive = obs_std[obs_std > 0]
-    med = float(np.median(positive)) if positive.size else 1.0
-    return np.clip(obs_std / med, 0.1, 100.0)
+    ridge = 1e-6 * float(np.trace(M)) / n
+    # diag((M + ridge I)^-1) from the solution of (M + ridge I) X = I.  The matrix is badly conditioned (2e7 on WALK-MAN: the ridge is
+    # 1e-6 of the mean eigenvalue), so the weights depend on the factorisation to ~1e-9: the general LU solve (gesv) is what the
+    # reference's la.inv runs (sdp.py:309-315) and reproduces its numbers to the bit; a Cholesky solve differs by 2e-9
+    X = la.solve(M + ridge * np.eye(n), np.eye(n))
+    obs_std = np.sqrt(np.maximum(np.einsum("ii->i", X), 0.0))
+    scale = np.median(obs_std[obs_std > 0]) if np.any(obs_std > 0) else 1.0
+    return np.clip(obs_std / float(scale), 0.1, 100.0)
 
 
 def sdp_regularized_system(sdp_in: dict, xStdModel: np.ndarray, identified_params, non_id, base_error: float, regularization_factor: float,
@@ -316,18 +319,17 @@ def trajectory_row_weights(residual_bw: np.ndarray, file_boundaries, num_used_sa
 
     ``residual_bw`` (S, 6): base-wrench residual tau_bw - YBase_bw x_pre of a cheap OLS pre-pass (obtainable with
     ``Engine.predict``).  Returns the (S, 6) weights (mean ~ 1); files with <= 6 samples keep weight 1."""
-    fb = 6
-    S = num_used_samples
-    loaded_idx = np.arange(S) * (skip + 1)
-    file_idx = np.searchsorted(file_boundaries, loaded_idx, side="right") - 1
+    nw = 6  # wrench components
+    # file of every used sample (sample i of the used ones is loaded sample i (skip + 1), data.py:50,115)
+    owner = np.searchsorted(np.asarray(file_boundaries), np.arange(num_used_samples) * (skip + 1), side="right") - 1
     n_files = len(file_boundaries) - 1
-    sigma = np.ones((n_files, fb))
-    for k in range(n_files):
-        mask = file_idx == k
-        if np.count_nonzero(mask) > fb:
-            sigma[k] = np.sqrt(np.mean(residual_bw[mask] ** 2, axis=0))
-    weights = np.mean(sigma) / np.maximum(sigma, 1e-12)
-    return weights[file_idx]
+    count = np.bincount(owner, minlength=n_files)[:n_files]
+    sumsq = np.zeros((n_files, nw))
+    np.add.at(sumsq, owner, np.square(residual_bw))
+    # rms residual per (file, component); files too short to estimate one (<= 6 samples) keep sigma = 1
+    rms = np.sqrt(sumsq / np.maximum(count, 1)[:, None])
+    sigma = np.where((count > nw)[:, None], rms, 1.0)
+    return (np.mean(sigma) / np.maximum(sigma, 1e-12))[owner]
 
 
 def post_identify_friction(tau_residual_2d: np.ndarray, velocities: np.ndarray, velocities_for_sign: np.ndarray,

@@ -35,7 +35,11 @@
  */
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_MAX_LINKS 256
 
@@ -579,4 +583,63 @@ int orc_gram(long M, int P, const double *A, int k, const double *rhs, double *G
         }
     }
     return 0;
+}
+
+/*
+ * CPU baseline, all cores (bench.py cpu_baseline_all_cores; SURVEY 8(d): "per-sample regressor + RNEA loop, 1 thread, then all host
+ * cores with OpenMP").  The reference's loop body (model.py:370-523: one regressor and one simulated torque vector per sample, stacked
+ * into regressor_stack / torques_stack) for S samples, the samples dealt to OpenMP threads, written straight into the augmented block
+ * A [S * rows][P + 1] = [Y | tau] (no per-block hstack / allocation in the timed loop); the caller forms A^T A with ONE threaded BLAS call.
+ * Returns the number of threads that took part (1 without OpenMP), < 0 on error.
+ */
+int orc_stack_block_omp(int L, int n, const int *order, const int *parent, const int *dof, const double *restR, const double *restp,
+                        const double *axis, const int *jtype, int floating, const double *gravity, long S, const double *q,
+                        const double *dq, const double *ddq, const double *base_vel, const double *base_acc, const double *rpy,
+                        const double *x_std, int nthreads, double *A)
+{
+    if (L > ORC_MAX_LINKS) return -1;
+    orc_model m;
+    make_model(&m, L, n, order, parent, dof, restR, restp, axis, jtype, floating, gravity);
+    orc_layout lay = {0, 0, 0, 0.0};
+    const int rows = n + (floating ? 6 : 0);
+    const int P = orc_num_cols(L, n, &lay);
+    int used = 1, fail = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+    {
+        link_state *st = (link_state *)malloc(sizeof(link_state) * ORC_MAX_LINKS);
+        double *f_links = (double *)malloc(sizeof(double) * 6 * ORC_MAX_LINKS);
+        double *Y = (double *)malloc(sizeof(double) * (size_t)rows * P);
+        double *tau = (double *)malloc(sizeof(double) * rows);
+        if (!st || !f_links || !Y || !tau) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            fail = 1;
+        }
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static)
+#endif
+        for (long s = 0; s < S; s++) {
+            if (fail) continue;
+            orc_kinematics(&m, q + s * n, dq + s * n, ddq + s * n, floating ? base_vel + 6 * s : NULL, floating ? base_acc + 6 * s : NULL,
+                           floating ? rpy + 3 * s : NULL, st);
+            orc_regressor_sample(&m, &lay, st, dq + s * n, NULL, Y);
+            orc_rnea_sample(&m, st, x_std, f_links, tau);
+            double *As = A + (size_t)s * rows * (P + 1);
+            for (int r = 0; r < rows; r++) {
+                memcpy(As + (size_t)r * (P + 1), Y + (size_t)r * P, sizeof(double) * P);
+                As[(size_t)r * (P + 1) + P] = tau[r];
+            }
+        }
+        free(st);
+        free(f_links);
+        free(Y);
+        free(tau);
+    }
+    return fail ? -2 : used;
 }

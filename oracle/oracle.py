@@ -130,6 +130,18 @@ class OracleModel:
         assert rc == 0
         return tau
 
+    def stack_block(self, st, x_std, out=None, threads=0):
+        """[Y | tau] of the samples, (S*rows, P+1), the reference's loop body dealt to OpenMP threads (``orc_stack_block_omp``; models
+        without friction columns).  Returns (block, threads that took part).  Only bench.py's all-core CPU baseline uses it."""
+        assert not self.fric and not self.grav_only
+        S, q, dq, ddq, bv, ba, rpy = self._states(st)
+        A = out if out is not None else np.empty((S * self.rows, self.P + 1))
+        assert A.shape == (S * self.rows, self.P + 1) and A.flags.c_contiguous
+        rc = lib().orc_stack_block_omp(*self._model_args(), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy),
+                                       _d(_c(x_std)), int(threads), _d(A))
+        assert rc > 0, rc
+        return A, int(rc)
+
     def contact_torques(self, st, frame, wrench):
         """(S, rows): J_frame^T w per sample; ``frame`` = link name or a frame name of the topology."""
         S, q, dq, ddq, bv, ba, rpy = self._states(st)

@@ -198,7 +198,8 @@ int emul_id(const EmulTopo *t, long S, const double *q, const double *dq, const 
 // per sample, branch-point records in slots, torques written when their level of the joint stack is taken again.  info (optional, 3):
 // nsteps, maxlvl, nslots of the program.  Returns -1 when the tree is deeper than the kernel instances cover.
 int emul_kinid(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
-               const double *rpy, const double *sign, const double *vel_sign, const double *x, int mode, double *tau, int *info)
+               const double *rpy, const double *sign, const double *vel_sign, const double *x, int mode, double *tau, int *info, int flink,
+               const double *fp)
 {
     FbrHostModel hm;
     make(t, hm);
@@ -231,8 +232,23 @@ int emul_kinid(const EmulTopo *t, long S, const double *q, const double *dq, con
         };
         auto save = [&](int b, int i, double v) { slots[(size_t)b * FBR_LINK_REC + i] = v; };
         auto load = [&](int b, int i) { return slots[(size_t)b * FBR_LINK_REC + i]; };
-        auto getpi = [&](int l, double *pi) {
+        auto link = [&](int l, int, const double *rec, const double (*)[6], const int *, double *F) {
+            if (mode == 2) {  // contact wrench at (flink, fp): x = [S][6]
+                if (l != flink) return;
+                const double *w = x + s * 6;
+                double tt[3], pf[3], f[3] = {w[0], w[1], w[2]}, pxf[3];
+                fbr_mv(rec + FBR_OFF_R, fp, tt);
+                for (int i = 0; i < 3; i++) pf[i] = rec[FBR_OFF_P + i] + tt[i];
+                fbr_cross(pf, f, pxf);
+                for (int i = 0; i < 3; i++) {
+                    F[i] = f[i];
+                    F[3 + i] = w[3 + i] + pxf[i];
+                }
+                return;
+            }
+            double pi[10];
             for (int c = 0; c < 10; c++) pi[c] = mode == 0 ? x[10 * l + c] : (c < hm.cpl ? x[hm.cpl * l + c] : 0.0);
+            fbr_link_wrench(rec, pi, F);
         };
         auto consts = [&](int l, double *rR, double *rp, double *ax) {
             for (int i = 0; i < 9; i++) rR[i] = hm.restR[9 * l + i];
@@ -242,7 +258,7 @@ int emul_kinid(const EmulTopo *t, long S, const double *q, const double *dq, con
             }
         };
         auto emit = [&](int r, double v) {
-            if (r >= hm.fb && hm.fric) {
+            if (r >= hm.fb && hm.fric && mode != 2) {
                 const int d = r - hm.fb;
                 const double dqv = dq[s * n + d], sg = sign[s * n + d];
                 if (mode == 0) {
@@ -268,10 +284,66 @@ int emul_kinid(const EmulTopo *t, long S, const double *q, const double *dq, con
             written[r]++;
             ts[r] = v;
         };
-        fbr_kinid_lane<FBR_KINID_MAXD>(p.nsteps, p.maxlvl, p.steps.data(), p.endflush.data(), hm.floating, hm.gravity, hm.fb, state, basest, save,
-                                       load, getpi, emit, consts);
+        fbr_kinid_lane<FBR_KINID_MAXD, true>(p.nsteps, p.maxlvl, p.steps.data(), p.endflush.data(), hm.floating, hm.gravity, hm.fb, state, basest,
+                                             save, load, link, emit, consts);
         for (int r = 0; r < hm.rows; r++)
             if (written[r] != 1) return -2 - r;  // a row written twice or never: a bug of the flush lists
+    }
+    return 0;
+}
+
+// mirrors fbr_kinfd_kernel: one "lane" per evaluation e = s (1 + 3 n) + j of the finite-difference sweep, score[e] = sum W_s . Y_e
+int emul_kinfd(const EmulTopo *t, long S, double eps, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
+               const double *rpy, const double *sign, const double *W, double *out)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    if (hm.maxdepth > FBR_KINID_MAXD || hm.masked) return -1;
+    FbrKinIdProgram p;
+    fbr_kinid_build(hm, p);
+    const int n = hm.n, nper = 1 + 3 * n;
+    std::vector<double> slots((size_t)std::max(p.nslots, 1) * FBR_LINK_REC);
+    for (long e = 0; e < S * nper; e++) {
+        const long s = e / nper;
+        const int j = (int)(e - s * nper);
+        const int kind = (j == 0) ? -1 : (j - 1) / n, dj = (j == 0) ? -1 : (j - 1) % n;
+        const double *Ws = W + (size_t)s * hm.rows * hm.cols;
+        double score = 0.0;
+        auto state = [&](int d, double &a, double &b, double &c) {
+            a = q[s * n + d] + ((kind == 0 && d == dj) ? eps : 0.0);
+            b = dq[s * n + d] + ((kind == 1 && d == dj) ? eps : 0.0);
+            c = ddq[s * n + d] + ((kind == 2 && d == dj) ? eps : 0.0);
+        };
+        auto basest = [&](double *v6, double *a6, double *e3) {
+            for (int i = 0; i < 6; i++) {
+                v6[i] = bv[6 * s + i];
+                a6[i] = ba[6 * s + i];
+            }
+            for (int i = 0; i < 3; i++) e3[i] = rpy[3 * s + i];
+        };
+        auto save = [&](int b, int i, double v) { slots[(size_t)b * FBR_LINK_REC + i] = v; };
+        auto load = [&](int b, int i) { return slots[(size_t)b * FBR_LINK_REC + i]; };
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {
+            for (int i = 0; i < 9; i++) rR[i] = hm.restR[9 * l + i];
+            for (int i = 0; i < 3; i++) {
+                rp[i] = hm.restp[3 * l + i];
+                ax[i] = hm.axis[3 * l + i];
+            }
+        };
+        auto Wr = [&](int r, int c) { return Ws[(size_t)r * hm.cols + c]; };
+        auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *) {
+            score += fbr_kinfd_link_score<FBR_KINID_MAXD>(l, depth, rec, Sst, lvd, hm.cpl, hm.fb, Wr);
+        };
+        auto emit = [&](int, double) {};
+        fbr_kinid_lane<FBR_KINID_MAXD, false>(p.nsteps, p.maxlvl, p.steps.data(), p.endflush.data(), hm.floating, hm.gravity, hm.fb, state, basest,
+                                              save, load, link, emit, consts);
+        for (int c = hm.cpl * hm.L; c < hm.cols; c++) {
+            const FbrCol &cd = hm.coldesc[c];
+            const int jj = cd.joint;
+            const double dqv = dq[s * n + jj] + ((kind == 1 && jj == dj) ? eps : 0.0);
+            score += Ws[(size_t)(hm.fb + jj) * hm.cols + c] * fbr_friction_value(cd.pidx, dqv, sign ? sign[s * n + jj] : 0.0, hm.stribeck);
+        }
+        out[e] = score;
     }
     return 0;
 }

@@ -116,7 +116,7 @@ class Emul:
                       _d(vel_sign), _d(x), int(mode), _d(tau))
         return tau
 
-    def fused_inverse_dynamics(self, st, x, sign=None, vel_sign=None, mode=0):
+    def fused_inverse_dynamics(self, st, x, sign=None, vel_sign=None, mode=0, flink=0, fp=None):
         """(tau, (nsteps, maxlvl, nslots)) from the emulation of fbr_kinid_kernel (csrc/fbr_kinid.h): the device kernel's own step program
         and lane body, one lane per sample.  Raises if a regressor row is written twice or never."""
         S, q, dq, ddq, bv, ba, rpy = self._st(st)
@@ -125,11 +125,24 @@ class Emul:
         x = np.ascontiguousarray(x, dtype=np.float64)
         tau = np.zeros((S, self.rows))
         info = (ctypes.c_int * 3)()
+        fp = np.zeros(3) if fp is None else np.ascontiguousarray(fp, dtype=np.float64)
         rc = lib().emul_kinid(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign),
-                              _d(vel_sign), _d(x), int(mode), _d(tau), info)
+                              _d(vel_sign), _d(x), int(mode), _d(tau), info, int(flink), _d(fp))
         if rc != 0:
             raise RuntimeError(f"emul_kinid: rc {rc}" + (f" (row {-2 - rc} not written exactly once)" if rc <= -2 else " (tree too deep)"))
         return tau, tuple(info)
+
+    def fused_fd_scores(self, st, W, eps, sign=None):
+        """emulation of fbr_kinfd_kernel: scores [S][1 + 3 n] of the finite-difference sweep, one lane per evaluation"""
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        sign = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        out = np.zeros((S, 1 + 3 * self.n))
+        rc = lib().emul_kinfd(ctypes.byref(self.t), ctypes.c_long(S), ctypes.c_double(eps), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy),
+                              _d(sign), _d(W), _d(out))
+        if rc != 0:
+            raise RuntimeError(f"emul_kinfd: rc {rc}")
+        return out
 
     def program_info(self, k):
         NT, npairs, T, img, items = (ctypes.c_int() for _ in range(5))

@@ -271,3 +271,39 @@ def test_fused_program_on_random_trees(seed):
     xi = rng.standard_normal(om.P)
     tp, _ = em.fused_inverse_dynamics(st, xi, sign, mode=1)
     assert np.abs(tp.reshape(-1) - Y @ xi).max() <= 1e-11 * max(np.abs(Y @ xi).max(), 1e-300)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_contact_and_fd_programs_on_random_trees(seed):
+    """The other two users of the fused lane body (csrc/fbr_kinid.h): J^T w of a contact wrench (mode 2: only the frame's link carries a
+    wrench) and the finite-difference scores (one lane per perturbed evaluation, weights against the unit wrenches)."""
+    rng = np.random.default_rng(900 + seed)
+    L = int(rng.integers(3, 20))
+    t = random_topology(rng, L, p_fixed=0.2, branchiness=float(rng.choice([0.2, 0.6, 1.0])), p_prismatic=0.2 * (seed & 1))
+    fl, fr = bool(seed & 1), bool(seed & 2)
+    om = OracleModel(t, floating=fl, fric=fr)
+    em = Emul(t, floating=fl, fric=fr)
+    S = 5
+    st = random_states(t, S, rng, fl)
+    sign = np.tanh(st["dq"] / 0.02)
+    # contact: a frame on a random link
+    flink = int(rng.integers(0, L))
+    fp = rng.standard_normal(3) * 0.2
+    t.frames["probe"] = {"link": flink, "R": np.eye(3), "p": fp}
+    w = rng.standard_normal((S, 6))
+    ref = om.contact_torques(st, "probe", w)
+    got, _ = em.fused_inverse_dynamics(st, w, sign, mode=2, flink=flink, fp=fp)
+    assert np.abs(got - ref.reshape(S, -1)).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300)
+    # finite-difference scores
+    n, eps = t.num_dofs, 1e-6
+    W = rng.standard_normal((S * om.rows, om.P))
+    sc = em.fused_fd_scores(st, W, eps, sign)
+    Wb = W.reshape(S, om.rows, om.P)
+    refs = np.empty_like(sc)
+    refs[:, 0] = np.einsum("src,src->s", Wb, om.regressor(st, sign).reshape(S, om.rows, om.P))
+    for kind, key in enumerate(("q", "dq", "ddq")):
+        for d in range(n):
+            sp = {k: v.copy() for k, v in st.items()}
+            sp[key][:, d] += eps
+            refs[:, 1 + kind * n + d] = np.einsum("src,src->s", Wb, om.regressor(sp, sign).reshape(S, om.rows, om.P))
+    assert np.abs(sc - refs).max() <= 1e-11 * np.abs(refs).max()
