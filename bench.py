@@ -220,7 +220,7 @@ def cpu_baseline_all_cores(topo, one_thread_rate=None, budget_s=10.0):
             t1 = time.perf_counter()
             _, thr = om.stack_block(st, x, out=A, threads=cores)
             t2 = time.perf_counter()
-            G += dsyrk(1.0, A, trans=1, lower=0)   # upper triangle of A^T A (A is C-contiguous: trans on the Fortran view is handled by SciPy)
+            G += dsyrk(1.0, A.T, trans=0, lower=0)   # upper triangle of A^T A: A.T is the Fortran-ordered view of the C-ordered block (no copy)
             t3 = time.perf_counter()
             t_stack += t2 - t1
             t_syrk += t3 - t2

@@ -394,6 +394,29 @@ __global__ __launch_bounds__(256) void fbr_groups_clear_pad_kernel(const FbrDevG
     const long cnt = (Sslot - S) * grp[g].ld;
     for (long i = threadIdx.x; i < cnt; i += blockDim.x) p[i] = 0.0;
 }
+// The same for the COLUMN-major chunks of the lane writer (fbr_kinid.h fbr_kinwrite_kernel): element (slot, sample, column c) at
+// A[c * ldc + slot * Sslot + sample], ldc = nrows[g] * Sslot.  Rows [S, Sslot) of every slot := 0 in the columns < pa[g], and the padding
+// columns [pa[g], ld) := 0 over all rows.  grid = (groups, maxrows + FBR_CM_PADWG): blocks y < nrows[g] take a slot's padding rows, the
+// last FBR_CM_PADWG blocks share the padding columns.
+#define FBR_CM_PADWG 64
+__global__ __launch_bounds__(256) void fbr_groups_clear_cm_kernel(const FbrDevGroup *__restrict__ grp, const int *__restrict__ nrows, const int *__restrict__ pa,
+                                                                  long S, long Sslot, int maxrows)
+{
+    const int g = blockIdx.x, y = blockIdx.y;
+    const long ldc = (long)nrows[g] * Sslot;
+    if (y < maxrows) {
+        const long padr = Sslot - S;
+        if (y >= nrows[g] || padr <= 0) return;
+        for (long i = threadIdx.x; i < padr * pa[g]; i += blockDim.x) {
+            const long c = i / padr, r = i - c * padr;
+            grp[g].A[c * ldc + (long)y * Sslot + S + r] = 0.0;
+        }
+    } else {
+        double *p = grp[g].A + (long)pa[g] * ldc;
+        const long cnt = (long)(grp[g].ld - pa[g]) * ldc;
+        for (long i = (long)(y - maxrows) * blockDim.x + threadIdx.x; i < cnt; i += (long)FBR_CM_PADWG * blockDim.x) p[i] = 0.0;
+    }
+}
 __global__ __launch_bounds__(256) void fbr_regressor_groups_kernel(DevModel m, long S, const double *__restrict__ rec, const double *__restrict__ dq,
                                                                     const double *__restrict__ sign, const double *__restrict__ rhs, int k,
                                                                     const double *__restrict__ wts, const FbrDevGroup *__restrict__ grp, int ngroups,

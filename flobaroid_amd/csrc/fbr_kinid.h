@@ -38,28 +38,31 @@ struct FbrKinIdProgram {
 // psave: slot this link's record is saved to (a later link that is not the next step has it as parent), or -1.
 // level: 0-based depth of the link's own joint on its path (-1: fixed joint / base); depth: joints on the link's path (own one included).
 // flushdof: the dof that held `level` until now and is complete (every link below it has been walked), or -1.
-static inline void fbr_kinid_build(const FbrHostModel &hm, FbrKinIdProgram &p)
+// keep (optional, [L]): the program walks these links only -- a set closed under parents (fbr_kinid_build_parts).
+static inline void fbr_kinid_build(const FbrHostModel &hm, FbrKinIdProgram &p, const std::vector<char> *keep = nullptr)
 {
-    const int L = hm.L;
+    std::vector<int> ord;
+    for (int l : hm.order)
+        if (!keep || (*keep)[l]) ord.push_back(l);
+    const int L = (int)ord.size();
     p.nsteps = L;
-    p.steps.assign((size_t)L * FBR_KINID_STEP, -1);
-    std::vector<int> pos(L, 0), lastchild(L, -1);  // step of every link; the last step whose parent it is
-    for (int k = 0; k < L; k++) pos[hm.order[k]] = k;
+    p.steps.assign((size_t)std::max(L, 1) * FBR_KINID_STEP, -1);
+    std::vector<int> lastchild(hm.L, -1);  // the last step whose parent the link is
     for (int k = 0; k < L; k++) {
-        const int par = hm.parent[hm.order[k]];
+        const int par = hm.parent[ord[k]];
         if (par >= 0) lastchild[par] = std::max(lastchild[par], k);
     }
     // slots: a link holds one from its own step to the step of its last child whenever that child is not the very next step
-    std::vector<int> slot(L, -1), holder;  // holder[b]: link that holds slot b, or -1
+    std::vector<int> slot(hm.L, -1), holder;  // holder[b]: link that holds slot b, or -1
     int maxlvl = 0;
     std::vector<int> lvldof(std::max(hm.maxdepth, 1), -1);
     for (int k = 0; k < L; k++) {
-        const int l = hm.order[k], par = hm.parent[l];
+        const int l = ord[k], par = hm.parent[l];
         int *st = &p.steps[(size_t)k * FBR_KINID_STEP];
         for (int &h : holder)
             if (h >= 0 && lastchild[h] < k) h = -1;  // (its last child has been walked)
         st[0] = l;
-        st[1] = par < 0 ? -1 : (k > 0 && hm.order[k - 1] == par ? 0 : 1 + slot[par]);
+        st[1] = par < 0 ? -1 : (k > 0 && ord[k - 1] == par ? 0 : 1 + slot[par]);
         if (par >= 0 && st[1] != 0 && (slot[par] < 0 || holder[slot[par]] != par)) throw std::runtime_error("fbr_kinid_build: parent record not held");
         st[2] = -1;
         if (lastchild[l] > k + 1) {  // some child comes later than the next step
@@ -88,6 +91,36 @@ static inline void fbr_kinid_build(const FbrHostModel &hm, FbrKinIdProgram &p)
     p.maxlvl = maxlvl;
     p.endflush.assign(std::max(maxlvl, 1), -1);
     for (int v = 0; v < maxlvl; v++) p.endflush[v] = lvldof[v];
+}
+
+// The tree cut into `nparts` programs for waves that share one block of samples (the lane writer: every wave walks ITS links and the
+// ancestors they need, and writes the columns of its own links only).  The depth-first order is cut into contiguous ranges of about
+// equal cost (cost[l]: what link l costs its owner); own[p][l] = 1: part p owns link l.  Ancestors are walked redundantly (a trunk of a
+// few links on WALK-MAN); nothing is exchanged between the waves.
+static inline void fbr_kinid_build_parts(const FbrHostModel &hm, const std::vector<double> &cost, int nparts, std::vector<FbrKinIdProgram> &progs,
+                                         std::vector<std::vector<char>> &own)
+{
+    nparts = std::max(1, std::min(nparts, hm.L));
+    double total = 0.0;
+    for (int l = 0; l < hm.L; l++) total += cost[l];
+    progs.assign(nparts, FbrKinIdProgram());
+    own.assign(nparts, std::vector<char>(hm.L, 0));
+    double acc = 0.0;
+    int part = 0;
+    for (int k = 0; k < hm.L; k++) {
+        const int l = hm.order[k];
+        // (a part is closed when its share is reached; the last part takes what is left; every part gets at least one link)
+        if (part + 1 < nparts && acc >= total * (part + 1) / nparts && hm.L - k >= nparts - part - 1) part++;
+        own[part][l] = 1;
+        acc += cost[l];
+    }
+    for (int p = 0; p < nparts; p++) {
+        std::vector<char> keep = own[p];
+        for (int l = 0; l < hm.L; l++)
+            if (own[p][l])
+                for (int a = hm.parent[l]; a >= 0 && !keep[a]; a = hm.parent[a]) keep[a] = 1;
+        fbr_kinid_build(hm, progs[p], &keep);
+    }
 }
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
@@ -203,11 +236,14 @@ FBR_HD double fbr_kinfd_link_score(int l, int depth, const double *rec, const do
     return acc;
 }
 
-#if defined(__HIPCC__) && defined(FBR_KERNELS_CORE)
+#if defined(__HIPCC__)
 struct DevKinId {
     int nsteps, maxlvl, nslots, ldn;  // ldn: row stride (doubles, odd) of the staged joint states of one sample
     const int *steps, *endflush;
 };
+#endif
+
+#if defined(__HIPCC__) && defined(FBR_KERNELS_CORE)
 
 // mode 0: x = full standard vector (10 per link + friction slots); mode 1: x = identified-parameter vector (cols);
 // mode 2: contact wrench -> generalized force J^T w (fbr_contact_torques, model.py:535-555): x = [S][6] wrenches at the frame
@@ -387,6 +423,169 @@ __global__ __launch_bounds__(64) void fbr_kinfd_kernel(DevModel m, DevKinId p, l
             score += Ws[(long)(m.fb + jj) * m.cols + c] * fbr_friction_value(cd.z, dqv, sign ? sign[s * n + jj] : 0.0, m.stribeck);
         }
         if (live) out[e] = score;
+    }
+}
+#endif
+
+#if defined(__HIPCC__) && defined(FBR_KERNELS_GROUPS)
+// ------------------------------------------------------------------------------------------------
+// Regressor WRITER of the TSQR, one lane per sample, kinematics fused in (no records): the chunks the level-0 folds read, written
+// COLUMN-major -- element (chunk row o, column c) at A[c * ld + o] with o = slot * Sslot + sample -- so that the 64 samples of a wave
+// are 64 consecutive doubles of one column: every store instruction writes 512 contiguous bytes (four whole lines).  It replaces the
+// pair fbr_kin_kernel (9.5 KB of records per WALK-MAN sample, partially written lines) + fbr_regressor_groups_kernel (one workgroup
+// per sample, ~600 instructions per thread and sample, 8-byte stores at the chunks' row stride): 4.2 + 11.7 ms per 1 M samples.
+// What a column writes is resolved on the host into DESTINATIONS (chunk address of sample 0 of the row's slot in the column's position,
+// 0: the row's group does not hold the column / the row is switched off), in the order the lane produces the values -- no per-entry decode:
+//   colrec[c] = {first destination, number of explicit zeros};  dst[first ..]: [fb base-wrench rows][one per joint of the link's path, root
+//   first][the explicit zeros: rows of the groups that hold the column but are not on the link's path, right of their first supported tile]
+//   friction column: [its joint's row][zeros];  pseudo-column `cols`: per regressor row its k rhs destinations.
+// The tables are read through the scalar cache (constant address space, wave-uniform addresses).  The first version of this kernel decoded
+// (row, kind, level, position) entries with per-entry table lookups behind vector loads: 1350 cycles per entry; with scalar loads but a
+// level-indexed branch ladder per entry: 650.
+// lcol10[10 l + p]: the column of parameter p of link l (-1: not identified / not selected).  Row weights are applied here.
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) long *fbr_clong_ptr;
+typedef const __attribute__((address_space(4))) int *fbr_cint_ptr;
+#define FBR_KINWRITE_PARTS 4
+struct DevKinWrite {
+    const int *lcol10, *colrec;  // lcol10 [parts][10 L]: the columns a part's wave writes; colrec [cols + 1][2]
+    const long *dst;
+    int ninert, cols, k, has_w;
+    int nparts, part_nsteps[FBR_KINWRITE_PARTS], part_step0[FBR_KINWRITE_PARTS];  // wave w of a workgroup walks steps [step0, step0 + nsteps) of p.steps
+};
+
+// A workgroup = nparts waves sharing one block of 64 samples (their states are staged once): wave w walks part w of the tree.
+template <int MAXD>
+__global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinwrite_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, const double *__restrict__ q,
+                                                          const double *__restrict__ dq, const double *__restrict__ ddq, const double *__restrict__ bv,
+                                                          const double *__restrict__ ba, const double *__restrict__ rpy, const double *__restrict__ sign,
+                                                          const double *__restrict__ rhs, const double *__restrict__ wts, double *__restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nth = blockDim.x, tid = threadIdx.x;
+    const int n = m.n, ldn = p.ldn, ldw = m.rows | 1;
+    double *sq = smem, *sdq = sq + 64 * ldn, *sddq = sdq + 64 * ldn, *sw = sddq + 64 * ldn;  // sw: [64][ldw] row weights (has_w)
+    double *scr = scratch + ((long)blockIdx.x * wr.nparts + part) * p.nslots * FBR_LINK_REC * 64 + lane;
+    const long nblk = (S + 63) >> 6;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long base = blk << 6;
+        const int valid = (int)min(64L, S - base);
+        __syncthreads();
+        {
+            const long off = base * n;
+            const int cnt = valid * n;
+            int sr = tid / n, dc = tid - sr * n;
+            const int ds = nth / n, dd = nth - ds * n;
+            for (int i = tid; i < cnt; i += nth) {
+                const double a = q[off + i], b = dq[off + i], c = ddq[off + i];
+                sq[sr * ldn + dc] = a;
+                sdq[sr * ldn + dc] = b;
+                sddq[sr * ldn + dc] = c;
+                sr += ds;
+                dc += dd;
+                if (dc >= n) {
+                    dc -= n;
+                    sr++;
+                }
+            }
+            if (wr.has_w) {
+                const int rows = m.rows, cw = valid * rows;
+                int wr_ = tid / rows, wc = tid - wr_ * rows;
+                const int es = nth / rows, ed = nth - es * rows;
+                for (int i = tid; i < cw; i += nth) {
+                    sw[wr_ * ldw + wc] = wts[base * rows + i];
+                    wr_ += es;
+                    wc += ed;
+                    if (wc >= rows) {
+                        wc -= rows;
+                        wr_++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int ls = min(lane, valid - 1);
+        const long s = base + ls;
+        const bool live = lane < valid;
+        const double *mysq = sq + ls * ldn, *mysdq = sdq + ls * ldn, *mysddq = sddq + ls * ldn, *myw = sw + ls * ldw;
+        auto state = [&](int d, double &a, double &b, double &c) {
+            a = mysq[d];
+            b = mysdq[d];
+            c = mysddq[d];
+        };
+        auto basest = [&](double *v6, double *a6, double *e3) {
+            for (int i = 0; i < 6; i++) {
+                v6[i] = bv[s * 6 + i];
+                a6[i] = ba[s * 6 + i];
+            }
+            for (int i = 0; i < 3; i++) e3[i] = rpy[s * 3 + i];
+        };
+        auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
+        auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {
+            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+            for (int i = 0; i < 3; i++) {
+                rp[i] = m.restp[3 * l + i];
+                ax[i] = m.axis[3 * l + i];
+            }
+        };
+        const fbr_clong_ptr cdst = (fbr_clong_ptr)(unsigned long)wr.dst;
+        const fbr_cint_ptr crec = (fbr_cint_ptr)(unsigned long)wr.colrec, ccol = (fbr_cint_ptr)(unsigned long)(wr.lcol10 + (long)part * 10 * m.L);
+        // one value: to its destination (sample 0 of the chunk) + s; the lanes of a wave write 64 consecutive doubles
+        auto put = [&](long d0, double v) {
+            if (d0 != 0 && live) __builtin_nontemporal_store(v, (double *)d0 + s);  // (s: sample index inside the chunk -- one launch per chunk)
+        };
+        auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
+            (void)F;
+#pragma unroll
+            for (int pp = 0; pp < 10; pp++) {
+                const int c = ccol[10 * l + pp];
+                if (c < 0) continue;
+                const int d0 = crec[2 * c], nz = crec[2 * c + 1];
+                if (d0 < 0) continue;  // (the column is not factorised)
+                // the record's destinations are requested TOGETHER, before anything is computed (one round trip to the scalar cache / L2 per
+                // column instead of one per value; reads past the record's end stay inside the padded table and are never used)
+                long db[6], dj[MAXD];
+#pragma unroll
+                for (int i = 0; i < 6; i++) db[i] = cdst[d0 + i];
+#pragma unroll
+                for (int j = 0; j < MAXD; j++) dj[j] = cdst[d0 + m.fb + j];
+                double w6[6];
+                fbr_unit_wrench(rec, pp, w6);
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    if (i < m.fb) put(db[i], wr.has_w ? w6[i] * myw[i] : w6[i]);
+#pragma unroll
+                for (int j = 0; j < MAXD; j++)
+                    if (j < depth) {
+                        const double v = fbr_dot6(Sst[j], w6);
+                        put(dj[j], wr.has_w ? v * myw[m.fb + lvd[j]] : v);
+                    }
+                for (int z = 0; z < nz; z++) put(cdst[d0 + m.fb + depth + z], 0.0);
+            }
+        };
+        auto emit = [&](int, double) {};
+        fbr_kinid_lane<MAXD, false>(wr.part_nsteps[part], p.maxlvl, p.steps + wr.part_step0[part] * FBR_KINID_STEP, p.endflush, m.floating, m.g, m.fb,
+                                    state, basest, save, load, link, emit, consts);
+        if (part != wr.nparts - 1) continue;  // (friction and rhs columns: the last part, which the cut leaves the lightest)
+        // friction columns: one value on the row of the column's joint, explicit zeros on the other rows of the groups that hold it
+        for (int c = wr.ninert; c < wr.cols; c++) {
+            const int d0 = crec[2 * c], nz = crec[2 * c + 1];
+            if (d0 < 0) continue;
+            const int4 cd = m.coldesc[c];
+            const double fv = fbr_friction_value(cd.z, mysdq[cd.w], sign ? sign[s * n + cd.w] : 0.0, m.stribeck);
+            put(cdst[d0], wr.has_w ? fv * myw[m.fb + cd.w] : fv);
+            for (int z = 0; z < nz; z++) put(cdst[d0 + 1 + z], 0.0);
+        }
+        // rhs columns: k destinations per regressor row
+        {
+            const int d0 = crec[2 * wr.cols];
+            for (int r = 0; r < m.rows; r++)
+                for (int i = 0; i < wr.k; i++) {
+                    const double v = rhs[(s * m.rows + r) * wr.k + i];
+                    put(cdst[d0 + r * wr.k + i], wr.has_w ? v * myw[r] : v);
+                }
+        }
     }
 }
 #endif

@@ -64,6 +64,10 @@ struct FbrTsqrRowOrder {
     const int *first_col = nullptr;
     int rows = 0;
     long group = 0;
+    // > 0: the chunk is stored COLUMN-major, element (row o, column c) at A[c * colmajor_ld + o] -- the layout the one-lane-per-sample
+    // writers produce (fbr_kinid.h fbr_kinwrite_kernel: the 64 samples of a wave are 64 consecutive rows of one column = 512 contiguous
+    // bytes per store instruction).  0: row-major, leading dimension n.
+    long colmajor_ld = 0;
 };
 // input row (sample-major) of chunk row o
 __device__ __forceinline__ long fbr_tsqr_in_row(long o, int rows, long group)
@@ -452,7 +456,8 @@ __device__ __forceinline__ bool fbr_tsqr_wait_ge(const int *flag, int want)
 // between folds -- a wave that has consumed all its tiles of fold f loads its tiles of fold f + 1 and goes on while
 // the last, narrow panels of fold f are still being factorised by the other waves (up to RING panels of drift).
 struct FbrTsqrFoldDesc {
-    const double *B;  // block rows (row-major, leading dimension ldb), rows >= mrows are zero
+    const double *B;  // block rows: element (r, c) at B[r * ldb + c * cs]  (row-major: ldb = leading dimension, cs = 1; column-major chunk:
+                      // ldb = 1, cs = the chunk's column stride); rows >= mrows are zero
     int ldb, mrows, first_col;
     // XWG (cross-workgroup merge pipeline): per-wave progress counters (global memory, [waves]) of the block folded into the same factor
     // right before this one by ANOTHER workgroup (null: none), and of this block.  Counter of wave w: after iteration q it is q + 2 (0 =
@@ -461,6 +466,7 @@ struct FbrTsqrFoldDesc {
     // q + 1 (if the wave owns it) are final for this block and visible.
     const int *prev = nullptr;
     int *mine = nullptr;
+    long cs = 1;
 };
 
 // progress flags of the cross-workgroup pipeline: relaxed agent-scope atomics (the data travels as agent-scope atomics as well; the
@@ -544,9 +550,9 @@ __device__ __forceinline__ void fbr_tsqr_stream(double *__restrict__ R, int n, i
                     // (row group and tile clamped uniformly: scalar base + per-lane offset kk * ldb + li)
                     const int rg = 16 * sb + 4 * reg;
                     const bool gvalid = ct < NP && rg < fd.mrows;
-                    const double *Bs = fd.B + ((unsigned)(gvalid ? rg : 0) * (unsigned)fd.ldb + (gvalid ? 16u * (unsigned)ct : 0u));
+                    const double *Bs = fd.B + ((long)((unsigned)(gvalid ? rg : 0) * (unsigned)fd.ldb) + (gvalid ? 16 * ct : 0) * fd.cs);
                     const bool valid = gvalid && rg + kk < fd.mrows;
-                    const double x = Bs[(valid ? (unsigned)kk * (unsigned)fd.ldb : 0u) + (unsigned)li];
+                    const double x = Bs[(long)(valid ? (unsigned)kk * (unsigned)fd.ldb : 0u) + li * fd.cs];
                     C[t][sb][reg] = valid ? x : 0.0;
                 }
         }
@@ -739,7 +745,7 @@ template <int TPW, int SUB, bool TIMING, int W = FBR_TSQR_WAVES>
 __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_level0_kernel(const double *__restrict__ A, long Mpad, int n,
                                                                                double *__restrict__ Rw, long nblocks, unsigned *errflag,
                                                                                unsigned long long *dbg, const int *__restrict__ rowfc, int orows,
-                                                                               long ogroup, long M, int slot_stride)
+                                                                               long ogroup, long M, int slot_stride, long cm_ld)
 {
     // slot_stride: workgroup w folds into working factor w * slot_stride (1 for data chunks; 2^l when rows are folded into the factors
     // that are still alive after l levels of the merge tree: the embedded group factors of the tree-structured TSQR)
@@ -761,7 +767,9 @@ __global__ __launch_bounds__(64 * W, W == FBR_TSQR_WAVES ? 1 : 2) void fbr_tsqr_
         } else if (orows < 0) {  // upper-triangular input
             fc = (int)std::min<long>(r0, n);
         }
-        return FbrTsqrFoldDesc{A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc};
+        FbrTsqrFoldDesc fd{cm_ld > 0 ? A + r0 : A + r0 * n, cm_ld > 0 ? 1 : n, (int)std::min<long>(MB, Mpad - r0), fc};
+        fd.cs = cm_ld > 0 ? cm_ld : 1;
+        return fd;
     };
     fbr_tsqr_stream<TPW, SUB, TIMING, W, false>(R, n, LD, nfolds, fold_of, smem, errflag, tacc);
     if (TIMING && (threadIdx.x & 63) == 0) {
@@ -860,7 +868,7 @@ template <int SUB> __host__ __device__ constexpr size_t fbr_tsqr_narrow_lds_doub
 
 template <int NPT, int SUB>
 __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const double *__restrict__ B, unsigned ldb, int mrows, int first_col,
-                                                   double *lds, int lane)
+                                                   double *lds, int lane, long cs = 1)
 {
     constexpr int MB = 16 * SUB;
     constexpr unsigned ld = 16 * NPT;
@@ -881,9 +889,9 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
             for (int reg = 0; reg < 4; reg++) {
                 const int rg = 16 * sb + 4 * reg;
                 const bool gvalid = rg < mrows;
-                const double *Bs = B + ((unsigned)(gvalid ? rg : 0) * ldb + 16u * (unsigned)t);
+                const double *Bs = B + ((long)((unsigned)(gvalid ? rg : 0) * ldb) + 16 * t * cs);
                 const bool valid = gvalid && rg + kk < mrows;
-                const double x = Bs[(valid ? (unsigned)kk * ldb : 0u) + (unsigned)li];
+                const double x = Bs[(long)(valid ? (unsigned)kk * ldb : 0u) + li * cs];
                 C[t][sb][reg] = valid ? x : 0.0;
             }
     // rows 4 reg + kk of the 16 x 16 tile (row panel p, column tile t) of R
@@ -977,7 +985,7 @@ __device__ __forceinline__ void fbr_tsqr_wave_fold(double *__restrict__ R, const
 template <int NPT, int SUB>
 __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, (SUB > 3 ? 1 : 2)) void fbr_tsqr_narrow_level0_kernel(const double *__restrict__ A, long Mpad,
                                                                                                  double *__restrict__ Rw, long nblocks, int nwaves,
-                                                                                                 const int *__restrict__ rowfc, int orows, long ogroup, long M)
+                                                                                                 const int *__restrict__ rowfc, int orows, long ogroup, long M, long cm_ld)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int MB = 16 * SUB, n = 16 * NPT;
@@ -998,7 +1006,10 @@ __global__ __launch_bounds__(FBR_TSQR_NARROW_WAVES * 64, (SUB > 3 ? 1 : 2)) void
         } else if (orows < 0) {  // upper-triangular input
             fc = (int)std::min<long>(r0, n);
         }
-        fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc, lds, lane);
+        if (cm_ld > 0)
+            fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0, 1, (int)std::min<long>(MB, Mpad - r0), fc, lds, lane, cm_ld);
+        else
+            fbr_tsqr_wave_fold<NPT, SUB>(R, A + r0 * n, n, (int)std::min<long>(MB, Mpad - r0), fc, lds, lane);
     }
 }
 
@@ -1267,14 +1278,14 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
                 constexpr size_t lb = FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double);
                 (void)hipFuncSetAttribute((const void *)fbr_tsqr_narrow_level0_kernel<NPT, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64), lb, st, A, Mpad, wk.Rw, nblocks, nwaves,
-                                   ro.first_col, ro.rows, ro.group, M);
+                                   ro.first_col, ro.rows, ro.group, M, ro.colmajor_ld);
             });
             TSQR_HIP(hipGetLastError());
             return 0;
         }
         FBR_TSQR_NARROW_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_narrow_level0_kernel<NPT, SUB>), dim3(grid), dim3(FBR_TSQR_NARROW_WAVES * 64),
                                                             (FBR_TSQR_NARROW_WAVES * fbr_tsqr_narrow_lds_doubles<SUB>() * sizeof(double)), st, A, Mpad,
-                                                            wk.Rw, nblocks, nwaves, ro.first_col, ro.rows, ro.group, M));
+                                                            wk.Rw, nblocks, nwaves, ro.first_col, ro.rows, ro.group, M, ro.colmajor_ld));
         TSQR_HIP(hipGetLastError());
         return 0;
     }
@@ -1285,7 +1296,7 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         FBR_TSQR_DISPATCH_HALF(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, false, HW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                  (int)(fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double))));
         FBR_TSQR_DISPATCH_HALF(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, false, HW>), dim3(grid), dim3(64 * HW),
-                                                          (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride));
+                                                          (fbr_tsqr_lds_doubles<TPW, SUB, HW>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride, ro.colmajor_ld));
         TSQR_HIP(hipGetLastError());
         return 0;
     }
@@ -1297,12 +1308,12 @@ static inline int fbr_tsqr_fold_packed(FbrTsqrWork &wk, hipStream_t st, long M, 
         FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, true>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride));
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride, ro.colmajor_ld));
     } else {
         FBR_TSQR_DISPATCH(wk.tpw, (void)hipFuncSetAttribute((const void *)fbr_tsqr_level0_kernel<TPW, SUB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             (int)(fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double))));
         FBR_TSQR_DISPATCH(wk.tpw, hipLaunchKernelGGL((fbr_tsqr_level0_kernel<TPW, SUB, false>), dim3(grid), dim3(FBR_TSQR_THREADS),
-                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride));
+                                                     (fbr_tsqr_lds_doubles<TPW, SUB>() * sizeof(double)), st, A, Mpad, n, wk.Rw, nblocks, wk.err, dbg, ro.first_col, ro.rows, ro.group, M, slot_stride, ro.colmajor_ld));
     }
     TSQR_HIP(hipGetLastError());
     if (dbg) {
@@ -1349,7 +1360,15 @@ static inline int fbr_tsqr_fold_chunk(FbrTsqrWork &wk, hipStream_t st, long M, i
     }
     if (M <= 0) return 0;
     const long Mpad = (M + 15) & ~15L;
-    if (k == 0) {
+    if (ro.colmajor_ld > 0) {
+        // column-major chunk of a lane writer: every column < Pa written, padding columns and padding rows cleared by the writer's own
+        // clear kernel (fbr_groups_clear_cm_kernel); whole 16-row groups only
+        if (k != 0 || Mpad != M) {
+            g_tsqr_err = "column-major chunks carry their rhs columns and whole 16-row groups";
+            return -1;
+        }
+        wk.clean_key = -1;
+    } else if (k == 0) {
         // the writer has stored every column < Pa (rhs columns included): what is left are the zero padding columns -- written once per
         // buffer instead of once per chunk (WALK-MAN: 15 columns x 6 M base-wrench rows per 1 M samples) -- and the rows M..Mpad
         const long key = (long)wk.Pa * 4096 + wk.n;

@@ -350,12 +350,81 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         }
         tab.push_back((int)pents[var].size());
     }
+    // ---- the lane writer (fbr_kinid.h fbr_kinwrite_kernel, option tsqr_lane_writer): one lane per sample, kinematics fused in, chunks
+    // written column-major.  Its entries carry the level of the row's joint on the link's path instead of a motion-vector lookup.
+    const size_t lane_lds = ((size_t)3 * 64 * (std::max(hm.n, 1) | 1) + (dw ? (size_t)64 * (hm.rows | 1) : 0)) * sizeof(double);
+    const bool lane_writer = m->opt.tsqr_lane_writer != 0 && m->opt.tsqr_writer == 0 && m->kinid.nsteps > 0 && lane_lds <= (size_t)(120 << 10) && Pa < 1024;
+    // per destination slot of the lane writer: (regressor row, column position in the row's group), or row = -1: absent
+    std::vector<std::pair<int, int>> lslots;
+    size_t o_lrec = 0, o_lcol = 0, o_lsteps = 0;
+    int lane_parts = 1, lane_slots = 1, lane_step0[FBR_KINWRITE_PARTS] = {0, 0, 0, 0}, lane_nsteps[FBR_KINWRITE_PARTS] = {0, 0, 0, 0};
+    if (lane_writer) {
+        o_lrec = tab.size();
+        auto entry_of = [&](int c, int r, int kind, int *pos) {  // the writer entry (variant 1) of column c on row r, if any
+            for (int e = tab[o_ebeg[1] + c]; e < tab[o_ebeg[1] + c + 1]; e++)
+                if ((ents[1][e] & 0xff) == r && ((ents[1][e] >> 8) & 3) == kind) {
+                    *pos = ents[1][e] >> 10;
+                    return true;
+                }
+            return false;
+        };
+        for (int c = 0; c < hm.cols; c++) {
+            const FbrCol &cd = hm.coldesc[c];
+            if (tab[o_ebeg[1] + c] == tab[o_ebeg[1] + c + 1]) {  // no group holds the column
+                tab.push_back(-1);
+                tab.push_back(0);
+                continue;
+            }
+            tab.push_back((int)lslots.size());
+            int pos = 0, nz = 0;
+            if (cd.kind == 0) {
+                for (int r = 0; r < hm.fb; r++) lslots.push_back(entry_of(c, r, 0, &pos) ? std::make_pair(r, pos) : std::make_pair(-1, 0));
+                for (int dj : hm.path[cd.link]) lslots.push_back(entry_of(c, hm.fb + dj, 1, &pos) ? std::make_pair(hm.fb + dj, pos) : std::make_pair(-1, 0));
+            } else {
+                lslots.push_back(entry_of(c, hm.fb + cd.joint, 3, &pos) ? std::make_pair(hm.fb + cd.joint, pos) : std::make_pair(-1, 0));
+            }
+            for (int e = tab[o_ebeg[1] + c]; e < tab[o_ebeg[1] + c + 1]; e++)
+                if (((ents[1][e] >> 8) & 3) == 2) {
+                    lslots.push_back({ents[1][e] & 0xff, ents[1][e] >> 10});
+                    nz++;
+                }
+            tab.push_back(nz);
+        }
+        tab.push_back((int)lslots.size());  // pseudo-column `cols`: k rhs destinations per regressor row
+        tab.push_back(0);
+        for (int r = 0; r < hm.rows; r++)
+            for (int i = 0; i < k; i++)
+                lslots.push_back(gp.rowgroup[r] >= 0 ? std::make_pair(r, (int)gp.groups[gp.rowgroup[r]].sel.size() + i) : std::make_pair(-1, 0));
+        // the tree in parts: the waves of a workgroup share one block of samples, each walks its links (+ the ancestors they need) and
+        // writes the columns of its own links (fbr_kinid_build_parts); cost of a link: its kinematics + what its columns write
+        std::vector<double> lcost(hm.L, 30.0);
+        for (int c = 0; c < hm.ninert; c++)
+            if (tab[o_lrec + 2 * c] >= 0) lcost[hm.coldesc[c].link] += 10.0 + (double)(hm.fb + hm.path[hm.coldesc[c].link].size() + tab[o_lrec + 2 * c + 1]);
+        std::vector<FbrKinIdProgram> progs;
+        std::vector<std::vector<char>> own;
+        fbr_kinid_build_parts(hm, lcost, FBR_KINWRITE_PARTS, progs, own);
+        lane_parts = (int)progs.size();
+        o_lcol = tab.size();
+        tab.resize(tab.size() + (size_t)lane_parts * 10 * hm.L, -1);
+        for (int c = 0; c < hm.ninert; c++)
+            for (int pq = 0; pq < lane_parts; pq++)
+                if (own[pq][hm.coldesc[c].link]) tab[o_lcol + (size_t)pq * 10 * hm.L + 10 * hm.coldesc[c].link + hm.coldesc[c].pidx] = c;
+        o_lsteps = tab.size();
+        for (int pq = 0; pq < lane_parts; pq++) {
+            lane_step0[pq] = (int)((tab.size() - o_lsteps) / FBR_KINID_STEP);
+            lane_nsteps[pq] = progs[pq].nsteps;
+            lane_slots = std::max(lane_slots, progs[pq].nslots);
+            tab.insert(tab.end(), progs[pq].steps.begin(), progs[pq].steps.begin() + (size_t)progs[pq].nsteps * FBR_KINID_STEP);
+        }
+    }
     // LDS image of one sample's rows (fbr_regressor_groups_lds_kernel): offset of regressor row r, ld_g doubles each -- the padded width
     // of a group is only known once its factorisation has begun (below): the offsets are filled in there
     const size_t o_rowoff = tab.size();
     tab.resize(tab.size() + hm.rows, -1);
     const size_t o_nrows = tab.size();  // slots (regressor rows) of every group
     for (int g = 0; g < G; g++) tab.push_back((int)gp.groups[g].rows.size());
+    const size_t o_gpa = tab.size();    // columns (rhs included) of every group
+    for (int g = 0; g < G; g++) tab.push_back(gp.groups[g].Pa);
     std::vector<size_t> o_fc(G), o_emb(G);
     for (int g = 0; g < G; g++) {
         o_fc[g] = tab.size();
@@ -373,6 +442,8 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
     const size_t o_ent0 = tab.size() * sizeof(int), o_ent1 = o_ent0 + ents[0].size() * sizeof(int);
     const size_t o_pent0 = o_ent1 + ents[1].size() * sizeof(int), o_pent1 = o_pent0 + (pairable ? pents[0].size() : 0) * sizeof(int);
     const size_t o_grp = (o_pent1 + (pairable ? pents[1].size() : 0) * sizeof(int) + 15) & ~(size_t)15;
+    const size_t nlent = lslots.size() + 64;  // (padded: the kernel requests a record's destinations in fixed-size batches)
+    const size_t o_lent = (o_grp + (size_t)G * sizeof(FbrDevGroup) + 15) & ~(size_t)15;  // lane writer: two sets of nlent destinations (64-bit)
     // working factors and chunk buffers of the groups
     std::vector<FbrDevGroup> hg(G);
     bool skipzeros = false;
@@ -404,7 +475,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         const TsqrGroup &Gg = gp.groups[g];
         FbrTsqrWork &wk = work(g);
         double *A = nullptr;
-        if ((rc = fbr_tsqr_chunk_buffer(wk, ch * (long)Gg.rows.size(), &A)) || (rc = fbr_tsqr_chunk_clean(wk, pst)))
+        if ((rc = fbr_tsqr_chunk_buffer(wk, ch * (long)Gg.rows.size(), &A)) || (!lane_writer && (rc = fbr_tsqr_chunk_clean(wk, pst))))
             return tsqr_fail(rc, "tsqr group chunk");
         hg[g] = FbrDevGroup{A, wk.n, (int)Gg.sel.size()};
     }
@@ -426,12 +497,28 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         set_err("tsqr_writer = 32: the rows of a sample do not fit the LDS image of the staged writer");
         return FBR_E_UNSUPPORTED;
     }
+    // chunk row count per slot of this call's chunks (every chunk but the last holds ch samples; the last is padded to the granularity):
+    // the lane writer's column stride is fixed per chunk, its row pointers are rebuilt per chunk on the device side of the tables below
+    // set 0: the full chunks (ch samples per slot), set 1: the last chunk (padded to the granularity): an entry's destination is the address of
+    // (its row's slot, sample 0, its column) in the column-major chunk of the row's group
+    std::vector<long long> lane_dst(2 * nlent, 0);
+    const long last_cs = S > 0 ? S - (S - 1) / ch * ch : 0;
+    const long csp_of[2] = {ch, (last_cs + lcm - 1) / lcm * lcm};
+    if (lane_writer)
+        for (int j = 0; j < 2; j++)
+            for (size_t e = 0; e < lslots.size(); e++) {
+                const int r = lslots[e].first, pos = lslots[e].second;
+                if (r < 0) continue;
+                const int g = gp.rowgroup[r];
+                const long ldc = (long)gp.groups[g].rows.size() * csp_of[j];
+                lane_dst[j * nlent + e] = (long long)(uintptr_t)(hg[g].A + (long)pos * ldc + (long)gp.rowslot[r] * csp_of[j]);
+            }
     const char *dtab = nullptr;
     if ((rc = tsqr_upload_tables(m, par,
                                  {{tab.data(), tab.size() * sizeof(int)}, {ents[0].data(), ents[0].size() * sizeof(int)}, {ents[1].data(), ents[1].size() * sizeof(int)},
                                   {pents[0].data(), (pairable ? pents[0].size() : 0) * sizeof(int)}, {pents[1].data(), (pairable ? pents[1].size() : 0) * sizeof(int)},
-                                  {hg.data(), G * sizeof(FbrDevGroup)}},
-                                 {0, o_ent0, o_ent1, o_pent0, o_pent1, o_grp}, o_grp + G * sizeof(FbrDevGroup), pst, &dtab)))
+                                  {hg.data(), G * sizeof(FbrDevGroup)}, {lane_dst.data(), lane_dst.size() * sizeof(long long)}},
+                                 {0, o_ent0, o_ent1, o_pent0, o_pent1, o_grp, o_lent}, o_lent + lane_dst.size() * sizeof(long long), pst, &dtab)))
         return rc;
     const int *t = (const int *)dtab;
     const FbrDevGroup *dgrp = (const FbrDevGroup *)(dtab + o_grp);
@@ -516,12 +603,65 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         const long cs = std::min(ch, S - s0);
         const long k0 = s0 / kin_span * kin_span;
         hipStream_t cst = s0 == 0 ? pst : m->stream;  // the first chunk's kinematics and writer belong to the prologue
-        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0), cst))) return rc;
-        const double *recs = m->rec.as<double>() + (size_t)(s0 - k0) * hm.rec_size();
         // every slot of the chunk holds csp >= cs rows, a whole number of fold blocks in every group (the last chunk is padded with zero
         // rows): a block never straddles two regressor rows, and the structural zeros left of a row's first supported column tile are
         // never written (the folds do not read them)
         const long csp = (cs + lcm - 1) / lcm * lcm;
+        if (lane_writer) {
+            // one kernel: kinematics + every entry of the groups' chunks, column-major (512-byte runs); padding rows / columns cleared first
+            size_t maxrows = 1;
+            for (int g = 0; g < G; g++) maxrows = std::max(maxrows, gp.groups[g].rows.size());
+            hipLaunchKernelGGL(fbr_groups_clear_cm_kernel, dim3(G, (unsigned)maxrows + FBR_CM_PADWG), dim3(256), 0, cst, dgrp, t + o_nrows, t + o_gpa, cs, csp, (int)maxrows);
+            HIPCHK(hipGetLastError());
+            const int set = (csp == csp_of[0] && cs == ch) ? 0 : 1;
+            if (csp != csp_of[set]) {
+                set_err("internal: chunk stride of the lane writer does not match its row tables");
+                return FBR_E_INVALID;
+            }
+            DevKinId kp;
+            kp.nsteps = m->kinid.nsteps;
+            kp.maxlvl = m->kinid.maxlvl;
+            kp.nslots = lane_slots;
+            kp.ldn = std::max(hm.n, 1) | 1;
+            kp.steps = t + o_lsteps;
+            kp.endflush = m->kinid_endflush;
+            DevKinWrite kw;
+            kw.nparts = lane_parts;
+            for (int pq = 0; pq < FBR_KINWRITE_PARTS; pq++) {
+                kw.part_nsteps[pq] = lane_nsteps[pq];
+                kw.part_step0[pq] = lane_step0[pq];
+            }
+            kw.lcol10 = t + o_lcol;
+            kw.colrec = t + o_lrec;
+            kw.dst = (const long *)(dtab + o_lent) + (size_t)set * nlent;
+            kw.ninert = hm.ninert;
+            kw.cols = hm.cols;
+            kw.k = k;
+            kw.has_w = dw ? 1 : 0;
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8 / lane_parts, (size_t)(150 << 10) / std::max<size_t>(lane_lds, 1)));
+            const int blocks = (int)std::min<long>((cs + 63) / 64, (long)m->num_cus * per_cu);
+            if ((rc = m->kinid_scratch.ensure((size_t)blocks * lane_parts * std::max(kp.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
+            ProfScope ps(m, FBR_PROF_REGRESSOR, cst);
+#define FBR_KINWRITE_LAUNCH(D)                                                                                                                  \
+    do {                                                                                                                                        \
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_kinwrite_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_lds));          \
+        hipLaunchKernelGGL(fbr_kinwrite_kernel<D>, dim3(blocks), dim3(64 * lane_parts), lane_lds, cst, m->dm, kp, kw, cs, d.q + s0 * hm.n, d.dq + s0 * hm.n,  \
+                           d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr, d.rpy ? d.rpy + s0 * 3 : nullptr, \
+                           d.sign ? d.sign + s0 * hm.n : nullptr, drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr,                            \
+                           dw ? dw + (size_t)s0 * hm.rows : nullptr, m->kinid_scratch.as<double>());                                            \
+    } while (0)
+            if (kp.maxlvl <= 4)
+                FBR_KINWRITE_LAUNCH(4);
+            else if (kp.maxlvl <= 8)
+                FBR_KINWRITE_LAUNCH(8);
+            else if (kp.maxlvl <= 12)
+                FBR_KINWRITE_LAUNCH(12);
+            else
+                FBR_KINWRITE_LAUNCH(FBR_KINID_MAXD);
+#undef FBR_KINWRITE_LAUNCH
+        } else {
+        if (s0 == k0 && (rc = run_kin(m, d, k0, std::min(kin_span, S - k0), cst))) return rc;
+        const double *recs = m->rec.as<double>() + (size_t)(s0 - k0) * hm.rec_size();
         skipzeros = true;
         if (csp > cs) {
             size_t maxrows = 1;
@@ -548,6 +688,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
                                    drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr, k, dw ? dw + (size_t)s0 * hm.rows : nullptr, dgrp, G, t, t + hm.rows,
                                    t + o_ebeg[skipzeros ? 1 : 0], (const int *)(dtab + (skipzeros ? o_ent1 : o_ent0)), csp);
         }
+        }
         HIPCHK(hipGetLastError());
         if (cst != m->stream) {  // the folds (main stream) wait for the prologue
             HIPCHK(hipEventRecord(m->ev_tsqr_pro, cst));
@@ -560,6 +701,7 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
             ro.first_col = t + o_fc[g];
             ro.rows = (int)Gg.rows.size();
             ro.group = csp;
+            if (lane_writer) ro.colmajor_ld = csp * (long)Gg.rows.size();
             if ((rc = fbr_tsqr_fold_chunk(work(g), m->stream, csp * (long)Gg.rows.size(), Gg.Pa, 0, nullptr, ro))) return tsqr_fail(rc, "tsqr group fold");
             return FBR_OK;
         };

@@ -292,6 +292,67 @@ int emul_kinid(const EmulTopo *t, long S, const double *q, const double *dq, con
     return 0;
 }
 
+// The tree cut into parts (fbr_kinid_build_parts: what the waves of the lane writer's workgroups walk): every part's program run on its own,
+// a link contributing its wrench only in the part that owns it -- the parts' torques must add up to the whole robot's.  No friction.
+int emul_kinid_parts(const EmulTopo *t, int nparts, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
+                     const double *rpy, const double *x, double *tau, int *steps_out)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    if (hm.maxdepth > FBR_KINID_MAXD) return -1;
+    std::vector<FbrKinIdProgram> progs;
+    std::vector<std::vector<char>> own;
+    std::vector<double> cost(hm.L, 1.0);
+    for (int l = 0; l < hm.L; l++) cost[l] += (double)hm.path[l].size();
+    fbr_kinid_build_parts(hm, cost, nparts, progs, own);
+    const int n = hm.n;
+    for (int l = 0; l < hm.L; l++) {  // every link is owned exactly once
+        int c = 0;
+        for (size_t p = 0; p < own.size(); p++) c += own[p][l];
+        if (c != 1) return -3;
+    }
+    for (long s = 0; s < S; s++) {
+        double *ts = tau + (size_t)s * hm.rows;
+        for (int r = 0; r < hm.rows; r++) ts[r] = 0.0;
+        for (size_t pi = 0; pi < progs.size(); pi++) {
+            const FbrKinIdProgram &p = progs[pi];
+            if (steps_out) steps_out[pi] = p.nsteps;
+            std::vector<double> slots((size_t)std::max(p.nslots, 1) * FBR_LINK_REC, std::nan(""));
+            auto state = [&](int d, double &a, double &b, double &c) {
+                a = q[s * n + d];
+                b = dq[s * n + d];
+                c = ddq[s * n + d];
+            };
+            auto basest = [&](double *v6, double *a6, double *e3) {
+                for (int i = 0; i < 6; i++) {
+                    v6[i] = bv[6 * s + i];
+                    a6[i] = ba[6 * s + i];
+                }
+                for (int i = 0; i < 3; i++) e3[i] = rpy[3 * s + i];
+            };
+            auto save = [&](int b, int i, double v) { slots[(size_t)b * FBR_LINK_REC + i] = v; };
+            auto load = [&](int b, int i) { return slots[(size_t)b * FBR_LINK_REC + i]; };
+            auto link = [&](int l, int, const double *rec, const double (*)[6], const int *, double *F) {
+                if (!own[pi][l]) return;
+                double pi10[10];
+                for (int c = 0; c < 10; c++) pi10[c] = x[10 * l + c];
+                fbr_link_wrench(rec, pi10, F);
+            };
+            auto consts = [&](int l, double *rR, double *rp, double *ax) {
+                for (int i = 0; i < 9; i++) rR[i] = hm.restR[9 * l + i];
+                for (int i = 0; i < 3; i++) {
+                    rp[i] = hm.restp[3 * l + i];
+                    ax[i] = hm.axis[3 * l + i];
+                }
+            };
+            auto emit = [&](int r, double v) { ts[r] += v; };
+            fbr_kinid_lane<FBR_KINID_MAXD, true>(p.nsteps, p.maxlvl, p.steps.data(), p.endflush.data(), hm.floating, hm.gravity, hm.fb, state, basest, save,
+                                                 load, link, emit, consts);
+        }
+    }
+    return (int)progs.size();
+}
+
 // mirrors fbr_kinfd_kernel: one "lane" per evaluation e = s (1 + 3 n) + j of the finite-difference sweep, score[e] = sum W_s . Y_e
 int emul_kinfd(const EmulTopo *t, long S, double eps, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
                const double *rpy, const double *sign, const double *W, double *out)

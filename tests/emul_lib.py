@@ -132,6 +132,17 @@ class Emul:
             raise RuntimeError(f"emul_kinid: rc {rc}" + (f" (row {-2 - rc} not written exactly once)" if rc <= -2 else " (tree too deep)"))
         return tau, tuple(info)
 
+    def fused_parts_inverse_dynamics(self, st, x, nparts):
+        """(tau, steps per part): the tree cut into ``nparts`` programs (fbr_kinid_build_parts), every link's wrench added by its owner only"""
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        tau = np.zeros((S, self.rows))
+        steps = (ctypes.c_int * 8)()
+        rc = lib().emul_kinid_parts(ctypes.byref(self.t), int(nparts), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(x), _d(tau), steps)
+        if rc <= 0:
+            raise RuntimeError(f"emul_kinid_parts: rc {rc}")
+        return tau, list(steps)[:rc]
+
     def fused_fd_scores(self, st, W, eps, sign=None):
         """emulation of fbr_kinfd_kernel: scores [S][1 + 3 n] of the finite-difference sweep, one lane per evaluation"""
         S, q, dq, ddq, bv, ba, rpy = self._st(st)

@@ -307,3 +307,26 @@ def test_fused_contact_and_fd_programs_on_random_trees(seed):
             sp[key][:, d] += eps
             refs[:, 1 + kind * n + d] = np.einsum("src,src->s", Wb, om.regressor(sp, sign).reshape(S, om.rows, om.P))
     assert np.abs(sc - refs).max() <= 1e-11 * np.abs(refs).max()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tree_parts_of_the_lane_writer(seed):
+    """fbr_kinid_build_parts (csrc/fbr_kinid.h): the tree cut into programs for the waves of one workgroup -- every part closed under
+    parents, every link owned once; the parts' torques (each link's wrench added by its owner) sum to the robot's."""
+    rng = np.random.default_rng(1300 + seed)
+    if seed == 0:
+        t, fl = load_topo("walkman_apriori"), True
+    else:
+        t = random_topology(rng, int(rng.integers(2, 25)), p_fixed=0.2, branchiness=float(rng.choice([0.0, 0.4, 1.0])), p_prismatic=0.2)   # (joint paths of at most 24: FBR_KINID_MAXD)
+        fl = bool(seed & 1)
+    om = OracleModel(t, floating=fl)
+    em = Emul(t, floating=fl)
+    st = random_states(t, 5, rng, fl)
+    x = t.x_std()
+    tau = om.inverse_dynamics(st, x)
+    for nparts in (1, 2, 4):
+        tp, steps = em.fused_parts_inverse_dynamics(st, x, nparts)
+        assert len(steps) == min(nparts, t.num_links)
+        assert np.abs(tp - tau).max() <= 1e-12 * max(np.abs(tau).max(), 1e-300), (nparts, steps)
+    if seed == 0:   # WALK-MAN: four parts walk 48 links + a short trunk each
+        assert sum(steps) <= 48 + 4 * 6, steps
