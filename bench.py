@@ -194,54 +194,43 @@ def cpu_baseline(topo, budget_s=12.0):
 
 
 def cpu_baseline_all_cores(topo, one_thread_rate=None, budget_s=10.0):
-    """The same port on every host core, ONE process: the reference's loop body (regressor + simulated torques of a sample, stacked) dealt
-    to OpenMP threads inside the C oracle (``orc_stack_block_omp``: straight into the augmented block, nothing allocated per block), then
-    A^T A of the whole block with one threaded BLAS call (``dsyrk``: the symmetric half, as NumPy's ``A.T @ A`` does).  SURVEY 8(d):
-    "1 thread, then all host cores with OpenMP".  Reports both phases, the threads, and the parallel efficiency against the one-thread
-    figure of ``cpu_baseline`` -- with what bounds it."""
+    """The same port on every host core, ONE process: the reference's loop body (regressor + simulated torques of a sample) AND the A^T A
+    accumulation dealt to OpenMP threads inside the C oracle (``orc_stack_gram_omp``: per-thread upper-triangular sums of rank-1 updates,
+    added at the end; nothing tall is stored).  SURVEY 8(d): "1 thread, then all host cores with OpenMP".  NumPy's BLAS is no way to
+    use the cores here: OpenBLAS serialises level-3 calls that come from several threads (why round 5's thread pool scaled 10.7 x on 256
+    threads), and ONE threaded dsyrk of a 482-column block parallelises over the columns only (measured in round 6: 89 GFLOP/s on 256
+    threads).  Reports the rate, the one-thread rate of the SAME function and the parallel efficiency between the two."""
     from oracle.oracle import OracleModel
-    from scipy.linalg.blas import dsyrk
-    from threadpoolctl import threadpool_info, threadpool_limits
 
     cores = os.cpu_count() or 1
     om = OracleModel(topo, floating=True)
     x = topo.x_std()
-    block = max(512, min(16384, 64 * cores))
-    st = _np_states(topo, block, 4321)
-    A = np.empty((block * om.rows, om.P + 1))
-    G = np.zeros((om.P + 1, om.P + 1))
-    om.stack_block(st, x, out=A, threads=cores)  # (page in the block, start the OpenMP team)
-    t_stack = t_syrk = 0.0
+    st1 = _np_states(topo, 512, 4321)
+    om.stack_gram(st1, x, threads=1)
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < 2.0:
+        om.stack_gram(st1, x, threads=1)
+        n1 += 512
+    rate1 = n1 / (time.perf_counter() - t0)
+    block = max(512, 64 * cores)
+    st = _np_states(topo, block, 4322)
+    _, thr = om.stack_gram(st, x, threads=cores)  # (starts the OpenMP team)
     done = 0
-    thr = 1
-    with threadpool_limits(limits=cores):
-        t0 = time.perf_counter()
-        while True:
-            t1 = time.perf_counter()
-            _, thr = om.stack_block(st, x, out=A, threads=cores)
-            t2 = time.perf_counter()
-            G += dsyrk(1.0, A.T, trans=0, lower=0)   # upper triangle of A^T A: A.T is the Fortran-ordered view of the C-ordered block (no copy)
-            t3 = time.perf_counter()
-            t_stack += t2 - t1
-            t_syrk += t3 - t2
-            done += block
-            if time.perf_counter() - t0 > budget_s:
-                break
-        dt = time.perf_counter() - t0
-    blas = [f"{d.get('internal_api')} {d.get('version')} x{d.get('num_threads')}" for d in threadpool_info() if d.get("user_api") == "blas"]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, thr = om.stack_gram(st, x, threads=cores)
+        done += block
+    dt = time.perf_counter() - t0
     rate = done / dt
     out = {"value": rate, "unit": "samples/s", "cores": cores, "omp_threads": thr, "kind": "port", "seconds": dt,
-           "phase_seconds": {"regressor_and_rnea_openmp": t_stack, "AtA_threaded_blas_syrk": t_syrk},
-           "phase_rates_samples_per_s": {"regressor_and_rnea_openmp": done / max(t_stack, 1e-12), "AtA_threaded_blas_syrk": done / max(t_syrk, 1e-12)},
-           "syrk_GFLOP_per_s": done * om.rows * (om.P + 1) * (om.P + 2) / max(t_syrk, 1e-12) / 1e9, "blas": blas,
-           "sample": f"{done} WALK-MAN floating-base samples in blocks of {block}: C oracle regressor + RNEA over {thr} OpenMP threads into [Y|tau], "
-                     f"then one threaded dsyrk per block, {dt:.1f} s"}
+           "one_thread_same_function_samples_per_s": rate1, "speedup_vs_one_thread_same_function": rate / rate1,
+           "parallel_efficiency_per_thread": rate / rate1 / max(thr, 1),
+           "sample": f"{done} WALK-MAN floating-base samples in blocks of {block}: C oracle regressor + RNEA + rank-1 A^T A accumulation (structural zeros "
+                     f"skipped) over {thr} OpenMP threads, per-thread sums added at the end, {dt:.1f} s",
+           "note": f"hardware threads are SMT siblings ({cores} threads on about {cores // 2} cores): an efficiency of 0.5 per thread is one per core"}
     if one_thread_rate:
-        out["speedup_vs_one_thread"] = rate / one_thread_rate
-        out["parallel_efficiency"] = rate / one_thread_rate / cores
-        bound = "the threaded BLAS A^T A (fp64 peak of the host)" if t_syrk > t_stack else "the per-sample regressor loop (memory bandwidth of writing the 134 KB block per sample)"
-        out["bound_by"] = (f"{bound}: {t_syrk / dt:.0%} of the time in dsyrk, {t_stack / dt:.0%} in the OpenMP loop; hardware threads are SMT siblings "
-                           f"({cores} threads on about {cores // 2} cores): the efficiency is quoted per thread")
+        out["speedup_vs_cpu_baseline_one_thread_blas"] = rate / one_thread_rate
     return out
 
 

@@ -142,6 +142,17 @@ class OracleModel:
         assert rc > 0, rc
         return A, int(rc)
 
+    def stack_gram(self, st, x_std, threads=0):
+        """Upper triangle of [Y | tau]^T [Y | tau] over the samples, accumulated inside the OpenMP loop of ``orc_stack_gram_omp`` (per-thread
+        sums, added at the end).  Returns (G, threads).  Only bench.py's all-core CPU baseline and its test use it."""
+        assert not self.fric and not self.grav_only
+        S, q, dq, ddq, bv, ba, rpy = self._states(st)
+        G = np.zeros((self.P + 1, self.P + 1))
+        rc = lib().orc_stack_gram_omp(*self._model_args(), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(_c(x_std)),
+                                      int(threads), _d(G))
+        assert rc > 0, rc
+        return G, int(rc)
+
     def contact_torques(self, st, frame, wrench):
         """(S, rows): J_frame^T w per sample; ``frame`` = link name or a frame name of the topology."""
         S, q, dq, ddq, bv, ba, rpy = self._states(st)

@@ -274,3 +274,18 @@ def _base(t, st, floating):
         return np.transpose(nd.rpy_R(st["rpy"]), (0, 2, 1)), st["base_vel"][:, :3], st["base_vel"][:, 3:], st["base_acc"][:, :3], st["base_acc"][:, 3:]
     z = np.zeros((S, 3))
     return np.tile(np.eye(3), (S, 1, 1)), z, z, z, z
+
+
+def test_openmp_gram_pass_of_the_cpu_baseline():
+    """orc_stack_gram_omp / orc_stack_block_omp (bench.py's all-core CPU baseline): the per-thread rank-1 accumulation equals the stacked
+    [Y | tau]^T [Y | tau] of the serial functions, whatever the thread count."""
+    t = load_topo("walkman_apriori")
+    om = OracleModel(t, floating=True)
+    st = random_states(t, 130, np.random.default_rng(8), True)
+    A = np.hstack([om.regressor(st), om.inverse_dynamics(st, t.x_std()).reshape(-1, 1)])
+    B, thr = om.stack_block(st, t.x_std())
+    assert thr >= 1 and np.array_equal(A, B)
+    ref = np.triu(A.T @ A)
+    for threads in (1, 3):
+        G, used = om.stack_gram(st, t.x_std(), threads=threads)
+        assert used == threads and np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max() and not np.tril(G, -1).any()

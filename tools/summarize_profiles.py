@@ -116,7 +116,7 @@ for name, reps in (("tsqr_full", 4), ("tsqr_shard", 6)):   # tools/tsqr_probe.py
     cls = collections.defaultdict(float)
     for r in rows:
         n = short(r["Name"])
-        key = ("merge trees" if "tree" in n else "level-0 folds" if "level0" in n else "regressor writer" if "regressor" in n else
+        key = ("merge trees" if "tree" in n else "level-0 folds" if "level0" in n else "regressor writer (lane per sample, kinematics fused)" if "kinwrite" in n else "regressor writer" if "regressor" in n else
                "kinematics" if "kin" in n else "other")
         cls[key] += float(r["TotalDurationNs"]) / reps / 1e6
     splits[name] = {"kernel_ms_per_call": {k: round(v, 3) for k, v in sorted(cls.items(), key=lambda kv: -kv[1])},
@@ -186,7 +186,8 @@ if splits:
                          + f" per call; merge trees = {100 * sp['tree_share_of_kernel_time']:.1f} % of the kernel time")
 lines += [
     "* `r02_coissue_probe.txt` – `tools/coissue_probe.hip`: fp64 VALU beside fp64 MFMA on one SIMD (they share the DP pipe)",
-    "* `r02_tsqr_timing.txt` – `FBR_TSQR_TIMING=1 tools/tsqr_timing_probe.py`: per-phase cycles of the wide TSQR fold",
+    "* `r02_tsqr_timing.txt` – `tools/tsqr_timing_probe.py` (engine option `tsqr_timing`): per-phase cycles of the wide TSQR fold",
+    "* `r05a/b/c_*` – round 5 (kinematics kernel + workgroup-per-sample writers / torque kernels, before the fused one-lane-per-sample kernels of round 6)",
     "* `r04_*` – this round BEFORE the column reductions (all 480 columns: 12.7 M samples/s on that box, Gram kernel 0.41, TSQR 160.6 ms); "
     "`r03b_*` – round 3; `r02a/b/c_*` – round 2 (before / after the link-depth column order / with the tree-structured TSQR); `r01n_*`, `r01_mfma_f64_peak.txt` – round 1",
     "",
