@@ -135,6 +135,7 @@ _SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, _ip, _ip, ctypes.POINTER(ctypes.c_int64), _ip],
     ),
+    "fbr_gram_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "fbr_model_link_merge_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _ip, _ip]),
     "fbr_model_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
     "fbr_model_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
@@ -663,3 +664,12 @@ class Engine:
             "fbr_gram_program_info",
         )
         return {"tiles": nt.value, "pairs": npairs.value, "mfma_per_sample": mf.value, "parts": parts.value}
+
+    def gram_lane_info(self, k: int = 0, num_samples: int = -1) -> dict:
+        """The sample-contiguous Gram pass (option ``gram_lane``) for such a batch; ``active`` False: the per-sample-image pass runs."""
+        a = (ctypes.c_int64 * 8)()
+        _check(self._lib.fbr_gram_lane_info(self._h, int(k), int(num_samples), a), "fbr_gram_lane_info")
+        keys = ("active", "tile_rows", "block_image_bytes", "mfma_per_block", "levels", "max_slabs", "lds_bytes", "tiles")
+        d = dict(zip(keys, (int(v) for v in a)))
+        d["active"] = bool(d["active"])
+        return d

@@ -1,0 +1,430 @@
+// fbr_gram64.h -- the fused Gram over SAMPLE-CONTIGUOUS images (round 6, option "gram_lane").
+//
+// The contraction G_ab = sum_s sum_r Y_s[r, a] Y_s[r, b] does not care in which order (s, r) is walked.  The first fused pass
+// (fbr_kernels.h K5a / K5b) takes ONE sample's image per LDS-DMA and runs the MFMA k-steps over four ROWS of that sample: its producer has to
+// lay out a sample's 20 KB contiguously, which a one-lane-per-sample producer can only do with 8-byte stores at a 33 KB stride (partially
+// written lines) -- hence the record round trip kinematics kernel -> HBM -> workgroup-per-sample packer, which bounds that pass.
+// Here the k-steps run over four SAMPLES of one regressor row:
+//   * image of a block of 64 samples: [tile row tr][half][16 columns][32 samples], tile row = (column tile, real row of the tile: the fb
+//     base-wrench rows, then the joints of the tile's path); no row padding, no paired base rows.  Inside a 32-sample run sample s of
+//     column slot c sits at s ^ 4 (c & 7): the operand reads of the MFMAs (lane (kk, li) -> column li, sample 4 ks + kk) then hit every
+//     LDS bank pair exactly twice, with the LDS layout EQUAL to the global one (one contiguous 4 KB DMA per slab);
+//   * producer fbr_kinimg_kernel: one lane per sample, kinematics fused in, the tree cut into parts for the waves of a workgroup
+//     (fbr_kinid.h); every value of a (column, row) goes out as two 256-byte runs per wave;  tau's products with the columns (k <= 1) are
+//     accumulated on the way: per column one dot product per joint row it already holds, a wave reduction per block;
+//   * consumer fbr_gram64_kernel: one workgroup of 8 waves per CU, the accumulators of the tile pairs in registers for the whole pass;
+//     a stage = (row level, 32 samples): the slabs of the tiles that have the level arrive by LDS-DMA into one of two buffers while the
+//     MFMAs of the stage before run; a pair takes part in the levels below its common depth; 8 MFMAs per pair and stage.
+// Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), one part, device-resident inputs, one group.
+#pragma once
+#include "fbr_kinid.h"
+
+struct FbrGram64 {  // host program
+    int NT = 0, nlev = 0, fb = 0, ntr = 0, maxact = 0, segw = 0, nseg = 0;
+    long blk_doubles = 0;
+    std::vector<int> trow;       // [NT][nlev] tile-row index or -1
+    std::vector<int> slab;       // [nlev][NT] slab index inside the stage or -1
+    std::vector<int> lev_begin;  // [nlev + 1] into pieces
+    std::vector<int> pieces;     // pairs: global offset (doubles, inside the block image, half 0), LDS offset (doubles, inside a stage buffer)
+    std::vector<int> wmeta;      // [8 waves][nseg][2 + 2 segw]: tile I (-1: empty), max cp of the segment, then (tile J, cp) per slot (J = -1: empty)
+    std::vector<int> slot_tiles; // [8 * npw * 2] for the reduction
+    long mfma_per_block = 0;
+};
+
+// tiles / pairs / slots of a one-part program built WITHOUT rhs tiles (moments); false: the model is outside this pass
+static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram &gp, FbrGram64 &g)
+{
+    if (gp.T != 1 || hm.fric || (gp.k > 0 && gp.rhs_tiles)) return false;
+    g.NT = gp.NT;
+    g.fb = hm.fb;
+    g.segw = gp.cfg.segw;
+    g.nseg = gp.cfg.nseg;
+    g.nlev = 0;
+    for (const FbrTile &t : gp.tiles) {
+        if (t.type != 0 || t.friction) return false;
+        g.nlev = std::max(g.nlev, hm.fb + (int)t.tpath.size());
+    }
+    if (g.nlev == 0) return false;
+    g.trow.assign((size_t)g.NT * g.nlev, -1);
+    g.ntr = 0;
+    for (int t = 0; t < g.NT; t++)
+        for (int lv = 0; lv < hm.fb + (int)gp.tiles[t].tpath.size(); lv++) g.trow[(size_t)t * g.nlev + lv] = g.ntr++;
+    g.blk_doubles = (long)g.ntr * 1024;
+    g.slab.assign((size_t)g.nlev * g.NT, -1);
+    g.lev_begin.assign(g.nlev + 1, 0);
+    g.maxact = 0;
+    for (int lv = 0; lv < g.nlev; lv++) {
+        g.lev_begin[lv] = (int)g.pieces.size() / 2;
+        int idx = 0;
+        for (int t = 0; t < g.NT; t++) {
+            const int tr = g.trow[(size_t)t * g.nlev + lv];
+            if (tr < 0) continue;
+            g.slab[(size_t)lv * g.NT + t] = idx;
+            for (int p = 0; p < 4; p++) {
+                g.pieces.push_back(tr * 1024 + p * 128);
+                g.pieces.push_back(idx * 512 + p * 128);
+            }
+            idx++;
+        }
+        g.maxact = std::max(g.maxact, idx);
+    }
+    g.lev_begin[g.nlev] = (int)g.pieces.size() / 2;
+    const int npw = g.segw * g.nseg, W = FBR_WPB;
+    g.wmeta.assign((size_t)W * g.nseg * (2 + 2 * g.segw), -1);
+    g.slot_tiles.assign((size_t)W * npw * 2, -1);
+    g.mfma_per_block = 0;
+    for (int w = 0; w < W; w++)
+        for (int sg = 0; sg < g.nseg; sg++) {
+            int *mm = &g.wmeta[((size_t)w * g.nseg + sg) * (2 + 2 * g.segw)];
+            mm[1] = 0;
+            for (int j = 0; j < g.segw; j++) {
+                const size_t s = (size_t)w * npw + sg * g.segw + j;
+                const int pi = gp.slots[s].pair;
+                if (pi < 0) continue;
+                const FbrPair &p = gp.pairs[pi];
+                if (p.mode != 0) return false;
+                if (mm[0] >= 0 && mm[0] != p.I) return false;  // (a row segment shares its tile I)
+                mm[0] = p.I;
+                const std::vector<int> &a = gp.tiles[p.I].tpath, &b = gp.tiles[p.J].tpath;
+                const int cpj = FbrGramProgram::common_prefix(a, b);
+                const int cp = hm.fb + (cpj == (int)std::min(a.size(), b.size()) ? (int)std::min(a.size(), b.size()) : cpj);
+                mm[2 + 2 * j] = p.J;
+                mm[3 + 2 * j] = cp;
+                mm[1] = std::max(mm[1], cp);
+                g.slot_tiles[2 * s] = p.I;
+                g.slot_tiles[2 * s + 1] = p.J;
+                g.mfma_per_block += 16L * cp;  // 8 MFMAs per level and half
+            }
+        }
+    return true;
+}
+
+// Producer tables: the tree in parts for the waves of a workgroup (fbr_kinid.h) and, per (part, link, parameter), ONE destination word:
+// byte offset inside an image buffer of (level-0 tile row of the column's tile, column slot, sample 0) -- a multiple of 256 -- with
+// 4 (slot & 7) in its low byte and bit 62 set (0: the part does not write that column).  The tile rows of a tile are consecutive
+// (fbr_gram64_build), so level lv of the column is 8192 bytes x lv further on.
+struct FbrGram64Producer {
+    int nparts = 1, nslots = 1, step0[FBR_KINWRITE_PARTS] = {0, 0, 0, 0}, nsteps[FBR_KINWRITE_PARTS] = {0, 0, 0, 0};
+    std::vector<long long> rel;  // [nparts][10 L]
+    std::vector<int> lcol;       // [nparts][10 L] the column (for the rhs moments) or -1
+    std::vector<int> steps;      // the parts' step programs, one after the other
+};
+
+static inline bool fbr_gram64_build_producer(const FbrHostModel &hm, const FbrGramProgram &gp, const FbrGram64 &g, FbrGram64Producer &pr)
+{
+    std::vector<int> tile_of(hm.cols, -1), slot_of(hm.cols, -1);
+    for (int t = 0; t < g.NT; t++)
+        for (int sl = 0; sl < FBR_TILE; sl++)
+            if (gp.tiles[t].col[sl] >= 0 && gp.tiles[t].col[sl] < hm.cols) {
+                tile_of[gp.tiles[t].col[sl]] = t;
+                slot_of[gp.tiles[t].col[sl]] = sl;
+            }
+    std::vector<double> lcost(hm.L, 30.0);
+    for (int c = 0; c < hm.ninert; c++)
+        if (tile_of[c] >= 0) lcost[hm.coldesc[c].link] += 10.0 + (double)(hm.fb + hm.path[hm.coldesc[c].link].size());
+    std::vector<FbrKinIdProgram> progs;
+    std::vector<std::vector<char>> own;
+    try {
+        fbr_kinid_build_parts(hm, lcost, FBR_KINWRITE_PARTS, progs, own);
+    } catch (const std::exception &) {
+        return false;
+    }
+    pr.nparts = (int)progs.size();
+    pr.rel.assign((size_t)pr.nparts * 10 * hm.L, 0);
+    pr.lcol.assign((size_t)pr.nparts * 10 * hm.L, -1);
+    for (int c = 0; c < hm.ninert; c++) {
+        const int t = tile_of[c], sl = slot_of[c], l = hm.coldesc[c].link;
+        if (t < 0) continue;  // (a column without a tile: structurally zero, e.g. the base link of a fixed base)
+        if (hm.fb + (int)hm.path[l].size() > hm.fb + (int)gp.tiles[t].tpath.size()) return false;  // (cannot happen: the tile's path contains the link's)
+        const int tr0 = g.trow[(size_t)t * g.nlev];
+        for (int pq = 0; pq < pr.nparts; pq++)
+            if (own[pq][l]) {
+                pr.rel[((size_t)pq * hm.L + l) * 10 + hm.coldesc[c].pidx] = (((long long)tr0 * 1024 + sl * 32) * 8) | (long long)(4 * (sl & 7)) | (1LL << 62);
+                pr.lcol[((size_t)pq * hm.L + l) * 10 + hm.coldesc[c].pidx] = c;
+            }
+    }
+    pr.steps.clear();
+    pr.nslots = 1;
+    for (int pq = 0; pq < pr.nparts; pq++) {
+        pr.step0[pq] = (int)(pr.steps.size() / FBR_KINID_STEP);
+        pr.nsteps[pq] = progs[pq].nsteps;
+        pr.nslots = std::max(pr.nslots, progs[pq].nslots);
+        pr.steps.insert(pr.steps.end(), progs[pq].steps.begin(), progs[pq].steps.begin() + (size_t)progs[pq].nsteps * FBR_KINID_STEP);
+    }
+    return true;
+}
+
+#if defined(__HIPCC__) && defined(FBR_KERNELS_GRAM)
+struct DevGram64 {
+    int NT, nlev, maxact, npieces;
+    long blk_doubles;
+    const int *slab, *lev_begin, *pieces, *wmeta;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Producer: the lane writer of fbr_kinid.h with the image addressing of this pass.  Destination word of a (column, row): address of the
+// slab position of column slot c, sample 0 (256-byte aligned) | 4 (c & 7) in its low byte; sample slot s of block b goes to
+// + b * blk_doubles + (s >> 5) * 512 + ((s & 31) ^ x).  Lanes behind the last sample of the last block store ZEROS (the Gram kernel runs
+// whole blocks).  mom (k == 1): [workgroup][cols + 1][64] per-lane running sums of (w Y)^T (w tau) per column and (w tau)^T (w tau), added in block order.
+// ------------------------------------------------------------------------------------------------
+template <int MAXD, bool HASW>
+__global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, long blk_doubles,
+                                                                              const double *__restrict__ q, const double *__restrict__ dq,
+                                                                              const double *__restrict__ ddq, const double *__restrict__ bv,
+                                                                              const double *__restrict__ ba, const double *__restrict__ rpy,
+                                                                              const double *__restrict__ rhs, const double *__restrict__ wts,
+                                                                              double *__restrict__ scratch, double *__restrict__ mom)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nth = blockDim.x, tid = threadIdx.x;
+    const int n = m.n, ldn = p.ldn, ldw = m.rows | 1, rows = m.rows;
+    double *sq = smem, *sdq = sq + 64 * ldn, *sddq = sdq + 64 * ldn, *sw = sddq + 64 * ldn;  // sw [64][ldw] row weights (has_w)
+    double *st = sw + (HASW ? 64 * ldw : 0);                                             // st [64][ldw] w^2 tau (k == 1)
+    double *scr = scratch + ((long)blockIdx.x * wr.nparts + part) * p.nslots * FBR_LINK_REC * 64 + lane;
+    double *mo = mom ? mom + (long)blockIdx.x * (wr.cols + 1) * 64 : nullptr;  // [cols + 1][64 lanes]
+    const long nblk = (S + 63) >> 6;
+    const fbr_clong_ptr cdst = (fbr_clong_ptr)(unsigned long)wr.dst;
+    const fbr_cint_ptr ccol = (fbr_cint_ptr)(unsigned long)(wr.lcol10 + (long)part * 10 * m.L);
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long base = blk << 6;
+        const int valid = (int)min(64L, S - base);
+        __syncthreads();
+        {
+            const long off = base * n;
+            const int cnt = valid * n;
+            int sr = tid / n, dc = tid - sr * n;
+            const int ds = nth / n, dd = nth - ds * n;
+            for (int i = tid; i < cnt; i += nth) {
+                const double a = q[off + i], b = dq[off + i], c = ddq[off + i];
+                sq[sr * ldn + dc] = a;
+                sdq[sr * ldn + dc] = b;
+                sddq[sr * ldn + dc] = c;
+                sr += ds;
+                dc += dd;
+                if (dc >= n) {
+                    dc -= n;
+                    sr++;
+                }
+            }
+            if (HASW || wr.k) {
+                const int cw = valid * rows;
+                int wr_ = tid / rows, wc = tid - wr_ * rows;
+                const int es = nth / rows, ed = nth - es * rows;
+                for (int i = tid; i < cw; i += nth) {
+                    const double wv = HASW ? wts[base * rows + i] : 1.0;
+                    if (HASW) sw[wr_ * ldw + wc] = wv;
+                    if (wr.k) st[wr_ * ldw + wc] = wv * wv * rhs[base * rows + i];
+                    wr_ += es;
+                    wc += ed;
+                    if (wc >= rows) {
+                        wc -= rows;
+                        wr_++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int ls = min(lane, valid - 1);
+        const long s = base + ls;
+        const bool live = lane < valid;
+        const double *mysq = sq + ls * ldn, *mysdq = sdq + ls * ldn, *mysddq = sddq + ls * ldn, *myw = sw + ls * ldw, *myt = st + ls * ldw;
+        const long slot_off = blk * blk_doubles + (long)(lane >> 5) * 512;
+        const int s31 = lane & 31;
+        auto state = [&](int d, double &a, double &b, double &c) {
+            a = mysq[d];
+            b = mysdq[d];
+            c = mysddq[d];
+        };
+        auto basest = [&](double *v6, double *a6, double *e3) {
+            for (int i = 0; i < 6; i++) {
+                v6[i] = bv[s * 6 + i];
+                a6[i] = ba[s * 6 + i];
+            }
+            for (int i = 0; i < 3; i++) e3[i] = rpy[s * 3 + i];
+        };
+        auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
+        auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {
+            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+            for (int i = 0; i < 3; i++) {
+                rp[i] = m.restp[3 * l + i];
+                ax[i] = m.axis[3 * l + i];
+            }
+        };
+        // byte offset of this lane's sample inside a (tile row, column) run, before the column's swizzle: block, half, sample
+        const unsigned vlane = (unsigned)(((unsigned long)slot_off + (unsigned long)s31) << 3);
+        auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
+            (void)F;
+            long d10[10];
+#pragma unroll
+            for (int pp = 0; pp < 10; pp++) d10[pp] = cdst[((long)part * m.L + l) * 10 + pp];
+            // tau's side of the moments: sum_r v_r t_r over the rows of one column = w6 . (t_base + sum_j S_j t_j), t = w^2 tau
+            double Ft[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (wr.k) {
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    if (i < m.fb) Ft[i] = myt[i];
+#pragma unroll
+                for (int j = 0; j < MAXD; j++)
+                    if (j < depth) {
+                        const double tj = myt[m.fb + lvd[j]];
+#pragma unroll
+                        for (int i = 0; i < 6; i++) Ft[i] += Sst[j][i] * tj;
+                    }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 10; pp++) {
+                const long d0 = d10[pp];
+                if (d0 == 0) continue;
+                const int c = ccol[10 * l + pp];
+                // inertia parameters (pp >= 4) produce a pure moment: the force rows of the base wrench are structural zeros of the image
+                // (never written), and the joint rows need the moment half of S only -- bit for bit what the full products give
+                const int i0 = pp >= 4 ? 3 : 0;
+                const fbr_gchar_ptr sb = (fbr_gchar_ptr)(d0 & ~0xffL);
+                const unsigned vo = vlane ^ ((unsigned)(d0 & 0xff) << 3);
+                double w6[6];
+                fbr_unit_wrench(rec, pp, w6);
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    if (i >= i0 && i < m.fb) {
+                        const double v = HASW ? w6[i] * myw[i] : w6[i];
+                        __builtin_nontemporal_store(live ? v : 0.0, (fbr_gdouble_ptr)(sb + (long)i * 8192 + vo));
+                    }
+#pragma unroll
+                for (int j = 0; j < MAXD; j++)
+                    if (j < depth) {
+                        const double d = pp >= 4 ? Sst[j][3] * w6[3] + Sst[j][4] * w6[4] + Sst[j][5] * w6[5] : fbr_dot6(Sst[j], w6);
+                        const double v = HASW ? d * myw[m.fb + lvd[j]] : d;
+                        __builtin_nontemporal_store(live ? v : 0.0, (fbr_gdouble_ptr)(sb + (long)(m.fb + j) * 8192 + vo));
+                    }
+                if (wr.k) {
+                    const double mc = pp >= 4 ? Ft[3] * w6[3] + Ft[4] * w6[4] + Ft[5] * w6[5] : fbr_dot6(Ft, w6);
+                    unsafeAtomicAdd(mo + (long)c * 64 + lane, live ? mc : 0.0);  // this lane's own running sum: one adder per address, in block order
+                }
+            }
+        };
+        auto emit = [&](int, double) {};
+        fbr_kinid_lane<MAXD, false>(wr.part_nsteps[part], p.maxlvl, p.steps + wr.part_step0[part] * FBR_KINID_STEP, p.endflush, m.floating, m.g, m.fb,
+                                    state, basest, save, load, link, emit, consts);
+        if (wr.k && part == wr.nparts - 1) {  // (w tau)^T (w tau)
+            double tt = 0.0;
+            for (int r = 0; r < rows; r++) {
+                const double wv = HASW ? myw[r] : 1.0, tv = rhs[s * rows + r] * wv;
+                tt += tv * tv;
+            }
+            unsafeAtomicAdd(mo + (long)wr.cols * 64 + lane, live ? tt : 0.0);
+        }
+    }
+}
+
+// rhs moments of a call -> G (k == 1): one workgroup per column sums the per-lane running sums of the producer's workgroups in a fixed order
+__global__ __launch_bounds__(256) void fbr_gram64_mom_reduce_kernel(int P, int nwg, const double *__restrict__ mom, double *__restrict__ G)
+{
+    __shared__ double part[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < nwg * 64; i += 256) s += mom[((long)(i >> 6) * (P + 1) + c) * 64 + (i & 63)];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) part[t] += part[t + o];
+        __syncthreads();
+    }
+    if (t) return;
+    const int Pa = P + 1;
+    if (c == P) {
+        G[(long)P * Pa + P] += part[0];
+    } else {
+        G[(long)c * Pa + P] += part[0];
+        G[(long)P * Pa + c] += part[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Consumer.  One workgroup (8 waves) per CU walks blocks blockIdx.x, + gridDim.x, ...; stage = (block, half, level).  partial:
+// [workgroup][wave][slot][4][64] (the layout fbr_gram_reduce_kernel sums); carry: start from it.
+// ------------------------------------------------------------------------------------------------
+template <int SEGW, int NSEG>
+__global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr_gram64_kernel(DevGram64 g, long nblk, const double *__restrict__ img,
+                                                                                              double *__restrict__ partial, int carry)
+{
+    constexpr int NPW = SEGW * NSEG, MW = 2 + 2 * SEGW;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int bufd = g.maxact * 512;
+    double *buf0 = smem, *buf1 = smem + bufd;
+    int *slab = (int *)(smem + 2 * bufd);      // [nlev][NT]
+    int *levb = slab + g.nlev * g.NT;          // [nlev + 1]
+    int *pcs = levb + g.nlev + 1;              // [npieces][2]
+    int *wm = pcs + 2 * g.npieces;             // [8][NSEG][MW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < g.nlev * g.NT; i += FBR_WPB * 64) slab[i] = g.slab[i];
+    for (int i = tid; i <= g.nlev; i += FBR_WPB * 64) levb[i] = g.lev_begin[i];
+    for (int i = tid; i < 2 * g.npieces; i += FBR_WPB * 64) pcs[i] = g.pieces[i];
+    for (int i = tid; i < FBR_WPB * NSEG * MW; i += FBR_WPB * 64) wm[i] = g.wmeta[i];
+    fbr_d4 acc[NPW];
+    double *pp = partial + (((long)blockIdx.x * FBR_WPB + wave) * NPW) * 256;
+    if (carry) {
+#pragma unroll
+        for (int q = 0; q < NPW; q++) acc[q] = (fbr_d4){pp[q * 256 + lane], pp[q * 256 + 64 + lane], pp[q * 256 + 128 + lane], pp[q * 256 + 192 + lane]};
+    } else {
+#pragma unroll
+        for (int q = 0; q < NPW; q++) acc[q] = (fbr_d4){0.0, 0.0, 0.0, 0.0};
+    }
+    __syncthreads();
+    const int nmine = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
+    const long nstage = (long)(nmine > 0 ? nmine : 0) * 2 * g.nlev;
+    // LDS-DMA of stage st into buffer (st & 1): wave w issues pieces w, w + 8, ... of the stage's level
+    auto dma = [&](long st) {
+        const int lv = (int)(st % g.nlev);
+        const long bh = st / g.nlev;
+        const long blk = (long)blockIdx.x + (bh >> 1) * gridDim.x;
+        const double *src = img + blk * g.blk_doubles + (bh & 1) * 512 + 2 * lane;
+        double *buf = (st & 1) ? buf1 : buf0;
+        for (int i = levb[lv] + wave; i < levb[lv + 1]; i += FBR_WPB) {
+            const int gx = __builtin_amdgcn_readfirstlane(pcs[2 * i]), lx = __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]);
+            __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + lx), 16, 0, 0);
+        }
+    };
+    if (nstage > 0) dma(0);
+    const int li = lane & 15, kk = lane >> 4;
+    const int lofs = li * 32, sx = 4 * (li & 7);
+    const int *wmeta = wm + wave * NSEG * MW;
+    for (long st = 0; st < nstage; st++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage st have landed
+        __syncthreads();                                  // everyone's have; the other buffer is free
+        if (st + 1 < nstage) dma(st + 1);
+        const int lv = (int)(st % g.nlev);
+        const double *buf = (st & 1) ? buf1 : buf0;
+        const int *sl = slab + lv * g.NT;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; sg++) {
+            const int mv = wmeta[sg * MW + (lane < MW ? lane : 0)];
+            const int tI = __builtin_amdgcn_readlane(mv, 0), cpmax = __builtin_amdgcn_readlane(mv, 1);
+            if (tI < 0 || cpmax <= lv) continue;
+            const double *pa = buf + __builtin_amdgcn_readfirstlane(sl[tI]) * 512 + lofs;
+            double a[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) a[ks] = pa[(4 * ks + kk) ^ sx];
+#pragma unroll
+            for (int j = 0; j < SEGW; j++) {
+                const int tJ = __builtin_amdgcn_readlane(mv, 2 + 2 * j), cp = __builtin_amdgcn_readlane(mv, 3 + 2 * j);
+                if (tJ < 0 || cp <= lv) continue;
+                const double *pb = buf + __builtin_amdgcn_readfirstlane(sl[tJ]) * 512 + lofs;
+                double b[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) b[ks] = pb[(4 * ks + kk) ^ sx];
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) acc[sg * SEGW + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc[sg * SEGW + j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPW; q++) {
+        pp[q * 256 + 0 * 64 + lane] = acc[q][0];
+        pp[q * 256 + 1 * 64 + lane] = acc[q][1];
+        pp[q * 256 + 2 * 64 + lane] = acc[q][2];
+        pp[q * 256 + 3 * 64 + lane] = acc[q][3];
+    }
+}
+#endif

@@ -217,6 +217,38 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int64_t num
     return FBR_OK;
 }
 
+static int get_gram64(fbr_model *m, GramHolder *h);
+
+extern "C" int fbr_gram_lane_info(const fbr_model *mc, int32_t k, int64_t num_samples, int64_t info[8])
+{
+    if (!mc || !info) {
+        set_err("null model / info");
+        return FBR_E_INVALID;
+    }
+    fbr_model *m = const_cast<fbr_model *>(mc);
+    if (int rc_enter = enter(m)) return rc_enter;
+    if (const int wr = pick_gram_reduction(m, num_samples < 0 ? -1 : (long)num_samples); wr >= 0) m = m->rdm[wr].get();
+    for (int i = 0; i < 8; i++) info[i] = 0;
+    const bool moments = fbr_gram_rhs_moments(m->hm, k, m->opt.gram_rhs_tile != 0);
+    GramHolder *h = nullptr;
+    int rc = get_gram(m, k, &h, moments);
+    if (rc) return rc;
+    if (!m->opt.gram_lane || k > 1 || (k == 1 && !moments) || m->hm.fric) return FBR_OK;
+    if ((rc = get_gram64(m, h))) return rc;
+    if (h->g64_state != 1) return FBR_OK;
+    const FbrGram64 &g = h->g64;
+    info[0] = 1;
+    info[1] = g.ntr;
+    info[2] = g.blk_doubles * (int64_t)sizeof(double);
+    info[3] = g.mfma_per_block;
+    info[4] = g.nlev;
+    info[5] = g.maxact;
+    info[6] = (int64_t)((size_t)2 * g.maxact * 512 * sizeof(double) +
+                        ((size_t)g.nlev * g.NT + g.nlev + 1 + g.pieces.size() + g.wmeta.size()) * sizeof(int));
+    info[7] = g.NT;
+    return FBR_OK;
+}
+
 // G (+)= R^T R for an upper-triangular R (Pa x Pa): the Gram of a robot the fused tile program does not cover, from its TSQR factor
 __global__ __launch_bounds__(256) void fbr_rtr_kernel(int Pa, const double *__restrict__ R, double *__restrict__ G, int accumulate)
 {
@@ -251,6 +283,172 @@ static int gram_via_tsqr(fbr_model *m, const fbr_states *st, const double *rhs, 
     HIPCHK(hipGetLastError());
     return finish_output(m, G, G_out, cnt, out_mem);
 }
+// ------------------------------------------------------------------------------------------------
+// The pass over sample-contiguous images (fbr_gram64.h): tables of a holder, built on first use
+// ------------------------------------------------------------------------------------------------
+static int get_gram64(fbr_model *m, GramHolder *h)
+{
+    if (h->g64_state) return FBR_OK;
+    h->g64_state = -1;
+    const FbrHostModel &hm = m->hm;
+    if (m->kinid.nsteps <= 0 || !fbr_gram64_build(hm, h->prog, h->g64)) return FBR_OK;
+    FbrGram64 &g = h->g64;
+    const size_t lds = (size_t)2 * g.maxact * 512 * sizeof(double) +
+                       ((size_t)g.nlev * g.NT + g.nlev + 1 + g.pieces.size() + g.wmeta.size()) * sizeof(int);
+    if (lds > 156 * 1024) return FBR_OK;
+    if (!fbr_gram64_build_producer(hm, h->prog, g, h->g64p)) return FBR_OK;
+    std::vector<int> wgbegin{0, 0};  // (filled per launch: one part)
+    int rc;
+    if ((rc = upload(h->pool, g.slab, &h->d64_slab)) || (rc = upload(h->pool, g.lev_begin, &h->d64_levb)) || (rc = upload(h->pool, g.pieces, &h->d64_pieces)) ||
+        (rc = upload(h->pool, g.wmeta, &h->d64_wmeta)) || (rc = upload(h->pool, h->g64p.lcol, &h->d64_lcol)) ||
+        (rc = upload(h->pool, h->g64p.steps, &h->d64_steps)) ||
+        (rc = upload(h->pool, g.slot_tiles, &h->d64_slot_tiles)))
+        return rc;
+    h->g64_state = 1;
+    return FBR_OK;
+}
+
+// One call of the fused pass through fbr_kinimg_kernel / fbr_gram64_kernel (device-resident inputs, one group, k <= 1); everything on the
+// model's stream.  G has been cleared / holds the running sum.
+static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const double *drhs, const double *dw, int k, double *G)
+{
+    const FbrHostModel &hm = m->hm;
+    FbrGram64 &g = h->g64;
+    const long S = d.S;
+    const int Pa = hm.cols + k;
+    int rc;
+    const long ch = 64L * std::max(1L, std::min<long>(((long)chunk_size(m, S) + 63) / 64, (long)((size_t)3 * 1024 * 1024 * 1024 / ((size_t)g.blk_doubles * 8))));
+    long chb = std::min((S + 63) / 64, ch / 64);  // blocks per chunk: whole rounds of the chip (both kernels walk blocks workgroup by workgroup)
+    if (chb > m->num_cus) chb = chb / m->num_cus * m->num_cus;
+    if (chb > h->img64_blocks) {
+        for (int b = 0; b < 2; b++) {
+            if ((rc = h->img64[b].ensure((size_t)chb * g.blk_doubles * sizeof(double)))) return rc;
+            HIPCHK(hipMemsetAsync(h->img64[b].p, 0, h->img64[b].bytes, m->stream));  // structural zeros and padding slots are never written
+            std::vector<long long> dst(h->g64p.rel.size(), 0);
+            for (size_t i = 0; i < dst.size(); i++)
+                if (h->g64p.rel[i]) dst[i] = (long long)(uintptr_t)h->img64[b].p + (h->g64p.rel[i] & ~(1LL << 62));
+            if ((rc = h->dst64[b].ensure(dst.size() * sizeof(long long)))) return rc;
+            HIPCHK(hipMemcpyAsync(h->dst64[b].p, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipStreamSynchronize(m->stream));  // (dst is a local)
+        }
+        h->img64_blocks = chb;
+    }
+    const int ldn = std::max(hm.n, 1) | 1, ldw = hm.rows | 1;
+    const size_t plds = ((size_t)3 * 64 * ldn + (dw ? (size_t)64 * ldw : 0) + (k ? (size_t)64 * ldw : 0)) * sizeof(double);
+    const int pblocks = (int)std::min<long>(chb, (long)m->num_cus);
+    const int gwgs = (int)std::min<long>(chb, (long)m->num_cus);
+    if ((rc = h->scr64.ensure((size_t)m->num_cus * h->g64p.nparts * std::max(h->g64p.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
+    if (k) {
+        if ((rc = h->mom64.ensure((size_t)m->num_cus * (hm.cols + 1) * 64 * sizeof(double)))) return rc;
+        HIPCHK(hipMemsetAsync(h->mom64.p, 0, (size_t)pblocks * (hm.cols + 1) * 64 * sizeof(double), m->stream));  // (the producer grid of this call)
+    }
+    const int npw = g.segw * g.nseg;
+    if ((rc = m->partial.ensure((size_t)m->num_cus * FBR_WPB * npw * 256 * sizeof(double)))) return rc;
+    const size_t glds = (size_t)2 * g.maxact * 512 * sizeof(double) + ((size_t)g.nlev * g.NT + g.nlev + 1 + g.pieces.size() + g.wmeta.size()) * sizeof(int);
+    DevKinId kp;
+    kp.nsteps = 0;
+    kp.maxlvl = m->kinid.maxlvl;
+    kp.nslots = h->g64p.nslots;
+    kp.ldn = ldn;
+    kp.steps = h->d64_steps;
+    kp.endflush = m->kinid_endflush;
+    DevGram64 dg;
+    dg.NT = g.NT;
+    dg.nlev = g.nlev;
+    dg.maxact = g.maxact;
+    dg.npieces = (int)g.pieces.size() / 2;
+    dg.blk_doubles = g.blk_doubles;
+    dg.slab = h->d64_slab;
+    dg.lev_begin = h->d64_levb;
+    dg.pieces = h->d64_pieces;
+    dg.wmeta = h->d64_wmeta;
+    typedef void (*g64_fn)(DevGram64, long, const double *, double *, int);
+    const g64_fn gk = (g.segw == 5) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
+    HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    int launches = 0, first_wgs = 0;
+    for (long b0 = 0; b0 * 64 < S; b0 += chb, launches++) {
+        const long s0 = b0 * 64, cs = std::min(chb * 64, S - s0), nb = (cs + 63) / 64;
+        const int b = launches & 1;
+        DevKinWrite kw;
+        kw.lcol10 = h->d64_lcol;
+        kw.colrec = nullptr;
+        kw.dst = (const long *)h->dst64[b].p;
+        kw.ninert = hm.ninert;
+        kw.cols = hm.cols;
+        kw.k = k;
+        kw.has_w = dw ? 1 : 0;
+        kw.nparts = h->g64p.nparts;
+        for (int pq = 0; pq < FBR_KINWRITE_PARTS; pq++) {
+            kw.part_nsteps[pq] = h->g64p.nsteps[pq];
+            kw.part_step0[pq] = h->g64p.step0[pq];
+        }
+        {
+            ProfScope ps(m, FBR_PROF_PACK);
+#define FBR_KINIMG_LAUNCH2(D, W)                                                                                                                    \
+    do {                                                                                                                                         \
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_kinimg_kernel<D, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                 \
+        hipLaunchKernelGGL((fbr_kinimg_kernel<D, W>), dim3(pblocks), dim3(64 * h->g64p.nparts), plds, m->stream, m->dm, kp, kw, cs, g.blk_doubles,       \
+                           d.q + s0 * hm.n, d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,    \
+                           d.rpy ? d.rpy + s0 * 3 : nullptr, drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr,                                    \
+                           dw ? dw + (size_t)s0 * hm.rows : nullptr, h->scr64.as<double>(), k ? h->mom64.as<double>() : nullptr);                 \
+    } while (0)
+#define FBR_KINIMG_LAUNCH(D)            \
+    do {                                \
+        if (dw)                         \
+            FBR_KINIMG_LAUNCH2(D, true); \
+        else                            \
+            FBR_KINIMG_LAUNCH2(D, false); \
+    } while (0)
+            if (kp.maxlvl <= 4)
+                FBR_KINIMG_LAUNCH(4);
+            else if (kp.maxlvl <= 8)
+                FBR_KINIMG_LAUNCH(8);
+            else if (kp.maxlvl <= 12)
+                FBR_KINIMG_LAUNCH(12);
+            else
+                FBR_KINIMG_LAUNCH(FBR_KINID_MAXD);
+#undef FBR_KINIMG_LAUNCH2
+#undef FBR_KINIMG_LAUNCH
+            HIPCHK(hipGetLastError());
+        }
+        // the accumulators are carried from chunk to chunk by workgroup index: every chunk but a shorter last one starts the same grid
+        const int wgs = (int)std::min<long>(nb, (long)gwgs);
+        if (launches == 0) first_wgs = wgs;
+        if (wgs > first_wgs) {
+            set_err("internal: Gram launch wider than the first one of the call");
+            return FBR_E_INVALID;
+        }
+        {
+            ProfScope ps(m, FBR_PROF_GRAM);
+            hipLaunchKernelGGL(gk, dim3(first_wgs), dim3(FBR_WPB * 64), glds, m->stream, dg, nb, h->img64[b].as<double>(), m->partial.as<double>(), launches > 0 ? 1 : 0);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (launches > 0) {
+        ProfScope ps(m, FBR_PROF_REDUCE);
+        DevGram dr = h->dev;  // the reduction of fbr_gram_reduce_kernel: one part of first_wgs workgroups
+        dr.wpg = first_wgs;
+        dr.npw = npw;
+        dr.slot_tiles = h->d64_slot_tiles;
+        if (h->d64_wgbegin == nullptr || h->g64_wb_wgs != first_wgs) {  // [0, workgroups]: uploaded when the grid of a call differs from the last one's
+            std::vector<int> wb{0, first_wgs};
+            const int *dwb = nullptr;
+            if ((rc = upload(h->pool, wb, &dwb))) return rc;
+            h->d64_wgbegin = dwb;
+            h->g64_wb_wgs = first_wgs;
+        }
+        dr.wg_begin = h->d64_wgbegin;
+        hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
+        HIPCHK(hipGetLastError());
+        if (k) {
+            hipLaunchKernelGGL(fbr_gram64_mom_reduce_kernel, dim3(hm.cols + 1), dim3(256), 0, m->stream, hm.cols, pblocks, h->mom64.as<double>(), G);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    (void)Pa;
+    return FBR_OK;
+}
+
 // async_ticket != nullptr: the pass is enqueued and NOT waited for (fbr_gram_submit): device-resident inputs and output only.
 static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs, int32_t k, const double *w, double *G_out,
                            int32_t out_mem, int32_t accumulate, int32_t ngroups, int64_t *async_ticket)
@@ -339,7 +537,16 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
         if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, gcount * sizeof(double), hipMemcpyHostToDevice, m->stream));
     }
     if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
-    if (S > 0) {
+    // the pass over sample-contiguous images (fbr_gram64.h) where the call allows it
+    bool lane_pass = false;
+    if (S > 0 && m->opt.gram_lane != 0 && ngroups == 1 && !h2d_chunked && !base_only && !m->opt.gram_timing && !m->opt.gram_serial &&
+        k <= 1 && (k == 0 || moments) && !hm.fric && d.q) {
+        if ((rc = get_gram64(m, h))) return rc;
+        lane_pass = h->g64_state == 1;
+    }
+    if (lane_pass) {
+        if ((rc = gram64_pass(m, h, d, drhs, dw, k, G))) return rc;
+    } else if (S > 0) {
         const int T = h->prog.T;
         const bool two_per_cu = h->prog.cfg == FBR_CFG_TWO_PER_CU;
         const int blocks_per_cu = (two_per_cu && h->lds_bytes <= 79 * 1024) ? 2 : 1;

@@ -19,6 +19,7 @@
 #include "fbr_options.h"
 #include "fbr_kernels.h"
 #include "fbr_kinid.h"
+#include "fbr_gram64.h"
 #include "fbr_tsqr_work.h"
 
 extern thread_local std::string g_fbr_err;
@@ -102,6 +103,15 @@ struct GramHolder {
     const int *itemcol = nullptr;  // [256] regressor column of pack thread t (-1: none)
     size_t lds_bytes = 0;     // streaming Gram kernel
     size_t pack_lds_bytes = 0;
+    // ---- the pass over sample-contiguous images (fbr_gram64.h, option gram_lane); built on first use, -1: the model is outside it
+    int g64_state = 0;        // 0 not looked at, 1 ready, -1 not applicable
+    FbrGram64 g64;
+    FbrGram64Producer g64p;   // producer tables (parts, destination words relative to an image buffer)
+    const int *d64_slab = nullptr, *d64_levb = nullptr, *d64_pieces = nullptr, *d64_wmeta = nullptr, *d64_lcol = nullptr,
+              *d64_steps = nullptr, *d64_slot_tiles = nullptr, *d64_wgbegin = nullptr;
+    DevBuf img64[2], dst64[2], mom64, scr64;
+    long img64_blocks = 0;    // capacity of the image buffers in blocks of 64 samples
+    int g64_wb_wgs = -1;      // the grid d64_wgbegin was uploaded for
     struct Deal { const int2 *tab; const int *begin; };
     std::map<int, Deal> deals;  // workgroups per sample group -> device tables of fbr_gram_deal (at most one per count)
 };

@@ -28,6 +28,8 @@
 #define FBR_KINID_STEP 8  // ints per step: link, psrc, psave, jtype, dof, level, depth, flushdof
 #define FBR_KINID_MAXD 24 // deepest joint path the register-stack instances cover (deeper trees keep the two-kernel path)
 
+#define FBR_KINWRITE_PARTS 4  // waves of a lane-WRITER workgroup = parts the tree is cut into (fbr_kinid_build_parts)
+
 struct FbrKinIdProgram {
     int nsteps = 0, maxlvl = 0, nslots = 0;
     std::vector<int> steps;     // [nsteps][FBR_KINID_STEP]
@@ -241,6 +243,19 @@ struct DevKinId {
     int nsteps, maxlvl, nslots, ldn;  // ldn: row stride (doubles, odd) of the staged joint states of one sample
     const int *steps, *endflush;
 };
+// tables of the lane WRITERS (fbr_kinwrite_kernel below, fbr_kinimg_kernel in fbr_gram64.h)
+typedef const __attribute__((address_space(4))) long *fbr_clong_ptr;
+typedef const __attribute__((address_space(4))) int *fbr_cint_ptr;
+// destinations arrive as integers: a pointer made from one is GENERIC (flat_store: counted by lgkmcnt as well, so that every wait for a scalar load
+// or an LDS read would also wait for the stores in flight) unless it is given the global address space explicitly
+typedef __attribute__((address_space(1))) char *fbr_gchar_ptr;
+typedef __attribute__((address_space(1))) double *fbr_gdouble_ptr;
+struct DevKinWrite {
+    const int *lcol10, *colrec;  // lcol10 [parts][10 L]: the columns a part's wave writes; colrec [cols + 1][2]
+    const long *dst;
+    int ninert, cols, k, has_w;
+    int nparts, part_nsteps[FBR_KINWRITE_PARTS], part_step0[FBR_KINWRITE_PARTS];  // wave w of a workgroup walks steps [step0, step0 + nsteps) of p.steps
+};
 #endif
 
 #if defined(__HIPCC__) && defined(FBR_KERNELS_CORE)
@@ -444,16 +459,6 @@ __global__ __launch_bounds__(64) void fbr_kinfd_kernel(DevModel m, DevKinId p, l
 // level-indexed branch ladder per entry: 650.
 // lcol10[10 l + p]: the column of parameter p of link l (-1: not identified / not selected).  Row weights are applied here.
 // ------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(4))) long *fbr_clong_ptr;
-typedef const __attribute__((address_space(4))) int *fbr_cint_ptr;
-#define FBR_KINWRITE_PARTS 4
-struct DevKinWrite {
-    const int *lcol10, *colrec;  // lcol10 [parts][10 L]: the columns a part's wave writes; colrec [cols + 1][2]
-    const long *dst;
-    int ninert, cols, k, has_w;
-    int nparts, part_nsteps[FBR_KINWRITE_PARTS], part_step0[FBR_KINWRITE_PARTS];  // wave w of a workgroup walks steps [step0, step0 + nsteps) of p.steps
-};
-
 // A workgroup = nparts waves sharing one block of 64 samples (their states are staged once): wave w walks part w of the tree.
 template <int MAXD>
 __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinwrite_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, const double *__restrict__ q,
@@ -532,8 +537,9 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinwrite_kernel(D
         const fbr_clong_ptr cdst = (fbr_clong_ptr)(unsigned long)wr.dst;
         const fbr_cint_ptr crec = (fbr_cint_ptr)(unsigned long)wr.colrec, ccol = (fbr_cint_ptr)(unsigned long)(wr.lcol10 + (long)part * 10 * m.L);
         // one value: to its destination (sample 0 of the chunk) + s; the lanes of a wave write 64 consecutive doubles
+        const unsigned sbyte = (unsigned)s << 3;  // (s: sample index inside the chunk -- one launch per chunk; a chunk's column is far below 4 GB)
         auto put = [&](long d0, double v) {
-            if (d0 != 0 && live) __builtin_nontemporal_store(v, (double *)d0 + s);  // (s: sample index inside the chunk -- one launch per chunk)
+            if (d0 != 0 && live) __builtin_nontemporal_store(v, (fbr_gdouble_ptr)((fbr_gchar_ptr)d0 + sbyte));  // scalar base + 32-bit lane offset
         };
         auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
             (void)F;

@@ -17,6 +17,7 @@ struct FbrOptions {
     // ---- per-sample entry points
     double fused_id = 1;                    // fbr_predict / fbr_inverse_dynamics_batch: kinematics + torques in one kernel, no records in HBM (0: two kernels)
     // ---- fused Gram program
+    double gram_lane = 1;                   // fused Gram over sample-contiguous images with the one-lane-per-sample producer where the model allows (fbr_gram64.h)
     double gram_shape = 0;                  // 0: by model, 1: one workgroup per CU (18 accumulators), 2: two per CU (10)
     double gram_rhs_tile = 0;               // 1: dense rhs tiles even for k <= 2 (default: tau's products come from the pack kernel)
     double gram_orient = 1;                 // pairs turned so that the row segments fill up
@@ -53,6 +54,7 @@ static inline const FbrOptionKey *fbr_option_keys(int *count)
         {"min_chunks", &FbrOptions::min_chunks, false},
         {"h2d_chunked", &FbrOptions::h2d_chunked, false},
         {"fused_id", &FbrOptions::fused_id, false},
+        {"gram_lane", &FbrOptions::gram_lane, false},
         {"gram_shape", &FbrOptions::gram_shape, true},
         {"gram_rhs_tile", &FbrOptions::gram_rhs_tile, true},
         {"gram_orient", &FbrOptions::gram_orient, true},

@@ -277,6 +277,12 @@ int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t ncols, int32_t
 int fbr_gram_program_info(const fbr_model *m, int32_t k, int64_t num_samples, int32_t *num_tiles, int32_t *num_pairs,
                           int64_t *mfma_per_sample, int32_t *num_parts);
 
+/* The sample-contiguous Gram pass (option "gram_lane", csrc/fbr_gram64.h) for the same batch: info[0] = 1 when the model qualifies and the
+   option is on (device-resident inputs, k <= 1), else every entry is 0; [1] tile rows of a 64-sample block image, [2] its bytes, [3] MFMA
+   instructions per block, [4] row levels, [5] slabs of the widest stage, [6] LDS bytes of the Gram kernel, [7] column tiles.  The image is
+   written once and read once per pass: 2 * info[2] / 64 bytes of HBM traffic per sample. */
+int fbr_gram_lane_info(const fbr_model *m, int32_t k, int64_t num_samples, int64_t info[8]);
+
 /*
  * Column reductions (options "link_merge" / "regroup" / "reduce_min_work" below).  The regressor columns of a link attached by a FIXED
  * joint are an exact, constant linear combination of the columns of the moving body it rides on (the 10 x 10 change of frame of the
@@ -302,6 +308,9 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "h2d_chunked"                1     pinned host inputs staged chunk by chunk on a copy stream, overlapped with the kernels
  *   "fused_id"                   1     fbr_predict / fbr_inverse_dynamics_batch run kinematics and torques in ONE kernel, the link records
  *                                      stay in registers (0: kinematics kernel + torque kernel with the records staged through HBM)
+ *   "gram_lane"                  1     fused Gram over SAMPLE-contiguous images (MFMA k-steps over four samples of one regressor row) with a
+ *                                      one-lane-per-sample producer, where the model allows: no friction columns, at most one rhs column,
+ *                                      one part, device-resident inputs (0: always the per-sample images of the kinematics + packer kernels)
  *   "gram_shape"                 0     fused Gram kernel shape: 0 by model, 1 one workgroup per CU, 2 two per CU
  *   "gram_rhs_tile"              0     1: dense tiles for the rhs columns even for k <= 2 (default: their products come from the packer)
  *   "gram_orient"                1     tile pairs turned so that the row segments fill up
