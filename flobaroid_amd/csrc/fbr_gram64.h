@@ -17,6 +17,9 @@
 //     MFMAs of the stage before run; a pair takes part in the levels below its common depth; 8 MFMAs per pair and stage.
 // Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), one part, device-resident inputs, one group.
 #pragma once
+#include <algorithm>
+#include <utility>
+
 #include "fbr_kinid.h"
 
 struct FbrGram64 {  // host program
@@ -70,32 +73,131 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
     }
     g.lev_begin[g.nlev] = (int)g.pieces.size() / 2;
     const int npw = g.segw * g.nseg, W = FBR_WPB;
-    g.wmeta.assign((size_t)W * g.nseg * (2 + 2 * g.segw), -1);
-    g.slot_tiles.assign((size_t)W * npw * 2, -1);
-    g.mfma_per_block = 0;
+    // The tile pairs of the program, as unordered pairs with their common depth: cp = fb + joints both tiles' columns have rows on.  Which
+    // tile of a pair is the A operand is free (the block is written with its mirror image by the reduction).
+    struct Pr {
+        int a, b, cp;
+    };
+    std::vector<Pr> prs;
+    const int nsegs = W * g.nseg;
+    std::vector<int> seg_of;
     for (int w = 0; w < W; w++)
-        for (int sg = 0; sg < g.nseg; sg++) {
-            int *mm = &g.wmeta[((size_t)w * g.nseg + sg) * (2 + 2 * g.segw)];
-            mm[1] = 0;
+        for (int sg = 0; sg < g.nseg; sg++)
             for (int j = 0; j < g.segw; j++) {
                 const size_t s = (size_t)w * npw + sg * g.segw + j;
                 const int pi = gp.slots[s].pair;
                 if (pi < 0) continue;
                 const FbrPair &p = gp.pairs[pi];
                 if (p.mode != 0) return false;
-                if (mm[0] >= 0 && mm[0] != p.I) return false;  // (a row segment shares its tile I)
-                mm[0] = p.I;
                 const std::vector<int> &a = gp.tiles[p.I].tpath, &b = gp.tiles[p.J].tpath;
                 const int cpj = FbrGramProgram::common_prefix(a, b);
                 const int cp = hm.fb + (cpj == (int)std::min(a.size(), b.size()) ? (int)std::min(a.size(), b.size()) : cpj);
-                mm[2 + 2 * j] = p.J;
-                mm[3 + 2 * j] = cp;
-                mm[1] = std::max(mm[1], cp);
-                g.slot_tiles[2 * s] = p.I;
-                g.slot_tiles[2 * s + 1] = p.J;
-                g.mfma_per_block += 16L * cp;  // 8 MFMAs per level and half
+                prs.push_back({p.I, p.J, std::min(cp, g.nlev)});
+                seg_of.push_back(w * g.nseg + sg);  // the tile program's own placement: a valid start (a row segment shares its tile I)
+            }
+    // Pairs -> (wave, segment).  All waves of the workgroup meet at every stage (level, half block), so a stage lasts as long as its busiest
+    // wave: the cost of a placement is  sum over levels of max over waves of the pairs active at the level,  not the waves' totals (the
+    // tile program's own placement, balanced by totals, leaves WALK-MAN at 156 against 126 for a perfect split).  Local search from the
+    // program's placement: move a pair to another segment / swap two pairs while (cost, sum of squared loads) falls; a segment keeps a
+    // tile common to all its pairs (the A operand, read once per k-step for the whole segment).  Deterministic.
+    const int NP = (int)prs.size();
+    std::vector<std::vector<int>> members(nsegs);
+    for (int i = 0; i < NP; i++) members[seg_of[i]].push_back(i);
+    auto common_tile = [&](const std::vector<int> &mem, int extra, int without) {  // a tile in every pair of mem (+ extra, - without), or -1
+        int ca = -1, cb = -1;
+        bool first = true;
+        auto take = [&](int i) {
+            if (first) {
+                ca = prs[i].a, cb = prs[i].b, first = false;
+                return;
+            }
+            if (ca >= 0 && ca != prs[i].a && ca != prs[i].b) ca = -1;
+            if (cb >= 0 && cb != prs[i].a && cb != prs[i].b) cb = -1;
+        };
+        for (int i : mem)
+            if (i != without) take(i);
+        if (extra >= 0) take(extra);
+        if (first) return -2;  // empty
+        return ca >= 0 ? ca : cb;
+    };
+    for (int sgi = 0; sgi < nsegs; sgi++)
+        if (!members[sgi].empty() && common_tile(members[sgi], -1, -1) < 0) return false;
+    std::vector<std::vector<int>> wl(W, std::vector<int>(g.nlev, 0));
+    for (int i = 0; i < NP; i++)
+        for (int lv = 0; lv < prs[i].cp; lv++) wl[seg_of[i] / g.nseg][lv]++;
+    auto score = [&](long &c, long &sq) {
+        c = 0, sq = 0;
+        for (int lv = 0; lv < g.nlev; lv++) {
+            int mx = 0;
+            for (int w = 0; w < W; w++) {
+                mx = std::max(mx, wl[w][lv]);
+                sq += (long)wl[w][lv] * wl[w][lv];
+            }
+            c += mx;
+        }
+    };
+    auto shift = [&](int i, int w, int sign) {
+        for (int lv = 0; lv < prs[i].cp; lv++) wl[w][lv] += sign;
+    };
+    long c0, q0;
+    score(c0, q0);
+    for (int sweep = 0, improved = 1; improved && sweep < 64; sweep++) {
+        improved = 0;
+        for (int i = 0; i < NP; i++) {
+            for (int t = 0; t < nsegs; t++) {  // move pair i to segment t
+                const int from = seg_of[i];
+                if (t == from || (int)members[t].size() >= g.segw || common_tile(members[t], i, -1) == -1) continue;
+                shift(i, from / g.nseg, -1), shift(i, t / g.nseg, +1);
+                long c1, q1;
+                score(c1, q1);
+                if (c1 < c0 || (c1 == c0 && q1 < q0)) {
+                    members[from].erase(std::find(members[from].begin(), members[from].end(), i));
+                    members[t].push_back(i);
+                    seg_of[i] = t, c0 = c1, q0 = q1, improved = 1;
+                } else {
+                    shift(i, t / g.nseg, -1), shift(i, from / g.nseg, +1);
+                }
+            }
+            for (int k2 = i + 1; k2 < NP; k2++) {  // swap the segments of pairs i and k2
+                const int si = seg_of[i], sk = seg_of[k2];
+                if (si / g.nseg == sk / g.nseg || prs[i].cp == prs[k2].cp) continue;
+                if (common_tile(members[si], k2, i) == -1 || common_tile(members[sk], i, k2) == -1) continue;
+                shift(i, si / g.nseg, -1), shift(k2, sk / g.nseg, -1), shift(i, sk / g.nseg, +1), shift(k2, si / g.nseg, +1);
+                long c1, q1;
+                score(c1, q1);
+                if (c1 < c0 || (c1 == c0 && q1 < q0)) {
+                    *std::find(members[si].begin(), members[si].end(), i) = k2;
+                    *std::find(members[sk].begin(), members[sk].end(), k2) = i;
+                    seg_of[i] = sk, seg_of[k2] = si, c0 = c1, q0 = q1, improved = 1;
+                } else {
+                    shift(i, sk / g.nseg, -1), shift(k2, si / g.nseg, -1), shift(i, si / g.nseg, +1), shift(k2, sk / g.nseg, +1);
+                }
             }
         }
+    }
+    g.wmeta.assign((size_t)W * g.nseg * (2 + 2 * g.segw), -1);
+    g.slot_tiles.assign((size_t)W * npw * 2, -1);
+    g.mfma_per_block = 0;
+    for (int sgi = 0; sgi < nsegs; sgi++) {
+        int *mm = &g.wmeta[(size_t)sgi * (2 + 2 * g.segw)];
+        mm[1] = 0;
+        if (members[sgi].empty()) continue;
+        std::sort(members[sgi].begin(), members[sgi].end());
+        const int I = common_tile(members[sgi], -1, -1);
+        if (I < 0) return false;
+        mm[0] = I;
+        for (size_t j = 0; j < members[sgi].size(); j++) {
+            const Pr &p = prs[members[sgi][j]];
+            const int J = p.a == I ? p.b : p.a;
+            const size_t s = (size_t)(sgi / g.nseg) * npw + (size_t)(sgi % g.nseg) * g.segw + j;
+            mm[2 + 2 * j] = J;
+            mm[3 + 2 * j] = p.cp;
+            mm[1] = std::max(mm[1], p.cp);
+            g.slot_tiles[2 * s] = I;
+            g.slot_tiles[2 * s + 1] = J;
+            g.mfma_per_block += 16L * p.cp;  // 8 MFMAs per level and half
+        }
+    }
     return true;
 }
 
@@ -164,8 +266,8 @@ struct DevGram64 {
 // ------------------------------------------------------------------------------------------------
 // Producer: the lane writer of fbr_kinid.h with the image addressing of this pass.  Destination word of a (column, row): address of the
 // slab position of column slot c, sample 0 (256-byte aligned) | 4 (c & 7) in its low byte; sample slot s of block b goes to
-// + b * blk_doubles + (s >> 5) * 512 + ((s & 31) ^ x).  Lanes behind the last sample of the last block store ZEROS (the Gram kernel runs
-// whole blocks).  mom (k == 1): [workgroup][cols + 1][64] per-lane running sums of (w Y)^T (w tau) per column and (w tau)^T (w tau), added in block order.
+// + b * blk_doubles + (s >> 5) * 512 + ((s & 31) ^ x).  The positions of the lanes behind the last sample of the last block are cleared by the host before the launch (the Gram
+// kernel runs whole blocks).  mom (k == 1): [workgroup][cols + 1][64] per-lane running sums of (w Y)^T (w tau) per column and (w tau)^T (w tau), added in block order.
 // ------------------------------------------------------------------------------------------------
 template <int MAXD, bool HASW>
 __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, long blk_doubles,
@@ -255,6 +357,10 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(Dev
         const unsigned vlane = (unsigned)(((unsigned long)slot_off + (unsigned long)s31) << 3);
         auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
             (void)F;
+            // Every vector load of the step (branch records, states) is waited for HERE, once: the stores below share the loads' counter, and
+            // behind the branches of the column code the compiler cannot tell how many of them sit in front of a load it still expects --
+            // it would wait for counter 0, i.e. for the store before, at every store (measured: 7.4 -> 5.4 ms per 1 M WALK-MAN samples).
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
             long d10[10];
 #pragma unroll
             for (int pp = 0; pp < 10; pp++) d10[pp] = cdst[((long)part * m.L + l) * 10 + pp];
@@ -272,47 +378,82 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(Dev
                         for (int i = 0; i < 6; i++) Ft[i] += Sst[j][i] * tj;
                     }
             }
-#pragma unroll
-            for (int pp = 0; pp < 10; pp++) {
-                const long d0 = d10[pp];
-                if (d0 == 0) continue;
-                const int c = ccol[10 * l + pp];
-                // inertia parameters (pp >= 4) produce a pure moment: the force rows of the base wrench are structural zeros of the image
-                // (never written), and the joint rows need the moment half of S only -- bit for bit what the full products give
-                const int i0 = pp >= 4 ? 3 : 0;
-                const fbr_gchar_ptr sb = (fbr_gchar_ptr)(d0 & ~0xffL);
+            // One value to (column q of the group, level lv).  Scalar base (the column's word, 8192 bytes per level) + this lane's 32-bit
+            // offset with the column's swizzle; a column the part does not write (word 0) skips the store only -- the products of a level
+            // are computed for the whole group first, branch-free, so that their dependent chains overlap.
+            auto store = [&](long d0, int lv, double v) {
+                if (d0 == 0) return;
                 const unsigned vo = vlane ^ ((unsigned)(d0 & 0xff) << 3);
-                double w6[6];
-                fbr_unit_wrench(rec, pp, w6);
+                __builtin_nontemporal_store(v, (fbr_gdouble_ptr)((fbr_gchar_ptr)(d0 & ~0xffL) + (long)lv * 8192 + vo));
+            };
+            {  // mass and first moments: full wrenches
+                double wA[4][6];
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) fbr_unit_wrench(rec, qq, wA[qq]);
 #pragma unroll
                 for (int i = 0; i < 6; i++)
-                    if (i >= i0 && i < m.fb) {
-                        const double v = HASW ? w6[i] * myw[i] : w6[i];
-                        __builtin_nontemporal_store(live ? v : 0.0, (fbr_gdouble_ptr)(sb + (long)i * 8192 + vo));
+                    if (i < m.fb) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) store(d10[qq], i, HASW ? wA[qq][i] * myw[i] : wA[qq][i]);
                     }
 #pragma unroll
                 for (int j = 0; j < MAXD; j++)
                     if (j < depth) {
-                        const double d = pp >= 4 ? Sst[j][3] * w6[3] + Sst[j][4] * w6[4] + Sst[j][5] * w6[5] : fbr_dot6(Sst[j], w6);
-                        const double v = HASW ? d * myw[m.fb + lvd[j]] : d;
-                        __builtin_nontemporal_store(live ? v : 0.0, (fbr_gdouble_ptr)(sb + (long)(m.fb + j) * 8192 + vo));
+                        double v[4];
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) v[qq] = fbr_dot6(Sst[j], wA[qq]);
+                        const double wj = HASW ? myw[m.fb + lvd[j]] : 1.0;
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) store(d10[qq], m.fb + j, HASW ? v[qq] * wj : v[qq]);
                     }
                 if (wr.k) {
-                    const double mc = pp >= 4 ? Ft[3] * w6[3] + Ft[4] * w6[4] + Ft[5] * w6[5] : fbr_dot6(Ft, w6);
-                    unsafeAtomicAdd(mo + (long)c * 64 + lane, live ? mc : 0.0);  // this lane's own running sum: one adder per address, in block order
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++)
+                        if (d10[qq]) unsafeAtomicAdd(mo + (long)ccol[10 * l + qq] * 64 + lane, fbr_dot6(Ft, wA[qq]));  // this lane's own running sum
+                }
+            }
+            {  // inertia entries: pure moments -- the force rows of the base wrench are structural zeros of the image (never written), the
+               // joint rows need the moment half of S only
+                double nB[6][3];
+#pragma unroll
+                for (int qq = 0; qq < 6; qq++) fbr_unit_moment3(rec, 4 + qq, nB[qq]);
+#pragma unroll
+                for (int i = 3; i < 6; i++)
+                    if (i < m.fb) {
+#pragma unroll
+                        for (int qq = 0; qq < 6; qq++) store(d10[4 + qq], i, HASW ? nB[qq][i - 3] * myw[i] : nB[qq][i - 3]);
+                    }
+#pragma unroll
+                for (int j = 0; j < MAXD; j++)
+                    if (j < depth) {
+                        double v[6];
+#pragma unroll
+                        for (int qq = 0; qq < 6; qq++) v[qq] = Sst[j][3] * nB[qq][0] + Sst[j][4] * nB[qq][1] + Sst[j][5] * nB[qq][2];
+                        const double wj = HASW ? myw[m.fb + lvd[j]] : 1.0;
+#pragma unroll
+                        for (int qq = 0; qq < 6; qq++) store(d10[4 + qq], m.fb + j, HASW ? v[qq] * wj : v[qq]);
+                    }
+                if (wr.k) {
+#pragma unroll
+                    for (int qq = 0; qq < 6; qq++)
+                        if (d10[4 + qq])
+                            unsafeAtomicAdd(mo + (long)ccol[10 * l + 4 + qq] * 64 + lane, Ft[3] * nB[qq][0] + Ft[4] * nB[qq][1] + Ft[5] * nB[qq][2]);
                 }
             }
         };
         auto emit = [&](int, double) {};
-        fbr_kinid_lane<MAXD, false>(wr.part_nsteps[part], p.maxlvl, p.steps + wr.part_step0[part] * FBR_KINID_STEP, p.endflush, m.floating, m.g, m.fb,
-                                    state, basest, save, load, link, emit, consts);
-        if (wr.k && part == wr.nparts - 1) {  // (w tau)^T (w tau)
-            double tt = 0.0;
-            for (int r = 0; r < rows; r++) {
-                const double wv = HASW ? myw[r] : 1.0, tv = rhs[s * rows + r] * wv;
-                tt += tv * tv;
+        // lanes behind the last sample of the last block take no part (EXEC off): their image positions were cleared by the host
+        if (live) {
+            fbr_kinid_lane<MAXD, false>(wr.part_nsteps[part], p.maxlvl, p.steps + wr.part_step0[part] * FBR_KINID_STEP, p.endflush, m.floating, m.g, m.fb,
+                                        state, basest, save, load, link, emit, consts);
+            if (wr.k && part == wr.nparts - 1) {  // (w tau)^T (w tau)
+                double tt = 0.0;
+                for (int r = 0; r < rows; r++) {
+                    const double wv = HASW ? myw[r] : 1.0, tv = rhs[s * rows + r] * wv;
+                    tt += tv * tv;
+                }
+                unsafeAtomicAdd(mo + (long)wr.cols * 64 + lane, tt);
             }
-            unsafeAtomicAdd(mo + (long)wr.cols * 64 + lane, live ? tt : 0.0);
         }
     }
 }

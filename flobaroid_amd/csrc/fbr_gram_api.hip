@@ -382,6 +382,8 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
             kw.part_nsteps[pq] = h->g64p.nsteps[pq];
             kw.part_step0[pq] = h->g64p.step0[pq];
         }
+        if (cs & 63)  // the block the producer fills partly: what its idle lanes would have written (a buffer is reused from chunk to chunk)
+            HIPCHK(hipMemsetAsync(h->img64[b].as<double>() + (nb - 1) * g.blk_doubles, 0, (size_t)g.blk_doubles * sizeof(double), m->stream));
         {
             ProfScope ps(m, FBR_PROF_PACK);
 #define FBR_KINIMG_LAUNCH2(D, W)                                                                                                                    \

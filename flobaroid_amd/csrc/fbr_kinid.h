@@ -543,6 +543,9 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinwrite_kernel(D
         };
         auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
             (void)F;
+            // the vector loads of the step are waited for here, once: the stores below share their counter, and behind the branches of the
+            // column code the compiler would otherwise wait for counter 0 -- the store before -- at every store (see fbr_gram64.h)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
             for (int pp = 0; pp < 10; pp++) {
                 const int c = ccol[10 * l + pp];

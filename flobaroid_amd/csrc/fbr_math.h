@@ -200,6 +200,26 @@ FBR_HD void fbr_unit_wrench(const double *rec, int pidx, double *w6)
     for (int i = 0; i < 3; i++) w6[3 + i] = nA[i] + pxf[i];
 }
 
+// Inertia parameters (pidx 4..9) produce a pure moment: the force half of fbr_unit_wrench's column is zero and its moment half is R n.
+// n3 = that moment in frame A -- bit for bit w6[3..5] of fbr_unit_wrench up to the sign of a zero.
+FBR_HD void fbr_unit_moment3(const double *rec, int pidx, double *n3)
+{
+    const double *w = rec + FBR_OFF_W, *dw = rec + FBR_OFF_DW;
+    const int ia = (pidx == 4 || pidx == 5 || pidx == 6) ? 0 : ((pidx == 7 || pidx == 8) ? 1 : 2);
+    const int ib = (pidx == 4) ? 0 : ((pidx == 5 || pidx == 7) ? 1 : 2);
+    double Edw[3] = {0, 0, 0}, Ew[3] = {0, 0, 0};
+    Edw[ia] = dw[ib];
+    Ew[ia] = w[ib];
+    if (ia != ib) {
+        Edw[ib] = dw[ia];
+        Ew[ib] = w[ia];
+    }
+    double wxEw[3], n[3];
+    fbr_cross(w, Ew, wxEw);
+    for (int i = 0; i < 3; i++) n[i] = Edw[i] + wxEw[i];
+    fbr_mv(rec + FBR_OFF_R, n, n3);
+}
+
 // Net wrench (frame A) of a link with the 10 parameters pi:  W_l pi  (used by inverse dynamics / predict)
 FBR_HD void fbr_link_wrench(const double *rec, const double *pi, double *w6)
 {

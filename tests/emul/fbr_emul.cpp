@@ -12,6 +12,7 @@
 #include "../../flobaroid_amd/csrc/fbr_program.h"
 #include "../../flobaroid_amd/csrc/fbr_reduce.h"
 #include "../../flobaroid_amd/csrc/fbr_kinid.h"
+#include "../../flobaroid_amd/csrc/fbr_gram64.h"
 
 extern "C" {
 
@@ -515,6 +516,169 @@ int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
 // mirrors fbr_pack_kernel + fbr_gram_kernel + fbr_gram_reduce_kernel: the packed image of each sample is
 // produced once; every part copies its DMA pieces into a part-local image, each (wave, slot) runs its k-steps
 // with the 16x16x4 MFMA lane mapping on part-local offsets, results are scattered into G.
+// The Gram pass over sample-contiguous images (csrc/fbr_gram64.h: fbr_kinimg_kernel / fbr_gram64_kernel), from the SAME host tables:
+// producer = per (part, link, parameter) one destination word, level stride 1024 doubles, the column swizzle inside a 32-sample run;
+// consumer = stage (level, half) staged through the pieces table, operand reads with the kernel's indexing, the pairs of a wave's
+// segments below their common depth; rhs moments as per-lane running sums.  Returns < 0 when the model is outside that pass.
+// stats (8 longs, optional): tile rows, MFMAs per block, levels, widest stage, sum over levels of the busiest wave's active pairs,
+// sum over levels of ceil(active pairs / waves), parts, pairs.
+int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
+                const double *rpy, const double *rhs, int k, const double *wts, double *G, long *stats)
+{
+    FbrHostModel hm;
+    make(t, hm);
+    FbrGramProgram gp;
+    fbr_gram_build_best(gp, hm, k, g_shape, !fbr_gram_rhs_moments(hm, k));
+    FbrGram64 g;
+    FbrGram64Producer pr;
+    if (k > 1 || !fbr_gram64_build(hm, gp, g) || !fbr_gram64_build_producer(hm, gp, g, pr)) return -1;
+    const int W = FBR_WPB, MW = 2 + 2 * g.segw, npw = g.segw * g.nseg;
+    if (stats) {
+        long crit = 0, bound = 0, npairs = 0;
+        for (int lv = 0; lv < g.nlev; lv++) {
+            int mx = 0, tot = 0;
+            for (int w = 0; w < W; w++) {
+                int n = 0;
+                for (int sg = 0; sg < g.nseg; sg++)
+                    for (int j = 0; j < g.segw; j++) {
+                        const int *mm = &g.wmeta[((size_t)w * g.nseg + sg) * MW];
+                        if (mm[0] >= 0 && mm[2 + 2 * j] >= 0 && mm[3 + 2 * j] > lv) n++;
+                    }
+                mx = std::max(mx, n);
+                tot += n;
+            }
+            crit += mx;
+            bound += (tot + W - 1) / W;
+            if (lv == 0) npairs = tot;
+        }
+        stats[0] = g.ntr; stats[1] = g.mfma_per_block; stats[2] = g.nlev; stats[3] = g.maxact;
+        stats[4] = crit; stats[5] = bound; stats[6] = pr.nparts; stats[7] = npairs;
+    }
+    if (S <= 0) return 0;
+    const int REC = hm.rec_size(), P = hm.cols, Pa = P + k;
+    const long nblk = (S + 63) / 64;
+    std::vector<double> rec(REC), img((size_t)g.blk_doubles), buf((size_t)g.maxact * 512);
+    std::vector<double> acc((size_t)W * npw * 256, 0.0), mom((size_t)(P + 1) * 64, 0.0);
+    std::vector<char> written((size_t)g.blk_doubles);
+    for (long blk = 0; blk < nblk; blk++) {
+        std::fill(img.begin(), img.end(), 0.0);  // (the buffer is zeroed once at allocation: what is never written stays zero)
+        std::fill(written.begin(), written.end(), 0);
+        const int valid = (int)std::min(64L, S - blk * 64);
+        for (int lane = 0; lane < 64; lane++) {
+            const bool live = lane < valid;
+            const long s = blk * 64 + std::min(lane, valid - 1);
+            kin_sample(hm, q + s * hm.n, dq + s * hm.n, ddq + s * hm.n, hm.floating ? bv + 6 * s : nullptr, hm.floating ? ba + 6 * s : nullptr,
+                       hm.floating ? rpy + 3 * s : nullptr, rec.data());
+            const double *ws = wts ? wts + (size_t)s * hm.rows : nullptr;
+            auto tv = [&](int r) { const double wv = ws ? ws[r] : 1.0; return wv * wv * rhs[(size_t)s * hm.rows + r]; };
+            for (int pq = 0; pq < pr.nparts; pq++)
+                for (int l = 0; l < hm.L; l++)
+                    for (int pp = 0; pp < 10; pp++) {
+                        const long long d0 = pr.rel[((size_t)pq * hm.L + l) * 10 + pp];
+                        if (!d0) continue;
+                        const int c = pr.lcol[((size_t)pq * hm.L + l) * 10 + pp];
+                        if (c < 0 || hm.coldesc[c].link != l || hm.coldesc[c].pidx != pp) return -2;
+                        const long base = (long)((d0 & ~(1LL << 62) & ~0xffLL) / 8);
+                        const int x = (int)(d0 & 0xff);
+                        double w6[6];
+                        fbr_unit_wrench(&rec[FBR_LINK_REC * l], pp, w6);
+                        double mc = 0.0;
+                        auto put = [&](int lv, double v, int r) {
+                            const long at = base + (long)lv * 1024 + (lane >> 5) * 512 + ((lane & 31) ^ x);
+                            if (at < 0 || at >= g.blk_doubles) return false;
+                            img[at] = live ? v * (ws ? ws[r] : 1.0) : 0.0;
+                            written[at]++;
+                            if (k) mc += v * tv(r);
+                            return true;
+                        };
+                        for (int i = (pp >= 4 ? 3 : 0); i < hm.fb; i++)
+                            if (!put(i, w6[i], i)) return -3;
+                        if (pp >= 4)
+                            for (int i = 0; i < std::min(3, hm.fb); i++)
+                                if (w6[i] != 0.0) return -4;  // (the force rows of an inertia column are structural zeros)
+                        int j = 0;
+                        for (int d : hm.path[l]) {
+                            if (!put(hm.fb + j, fbr_dot6(&rec[FBR_LINK_REC * hm.L + 6 * d], w6), hm.fb + d)) return -3;
+                            j++;
+                        }
+                        if (k && live) mom[(size_t)c * 64 + lane] += mc;
+                    }
+            if (k && live) {
+                double tt = 0.0;
+                for (int r = 0; r < hm.rows; r++) {
+                    const double v = rhs[(size_t)s * hm.rows + r] * (ws ? ws[r] : 1.0);
+                    tt += v * v;
+                }
+                mom[(size_t)P * 64 + lane] += tt;
+            }
+        }
+        for (char wv : written)
+            if (wv > 1) return -5;  // two writers of one image position
+        // consumer: stages (half, level)
+        for (int half = 0; half < 2; half++)
+            for (int lv = 0; lv < g.nlev; lv++) {
+                std::fill(buf.begin(), buf.end(), 1e300);  // (what the stage does not bring must not be read)
+                for (int i = g.lev_begin[lv]; i < g.lev_begin[lv + 1]; i++)
+                    for (int e = 0; e < 128; e++) buf[g.pieces[2 * i + 1] + e] = img[g.pieces[2 * i] + half * 512 + e];
+                const int *sl = &g.slab[(size_t)lv * g.NT];
+                for (int w = 0; w < W; w++)
+                    for (int sg = 0; sg < g.nseg; sg++) {
+                        const int *mm = &g.wmeta[((size_t)w * g.nseg + sg) * MW];
+                        const int tI = mm[0], cpmax = mm[1];
+                        if (tI < 0 || cpmax <= lv) continue;
+                        if (sl[tI] < 0) return -6;
+                        for (int j = 0; j < g.segw; j++) {
+                            const int tJ = mm[2 + 2 * j], cp = mm[3 + 2 * j];
+                            if (tJ < 0 || cp <= lv) continue;
+                            if (sl[tJ] < 0) return -6;
+                            double *a4 = &acc[((size_t)w * npw + sg * g.segw + j) * 256];
+                            for (int ks = 0; ks < 8; ks++) {
+                                double A[16][4], B[4][16];
+                                for (int lane = 0; lane < 64; lane++) {
+                                    const int li = lane & 15, kk = lane >> 4, sx = 4 * (li & 7);
+                                    A[li][kk] = buf[(size_t)sl[tI] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
+                                    B[kk][li] = buf[(size_t)sl[tJ] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
+                                }
+                                for (int lane = 0; lane < 64; lane++)
+                                    for (int reg = 0; reg < 4; reg++) {
+                                        const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+                                        double sum = 0;
+                                        for (int kk = 0; kk < 4; kk++) sum += A[row][kk] * B[kk][col];
+                                        a4[reg * 64 + lane] += sum;
+                                    }
+                            }
+                        }
+                    }
+            }
+    }
+    for (int w = 0; w < W; w++)
+        for (int sl = 0; sl < npw; sl++) {
+            const int tI = g.slot_tiles[2 * ((size_t)w * npw + sl)], tJ = g.slot_tiles[2 * ((size_t)w * npw + sl) + 1];
+            if (tI < 0) continue;
+            const double *a4 = &acc[((size_t)w * npw + sl) * 256];
+            for (int lane = 0; lane < 64; lane++)
+                for (int reg = 0; reg < 4; reg++) {
+                    const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+                    const int ci = gp.tiles[tI].col[row], cj = gp.tiles[tJ].col[col];
+                    if (ci < 0 || cj < 0 || ci >= P || cj >= P) continue;
+                    G[(size_t)ci * Pa + cj] += a4[reg * 64 + lane];
+                    if (tI != tJ) G[(size_t)cj * Pa + ci] += a4[reg * 64 + lane];
+                }
+        }
+    if (k)
+        for (int c = 0; c <= P; c++) {
+            double sum = 0.0;
+            for (int lane = 0; lane < 64; lane++) sum += mom[(size_t)c * 64 + lane];
+            if (c == P) {
+                G[(size_t)P * Pa + P] += sum;
+            } else {
+                G[(size_t)c * Pa + P] += sum;
+                G[(size_t)P * Pa + c] += sum;
+            }
+        }
+    return 0;
+}
+
 int emul_gram(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv,
               const double *ba, const double *rpy, const double *sign, const double *rhs, int k, const double *wts,
               double *G)

@@ -26,7 +26,7 @@ class EmulTopo(ctypes.Structure):
 def lib():
     global _lib
     if _lib is None:
-        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h"), os.path.join(_CSRC, "fbr_reduce.h"), os.path.join(_CSRC, "fbr_kinid.h")]
+        deps = [_SRC, os.path.join(_CSRC, "fbr_math.h"), os.path.join(_CSRC, "fbr_program.h"), os.path.join(_CSRC, "fbr_reduce.h"), os.path.join(_CSRC, "fbr_kinid.h"), os.path.join(_CSRC, "fbr_gram64.h")]
         if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
             os.makedirs(os.path.dirname(_OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _OUT, _SRC])
@@ -162,6 +162,24 @@ class Emul:
                                 ctypes.byref(T), ctypes.byref(img), ctypes.byref(items), ctypes.byref(uni))
         return dict(NT=NT.value, npairs=npairs.value, mfma=mfma.value, T=T.value, part_image_max=img.value,
                     dma_doubles=items.value, mfma_uniform=uni.value)
+
+    def gram64(self, st, rhs=None, w=None):
+        """(G, stats) of the pass over sample-contiguous images (csrc/fbr_gram64.h), or None when the model is outside it."""
+        S, q, dq, ddq, bv, ba, rpy = self._st(st)
+        k = 0
+        if rhs is not None:
+            rhs = np.ascontiguousarray(rhs, dtype=np.float64).reshape(S * self.rows, -1)
+            k = rhs.shape[1]
+        w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        G = np.zeros((self.cols + k, self.cols + k))
+        stats = (ctypes.c_long * 8)()
+        rc = lib().emul_gram64(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(rhs), int(k), _d(w),
+                               _d(G), stats)
+        if rc == -1:
+            return None
+        assert rc == 0, rc
+        keys = ("tile_rows", "mfma_per_block", "levels", "max_slabs", "busiest_wave_pair_levels", "balanced_pair_levels", "parts", "pairs")
+        return G, dict(zip(keys, (int(v) for v in stats)))
 
     def gram(self, st, rhs=None, sign=None, w=None):
         S, q, dq, ddq, bv, ba, rpy = self._st(st)

@@ -330,3 +330,56 @@ def test_tree_parts_of_the_lane_writer(seed):
         assert np.abs(tp - tau).max() <= 1e-12 * max(np.abs(tau).max(), 1e-300), (nparts, steps)
     if seed == 0:   # WALK-MAN: four parts walk 48 links + a short trunk each
         assert sum(steps) <= 48 + 4 * 6, steps
+
+
+@pytest.mark.parametrize("case", ["walkman_apriori", "walkman_left_arm", "kuka_lwr4", "random1", "random2", "random3", "random4", "prismatic5", "prismatic6"])
+@pytest.mark.parametrize("which", [-1, 0, 1], ids=["all_columns", "merged", "regrouped"])
+def test_gram_over_sample_contiguous_images(case, which):
+    """csrc/fbr_gram64.h without a GPU: the producer's destination words (one per part, link and parameter; level stride; the column
+    swizzle inside a 32-sample run; every image position written by exactly one lane; the force rows of the inertia columns left as
+    structural zeros), the consumer's stage tables (pieces, slabs, the pairs of a wave below their common depth) and the per-lane rhs
+    moments, on the full model and on the reduced robots the library runs for large batches -- against the oracle's [Y | tau] Gram, with
+    row weights, a block that is not full (70 samples) and k = 0 / 1."""
+    import emul_lib
+
+    rng = np.random.default_rng(91)
+    if case.startswith("random") or case.startswith("prismatic"):
+        seed = int(case[-1])
+        rng = np.random.default_rng(500 + seed)
+        t = random_topology(rng, 7 + 5 * (seed % 4), p_fixed=0.35, branchiness=0.5, p_prismatic=0.5 if case.startswith("prismatic") else 0.0)
+        floating = seed != 2
+    else:
+        t = load_topo(case)
+        floating = case != "kuka_lwr4"
+    if t.num_dofs == 0:
+        pytest.skip("no joints")
+    om = OracleModel(t, floating=floating)
+    em = emul_lib.Emul(t, floating=floating)
+    E = np.eye(om.P)
+    if which >= 0:
+        red = em.reduction(which)
+        if red is None:
+            pytest.skip("nothing to reduce")
+        em, E = red
+    S = 70
+    st = random_states(t, S, rng, floating)
+    Y = om.regressor(st, None)
+    tau = rng.standard_normal((Y.shape[0], 1))
+    w = rng.random(Y.shape[0]) + 0.5
+    got = em.gram64(st, tau, w)
+    if got is None:
+        # (WALK-MAN's 480 columns, and the 300 of its moving bodies, need a tile program in two parts; the regrouped robot the library
+        # runs on large batches is inside the pass)
+        assert case.startswith("random") or case.startswith("prismatic") or (case == "walkman_apriori" and which < 1)
+        pytest.skip("model outside the sample-contiguous pass")
+    Gr, stats = got
+    Ea = np.zeros((em.cols + 1, om.P + 1))
+    Ea[: em.cols, : om.P] = E
+    Ea[-1, -1] = 1.0
+    A = np.hstack([Y, tau]) * w[:, None]
+    assert np.linalg.norm(Ea.T @ Gr @ Ea - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
+    assert np.array_equal(Gr, Gr.T)
+    G0, stats0 = em.gram64(st)
+    assert np.linalg.norm(E.T @ G0 @ E - Y.T @ Y) <= 1e-12 * np.linalg.norm(Y.T @ Y)
+    assert stats0["mfma_per_block"] == stats["mfma_per_block"] and 1 <= stats["parts"] <= 4
+    assert stats["balanced_pair_levels"] <= stats["busiest_wave_pair_levels"] <= stats["pairs"] * stats["levels"]
