@@ -667,9 +667,10 @@ class Engine:
 
     def gram_lane_info(self, k: int = 0, num_samples: int = -1) -> dict:
         """The sample-contiguous Gram pass (option ``gram_lane``) for such a batch; ``active`` False: the per-sample-image pass runs."""
-        a = (ctypes.c_int64 * 8)()
+        a = (ctypes.c_int64 * 12)()
         _check(self._lib.fbr_gram_lane_info(self._h, int(k), int(num_samples), a), "fbr_gram_lane_info")
-        keys = ("active", "tile_rows", "block_image_bytes", "mfma_per_block", "levels", "max_slabs", "lds_bytes", "tiles")
+        keys = ("active", "tile_rows", "block_image_bytes", "mfma_per_block", "levels", "max_slabs", "lds_bytes", "tiles", "force_tiles",
+                "busiest_wave_pair_levels", "balanced_pair_levels", "stages")
         d = dict(zip(keys, (int(v) for v in a)))
         d["active"] = bool(d["active"])
         return d

@@ -13,8 +13,9 @@
 //     (fbr_kinid.h); every value of a (column, row) goes out as two 256-byte runs per wave;  tau's products with the columns (k <= 1) are
 //     accumulated on the way: per column one dot product per joint row it already holds, a wave reduction per block;
 //   * consumer fbr_gram64_kernel: one workgroup of 8 waves per CU, the accumulators of the tile pairs in registers for the whole pass;
-//     a stage = (row level, 32 samples): the slabs of the tiles that have the level arrive by LDS-DMA into one of two buffers while the
-//     MFMAs of the stage before run; a pair takes part in the levels below its common depth; 8 MFMAs per pair and stage.
+//     a stage = (a few consecutive row levels, 32 samples): the slabs of the tiles that have the levels arrive by LDS-DMA into one of two buffers while the
+//     MFMAs of the stage before run; a pair takes part in the levels below its common depth; 8 MFMAs per pair and stage;
+//   * the force rows of the base wrench (levels 0 .. 2) run on tiles of their own that hold the columns with a force only (fbr_gram64_build).
 // Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), one part, device-resident inputs, one group.
 #pragma once
 #include <algorithm>
@@ -23,191 +24,271 @@
 #include "fbr_kinid.h"
 
 struct FbrGram64 {  // host program
-    int NT = 0, nlev = 0, fb = 0, ntr = 0, maxact = 0, segw = 0, nseg = 0;
+    int NT = 0;      // column tiles of the tile program ("main" tiles)
+    int NF = 0;      // force tiles (below); tiles are numbered main 0 .. NT-1, force NT .. NT+NF-1
+    int nlev = 0, fb = 0, flev = 0, ntr = 0, maxact = 0, npw = 0;
     long blk_doubles = 0;
-    std::vector<int> trow;       // [NT][nlev] tile-row index or -1
-    std::vector<int> slab;       // [nlev][NT] slab index inside the stage or -1
+    std::vector<int> trow;       // [NT + NF][nlev] tile-row index or -1
+    std::vector<int> slab;       // [nlev][NT + NF] slab index inside the level's stage or -1
+    int nstage = 0;
+    std::vector<int> stage_lev;  // [nstage + 1] first level of each stage
     std::vector<int> lev_begin;  // [nlev + 1] into pieces
     std::vector<int> pieces;     // pairs: global offset (doubles, inside the block image, half 0), LDS offset (doubles, inside a stage buffer)
-    std::vector<int> wmeta;      // [8 waves][nseg][2 + 2 segw]: tile I (-1: empty), max cp of the segment, then (tile J, cp) per slot (J = -1: empty)
-    std::vector<int> slot_tiles; // [8 * npw * 2] for the reduction
+    std::vector<int> wmeta;      // [8 waves][npw][3]: tile I (-1: empty slot), tile J, first level | (one past the last level) << 8
+    std::vector<int> slot_tiles; // [2][8 * npw * 2] for the two reductions: main pairs, force pairs (the other kind's slots are -1)
+    std::vector<int> tilecol;    // [NT + NF][16] column of each tile slot, -1 = padding
+    std::vector<int> fcol_tile, fcol_slot;  // per column: its force tile / slot there, or -1
     long mfma_per_block = 0;
+    long busiest = 0, balanced = 0;  // sum over the stages of the busiest wave's pair-levels / of ceil(all pair-levels / 8)
 };
 
-// tiles / pairs / slots of a one-part program built WITHOUT rhs tiles (moments); false: the model is outside this pass
-static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram &gp, FbrGram64 &g)
+// Tiles / pairs of a one-part tile program built WITHOUT rhs tiles (moments); false: the model is outside this pass.
+//
+// FORCE TILES (floating base).  The first three regressor rows are the force rows of the base wrench, and only the mass and the first
+// moments of a link produce a force: in the column tiles of the program most entries of those rows are structural zeros (6 of 10 columns
+// of a full link, 5 of 7 of a regrouped one), yet every tile pair pays three levels for them -- a third of all MFMAs of WALK-MAN.  So the
+// force rows get tiles of their own: the columns that have a force, 16 to a tile in column order (base rows are common to all columns:
+// no path condition), every pair of force tiles runs levels 0 .. 2, and the program's tiles start at level 3.  An entry G_ab with two
+// force columns is the sum of its two blocks (two reductions, one after the other).  Used when the extra pairs fit the accumulator slots.
+static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram &gp, FbrGram64 &g, bool force_tiles = true)
 {
     if (gp.T != 1 || hm.fric || (gp.k > 0 && gp.rhs_tiles)) return false;
+    const int W = FBR_WPB;
     g.NT = gp.NT;
     g.fb = hm.fb;
-    g.segw = gp.cfg.segw;
-    g.nseg = gp.cfg.nseg;
+    g.npw = gp.cfg.segw * gp.cfg.nseg;
     g.nlev = 0;
     for (const FbrTile &t : gp.tiles) {
         if (t.type != 0 || t.friction) return false;
         g.nlev = std::max(g.nlev, hm.fb + (int)t.tpath.size());
     }
-    if (g.nlev == 0) return false;
-    g.trow.assign((size_t)g.NT * g.nlev, -1);
-    g.ntr = 0;
+    if (g.nlev == 0 || g.nlev > 255) return false;
+    // the tile pairs of the program: unordered, with their common depth cp = fb + joints both tiles' columns have rows on
+    struct Pr {
+        int a, b, lo, hi;
+    };
+    std::vector<Pr> prs;
+    for (size_t s = 0; s < gp.slots.size(); s++) {
+        const int pi = gp.slots[s].pair;
+        if (pi < 0) continue;
+        const FbrPair &p = gp.pairs[pi];
+        if (p.mode != 0) return false;
+        const int cp = hm.fb + FbrGramProgram::common_prefix(gp.tiles[p.I].tpath, gp.tiles[p.J].tpath);
+        prs.push_back({p.I, p.J, 0, std::min(cp, g.nlev)});
+    }
+    // force columns and their tiles
+    g.fcol_tile.assign(hm.cols, -1);
+    g.fcol_slot.assign(hm.cols, -1);
+    g.tilecol.assign((size_t)g.NT * FBR_TILE, -1);
+    std::vector<char> has_tile(hm.cols, 0);
     for (int t = 0; t < g.NT; t++)
-        for (int lv = 0; lv < hm.fb + (int)gp.tiles[t].tpath.size(); lv++) g.trow[(size_t)t * g.nlev + lv] = g.ntr++;
-    g.blk_doubles = (long)g.ntr * 1024;
-    g.slab.assign((size_t)g.nlev * g.NT, -1);
-    g.lev_begin.assign(g.nlev + 1, 0);
-    g.maxact = 0;
-    for (int lv = 0; lv < g.nlev; lv++) {
-        g.lev_begin[lv] = (int)g.pieces.size() / 2;
-        int idx = 0;
-        for (int t = 0; t < g.NT; t++) {
-            const int tr = g.trow[(size_t)t * g.nlev + lv];
-            if (tr < 0) continue;
-            g.slab[(size_t)lv * g.NT + t] = idx;
-            for (int p = 0; p < 4; p++) {
-                g.pieces.push_back(tr * 1024 + p * 128);
-                g.pieces.push_back(idx * 512 + p * 128);
+        for (int sl = 0; sl < FBR_TILE; sl++) {
+            const int c = gp.tiles[t].col[sl];
+            if (c >= 0 && c < hm.cols) {
+                g.tilecol[(size_t)t * FBR_TILE + sl] = c;
+                has_tile[c] = 1;
             }
-            idx++;
+        }
+    g.NF = 0;
+    g.flev = 0;
+    if (force_tiles && hm.fb == 6) {
+        int nf = 0;
+        for (int c = 0; c < hm.ninert; c++)
+            if (has_tile[c] && hm.coldesc[c].pidx < 4) {
+                g.fcol_tile[c] = g.NT + nf / FBR_TILE;
+                g.fcol_slot[c] = nf % FBR_TILE;
+                nf++;
+            }
+        const int NF = (nf + FBR_TILE - 1) / FBR_TILE;
+        if (NF > 0 && (long)prs.size() + (long)NF * (NF + 1) / 2 <= (long)W * g.npw) {
+            g.NF = NF;
+            g.flev = 3;
+        } else {
+            std::fill(g.fcol_tile.begin(), g.fcol_tile.end(), -1);
+            std::fill(g.fcol_slot.begin(), g.fcol_slot.end(), -1);
+        }
+    }
+    const int NTT = g.NT + g.NF;
+    g.tilecol.resize((size_t)NTT * FBR_TILE, -1);
+    for (int c = 0; c < hm.cols; c++)
+        if (g.fcol_tile[c] >= 0) g.tilecol[(size_t)g.fcol_tile[c] * FBR_TILE + g.fcol_slot[c]] = c;
+    for (Pr &p : prs) p.lo = g.flev;
+    for (int f = 0; f < g.NF; f++)
+        for (int f2 = f; f2 < g.NF; f2++) prs.push_back({g.NT + f, g.NT + f2, 0, g.flev});
+    // tile rows: the force tiles' first (so that "level 0" of a main tile, flev rows in front of its first row, is inside the image), then the
+    // rows of every main tile one after the other -- the producer relies on consecutive rows: level lv of a column sits 1024 doubles x lv
+    // behind its level 0
+    g.trow.assign((size_t)NTT * g.nlev, -1);
+    g.ntr = 0;
+    for (int f = 0; f < g.NF; f++)
+        for (int lv = 0; lv < g.flev; lv++) g.trow[(size_t)(g.NT + f) * g.nlev + lv] = g.ntr++;
+    for (int t = 0; t < g.NT; t++)
+        for (int lv = g.flev; lv < hm.fb + (int)gp.tiles[t].tpath.size(); lv++) g.trow[(size_t)t * g.nlev + lv] = g.ntr++;
+    g.blk_doubles = (long)g.ntr * 1024;
+    // Stages: consecutive levels whose slabs fit one LDS buffer together share a stage --
+    // one barrier and one round of LDS-DMA for the three force levels, or for the deep levels only a few tiles reach.
+    std::vector<int> nslab(g.nlev, 0);
+    int widest = 0;
+    for (int lv = 0; lv < g.nlev; lv++) {
+        for (int t = 0; t < NTT; t++) nslab[lv] += g.trow[(size_t)t * g.nlev + lv] >= 0;
+        widest = std::max(widest, nslab[lv]);
+    }
+    // (the two-per-CU shape of small models keeps its workgroups below half the LDS: 2 buffers x 8 slabs x 4 KB)
+    const int cap = std::max(widest, g.npw <= 10 ? 8 : 16);
+    g.stage_lev.assign(1, 0);
+    for (int lv = 0, in_stage = 0; lv < g.nlev; lv++) {
+        if (lv > g.stage_lev.back() && in_stage + nslab[lv] > cap) {
+            g.stage_lev.push_back(lv);
+            in_stage = 0;
+        }
+        in_stage += nslab[lv];
+    }
+    g.stage_lev.push_back(g.nlev);
+    g.nstage = (int)g.stage_lev.size() - 1;
+    g.slab.assign((size_t)g.nlev * NTT, -1);
+    g.lev_begin.assign(g.nlev + 1, 0);
+    g.pieces.clear();
+    g.maxact = 0;
+    for (int sg = 0; sg < g.nstage; sg++) {
+        int idx = 0;
+        for (int lv = g.stage_lev[sg]; lv < g.stage_lev[sg + 1]; lv++) {
+            g.lev_begin[lv] = (int)g.pieces.size() / 2;
+            for (int t = 0; t < NTT; t++) {
+                const int tr = g.trow[(size_t)t * g.nlev + lv];
+                if (tr < 0) continue;
+                g.slab[(size_t)lv * NTT + t] = idx;
+                for (int p = 0; p < 4; p++) {
+                    g.pieces.push_back(tr * 1024 + p * 128);
+                    g.pieces.push_back(idx * 512 + p * 128);
+                }
+                idx++;
+            }
         }
         g.maxact = std::max(g.maxact, idx);
     }
     g.lev_begin[g.nlev] = (int)g.pieces.size() / 2;
-    const int npw = g.segw * g.nseg, W = FBR_WPB;
-    // The tile pairs of the program, as unordered pairs with their common depth: cp = fb + joints both tiles' columns have rows on.  Which
-    // tile of a pair is the A operand is free (the block is written with its mirror image by the reduction).
-    struct Pr {
-        int a, b, cp;
-    };
-    std::vector<Pr> prs;
-    const int nsegs = W * g.nseg;
-    std::vector<int> seg_of;
-    for (int w = 0; w < W; w++)
-        for (int sg = 0; sg < g.nseg; sg++)
-            for (int j = 0; j < g.segw; j++) {
-                const size_t s = (size_t)w * npw + sg * g.segw + j;
-                const int pi = gp.slots[s].pair;
-                if (pi < 0) continue;
-                const FbrPair &p = gp.pairs[pi];
-                if (p.mode != 0) return false;
-                const std::vector<int> &a = gp.tiles[p.I].tpath, &b = gp.tiles[p.J].tpath;
-                const int cpj = FbrGramProgram::common_prefix(a, b);
-                const int cp = hm.fb + (cpj == (int)std::min(a.size(), b.size()) ? (int)std::min(a.size(), b.size()) : cpj);
-                prs.push_back({p.I, p.J, std::min(cp, g.nlev)});
-                seg_of.push_back(w * g.nseg + sg);  // the tile program's own placement: a valid start (a row segment shares its tile I)
-            }
-    // Pairs -> (wave, segment).  All waves of the workgroup meet at every stage (level, half block), so a stage lasts as long as its busiest
-    // wave: the cost of a placement is  sum over levels of max over waves of the pairs active at the level,  not the waves' totals (the
-    // tile program's own placement, balanced by totals, leaves WALK-MAN at 156 against 126 for a perfect split).  Local search from the
-    // program's placement: move a pair to another segment / swap two pairs while (cost, sum of squared loads) falls; a segment keeps a
-    // tile common to all its pairs (the A operand, read once per k-step for the whole segment).  Deterministic.
+    // Pairs -> waves.  All waves of the workgroup meet at every stage (level, half block), so a stage lasts as long as its busiest wave: the
+    // cost of a placement is  sum over levels of max over waves of the pairs active at the level,  not the waves' totals (the tile program's
+    // own placement, balanced by totals, leaves WALK-MAN at 156 against 126 for a perfect split).  Any pair may sit in any accumulator of
+    // any wave (the kernel reloads the A operand when the tile I of the next slot differs).  Deal by decreasing length, then local search:
+    // move a pair / swap two while (cost, sum of squared loads) falls.  Deterministic.
     const int NP = (int)prs.size();
-    std::vector<std::vector<int>> members(nsegs);
-    for (int i = 0; i < NP; i++) members[seg_of[i]].push_back(i);
-    auto common_tile = [&](const std::vector<int> &mem, int extra, int without) {  // a tile in every pair of mem (+ extra, - without), or -1
-        int ca = -1, cb = -1;
-        bool first = true;
-        auto take = [&](int i) {
-            if (first) {
-                ca = prs[i].a, cb = prs[i].b, first = false;
-                return;
-            }
-            if (ca >= 0 && ca != prs[i].a && ca != prs[i].b) ca = -1;
-            if (cb >= 0 && cb != prs[i].a && cb != prs[i].b) cb = -1;
-        };
-        for (int i : mem)
-            if (i != without) take(i);
-        if (extra >= 0) take(extra);
-        if (first) return -2;  // empty
-        return ca >= 0 ? ca : cb;
-    };
-    for (int sgi = 0; sgi < nsegs; sgi++)
-        if (!members[sgi].empty() && common_tile(members[sgi], -1, -1) < 0) return false;
+    if (NP > W * g.npw) return false;
+    std::vector<int> order(NP), wave_of(NP, -1), cnt(W, 0);
+    for (int i = 0; i < NP; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return prs[x].hi - prs[x].lo > prs[y].hi - prs[y].lo; });
     std::vector<std::vector<int>> wl(W, std::vector<int>(g.nlev, 0));
-    for (int i = 0; i < NP; i++)
-        for (int lv = 0; lv < prs[i].cp; lv++) wl[seg_of[i] / g.nseg][lv]++;
-    auto score = [&](long &c, long &sq) {
+    auto shift = [&](int i, int w, int sign) {
+        for (int lv = prs[i].lo; lv < prs[i].hi; lv++) wl[w][lv] += sign;
+        cnt[w] += sign;
+    };
+    auto score = [&](long &c, long &sq) {  // (the waves meet once per stage: the loads of a stage's levels add up)
         c = 0, sq = 0;
-        for (int lv = 0; lv < g.nlev; lv++) {
+        for (int sg = 0; sg < g.nstage; sg++) {
             int mx = 0;
             for (int w = 0; w < W; w++) {
-                mx = std::max(mx, wl[w][lv]);
-                sq += (long)wl[w][lv] * wl[w][lv];
+                int tot = 0;
+                for (int lv = g.stage_lev[sg]; lv < g.stage_lev[sg + 1]; lv++) tot += wl[w][lv];
+                mx = std::max(mx, tot);
+                sq += (long)tot * tot;
             }
             c += mx;
         }
     };
-    auto shift = [&](int i, int w, int sign) {
-        for (int lv = 0; lv < prs[i].cp; lv++) wl[w][lv] += sign;
-    };
+    for (int r = 0; r < NP; r++) {  // snake deal
+        const int round = r / W, pos = r % W, w = (round & 1) ? W - 1 - pos : pos;
+        wave_of[order[r]] = w;
+        shift(order[r], w, +1);
+    }
     long c0, q0;
     score(c0, q0);
     for (int sweep = 0, improved = 1; improved && sweep < 64; sweep++) {
         improved = 0;
         for (int i = 0; i < NP; i++) {
-            for (int t = 0; t < nsegs; t++) {  // move pair i to segment t
-                const int from = seg_of[i];
-                if (t == from || (int)members[t].size() >= g.segw || common_tile(members[t], i, -1) == -1) continue;
-                shift(i, from / g.nseg, -1), shift(i, t / g.nseg, +1);
+            for (int w2 = 0; w2 < W; w2++) {
+                const int w1 = wave_of[i];
+                if (w2 == w1 || cnt[w2] >= g.npw) continue;
+                shift(i, w1, -1), shift(i, w2, +1);
                 long c1, q1;
                 score(c1, q1);
                 if (c1 < c0 || (c1 == c0 && q1 < q0)) {
-                    members[from].erase(std::find(members[from].begin(), members[from].end(), i));
-                    members[t].push_back(i);
-                    seg_of[i] = t, c0 = c1, q0 = q1, improved = 1;
+                    wave_of[i] = w2, c0 = c1, q0 = q1, improved = 1;
                 } else {
-                    shift(i, t / g.nseg, -1), shift(i, from / g.nseg, +1);
+                    shift(i, w2, -1), shift(i, w1, +1);
                 }
             }
-            for (int k2 = i + 1; k2 < NP; k2++) {  // swap the segments of pairs i and k2
-                const int si = seg_of[i], sk = seg_of[k2];
-                if (si / g.nseg == sk / g.nseg || prs[i].cp == prs[k2].cp) continue;
-                if (common_tile(members[si], k2, i) == -1 || common_tile(members[sk], i, k2) == -1) continue;
-                shift(i, si / g.nseg, -1), shift(k2, sk / g.nseg, -1), shift(i, sk / g.nseg, +1), shift(k2, si / g.nseg, +1);
+            for (int k2 = i + 1; k2 < NP; k2++) {
+                const int w1 = wave_of[i], w2 = wave_of[k2];
+                if (w1 == w2 || (prs[i].lo == prs[k2].lo && prs[i].hi == prs[k2].hi)) continue;
+                shift(i, w1, -1), shift(k2, w2, -1), shift(i, w2, +1), shift(k2, w1, +1);
                 long c1, q1;
                 score(c1, q1);
                 if (c1 < c0 || (c1 == c0 && q1 < q0)) {
-                    *std::find(members[si].begin(), members[si].end(), i) = k2;
-                    *std::find(members[sk].begin(), members[sk].end(), k2) = i;
-                    seg_of[i] = sk, seg_of[k2] = si, c0 = c1, q0 = q1, improved = 1;
+                    wave_of[i] = w2, wave_of[k2] = w1, c0 = c1, q0 = q1, improved = 1;
                 } else {
-                    shift(i, sk / g.nseg, -1), shift(k2, si / g.nseg, -1), shift(i, si / g.nseg, +1), shift(k2, sk / g.nseg, +1);
+                    shift(i, w2, -1), shift(k2, w1, -1), shift(i, w1, +1), shift(k2, w2, +1);
                 }
             }
         }
     }
-    g.wmeta.assign((size_t)W * g.nseg * (2 + 2 * g.segw), -1);
-    g.slot_tiles.assign((size_t)W * npw * 2, -1);
+    g.busiest = c0;
+    g.balanced = 0;
+    for (int sg = 0; sg < g.nstage; sg++) {
+        int tot = 0;
+        for (int lv = g.stage_lev[sg]; lv < g.stage_lev[sg + 1]; lv++)
+            for (int w = 0; w < W; w++) tot += wl[w][lv];
+        g.balanced += (tot + W - 1) / W;
+    }
+    // slots of a wave: the A operand (tile I) of a slot is kept for the next one when it is the same tile, so the pairs of a wave are ordered
+    // by the tile most of them contain (which of a pair's two tiles is "I" is free: the reduction writes the block and its mirror image)
+    g.wmeta.assign((size_t)W * g.npw * 3, -1);
+    g.slot_tiles.assign((size_t)2 * W * g.npw * 2, -1);
     g.mfma_per_block = 0;
-    for (int sgi = 0; sgi < nsegs; sgi++) {
-        int *mm = &g.wmeta[(size_t)sgi * (2 + 2 * g.segw)];
-        mm[1] = 0;
-        if (members[sgi].empty()) continue;
-        std::sort(members[sgi].begin(), members[sgi].end());
-        const int I = common_tile(members[sgi], -1, -1);
-        if (I < 0) return false;
-        mm[0] = I;
-        for (size_t j = 0; j < members[sgi].size(); j++) {
-            const Pr &p = prs[members[sgi][j]];
-            const int J = p.a == I ? p.b : p.a;
-            const size_t s = (size_t)(sgi / g.nseg) * npw + (size_t)(sgi % g.nseg) * g.segw + j;
-            mm[2 + 2 * j] = J;
-            mm[3 + 2 * j] = p.cp;
-            mm[1] = std::max(mm[1], p.cp);
-            g.slot_tiles[2 * s] = I;
-            g.slot_tiles[2 * s + 1] = J;
-            g.mfma_per_block += 16L * p.cp;  // 8 MFMAs per level and half
+    for (int w = 0; w < W; w++) {
+        std::vector<int> mine;
+        for (int i = 0; i < NP; i++)
+            if (wave_of[i] == w) mine.push_back(i);
+        std::vector<char> done(NP, 0);
+        int q = 0;
+        for (size_t left = mine.size(); left > 0;) {
+            std::vector<int> freq(NTT, 0);
+            for (int i : mine)
+                if (!done[i]) {
+                    freq[prs[i].a]++;
+                    if (prs[i].b != prs[i].a) freq[prs[i].b]++;
+                }
+            int T = 0;
+            for (int t = 1; t < NTT; t++)
+                if (freq[t] > freq[T]) T = t;
+            for (int i : mine) {
+                if (done[i] || (prs[i].a != T && prs[i].b != T)) continue;
+                const int J = prs[i].a == T ? prs[i].b : prs[i].a;
+                const size_t s = (size_t)w * g.npw + q;
+                g.wmeta[3 * s] = T;
+                g.wmeta[3 * s + 1] = J;
+                g.wmeta[3 * s + 2] = prs[i].lo | (prs[i].hi << 8);
+                const int kind = T >= g.NT ? 1 : 0;
+                g.slot_tiles[((size_t)kind * W * g.npw + s) * 2] = T;
+                g.slot_tiles[((size_t)kind * W * g.npw + s) * 2 + 1] = J;
+                g.mfma_per_block += 16L * (prs[i].hi - prs[i].lo);  // 8 MFMAs per level and half
+                done[i] = 1;
+                q++;
+                left--;
+            }
         }
     }
     return true;
 }
 
-// Producer tables: the tree in parts for the waves of a workgroup (fbr_kinid.h) and, per (part, link, parameter), ONE destination word:
-// byte offset inside an image buffer of (level-0 tile row of the column's tile, column slot, sample 0) -- a multiple of 256 -- with
-// 4 (slot & 7) in its low byte and bit 62 set (0: the part does not write that column).  The tile rows of a tile are consecutive
-// (fbr_gram64_build), so level lv of the column is 8192 bytes x lv further on.
+// Producer tables: the tree in parts for the waves of a workgroup (fbr_kinid.h) and, per (part, link), 14 destination words: one per
+// parameter, then the FORCE-tile words of parameters 0 .. 3.  A word: byte offset inside an image buffer of (level 0 of the column's tile
+// rows, column slot, sample 0) -- a multiple of 256 -- with 4 (slot & 7) in its low byte and bit 62 set (0: the part does not write that
+// column).  Level lv of the column is 8192 bytes x lv further on (the tile rows of a tile are consecutive; with force tiles "level 0" of a
+// main tile is three rows in front of its first row, rows 0 .. 2 of a force column go through its force word).
+#define FBR_G64_WORDS 14
 struct FbrGram64Producer {
     int nparts = 1, nslots = 1, step0[FBR_KINWRITE_PARTS] = {0, 0, 0, 0}, nsteps[FBR_KINWRITE_PARTS] = {0, 0, 0, 0};
-    std::vector<long long> rel;  // [nparts][10 L]
+    std::vector<long long> rel;  // [nparts][L][14]
     std::vector<int> lcol;       // [nparts][10 L] the column (for the rhs moments) or -1
     std::vector<int> steps;      // the parts' step programs, one after the other
 };
@@ -232,17 +313,24 @@ static inline bool fbr_gram64_build_producer(const FbrHostModel &hm, const FbrGr
         return false;
     }
     pr.nparts = (int)progs.size();
-    pr.rel.assign((size_t)pr.nparts * 10 * hm.L, 0);
+    pr.rel.assign((size_t)pr.nparts * FBR_G64_WORDS * hm.L, 0);
     pr.lcol.assign((size_t)pr.nparts * 10 * hm.L, -1);
+    auto word = [](long long tile_row, int sl) { return ((tile_row * 1024 + sl * 32) * 8) | (long long)(4 * (sl & 7)) | (1LL << 62); };
     for (int c = 0; c < hm.ninert; c++) {
-        const int t = tile_of[c], sl = slot_of[c], l = hm.coldesc[c].link;
+        const int t = tile_of[c], sl = slot_of[c], l = hm.coldesc[c].link, pidx = hm.coldesc[c].pidx;
         if (t < 0) continue;  // (a column without a tile: structurally zero, e.g. the base link of a fixed base)
-        if (hm.fb + (int)hm.path[l].size() > hm.fb + (int)gp.tiles[t].tpath.size()) return false;  // (cannot happen: the tile's path contains the link's)
-        const int tr0 = g.trow[(size_t)t * g.nlev];
+        if (hm.path[l].size() > gp.tiles[t].tpath.size()) return false;  // (cannot happen: the tile's path contains the link's)
+        const long long tr0 = (long long)g.trow[(size_t)t * g.nlev + g.flev] - g.flev;
+        if (tr0 < 0) return false;  // (cannot happen: the force tiles' rows come first)
         for (int pq = 0; pq < pr.nparts; pq++)
             if (own[pq][l]) {
-                pr.rel[((size_t)pq * hm.L + l) * 10 + hm.coldesc[c].pidx] = (((long long)tr0 * 1024 + sl * 32) * 8) | (long long)(4 * (sl & 7)) | (1LL << 62);
-                pr.lcol[((size_t)pq * hm.L + l) * 10 + hm.coldesc[c].pidx] = c;
+                long long *w14 = &pr.rel[((size_t)pq * hm.L + l) * FBR_G64_WORDS];
+                w14[pidx] = word(tr0, sl);
+                if (g.fcol_tile[c] >= 0) {
+                    if (pidx >= 4) return false;
+                    w14[10 + pidx] = word(g.trow[(size_t)g.fcol_tile[c] * g.nlev], g.fcol_slot[c]);
+                }
+                pr.lcol[((size_t)pq * hm.L + l) * 10 + pidx] = c;
             }
     }
     pr.steps.clear();
@@ -258,9 +346,9 @@ static inline bool fbr_gram64_build_producer(const FbrHostModel &hm, const FbrGr
 
 #if defined(__HIPCC__) && defined(FBR_KERNELS_GRAM)
 struct DevGram64 {
-    int NT, nlev, maxact, npieces;
+    int NT, nlev, maxact, npieces, nstage;  // NT: main + force tiles
     long blk_doubles;
-    const int *slab, *lev_begin, *pieces, *wmeta;
+    const int *slab, *lev_begin, *pieces, *wmeta, *stage_lev;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -361,9 +449,11 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(Dev
             // behind the branches of the column code the compiler cannot tell how many of them sit in front of a load it still expects --
             // it would wait for counter 0, i.e. for the store before, at every store (measured: 7.4 -> 5.4 ms per 1 M WALK-MAN samples).
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
-            long d10[10];
+            long d10[10], dF[4];
 #pragma unroll
-            for (int pp = 0; pp < 10; pp++) d10[pp] = cdst[((long)part * m.L + l) * 10 + pp];
+            for (int pp = 0; pp < 10; pp++) d10[pp] = cdst[((long)part * m.L + l) * FBR_G64_WORDS + pp];
+#pragma unroll
+            for (int pp = 0; pp < 4; pp++) dF[pp] = cdst[((long)part * m.L + l) * FBR_G64_WORDS + 10 + pp];  // force-tile words (rows 0 .. flev-1)
             // tau's side of the moments: sum_r v_r t_r over the rows of one column = w6 . (t_base + sum_j S_j t_j), t = w^2 tau
             double Ft[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (wr.k) {
@@ -394,7 +484,7 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(Dev
                 for (int i = 0; i < 6; i++)
                     if (i < m.fb) {
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) store(d10[qq], i, HASW ? wA[qq][i] * myw[i] : wA[qq][i]);
+                        for (int qq = 0; qq < 4; qq++) store(i < wr.flev ? dF[qq] : d10[qq], i, HASW ? wA[qq][i] * myw[i] : wA[qq][i]);
                     }
 #pragma unroll
                 for (int j = 0; j < MAXD; j++)
@@ -489,20 +579,23 @@ template <int SEGW, int NSEG>
 __global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr_gram64_kernel(DevGram64 g, long nblk, const double *__restrict__ img,
                                                                                               double *__restrict__ partial, int carry)
 {
-    constexpr int NPW = SEGW * NSEG, MW = 2 + 2 * SEGW;
+    constexpr int NPW = SEGW * NSEG, MW = 3 * NPW;
+    static_assert(MW <= 64, "a wave's slot table is fetched with one load");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int bufd = g.maxact * 512;
     double *buf0 = smem, *buf1 = smem + bufd;
     int *slab = (int *)(smem + 2 * bufd);      // [nlev][NT]
     int *levb = slab + g.nlev * g.NT;          // [nlev + 1]
     int *pcs = levb + g.nlev + 1;              // [npieces][2]
-    int *wm = pcs + 2 * g.npieces;             // [8][NSEG][MW]
+    int *wm = pcs + 2 * g.npieces;             // [8][NPW][3]
+    int *stl = wm + FBR_WPB * MW;              // [nstage + 1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < g.nlev * g.NT; i += FBR_WPB * 64) slab[i] = g.slab[i];
     for (int i = tid; i <= g.nlev; i += FBR_WPB * 64) levb[i] = g.lev_begin[i];
     for (int i = tid; i < 2 * g.npieces; i += FBR_WPB * 64) pcs[i] = g.pieces[i];
-    for (int i = tid; i < FBR_WPB * NSEG * MW; i += FBR_WPB * 64) wm[i] = g.wmeta[i];
+    for (int i = tid; i < FBR_WPB * MW; i += FBR_WPB * 64) wm[i] = g.wmeta[i];
+    for (int i = tid; i <= g.nstage; i += FBR_WPB * 64) stl[i] = g.stage_lev[i];
     fbr_d4 acc[NPW];
     double *pp = partial + (((long)blockIdx.x * FBR_WPB + wave) * NPW) * 256;
     if (carry) {
@@ -514,49 +607,63 @@ __global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr
     }
     __syncthreads();
     const int nmine = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
-    const long nstage = (long)(nmine > 0 ? nmine : 0) * 2 * g.nlev;
-    // LDS-DMA of stage st into buffer (st & 1): wave w issues pieces w, w + 8, ... of the stage's level
+    const long nst = (long)(nmine > 0 ? nmine : 0) * 2 * g.nstage;
+    // LDS-DMA of step st = (block, half, stage) into buffer (st & 1): wave w issues pieces w, w + 8, ... of the stage's levels
     auto dma = [&](long st) {
-        const int lv = (int)(st % g.nlev);
-        const long bh = st / g.nlev;
+        const int sg = (int)(st % g.nstage);
+        const long bh = st / g.nstage;
         const long blk = (long)blockIdx.x + (bh >> 1) * gridDim.x;
         const double *src = img + blk * g.blk_doubles + (bh & 1) * 512 + 2 * lane;
         double *buf = (st & 1) ? buf1 : buf0;
-        for (int i = levb[lv] + wave; i < levb[lv + 1]; i += FBR_WPB) {
+        for (int i = levb[stl[sg]] + wave; i < levb[stl[sg + 1]]; i += FBR_WPB) {
             const int gx = __builtin_amdgcn_readfirstlane(pcs[2 * i]), lx = __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]);
             __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + lx), 16, 0, 0);
         }
     };
-    if (nstage > 0) dma(0);
+    if (nst > 0) dma(0);
     const int li = lane & 15, kk = lane >> 4;
     const int lofs = li * 32, sx = 4 * (li & 7);
-    const int *wmeta = wm + wave * NSEG * MW;
-    for (long st = 0; st < nstage; st++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage st have landed
+    const int mv = wm[wave * MW + (lane < MW ? lane : 0)];  // this wave's slots: (tile I, tile J, first level | end level << 8)
+    const int idxv = (lane < MW && (lane % 3) != 2 && mv >= 0) ? mv : 0;  // the tile this lane looks up per level (lanes 3q, 3q + 1)
+    // this lane's operand position inside a slab (doubles) at k-step ks: column li, sample (4 ks + kk) ^ sx = p0 ^ (4 ks)
+    const int p0c = lofs | sx | kk;
+    for (long st = 0; st < nst; st++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step st have landed
         __syncthreads();                                  // everyone's have; the other buffer is free
-        if (st + 1 < nstage) dma(st + 1);
-        const int lv = (int)(st % g.nlev);
+        if (st + 1 < nst) dma(st + 1);
+        const int sg = (int)(st % g.nstage);
         const double *buf = (st & 1) ? buf1 : buf0;
-        const int *sl = slab + lv * g.NT;
+        const int lv1 = __builtin_amdgcn_readfirstlane(stl[sg + 1]);
+        for (int lv = __builtin_amdgcn_readfirstlane(stl[sg]); lv < lv1; lv++) {
+            const int offv = slab[lv * g.NT + idxv] * 512;  // the slab offsets of all slots of the wave at this level: one LDS read
+            int curI = -1;  // the tile whose operand the registers a[] hold (of this level)
+            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int sg = 0; sg < NSEG; sg++) {
-            const int mv = wmeta[sg * MW + (lane < MW ? lane : 0)];
-            const int tI = __builtin_amdgcn_readlane(mv, 0), cpmax = __builtin_amdgcn_readlane(mv, 1);
-            if (tI < 0 || cpmax <= lv) continue;
-            const double *pa = buf + __builtin_amdgcn_readfirstlane(sl[tI]) * 512 + lofs;
-            double a[8];
+            for (int q = 0; q < NPW; q++) {
+                const int tI = __builtin_amdgcn_readlane(mv, 3 * q), rg = __builtin_amdgcn_readlane(mv, 3 * q + 2);
+                if (tI < 0 || lv < (rg & 0xff) || lv >= (rg >> 8)) continue;
+                const double *pb = buf + __builtin_amdgcn_readlane(offv, 3 * q + 1);
+                double b[NPW <= 10 ? 4 : 8];
+                int p0 = p0c;
+                if constexpr (NPW <= 10) asm volatile("" : "+v"(p0));  // (the 128-register shape: the eight positions are recomputed, not kept)
+                if (tI != curI) {
+                    const double *pa = buf + __builtin_amdgcn_readlane(offv, 3 * q);
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) a[ks] = pa[(4 * ks + kk) ^ sx];
+                    for (int ks = 0; ks < 8; ks++) a[ks] = pa[p0 ^ (4 * ks)];
+                    curI = tI;
+                }
+                // all operand reads of a group of k-steps are in flight before its first MFMA (the compiler would otherwise pair every MFMA
+                // with the read in front of it and wait for each); the 128-register shape reads four k-steps at a time
+                constexpr int KG = NPW <= 10 ? 4 : 8;
 #pragma unroll
-            for (int j = 0; j < SEGW; j++) {
-                const int tJ = __builtin_amdgcn_readlane(mv, 2 + 2 * j), cp = __builtin_amdgcn_readlane(mv, 3 + 2 * j);
-                if (tJ < 0 || cp <= lv) continue;
-                const double *pb = buf + __builtin_amdgcn_readfirstlane(sl[tJ]) * 512 + lofs;
-                double b[8];
+                for (int k0 = 0; k0 < 8; k0 += KG) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ks++) b[ks] = pb[(4 * ks + kk) ^ sx];
+                    for (int ks = k0; ks < k0 + KG; ks++) b[ks - k0] = pb[p0 ^ (4 * ks)];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 8; ks++) acc[sg * SEGW + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc[sg * SEGW + j], 0, 0, 0);
+                    for (int ks = k0; ks < k0 + KG; ks++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks - k0], acc[q], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }

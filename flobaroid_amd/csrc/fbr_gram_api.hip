@@ -219,7 +219,7 @@ extern "C" int fbr_gram_program_info(const fbr_model *mc, int32_t k, int64_t num
 
 static int get_gram64(fbr_model *m, GramHolder *h);
 
-extern "C" int fbr_gram_lane_info(const fbr_model *mc, int32_t k, int64_t num_samples, int64_t info[8])
+extern "C" int fbr_gram_lane_info(const fbr_model *mc, int32_t k, int64_t num_samples, int64_t info[12])
 {
     if (!mc || !info) {
         set_err("null model / info");
@@ -228,7 +228,7 @@ extern "C" int fbr_gram_lane_info(const fbr_model *mc, int32_t k, int64_t num_sa
     fbr_model *m = const_cast<fbr_model *>(mc);
     if (int rc_enter = enter(m)) return rc_enter;
     if (const int wr = pick_gram_reduction(m, num_samples < 0 ? -1 : (long)num_samples); wr >= 0) m = m->rdm[wr].get();
-    for (int i = 0; i < 8; i++) info[i] = 0;
+    for (int i = 0; i < 12; i++) info[i] = 0;
     const bool moments = fbr_gram_rhs_moments(m->hm, k, m->opt.gram_rhs_tile != 0);
     GramHolder *h = nullptr;
     int rc = get_gram(m, k, &h, moments);
@@ -244,8 +244,12 @@ extern "C" int fbr_gram_lane_info(const fbr_model *mc, int32_t k, int64_t num_sa
     info[4] = g.nlev;
     info[5] = g.maxact;
     info[6] = (int64_t)((size_t)2 * g.maxact * 512 * sizeof(double) +
-                        ((size_t)g.nlev * g.NT + g.nlev + 1 + g.pieces.size() + g.wmeta.size()) * sizeof(int));
+                        ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int));
     info[7] = g.NT;
+    info[8] = g.NF;
+    info[9] = g.busiest;
+    info[10] = g.balanced;
+    info[11] = g.nstage;
     return FBR_OK;
 }
 
@@ -291,10 +295,10 @@ static int get_gram64(fbr_model *m, GramHolder *h)
     if (h->g64_state) return FBR_OK;
     h->g64_state = -1;
     const FbrHostModel &hm = m->hm;
-    if (m->kinid.nsteps <= 0 || !fbr_gram64_build(hm, h->prog, h->g64)) return FBR_OK;
+    if (m->kinid.nsteps <= 0 || !fbr_gram64_build(hm, h->prog, h->g64, m->opt.gram_force_tiles != 0)) return FBR_OK;
     FbrGram64 &g = h->g64;
     const size_t lds = (size_t)2 * g.maxact * 512 * sizeof(double) +
-                       ((size_t)g.nlev * g.NT + g.nlev + 1 + g.pieces.size() + g.wmeta.size()) * sizeof(int);
+                       ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int);
     if (lds > 156 * 1024) return FBR_OK;
     if (!fbr_gram64_build_producer(hm, h->prog, g, h->g64p)) return FBR_OK;
     std::vector<int> wgbegin{0, 0};  // (filled per launch: one part)
@@ -302,7 +306,8 @@ static int get_gram64(fbr_model *m, GramHolder *h)
     if ((rc = upload(h->pool, g.slab, &h->d64_slab)) || (rc = upload(h->pool, g.lev_begin, &h->d64_levb)) || (rc = upload(h->pool, g.pieces, &h->d64_pieces)) ||
         (rc = upload(h->pool, g.wmeta, &h->d64_wmeta)) || (rc = upload(h->pool, h->g64p.lcol, &h->d64_lcol)) ||
         (rc = upload(h->pool, h->g64p.steps, &h->d64_steps)) ||
-        (rc = upload(h->pool, g.slot_tiles, &h->d64_slot_tiles)))
+        (rc = upload(h->pool, g.slot_tiles, &h->d64_slot_tiles)) || (rc = upload(h->pool, g.tilecol, &h->d64_tilecol)) ||
+        (rc = upload(h->pool, g.stage_lev, &h->d64_stagelev)))
         return rc;
     h->g64_state = 1;
     return FBR_OK;
@@ -342,9 +347,9 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         if ((rc = h->mom64.ensure((size_t)m->num_cus * (hm.cols + 1) * 64 * sizeof(double)))) return rc;
         HIPCHK(hipMemsetAsync(h->mom64.p, 0, (size_t)pblocks * (hm.cols + 1) * 64 * sizeof(double), m->stream));  // (the producer grid of this call)
     }
-    const int npw = g.segw * g.nseg;
+    const int npw = g.npw;
     if ((rc = m->partial.ensure((size_t)m->num_cus * FBR_WPB * npw * 256 * sizeof(double)))) return rc;
-    const size_t glds = (size_t)2 * g.maxact * 512 * sizeof(double) + ((size_t)g.nlev * g.NT + g.nlev + 1 + g.pieces.size() + g.wmeta.size()) * sizeof(int);
+    const size_t glds = (size_t)2 * g.maxact * 512 * sizeof(double) + ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int);
     DevKinId kp;
     kp.nsteps = 0;
     kp.maxlvl = m->kinid.maxlvl;
@@ -353,7 +358,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     kp.steps = h->d64_steps;
     kp.endflush = m->kinid_endflush;
     DevGram64 dg;
-    dg.NT = g.NT;
+    dg.NT = g.NT + g.NF;
     dg.nlev = g.nlev;
     dg.maxact = g.maxact;
     dg.npieces = (int)g.pieces.size() / 2;
@@ -362,8 +367,10 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     dg.lev_begin = h->d64_levb;
     dg.pieces = h->d64_pieces;
     dg.wmeta = h->d64_wmeta;
+    dg.nstage = g.nstage;
+    dg.stage_lev = h->d64_stagelev;
     typedef void (*g64_fn)(DevGram64, long, const double *, double *, int);
-    const g64_fn gk = (g.segw == 5) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
+    const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
     HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     int launches = 0, first_wgs = 0;
     for (long b0 = 0; b0 * 64 < S; b0 += chb, launches++) {
@@ -377,6 +384,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         kw.cols = hm.cols;
         kw.k = k;
         kw.has_w = dw ? 1 : 0;
+        kw.flev = g.flev;
         kw.nparts = h->g64p.nparts;
         for (int pq = 0; pq < FBR_KINWRITE_PARTS; pq++) {
             kw.part_nsteps[pq] = h->g64p.nsteps[pq];
@@ -440,8 +448,14 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
             h->g64_wb_wgs = first_wgs;
         }
         dr.wg_begin = h->d64_wgbegin;
+        dr.tilecol = h->d64_tilecol;
         hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
         HIPCHK(hipGetLastError());
+        if (g.NF > 0) {  // the blocks of the force tiles: entries the main blocks have written too, hence a launch of their own
+            dr.slot_tiles = h->d64_slot_tiles + (size_t)FBR_WPB * npw * 2;
+            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
+            HIPCHK(hipGetLastError());
+        }
         if (k) {
             hipLaunchKernelGGL(fbr_gram64_mom_reduce_kernel, dim3(hm.cols + 1), dim3(256), 0, m->stream, hm.cols, pblocks, h->mom64.as<double>(), G);
             HIPCHK(hipGetLastError());

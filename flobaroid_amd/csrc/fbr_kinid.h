@@ -254,6 +254,7 @@ struct DevKinWrite {
     const int *lcol10, *colrec;  // lcol10 [parts][10 L]: the columns a part's wave writes; colrec [cols + 1][2]
     const long *dst;
     int ninert, cols, k, has_w;
+    int flev;  // (fbr_kinimg_kernel) base rows below this level go through the force-tile words
     int nparts, part_nsteps[FBR_KINWRITE_PARTS], part_step0[FBR_KINWRITE_PARTS];  // wave w of a workgroup walks steps [step0, step0 + nsteps) of p.steps
 };
 #endif

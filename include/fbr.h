@@ -279,9 +279,10 @@ int fbr_gram_program_info(const fbr_model *m, int32_t k, int64_t num_samples, in
 
 /* The sample-contiguous Gram pass (option "gram_lane", csrc/fbr_gram64.h) for the same batch: info[0] = 1 when the model qualifies and the
    option is on (device-resident inputs, k <= 1), else every entry is 0; [1] tile rows of a 64-sample block image, [2] its bytes, [3] MFMA
-   instructions per block, [4] row levels, [5] slabs of the widest stage, [6] LDS bytes of the Gram kernel, [7] column tiles.  The image is
-   written once and read once per pass: 2 * info[2] / 64 bytes of HBM traffic per sample. */
-int fbr_gram_lane_info(const fbr_model *m, int32_t k, int64_t num_samples, int64_t info[8]);
+   instructions per block, [4] row levels, [5] slabs of the widest stage, [6] LDS bytes of the Gram kernel, [7] column tiles, [8] force
+   tiles (option "gram_force_tiles"), [9] sum over the levels of the busiest wave's active tile pairs, [10] the same for a perfect split
+   over the 8 waves, [11] stages (barriers) per half block.  The image is written once and read once per pass: 2 * info[2] / 64 bytes of HBM traffic per sample. */
+int fbr_gram_lane_info(const fbr_model *m, int32_t k, int64_t num_samples, int64_t info[12]);
 
 /*
  * Column reductions (options "link_merge" / "regroup" / "reduce_min_work" below).  The regressor columns of a link attached by a FIXED
@@ -311,6 +312,9 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "gram_lane"                  1     fused Gram over SAMPLE-contiguous images (MFMA k-steps over four samples of one regressor row) with a
  *                                      one-lane-per-sample producer, where the model allows: no friction columns, at most one rhs column,
  *                                      one part, device-resident inputs (0: always the per-sample images of the kinematics + packer kernels)
+ *   "gram_force_tiles"           1     gram_lane: the three force rows of the base wrench run on tiles of their own that hold only the columns
+ *                                      with a force (mass, first moments), when the extra tile pairs fit the accumulators (0: every tile pair
+ *                                      pays the three levels)
  *   "gram_shape"                 0     fused Gram kernel shape: 0 by model, 1 one workgroup per CU, 2 two per CU
  *   "gram_rhs_tile"              0     1: dense tiles for the rhs columns even for k <= 2 (default: their products come from the packer)
  *   "gram_orient"                1     tile pairs turned so that the row segments fill up

@@ -520,8 +520,10 @@ int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
 // producer = per (part, link, parameter) one destination word, level stride 1024 doubles, the column swizzle inside a 32-sample run;
 // consumer = stage (level, half) staged through the pieces table, operand reads with the kernel's indexing, the pairs of a wave's
 // segments below their common depth; rhs moments as per-lane running sums.  Returns < 0 when the model is outside that pass.
-// stats (8 longs, optional): tile rows, MFMAs per block, levels, widest stage, sum over levels of the busiest wave's active pairs,
-// sum over levels of ceil(active pairs / waves), parts, pairs.
+// stats (10 longs, optional): tile rows, MFMAs per block, levels, widest stage, sum over levels of the busiest wave's active pairs,
+// sum over levels of ceil(active pairs / waves), parts, pairs, force tiles, stages.
+static int g_force_tiles = 1;
+void emul_set_force_tiles(int on) { g_force_tiles = on; }
 int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
                 const double *rpy, const double *rhs, int k, const double *wts, double *G, long *stats)
 {
@@ -531,28 +533,13 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
     fbr_gram_build_best(gp, hm, k, g_shape, !fbr_gram_rhs_moments(hm, k));
     FbrGram64 g;
     FbrGram64Producer pr;
-    if (k > 1 || !fbr_gram64_build(hm, gp, g) || !fbr_gram64_build_producer(hm, gp, g, pr)) return -1;
-    const int W = FBR_WPB, MW = 2 + 2 * g.segw, npw = g.segw * g.nseg;
+    if (k > 1 || !fbr_gram64_build(hm, gp, g, g_force_tiles != 0) || !fbr_gram64_build_producer(hm, gp, g, pr)) return -1;
+    const int W = FBR_WPB, npw = g.npw, NTT = g.NT + g.NF;
     if (stats) {
-        long crit = 0, bound = 0, npairs = 0;
-        for (int lv = 0; lv < g.nlev; lv++) {
-            int mx = 0, tot = 0;
-            for (int w = 0; w < W; w++) {
-                int n = 0;
-                for (int sg = 0; sg < g.nseg; sg++)
-                    for (int j = 0; j < g.segw; j++) {
-                        const int *mm = &g.wmeta[((size_t)w * g.nseg + sg) * MW];
-                        if (mm[0] >= 0 && mm[2 + 2 * j] >= 0 && mm[3 + 2 * j] > lv) n++;
-                    }
-                mx = std::max(mx, n);
-                tot += n;
-            }
-            crit += mx;
-            bound += (tot + W - 1) / W;
-            if (lv == 0) npairs = tot;
-        }
+        long npairs = 0;
+        for (size_t i = 0; i < g.wmeta.size(); i += 3) npairs += g.wmeta[i] >= 0;
         stats[0] = g.ntr; stats[1] = g.mfma_per_block; stats[2] = g.nlev; stats[3] = g.maxact;
-        stats[4] = crit; stats[5] = bound; stats[6] = pr.nparts; stats[7] = npairs;
+        stats[4] = g.busiest; stats[5] = g.balanced; stats[6] = pr.nparts; stats[7] = npairs; stats[8] = g.NF; stats[9] = g.nstage;
     }
     if (S <= 0) return 0;
     const int REC = hm.rec_size(), P = hm.cols, Pa = P + k;
@@ -574,16 +561,21 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
             for (int pq = 0; pq < pr.nparts; pq++)
                 for (int l = 0; l < hm.L; l++)
                     for (int pp = 0; pp < 10; pp++) {
-                        const long long d0 = pr.rel[((size_t)pq * hm.L + l) * 10 + pp];
-                        if (!d0) continue;
+                        const long long *w14 = &pr.rel[((size_t)pq * hm.L + l) * FBR_G64_WORDS];
+                        const long long d0 = w14[pp], dF = pp < 4 ? w14[10 + pp] : 0;
+                        if (!d0) {
+                            if (dF) return -2;
+                            continue;
+                        }
                         const int c = pr.lcol[((size_t)pq * hm.L + l) * 10 + pp];
                         if (c < 0 || hm.coldesc[c].link != l || hm.coldesc[c].pidx != pp) return -2;
-                        const long base = (long)((d0 & ~(1LL << 62) & ~0xffLL) / 8);
-                        const int x = (int)(d0 & 0xff);
                         double w6[6];
                         fbr_unit_wrench(&rec[FBR_LINK_REC * l], pp, w6);
                         double mc = 0.0;
-                        auto put = [&](int lv, double v, int r) {
+                        auto put = [&](long long dw, int lv, double v, int r) {
+                            if (!dw) return false;
+                            const long base = (long)((dw & ~(1LL << 62) & ~0xffLL) / 8);
+                            const int x = (int)(dw & 0xff);
                             const long at = base + (long)lv * 1024 + (lane >> 5) * 512 + ((lane & 31) ^ x);
                             if (at < 0 || at >= g.blk_doubles) return false;
                             img[at] = live ? v * (ws ? ws[r] : 1.0) : 0.0;
@@ -592,13 +584,13 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
                             return true;
                         };
                         for (int i = (pp >= 4 ? 3 : 0); i < hm.fb; i++)
-                            if (!put(i, w6[i], i)) return -3;
+                            if (!put(i < g.flev ? dF : d0, i, w6[i], i)) return -3;
                         if (pp >= 4)
                             for (int i = 0; i < std::min(3, hm.fb); i++)
                                 if (w6[i] != 0.0) return -4;  // (the force rows of an inertia column are structural zeros)
                         int j = 0;
                         for (int d : hm.path[l]) {
-                            if (!put(hm.fb + j, fbr_dot6(&rec[FBR_LINK_REC * hm.L + 6 * d], w6), hm.fb + d)) return -3;
+                            if (!put(d0, hm.fb + j, fbr_dot6(&rec[FBR_LINK_REC * hm.L + 6 * d], w6), hm.fb + d)) return -3;
                             j++;
                         }
                         if (k && live) mom[(size_t)c * 64 + lane] += mc;
@@ -614,52 +606,56 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
         }
         for (char wv : written)
             if (wv > 1) return -5;  // two writers of one image position
-        // consumer: stages (half, level)
+        // consumer: steps (half, stage), a stage = consecutive levels staged together
         for (int half = 0; half < 2; half++)
             for (int lv = 0; lv < g.nlev; lv++) {
-                std::fill(buf.begin(), buf.end(), 1e300);  // (what the stage does not bring must not be read)
-                for (int i = g.lev_begin[lv]; i < g.lev_begin[lv + 1]; i++)
-                    for (int e = 0; e < 128; e++) buf[g.pieces[2 * i + 1] + e] = img[g.pieces[2 * i] + half * 512 + e];
-                const int *sl = &g.slab[(size_t)lv * g.NT];
+                int sgi = 0;
+                while (g.stage_lev[sgi + 1] <= lv) sgi++;
+                if (lv == g.stage_lev[sgi]) {
+                    std::fill(buf.begin(), buf.end(), 1e300);  // (what the stage does not bring must not be read)
+                    std::vector<char> hit(buf.size(), 0);
+                    for (int i = g.lev_begin[g.stage_lev[sgi]]; i < g.lev_begin[g.stage_lev[sgi + 1]]; i++)
+                        for (int e = 0; e < 128; e++) {
+                            if (g.pieces[2 * i + 1] + e >= (int)buf.size() || hit[g.pieces[2 * i + 1] + e]++) return -11;  // outside the buffer / two pieces on one place
+                            buf[g.pieces[2 * i + 1] + e] = img[g.pieces[2 * i] + half * 512 + e];
+                        }
+                }
+                const int *sl = &g.slab[(size_t)lv * NTT];
                 for (int w = 0; w < W; w++)
-                    for (int sg = 0; sg < g.nseg; sg++) {
-                        const int *mm = &g.wmeta[((size_t)w * g.nseg + sg) * MW];
-                        const int tI = mm[0], cpmax = mm[1];
-                        if (tI < 0 || cpmax <= lv) continue;
-                        if (sl[tI] < 0) return -6;
-                        for (int j = 0; j < g.segw; j++) {
-                            const int tJ = mm[2 + 2 * j], cp = mm[3 + 2 * j];
-                            if (tJ < 0 || cp <= lv) continue;
-                            if (sl[tJ] < 0) return -6;
-                            double *a4 = &acc[((size_t)w * npw + sg * g.segw + j) * 256];
-                            for (int ks = 0; ks < 8; ks++) {
-                                double A[16][4], B[4][16];
-                                for (int lane = 0; lane < 64; lane++) {
-                                    const int li = lane & 15, kk = lane >> 4, sx = 4 * (li & 7);
-                                    A[li][kk] = buf[(size_t)sl[tI] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
-                                    B[kk][li] = buf[(size_t)sl[tJ] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
-                                }
-                                for (int lane = 0; lane < 64; lane++)
-                                    for (int reg = 0; reg < 4; reg++) {
-                                        const int row = (lane >> 4) + 4 * reg, col = lane & 15;
-                                        double sum = 0;
-                                        for (int kk = 0; kk < 4; kk++) sum += A[row][kk] * B[kk][col];
-                                        a4[reg * 64 + lane] += sum;
-                                    }
+                    for (int qs = 0; qs < npw; qs++) {
+                        const int *mm = &g.wmeta[((size_t)w * npw + qs) * 3];
+                        const int tI = mm[0], tJ = mm[1], lo = mm[2] & 0xff, hi = mm[2] >> 8;
+                        if (tI < 0 || lv < lo || lv >= hi) continue;
+                        if (sl[tI] < 0 || sl[tJ] < 0) return -6;
+                        double *a4 = &acc[((size_t)w * npw + qs) * 256];
+                        for (int ks = 0; ks < 8; ks++) {
+                            double A[16][4], B[4][16];
+                            for (int lane = 0; lane < 64; lane++) {
+                                const int li = lane & 15, kk = lane >> 4, sx = 4 * (li & 7);
+                                A[li][kk] = buf[(size_t)sl[tI] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
+                                B[kk][li] = buf[(size_t)sl[tJ] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
                             }
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int reg = 0; reg < 4; reg++) {
+                                    const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+                                    double sum = 0;
+                                    for (int kk = 0; kk < 4; kk++) sum += A[row][kk] * B[kk][col];
+                                    a4[reg * 64 + lane] += sum;
+                                }
                         }
                     }
             }
     }
+    for (int kind = 0; kind < 2; kind++)  // the two reductions: main blocks, force blocks
     for (int w = 0; w < W; w++)
         for (int sl = 0; sl < npw; sl++) {
-            const int tI = g.slot_tiles[2 * ((size_t)w * npw + sl)], tJ = g.slot_tiles[2 * ((size_t)w * npw + sl) + 1];
+            const int tI = g.slot_tiles[2 * ((size_t)kind * W * npw + (size_t)w * npw + sl)], tJ = g.slot_tiles[2 * ((size_t)kind * W * npw + (size_t)w * npw + sl) + 1];
             if (tI < 0) continue;
             const double *a4 = &acc[((size_t)w * npw + sl) * 256];
             for (int lane = 0; lane < 64; lane++)
                 for (int reg = 0; reg < 4; reg++) {
                     const int row = (lane >> 4) + 4 * reg, col = lane & 15;
-                    const int ci = gp.tiles[tI].col[row], cj = gp.tiles[tJ].col[col];
+                    const int ci = g.tilecol[(size_t)tI * FBR_TILE + row], cj = g.tilecol[(size_t)tJ * FBR_TILE + col];
                     if (ci < 0 || cj < 0 || ci >= P || cj >= P) continue;
                     G[(size_t)ci * Pa + cj] += a4[reg * 64 + lane];
                     if (tI != tJ) G[(size_t)cj * Pa + ci] += a4[reg * 64 + lane];

@@ -172,13 +172,13 @@ class Emul:
             k = rhs.shape[1]
         w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
         G = np.zeros((self.cols + k, self.cols + k))
-        stats = (ctypes.c_long * 8)()
+        stats = (ctypes.c_long * 10)()
         rc = lib().emul_gram64(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(rhs), int(k), _d(w),
                                _d(G), stats)
         if rc == -1:
             return None
         assert rc == 0, rc
-        keys = ("tile_rows", "mfma_per_block", "levels", "max_slabs", "busiest_wave_pair_levels", "balanced_pair_levels", "parts", "pairs")
+        keys = ("tile_rows", "mfma_per_block", "levels", "max_slabs", "busiest_wave_pair_levels", "balanced_pair_levels", "parts", "pairs", "force_tiles", "stages")
         return G, dict(zip(keys, (int(v) for v in stats)))
 
     def gram(self, st, rhs=None, sign=None, w=None):

@@ -373,6 +373,19 @@ def test_gram_over_sample_contiguous_images(case, which):
         assert case.startswith("random") or case.startswith("prismatic") or (case == "walkman_apriori" and which < 1)
         pytest.skip("model outside the sample-contiguous pass")
     Gr, stats = got
+    # without the force tiles (option gram_force_tiles = 0): the same Gram, more MFMAs when the base floats
+    emul_lib.lib().emul_set_force_tiles(0)
+    try:
+        Gn, stats_n = em.gram64(st, tau, w)
+    finally:
+        emul_lib.lib().emul_set_force_tiles(1)
+    assert np.linalg.norm(Gn - Gr) <= 1e-13 * np.linalg.norm(Gr) and stats_n["force_tiles"] == 0
+    if floating and stats["force_tiles"]:   # (0: the extra tile pairs did not fit the accumulator slots)
+        assert stats["mfma_per_block"] < stats_n["mfma_per_block"]
+    elif floating:
+        assert not case.startswith("walkman")
+    else:
+        assert stats["force_tiles"] == 0 and stats["mfma_per_block"] == stats_n["mfma_per_block"]
     Ea = np.zeros((em.cols + 1, om.P + 1))
     Ea[: em.cols, : om.P] = E
     Ea[-1, -1] = 1.0
@@ -382,4 +395,4 @@ def test_gram_over_sample_contiguous_images(case, which):
     G0, stats0 = em.gram64(st)
     assert np.linalg.norm(E.T @ G0 @ E - Y.T @ Y) <= 1e-12 * np.linalg.norm(Y.T @ Y)
     assert stats0["mfma_per_block"] == stats["mfma_per_block"] and 1 <= stats["parts"] <= 4
-    assert stats["balanced_pair_levels"] <= stats["busiest_wave_pair_levels"] <= stats["pairs"] * stats["levels"]
+    assert stats["balanced_pair_levels"] <= stats["busiest_wave_pair_levels"] <= stats["balanced_pair_levels"] + stats["levels"] and 1 <= stats["stages"] <= stats["levels"]
