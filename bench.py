@@ -202,7 +202,21 @@ def cpu_baseline_all_cores(topo, one_thread_rate=None, budget_s=10.0):
     threads).  Reports the rate, the one-thread rate of the SAME function and the parallel efficiency between the two."""
     from oracle.oracle import OracleModel
 
-    cores = os.cpu_count() or 1
+    # what this process may actually use: the affinity mask and the cgroup CPU quota of the box, not the socket's thread count
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except Exception:
+            pass
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
     om = OracleModel(topo, floating=True)
     x = topo.x_std()
     st1 = _np_states(topo, 512, 4321)
@@ -215,6 +229,15 @@ def cpu_baseline_all_cores(topo, one_thread_rate=None, budget_s=10.0):
     rate1 = n1 / (time.perf_counter() - t0)
     block = max(512, 64 * cores)
     st = _np_states(topo, block, 4322)
+    # thread-count sweep (one block each): the rate of a team is bounded by the cores the box really schedules, whatever it reports
+    sweep = {}
+    for th in sorted({max(1, cores // 16), max(1, cores // 4), max(1, cores // 2), cores}):
+        om.stack_gram(_np_states(topo, 8 * th, 1), x, threads=th)
+        t0 = time.perf_counter()
+        om.stack_gram(st, x, threads=th)
+        sweep[th] = block / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
+    cores_detected, cores = cores, best
     _, thr = om.stack_gram(st, x, threads=cores)  # (starts the OpenMP team)
     done = 0
     t0 = time.perf_counter()
@@ -228,7 +251,10 @@ def cpu_baseline_all_cores(topo, one_thread_rate=None, budget_s=10.0):
            "parallel_efficiency_per_thread": rate / rate1 / max(thr, 1),
            "sample": f"{done} WALK-MAN floating-base samples in blocks of {block}: C oracle regressor + RNEA + rank-1 A^T A accumulation (structural zeros "
                      f"skipped) over {thr} OpenMP threads, per-thread sums added at the end, {dt:.1f} s",
-           "note": f"hardware threads are SMT siblings ({cores} threads on about {cores // 2} cores): an efficiency of 0.5 per thread is one per core"}
+           "threads_available": cores_detected, "cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota,
+           "thread_sweep_samples_per_s": {str(k): v for k, v in sweep.items()},
+           "note": "the timed loop uses the thread count of the sweep with the best rate; hardware threads are SMT siblings: an efficiency of 0.5 per "
+                   "thread is one per core"}
     if one_thread_rate:
         out["speedup_vs_cpu_baseline_one_thread_blas"] = rate / one_thread_rate
     return out
@@ -524,6 +550,10 @@ def run_rank(args) -> int:
     ms_per_step = dt / args.steps * 1e3
     value = S_total / (dt / args.steps)
     info = eng.gram_program_info(1, S) if on_gpu else eng.gram_program_info(1)  # (the program a pass over S samples executes)
+    # the pass over sample-contiguous images (option gram_lane, csrc/fbr_gram64.h) runs its own tile pairs: its MFMA count per 64-sample block
+    lane = eng.gram_lane_info(1, S) if on_gpu and hasattr(eng, "gram_lane_info") else {"active": False}
+    if lane.get("active"):
+        info = dict(info, mfma_per_sample=lane["mfma_per_block"] / 64.0)
     gram_ms, gram_n = prof["gram"]
     samples_per_launch = S * args.steps / max(gram_n, 1)
     alg_flop_per_sample = rows * P * (P + 1) + 2 * rows * P * 1  # symmetric Gram count + 1 rhs column
@@ -577,7 +607,8 @@ def run_rank(args) -> int:
         "gram_checksum": {"trace": float(torch.trace(G_sharded).item()), "fro": float(torch.linalg.norm(G_sharded).item())},
         "roofline": {
             "bound": "mfma",
-            "kernel": "fbr_gram_kernel",
+            "kernel": "fbr_gram64_kernel" if lane.get("active") else "fbr_gram_kernel",
+            "gram_lane": lane,
             # what the MFMA pipe executed (the kernel skips the structurally zero k-steps of the tile pairs; the PMC pass counts
             # exactly mfma_per_sample x samples): executed flop / launch time measured with HIP events on the launch stream
             "achieved": executed,
@@ -617,8 +648,11 @@ def run_rank(args) -> int:
 
         src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gram_pmc_traffic.json")))[-1]
         pm = json.load(open(src))
-        out["roofline"]["traffic"] = pm["hbm_bytes_per_sample"] * samples_per_launch
-        out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(src)} (HBM bytes per sample x samples per launch)"
+        if pm.get("gram_kernel_name", "fbr_gram_kernel").startswith(out["roofline"]["kernel"]):
+            out["roofline"]["traffic"] = pm["hbm_bytes_per_sample"] * samples_per_launch
+            out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(src)} (HBM bytes per sample x samples per launch)"
+        else:  # (counters of another kernel: the image of the pass is read once -- its size is the traffic of a launch, to the byte)
+            raise KeyError("stale counters")
         # staging traffic of the whole pass (kinematic records written and read, tile images written and streamed): counter bytes per
         # sample of every kernel of the step at this run's rate, against the HBM peak -- the pass's algorithmic I/O is 0.8 KB per sample
         if "staging" in pm:
@@ -629,6 +663,9 @@ def run_rank(args) -> int:
                                           "algorithmic_io_bytes_per_sample": 8 * (3 * topo.num_dofs + 15 + rows), "source": f"profiles/{os.path.basename(src)}"}
     except Exception:
         pass
+    if out["roofline"]["traffic"] is None and lane.get("active"):
+        out["roofline"]["traffic"] = lane["block_image_bytes"] / 64.0 * samples_per_launch
+        out["roofline"]["traffic_source"] = "fbr_gram_lane_info: bytes of the block images one launch reads (no committed PMC pass of this kernel found)"
 
     if not args.no_secondary:
         secondary(args, out, eng, topo, st, rhs, G_sharded, dev, world, rank, use_dist, on_gpu, timed, barrier, sync, max_over_ranks)

@@ -7,8 +7,10 @@
 // Here the k-steps run over four SAMPLES of one regressor row:
 //   * image of a block of 64 samples: [tile row tr][half][16 columns][32 samples], tile row = (column tile, real row of the tile: the fb
 //     base-wrench rows, then the joints of the tile's path); no row padding, no paired base rows.  Inside a 32-sample run sample s of
-//     column slot c sits at s ^ 4 (c & 7): the operand reads of the MFMAs (lane (kk, li) -> column li, sample 4 ks + kk) then hit every
-//     LDS bank pair exactly twice, with the LDS layout EQUAL to the global one (one contiguous 4 KB DMA per slab);
+//     column slot c sits at s ^ 2 c: an operand read of the MFMAs (lane (kk, li) -> column li, sample 4 ks + kk) is served half a wave at a
+//     time, and the 32 lanes of a half (16 columns x two values of kk) then fall on the 32 different bank pairs of the LDS (with s ^ 4 (c & 7),
+//     round 6's first layout, columns c and c + 8 collided: SQ_LDS_BANK_CONFLICT 42 % of the LDS cycles of the kernel), with the LDS layout
+//     EQUAL to the global one (one contiguous 4 KB DMA per slab);
 //   * producer fbr_kinimg_kernel: one lane per sample, kinematics fused in, the tree cut into parts for the waves of a workgroup
 //     (fbr_kinid.h); every value of a (column, row) goes out as two 256-byte runs per wave;  tau's products with the columns (k <= 1) are
 //     accumulated on the way: per column one dot product per joint row it already holds, a wave reduction per block;
@@ -18,6 +20,8 @@
 //   * the force rows of the base wrench (levels 0 .. 2) run on tiles of their own that hold the columns with a force only (fbr_gram64_build).
 // Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), one part, device-resident inputs, one group.
 #pragma once
+// the swizzle of column slot c inside its 32-sample run (see the image layout above)
+#define FBR_G64_SWZ(c) (2 * ((c) & 15))
 #include <algorithm>
 #include <utility>
 
@@ -282,7 +286,7 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
 
 // Producer tables: the tree in parts for the waves of a workgroup (fbr_kinid.h) and, per (part, link), 14 destination words: one per
 // parameter, then the FORCE-tile words of parameters 0 .. 3.  A word: byte offset inside an image buffer of (level 0 of the column's tile
-// rows, column slot, sample 0) -- a multiple of 256 -- with 4 (slot & 7) in its low byte and bit 62 set (0: the part does not write that
+// rows, column slot, sample 0) -- a multiple of 256 -- with the slot's swizzle (FBR_G64_SWZ) in its low byte and bit 62 set (0: the part does not write that
 // column).  Level lv of the column is 8192 bytes x lv further on (the tile rows of a tile are consecutive; with force tiles "level 0" of a
 // main tile is three rows in front of its first row, rows 0 .. 2 of a force column go through its force word).
 #define FBR_G64_WORDS 14
@@ -315,7 +319,7 @@ static inline bool fbr_gram64_build_producer(const FbrHostModel &hm, const FbrGr
     pr.nparts = (int)progs.size();
     pr.rel.assign((size_t)pr.nparts * FBR_G64_WORDS * hm.L, 0);
     pr.lcol.assign((size_t)pr.nparts * 10 * hm.L, -1);
-    auto word = [](long long tile_row, int sl) { return ((tile_row * 1024 + sl * 32) * 8) | (long long)(4 * (sl & 7)) | (1LL << 62); };
+    auto word = [](long long tile_row, int sl) { return ((tile_row * 1024 + sl * 32) * 8) | (long long)FBR_G64_SWZ(sl) | (1LL << 62); };
     for (int c = 0; c < hm.ninert; c++) {
         const int t = tile_of[c], sl = slot_of[c], l = hm.coldesc[c].link, pidx = hm.coldesc[c].pidx;
         if (t < 0) continue;  // (a column without a tile: structurally zero, e.g. the base link of a fixed base)
@@ -353,7 +357,7 @@ struct DevGram64 {
 
 // ------------------------------------------------------------------------------------------------
 // Producer: the lane writer of fbr_kinid.h with the image addressing of this pass.  Destination word of a (column, row): address of the
-// slab position of column slot c, sample 0 (256-byte aligned) | 4 (c & 7) in its low byte; sample slot s of block b goes to
+// slab position of column slot c, sample 0 (256-byte aligned) | the slot's swizzle in its low byte; sample slot s of block b goes to
 // + b * blk_doubles + (s >> 5) * 512 + ((s & 31) ^ x).  The positions of the lanes behind the last sample of the last block are cleared by the host before the launch (the Gram
 // kernel runs whole blocks).  mom (k == 1): [workgroup][cols + 1][64] per-lane running sums of (w Y)^T (w tau) per column and (w tau)^T (w tau), added in block order.
 // ------------------------------------------------------------------------------------------------
@@ -622,11 +626,11 @@ __global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr
     };
     if (nst > 0) dma(0);
     const int li = lane & 15, kk = lane >> 4;
-    const int lofs = li * 32, sx = 4 * (li & 7);
+    const int lofs = li * 32, sx = FBR_G64_SWZ(li);
     const int mv = wm[wave * MW + (lane < MW ? lane : 0)];  // this wave's slots: (tile I, tile J, first level | end level << 8)
     const int idxv = (lane < MW && (lane % 3) != 2 && mv >= 0) ? mv : 0;  // the tile this lane looks up per level (lanes 3q, 3q + 1)
     // this lane's operand position inside a slab (doubles) at k-step ks: column li, sample (4 ks + kk) ^ sx = p0 ^ (4 ks)
-    const int p0c = lofs | sx | kk;
+    const int p0c = lofs | (sx ^ kk);
     for (long st = 0; st < nst; st++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step st have landed
         __syncthreads();                                  // everyone's have; the other buffer is free

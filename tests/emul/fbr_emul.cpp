@@ -631,7 +631,7 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
                         for (int ks = 0; ks < 8; ks++) {
                             double A[16][4], B[4][16];
                             for (int lane = 0; lane < 64; lane++) {
-                                const int li = lane & 15, kk = lane >> 4, sx = 4 * (li & 7);
+                                const int li = lane & 15, kk = lane >> 4, sx = FBR_G64_SWZ(li);
                                 A[li][kk] = buf[(size_t)sl[tI] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
                                 B[kk][li] = buf[(size_t)sl[tJ] * 512 + li * 32 + ((4 * ks + kk) ^ sx)];
                             }

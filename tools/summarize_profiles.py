@@ -61,14 +61,18 @@ json.dump({"command": "rocprofv3 --pmc <set> --kernel-trace -- python bench.py -
           open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 
 S = 200000
-gk = [k for k in pmc.get("FETCH_SIZE", {}) if k.startswith("fbr_gram_kernel")]
+def is_gram(k):
+    return k.startswith("fbr_gram_kernel") or k.startswith("fbr_gram64_kernel")
+
+
+gk = sorted((k for k in pmc.get("FETCH_SIZE", {}) if is_gram(k)), key=lambda k: -pmc["FETCH_SIZE"][k]["per_launch"] * pmc["FETCH_SIZE"][k]["launches"])
 if gk:
     g = gk[0]
     nl = pmc["FETCH_SIZE"][g]["launches"]
     spl = S / nl
     fetch_kb = pmc["FETCH_SIZE"][g]["per_launch"]
     write_kb = pmc.get("WRITE_SIZE", {}).get(g, {}).get("per_launch", 0.0)
-    out = {"command": "tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes, 200000 samples)", "samples_per_gram_launch": spl,
+    out = {"command": "tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes, 200000 samples)", "samples_per_gram_launch": spl, "gram_kernel_name": g,
            "gram_kernel": {"fetch_KB_per_launch_raw": fetch_kb, "write_KB_per_launch_raw": write_kb,
                            "fetch_bytes_per_sample_corrected": 2.0 * fetch_kb * 1024 / spl,
                            "write_bytes_per_sample": write_kb * 1024 / spl},
@@ -89,9 +93,9 @@ if gk:
         pq = {r["Queue_Id"] for r in rows_ if short(r["Kernel_Name"]).startswith("fbr_pack_kernel")}
         for r in rows_:
             k = short(r["Kernel_Name"])
-            if not k.startswith("fbr_") or k.startswith("fbr_id_kernel") or (k.startswith("fbr_kin_kernel") and r["Queue_Id"] not in pq):
+            if not k.startswith("fbr_") or k.startswith("fbr_id_kernel") or k.startswith("fbr_kinid_kernel") or (k.startswith("fbr_kin_kernel") and r["Queue_Id"] not in pq):
                 continue
-            v = float(r["Counter_Value"]) * 1024 / S * (factor_gram if k.startswith("fbr_gram_kernel") else 1.0)
+            v = float(r["Counter_Value"]) * 1024 / S * (factor_gram if is_gram(k) else 1.0)
             per_kernel.setdefault(k, {"fetch": 0.0, "write": 0.0})[field] += v
     per_kernel = {k: {f: round(x, 1) for f, x in v.items()} for k, v in per_kernel.items() if v["fetch"] + v["write"] > 1.0}
     out["staging"] = {"per_kernel_bytes_per_sample": per_kernel,
@@ -132,17 +136,17 @@ gl = []
 tr = os.path.join(src, "bench_kernel_trace.csv")
 if os.path.exists(tr):
     for r in csv.DictReader(open(tr)):
-        if "fbr_gram_kernel" in r["Kernel_Name"]:
+        if "fbr_gram_kernel" in r["Kernel_Name"] or "fbr_gram64_kernel" in r["Kernel_Name"]:
             gl.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 full = [x for x in gl if x > 0.8 * statistics.median(gl)] if gl else []
-gram_line = (f"`fbr_gram_kernel`: {len(gl)} launches in the bench command, {len(full)} of them full-size ({bench['roofline']['samples_per_launch']:.0f} samples): median {statistics.median(full):.3f} ms, "
+gram_line = (f"`{bench['roofline'].get('kernel', 'fbr_gram_kernel')}`: {len(gl)} launches in the bench command, {len(full)} of them full-size ({bench['roofline']['samples_per_launch']:.0f} samples): median {statistics.median(full):.3f} ms, "
              f"mean {statistics.mean(full):.3f} ms (the bench's HIP events: {bench['roofline']['avg_launch_ms']:.3f} ms over the timed steps)") if full else ""
 
 # ---- profiles/README.md is GENERATED here (numbers cannot go stale)
 traffic = json.load(open(os.path.join(dst, tag + "_gram_pmc_traffic.json")))["hbm_bytes_per_sample"] if os.path.exists(os.path.join(dst, tag + "_gram_pmc_traffic.json")) else None
 mops = None
 for k, v in pmc.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).items():
-    if k.startswith("fbr_gram_kernel"):
+    if is_gram(k):
         mops = v
 lines = [
     "# profiles/", "",
