@@ -145,7 +145,7 @@ _SIGNATURES = {
 # Options every new Engine starts with (``fbr_model_set_option``, include/fbr.h lists the keys), on top of the library's defaults and below
 # the ``options`` argument of the constructor.  A plain Python dict: the library itself never reads the process environment.  The test
 # suite uses it to run whole modules with the column reductions forced / switched off (tests/conftest.py: reduction_mode).
-FBR_VERSION = 101  # include/fbr.h FBR_VERSION: the C-ABI these ctypes signatures describe
+FBR_VERSION = 102  # include/fbr.h FBR_VERSION: the C-ABI these ctypes signatures describe
 DEFAULT_OPTIONS: dict = {}
 
 

@@ -83,8 +83,9 @@ typedef struct {
 /* ---- library / device ------------------------------------------------------------------------- */
 /* Version of THIS header.  fbr_version() returns the value the loaded library was built with: a caller compares the two before its first
  * call (flobaroid_amd/_lib.py load_library refuses a mismatch), because the C-ABI has grown in place -- 101: fbr_topology.joint_type,
- * the num_samples argument of fbr_gram_program_info / fbr_model_link_merge_info, option "fused_id". */
-#define FBR_VERSION 101
+ * the num_samples argument of fbr_gram_program_info / fbr_model_link_merge_info, option "fused_id"; 102: fbr_gram_lane_info, options
+ * "gram_lane" / "gram_force_tiles". */
+#define FBR_VERSION 102
 int fbr_version(void);
 int fbr_device_count(void);        /* number of visible HIP devices (0 if none / no runtime) */
 const char *fbr_last_error(void);  /* thread-local message of the last failing call */

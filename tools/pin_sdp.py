@@ -121,6 +121,12 @@ def run(reference: str, robot: str, samples: int, stub: bool, gpu_engine: str, w
         import stub_cvxpy
 
         sys.modules["cvxpy"] = stub_cvxpy
+    # reference modules another caller of this process imported earlier hold THEIR cvxpy (tools/make_fixtures.py installs blank placeholders for
+    # modules it does not need): import them afresh so that sdp.py binds the solver module chosen here
+    for name, mod in list(sys.modules.items()):
+        f = getattr(mod, "__file__", None) or ""
+        if f.startswith(os.path.abspath(reference) + os.sep):
+            del sys.modules[name]
     rident = mf._import_reference("identifier")      # (colorama / idyntree / plotting modules become placeholders; cvxpy must be real or the stub)
     rsdp = sys.modules["identification.sdp"]
     import cpu_engine
