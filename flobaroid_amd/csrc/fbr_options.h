@@ -31,6 +31,7 @@ struct FbrOptions {
     double tsqr_tree_one_wg = 0;            // merges by one workgroup instead of pipelined across workgroups (bit-identical, slower)
     double tsqr_narrow = 1;                 // wave-private kernels for <= 128 columns
     double tsqr_narrow_tall = 1;            // ... with 96-row level-0 blocks at one wave per SIMD for long calls over <= 6 column tiles (0: 48-row blocks, two waves)
+    double tsqr_force_group = 1;            // row-group TSQR: the force rows of a floating base as a group of their own over the columns that have a force
     double tsqr_lane_writer = 1;            // regressor writer of the TSQR: one lane per sample, kinematics fused, column-major chunks (0: kinematics kernel + workgroup-per-sample writers)
     double tsqr_writer = 0;                 // grouped regressor writer: 0 by work-item count; 8 / 16: store width forced; 32: rows staged in the LDS
     double tsqr_prologue_overlap = 1;       // a submission's kinematics / first writer beside the trees of the one before
@@ -69,6 +70,7 @@ static inline const FbrOptionKey *fbr_option_keys(int *count)
         {"tsqr_narrow", &FbrOptions::tsqr_narrow, false},
         {"tsqr_narrow_tall", &FbrOptions::tsqr_narrow_tall, false},
         {"tsqr_lane_writer", &FbrOptions::tsqr_lane_writer, false},
+        {"tsqr_force_group", &FbrOptions::tsqr_force_group, false},
         {"tsqr_writer", &FbrOptions::tsqr_writer, false},
         {"tsqr_prologue_overlap", &FbrOptions::tsqr_prologue_overlap, false},
         {"tsqr_timing", &FbrOptions::tsqr_timing, false},

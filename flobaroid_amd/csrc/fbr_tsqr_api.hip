@@ -125,7 +125,8 @@ struct TsqrGroupPlan {
     int main = -1;  // group whose rows are dense in every factorised column (base-wrench rows): factorised in the caller's column order
                     // straight into the final factor, the other groups' factors are folded into it
 };
-static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols, int32_t ncols, int k, const std::vector<char> *active = nullptr)
+static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols, int32_t ncols, int k, const std::vector<char> *active = nullptr,
+                                     bool m_force_group = true)
 {
     TsqrGroupPlan gp;
     const int Psel = cols ? ncols : hm.cols;
@@ -151,16 +152,22 @@ static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols
         if (nchild[p + 1] == 1 && pg < 0) pg = base_group = ngroups++;  // fixed base, single chain from the root
         jgroup[d] = (nchild[p + 1] == 1) ? pg : ngroups++;
     }
+    // The FORCE rows of the base wrench (rows 0 .. 2 of a floating base) are non-zero only in the columns that produce a force -- a link's
+    // mass and first moments (an inertia entry is a pure moment) --: a group of their own, factorised over those columns (WALK-MAN, regrouped:
+    // 62 of 213), leaves the dense group the three moment rows: the widest group folds half the rows (round 6; option tsqr_force_group)
+    const bool force_split = hm.fb == 6 && m_force_group;
+    const int force_group = force_split ? ngroups++ : -1;
     std::vector<std::vector<int>> grows(ngroups);
     auto on = [&](int r) { return !active || (*active)[r]; };  // rows switched off by the weights belong to no group
     for (int r = 0; r < hm.fb; r++)
-        if (on(r)) grows[base_group].push_back(r);
+        if (on(r)) grows[(force_split && r < 3) ? force_group : base_group].push_back(r);
     for (int d = 0; d < hm.n; d++)
         if (on(hm.fb + d)) grows[jgroup[d]].push_back(hm.fb + d);
     for (int r = 0; r < hm.rows; r++) gp.masked = gp.masked || !on(r);
     auto touches = [&](int r, int uc) {
         const FbrCol &cd = hm.coldesc[uc];
         if (cd.kind != 0) return cd.joint == r - hm.fb;
+        if (force_split && r < 3) return cd.pidx < 4;
         if (r < hm.fb) return true;
         const std::vector<int> &pa = hm.path[cd.link];
         return std::find(pa.begin(), pa.end(), r - hm.fb) != pa.end();
@@ -877,7 +884,7 @@ static int tsqr_impl_inner(fbr_model *m, const fbr_states *st, const int32_t *co
         // (row weights on the device are scanned for switched-off rows: that read-back waits for the stream, i.e. for a submission in flight)
         std::vector<char> act;
         if ((rc = active_rows(m, dw, S, &act))) return rc;
-        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k, &act);
+        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k, &act, m->opt.tsqr_force_group != 0);
         if (hm.rows <= 255 && tsqr_use_groups(m, gp, S)) {  // (the writer's entries hold the regressor row in 8 bits)
             if ((rc = tsqr_groups_impl(m, d, gp, cols, Psel, k, drhs, dw, Rin_dev, R, par, overlap))) return rc;
             return done();
@@ -981,7 +988,7 @@ static int pick_tsqr_reduction(fbr_model *m, long S)
         r0 && S >= 0 && (double)S * (m->hm.cols - r0->hm.cols) * m->hm.cols < m->opt.reduce_min_work / 8) return -1;
     if (m->rdm[1] && m->opt.regroup && m->opt.tsqr_groups) {
         if (m->rd_grouped < 0) {
-            const TsqrGroupPlan gp = tsqr_group_plan(m->rdm[1]->hm, nullptr, 0, 0);
+            const TsqrGroupPlan gp = tsqr_group_plan(m->rdm[1]->hm, nullptr, 0, 0, nullptr, m->opt.tsqr_force_group != 0);
             m->rd_grouped = gp.groups.size() > 1 && m->rdm[1]->hm.rows <= 255;
         }
         if (m->rd_grouped && S >= (long)m->opt.tsqr_group_min_samples) return 1;
@@ -1194,7 +1201,7 @@ extern "C" int fbr_tsqr_work_info(fbr_model *m, const int32_t *cols, int32_t nco
     {
         // tree-structured path (tsqr_groups_impl): level 0 of every group over its own chunks, the groups' trees, and the final factor
         // that folds the embedded group factors (dense rows) and runs its own tree
-        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k);
+        const TsqrGroupPlan gp = tsqr_group_plan(hm, cols, ncols, k, nullptr, m->opt.tsqr_force_group != 0);
         if (hm.rows <= 255 && tsqr_use_groups(m, gp, (long)num_samples)) {
             long lcm = 1;
             const long ch = tsqr_group_chunk_samples(m, gp, (long)num_samples, &lcm);

@@ -327,6 +327,9 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *                                      (0: 48-row blocks, two waves per SIMD)
  *   "tsqr_lane_writer"           1     regressor writer of the TSQR: one lane per sample with the kinematics fused in (no records in HBM), chunks
  *                                      written column-major in 512-byte runs (0: kinematics kernel + the workgroup-per-sample writers below)
+ *   "tsqr_force_group"           1     row groups of a floating base: the three FORCE rows of the base wrench form a group of their own, factorised
+ *                                      over the columns that produce a force (a link's mass and first moments); the dense group keeps the three
+ *                                      moment rows (0: one dense group of six rows)
  *   "tsqr_writer"                0     grouped regressor writer: 0 by work-item count; 8 / 16: one thread per column / column pair, stores of that
  *                                      width; 32: rows staged in the LDS and streamed out in 16-byte pieces (measured: no faster)
  *   "tsqr_tree_one_wg"           0     merges by one workgroup instead of pipelined across workgroups (bit-identical, slower)

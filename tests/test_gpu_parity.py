@@ -452,7 +452,12 @@ def test_tsqr_row_groups_along_the_tree(cfg):
         assert np.linalg.norm(norm(R) - norm(Rc0)) <= 1e-9 * np.linalg.norm(Rc0)
     if cfg[0] == "walkman_apriori":   # branched tree: legs / arms / head / waist / base rows are separate factorisations
         assert big1["flop"] < 0.6 * big0["flop"]
-    else:                             # one chain: one group, the single factorisation
+    elif cfg[1]:                      # one chain on a floating base: the force rows of the base wrench are a group of their own, over the
+        assert big1["flop"] < big0["flop"]   # columns that have a force (option tsqr_force_group)
+        eng.set_option("tsqr_groups", 1)
+        eng.set_option("tsqr_force_group", 0)
+        assert eng.tsqr_work_info(1000000, k=2)["flop"] == big0["flop"]   # without it: one group, the single factorisation
+    else:                             # one chain, fixed base: one group, the single factorisation
         assert big1["flop"] == big0["flop"]
 
 
