@@ -34,7 +34,7 @@ struct FbrGram64 {  // host program
     long blk_doubles = 0;
     std::vector<int> trow;       // [NT + NF][nlev] tile-row index or -1
     std::vector<int> slab;       // [nlev][NT + NF] slab index inside the level's stage or -1
-    int nstage = 0;
+    int nstage = 0, base_stages = 0;
     std::vector<int> stage_lev;  // [nstage + 1] first level of each stage
     std::vector<int> lev_begin;  // [nlev + 1] into pieces
     std::vector<int> pieces;     // pairs: global offset (doubles, inside the block image, half 0), LDS offset (doubles, inside a stage buffer)
@@ -141,7 +141,7 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
     const int cap = std::max(widest, g.npw <= 10 ? 8 : 16);
     g.stage_lev.assign(1, 0);
     for (int lv = 0, in_stage = 0; lv < g.nlev; lv++) {
-        if (lv > g.stage_lev.back() && in_stage + nslab[lv] > cap) {
+        if (lv > g.stage_lev.back() && (in_stage + nslab[lv] > cap || lv == hm.fb)) {  // (the base-wrench rows end a stage: base_stages)
             g.stage_lev.push_back(lv);
             in_stage = 0;
         }
@@ -149,6 +149,8 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
     }
     g.stage_lev.push_back(g.nlev);
     g.nstage = (int)g.stage_lev.size() - 1;
+    g.base_stages = 0;  // stages of the base-wrench rows alone: all a call runs whose row weights switch every joint row off
+    while (g.base_stages < g.nstage && g.stage_lev[g.base_stages + 1] <= hm.fb) g.base_stages++;
     g.slab.assign((size_t)g.nlev * NTT, -1);
     g.lev_begin.assign(g.nlev + 1, 0);
     g.pieces.clear();
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(Dev
         const unsigned vlane = (unsigned)(((unsigned long)slot_off + (unsigned long)s31) << 3);
         auto link = [&](int l, int depth, const double *rec, const double (*Sst)[6], const int *lvd, double *F) {
             (void)F;
+            if (wr.base_only) depth = 0;  // (row weights switch every joint row off: identifier.py:629-636 -- only the base-wrench rows are produced)
             // Every vector load of the step (branch records, states) is waited for HERE, once: the stores below share the loads' counter, and
             // behind the branches of the column code the compiler cannot tell how many of them sit in front of a load it still expects --
             // it would wait for counter 0, i.e. for the store before, at every store (measured: 7.4 -> 5.4 ms per 1 M WALK-MAN samples).

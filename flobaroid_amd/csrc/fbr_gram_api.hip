@@ -315,7 +315,7 @@ static int get_gram64(fbr_model *m, GramHolder *h)
 
 // One call of the fused pass through fbr_kinimg_kernel / fbr_gram64_kernel (device-resident inputs, one group, k <= 1); everything on the
 // model's stream.  G has been cleared / holds the running sum.
-static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const double *drhs, const double *dw, int k, double *G)
+static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const double *drhs, const double *dw, int k, double *G, bool base_only)
 {
     const FbrHostModel &hm = m->hm;
     FbrGram64 &g = h->g64;
@@ -367,7 +367,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     dg.lev_begin = h->d64_levb;
     dg.pieces = h->d64_pieces;
     dg.wmeta = h->d64_wmeta;
-    dg.nstage = g.nstage;
+    dg.nstage = base_only ? g.base_stages : g.nstage;  // (base-wrench-only row masks: the joint levels' stages are not run)
     dg.stage_lev = h->d64_stagelev;
     typedef void (*g64_fn)(DevGram64, long, const double *, double *, int);
     const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
@@ -385,6 +385,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         kw.k = k;
         kw.has_w = dw ? 1 : 0;
         kw.flev = g.flev;
+        kw.base_only = base_only ? 1 : 0;
         kw.nparts = h->g64p.nparts;
         for (int pq = 0; pq < FBR_KINWRITE_PARTS; pq++) {
             kw.part_nsteps[pq] = h->g64p.nsteps[pq];
@@ -555,13 +556,13 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
     if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
     // the pass over sample-contiguous images (fbr_gram64.h) where the call allows it
     bool lane_pass = false;
-    if (S > 0 && m->opt.gram_lane != 0 && ngroups == 1 && !h2d_chunked && !base_only && !m->opt.gram_timing && !m->opt.gram_serial &&
+    if (S > 0 && m->opt.gram_lane != 0 && ngroups == 1 && !h2d_chunked && !m->opt.gram_timing && !m->opt.gram_serial &&
         k <= 1 && (k == 0 || moments) && !hm.fric && d.q) {
         if ((rc = get_gram64(m, h))) return rc;
         lane_pass = h->g64_state == 1;
     }
     if (lane_pass) {
-        if ((rc = gram64_pass(m, h, d, drhs, dw, k, G))) return rc;
+        if ((rc = gram64_pass(m, h, d, drhs, dw, k, G, base_only && h->g64.base_stages > 0))) return rc;
     } else if (S > 0) {
         const int T = h->prog.T;
         const bool two_per_cu = h->prog.cfg == FBR_CFG_TWO_PER_CU;
