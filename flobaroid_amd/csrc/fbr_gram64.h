@@ -23,6 +23,7 @@
 // the swizzle of column slot c inside its 32-sample run (see the image layout above)
 #define FBR_G64_SWZ(c) (2 * ((c) & 15))
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 
 #include "fbr_kinid.h"
@@ -364,7 +365,7 @@ struct DevGram64 {
 // kernel runs whole blocks).  mom (k == 1): [workgroup][cols + 1][64] per-lane running sums of (w Y)^T (w tau) per column and (w tau)^T (w tau), added in block order.
 // ------------------------------------------------------------------------------------------------
 template <int MAXD, bool HASW>
-__global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, long blk_doubles,
+__global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void fbr_kinimg_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, long blk_doubles,
                                                                               const double *__restrict__ q, const double *__restrict__ dq,
                                                                               const double *__restrict__ ddq, const double *__restrict__ bv,
                                                                               const double *__restrict__ ba, const double *__restrict__ rpy,
@@ -483,59 +484,73 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinimg_kernel(Dev
                 const unsigned vo = vlane ^ ((unsigned)(d0 & 0xff) << 3);
                 __builtin_nontemporal_store(v, (fbr_gdouble_ptr)((fbr_gchar_ptr)(d0 & ~0xffL) + (long)lv * 8192 + vo));
             };
-            {  // mass and first moments: full wrenches
-                double wA[4][6];
+            // mass and first moments: full wrenches, NQ columns at a time
+            auto full_group = [&](auto q0c, auto nqc) {
+                constexpr int Q0 = decltype(q0c)::value, NQ = decltype(nqc)::value;
+                double wA[NQ][6];
 #pragma unroll
-                for (int qq = 0; qq < 4; qq++) fbr_unit_wrench(rec, qq, wA[qq]);
+                for (int qq = 0; qq < NQ; qq++) fbr_unit_wrench(rec, Q0 + qq, wA[qq]);
 #pragma unroll
                 for (int i = 0; i < 6; i++)
                     if (i < m.fb) {
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) store(i < wr.flev ? dF[qq] : d10[qq], i, HASW ? wA[qq][i] * myw[i] : wA[qq][i]);
+                        for (int qq = 0; qq < NQ; qq++) store(i < wr.flev ? dF[Q0 + qq] : d10[Q0 + qq], i, HASW ? wA[qq][i] * myw[i] : wA[qq][i]);
                     }
 #pragma unroll
                 for (int j = 0; j < MAXD; j++)
                     if (j < depth) {
-                        double v[4];
+                        double v[NQ];
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) v[qq] = fbr_dot6(Sst[j], wA[qq]);
+                        for (int qq = 0; qq < NQ; qq++) v[qq] = fbr_dot6(Sst[j], wA[qq]);
                         const double wj = HASW ? myw[m.fb + lvd[j]] : 1.0;
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) store(d10[qq], m.fb + j, HASW ? v[qq] * wj : v[qq]);
+                        for (int qq = 0; qq < NQ; qq++) store(d10[Q0 + qq], m.fb + j, HASW ? v[qq] * wj : v[qq]);
                     }
                 if (wr.k) {
 #pragma unroll
-                    for (int qq = 0; qq < 4; qq++)
-                        if (d10[qq]) unsafeAtomicAdd(mo + (long)ccol[10 * l + qq] * 64 + lane, fbr_dot6(Ft, wA[qq]));  // this lane's own running sum
+                    for (int qq = 0; qq < NQ; qq++)
+                        if (d10[Q0 + qq]) unsafeAtomicAdd(mo + (long)ccol[10 * l + Q0 + qq] * 64 + lane, fbr_dot6(Ft, wA[qq]));  // this lane's own running sum
                 }
-            }
-            {  // inertia entries: pure moments -- the force rows of the base wrench are structural zeros of the image (never written), the
-               // joint rows need the moment half of S only
-                double nB[6][3];
+            };
+            // inertia entries: pure moments -- the force rows of the base wrench are structural zeros of the image (never written), the joint
+            // rows need the moment half of S only
+            auto moment_group = [&](auto q0c, auto nqc) {
+                constexpr int Q0 = decltype(q0c)::value, NQ = decltype(nqc)::value;
+                double nB[NQ][3];
 #pragma unroll
-                for (int qq = 0; qq < 6; qq++) fbr_unit_moment3(rec, 4 + qq, nB[qq]);
+                for (int qq = 0; qq < NQ; qq++) fbr_unit_moment3(rec, 4 + Q0 + qq, nB[qq]);
 #pragma unroll
                 for (int i = 3; i < 6; i++)
                     if (i < m.fb) {
 #pragma unroll
-                        for (int qq = 0; qq < 6; qq++) store(d10[4 + qq], i, HASW ? nB[qq][i - 3] * myw[i] : nB[qq][i - 3]);
+                        for (int qq = 0; qq < NQ; qq++) store(d10[4 + Q0 + qq], i, HASW ? nB[qq][i - 3] * myw[i] : nB[qq][i - 3]);
                     }
 #pragma unroll
                 for (int j = 0; j < MAXD; j++)
                     if (j < depth) {
-                        double v[6];
+                        double v[NQ];
 #pragma unroll
-                        for (int qq = 0; qq < 6; qq++) v[qq] = Sst[j][3] * nB[qq][0] + Sst[j][4] * nB[qq][1] + Sst[j][5] * nB[qq][2];
+                        for (int qq = 0; qq < NQ; qq++) v[qq] = Sst[j][3] * nB[qq][0] + Sst[j][4] * nB[qq][1] + Sst[j][5] * nB[qq][2];
                         const double wj = HASW ? myw[m.fb + lvd[j]] : 1.0;
 #pragma unroll
-                        for (int qq = 0; qq < 6; qq++) store(d10[4 + qq], m.fb + j, HASW ? v[qq] * wj : v[qq]);
+                        for (int qq = 0; qq < NQ; qq++) store(d10[4 + Q0 + qq], m.fb + j, HASW ? v[qq] * wj : v[qq]);
                     }
                 if (wr.k) {
 #pragma unroll
-                    for (int qq = 0; qq < 6; qq++)
-                        if (d10[4 + qq])
-                            unsafeAtomicAdd(mo + (long)ccol[10 * l + 4 + qq] * 64 + lane, Ft[3] * nB[qq][0] + Ft[4] * nB[qq][1] + Ft[5] * nB[qq][2]);
+                    for (int qq = 0; qq < NQ; qq++)
+                        if (d10[4 + Q0 + qq])
+                            unsafeAtomicAdd(mo + (long)ccol[10 * l + 4 + Q0 + qq] * 64 + lane, Ft[3] * nB[qq][0] + Ft[4] * nB[qq][1] + Ft[5] * nB[qq][2]);
                 }
+            };
+            using std::integral_constant;
+            if constexpr (MAXD > 8 && MAXD <= 10) {  // (the instance that has to fit 256 registers for two waves per SIMD: smaller groups)
+                full_group(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+                full_group(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+                moment_group(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+                moment_group(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+            } else {
+                full_group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+                moment_group(integral_constant<int, 0>{}, integral_constant<int, 6>{});
             }
         };
         auto emit = [&](int, double) {};

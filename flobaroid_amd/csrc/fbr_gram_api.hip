@@ -340,11 +340,13 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     }
     const int ldn = std::max(hm.n, 1) | 1, ldw = hm.rows | 1;
     const size_t plds = ((size_t)3 * 64 * ldn + (dw ? (size_t)64 * ldw : 0) + (k ? (size_t)64 * ldw : 0)) * sizeof(double);
-    const int pblocks = (int)std::min<long>(chb, (long)m->num_cus);
+    // producer grid: two workgroups per CU where the kernel instance fits 256 registers (fbr_kinimg_kernel's launch bounds)
+    const int pgrid_max = (m->kinid.maxlvl <= 10 ? 2 : 1) * m->num_cus;
+    const int pblocks = (int)std::min<long>(chb, (long)pgrid_max);
     const int gwgs = (int)std::min<long>(chb, (long)m->num_cus);
-    if ((rc = h->scr64.ensure((size_t)m->num_cus * h->g64p.nparts * std::max(h->g64p.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
+    if ((rc = h->scr64.ensure((size_t)pgrid_max * h->g64p.nparts * std::max(h->g64p.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
     if (k) {
-        if ((rc = h->mom64.ensure((size_t)m->num_cus * (hm.cols + 1) * 64 * sizeof(double)))) return rc;
+        if ((rc = h->mom64.ensure((size_t)pgrid_max * (hm.cols + 1) * 64 * sizeof(double)))) return rc;
         HIPCHK(hipMemsetAsync(h->mom64.p, 0, (size_t)pblocks * (hm.cols + 1) * 64 * sizeof(double), m->stream));  // (the producer grid of this call)
     }
     const int npw = g.npw;
@@ -414,6 +416,8 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
                 FBR_KINIMG_LAUNCH(4);
             else if (kp.maxlvl <= 8)
                 FBR_KINIMG_LAUNCH(8);
+            else if (kp.maxlvl <= 10)
+                FBR_KINIMG_LAUNCH(10);
             else if (kp.maxlvl <= 12)
                 FBR_KINIMG_LAUNCH(12);
             else

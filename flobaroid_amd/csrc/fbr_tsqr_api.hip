@@ -221,7 +221,8 @@ static TsqrGroupPlan tsqr_group_plan(const FbrHostModel &hm, const int32_t *cols
 static bool tsqr_use_groups(const fbr_model *m, const TsqrGroupPlan &gp, long S)
 {
     const long min_s = (long)m->opt.tsqr_group_min_samples;  // (tests force the path at small sizes) default 24000: measured on WALK-MAN, groups vs one factorisation: 16 k samples 16 vs 15.8 ms, 32 k 18.5 vs 21.4, 64 k 24 vs 32, 125 k 34 vs 52
-    // (a robot that is one chain has ONE group and keeps the plain path.  Measured, round 6: sending it through the row-group path for the sake
+    // (a chain on a FIXED base has ONE group and keeps the plain path; on a floating base the force rows are a second group -- tsqr_force_group --
+    // and the call takes the row-group path: left arm 500 k samples 3.8 instead of 7.3 ms.  Measured, round 6, with ONE group: sending it through the row-group path for the sake
     // of the lane writer -- column-major chunks -- costs the wave-private level-0 kernel more than the writer saves: left arm 500 k samples
     // 8.5 instead of 7.3 ms (folds 6.6 instead of 5.7 ms: one wave per SIMD cannot hide the 16-lines-per-instruction block loads), KUKA 4.07
     // instead of 4.23)
