@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64) void fbr_kinfd_kernel(DevModel m, DevKinId p, l
 // ------------------------------------------------------------------------------------------------
 // A workgroup = nparts waves sharing one block of 64 samples (their states are staged once): wave w walks part w of the tree.
 template <int MAXD>
-__global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS) void fbr_kinwrite_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, const double *__restrict__ q,
+__global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void fbr_kinwrite_kernel(DevModel m, DevKinId p, DevKinWrite wr, long S, const double *__restrict__ q,
                                                           const double *__restrict__ dq, const double *__restrict__ ddq, const double *__restrict__ bv,
                                                           const double *__restrict__ ba, const double *__restrict__ rpy, const double *__restrict__ sign,
                                                           const double *__restrict__ rhs, const double *__restrict__ wts, double *__restrict__ scratch)

@@ -666,6 +666,8 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
                 FBR_KINWRITE_LAUNCH(4);
             else if (kp.maxlvl <= 8)
                 FBR_KINWRITE_LAUNCH(8);
+            else if (kp.maxlvl <= 10)
+                FBR_KINWRITE_LAUNCH(10);
             else if (kp.maxlvl <= 12)
                 FBR_KINWRITE_LAUNCH(12);
             else
