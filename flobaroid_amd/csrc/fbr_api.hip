@@ -9,8 +9,12 @@ thread_local std::string g_fbr_err;
 
 // ------------------------------------------------------------------------------------------------
 // 101 (round 6): fbr_topology.joint_type, the num_samples argument of fbr_gram_program_info / fbr_model_link_merge_info (both added in
-// round 5 under 100), option "fused_id".  flobaroid_amd/_lib.py refuses a library of another version than the header it was written for.
+// round 5 under 100), option "fused_id"; 102: fbr_gram_lane_info, options "gram_lane" / "gram_force_tiles" / "tsqr_force_group".
+// flobaroid_amd/_lib.py refuses a library of another version than the header it was written for.
 extern "C" int fbr_version(void) { return FBR_VERSION; }
+
+// (dispatched once on each of a model's two Gram streams at creation: see create_model)
+__global__ void fbr_noop_kernel() {}
 
 // The HIP runtime does not survive fork(): a child that inherits an initialised runtime hangs or fails in its first call.  The
 // reference's multi-process users build one Model per worker AFTER the fork (analyticalGradient.py:188-210); this records the process
@@ -93,6 +97,12 @@ static int create_model(const fbr_topology *t, int device, fbr_model **out, bool
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, least));
+        // HIP binds a stream to a hardware queue at its first dispatch: both streams of the Gram pass dispatch once HERE, so that their queues do not
+        // depend on which other streams (TSQR trees, copies, the caller's) were used first -- seen in bench.py, round 6: the grouped Gram after a
+        // masked TSQR call 13.3 instead of 5.2 ms when the producer stream's first kernel came after the TSQR's side streams'
+        hipLaunchKernelGGL(fbr_noop_kernel, dim3(1), dim3(64), 0, m->own_stream);
+        hipLaunchKernelGGL(fbr_noop_kernel, dim3(1), dim3(64), 0, m->side);
+        HIPCHK(hipGetLastError());
     }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming));

@@ -87,3 +87,98 @@ def test_an_engine_destroyed_after_a_reduced_pass_leaves_the_next_one_working():
     eng = Engine(load_topo("kuka_lwr4"))
     assert np.isfinite(eng.gram(random_states(load_topo("kuka_lwr4"), 100, rng, False))).all()
     eng.close()
+
+
+@pytest.mark.parametrize("name,floating", [("walkman_apriori", True), ("walkman_left_arm", True), ("kuka_lwr4", False)])
+@pytest.mark.parametrize("mode", ["direct", "reduced"])
+def test_gram_lane_and_force_tiles_are_switches_not_results(name, floating, mode):
+    """Round 6's Gram pass over sample-contiguous images (options gram_lane, gram_force_tiles; fbr.h fbr_gram_lane_info): on or off, with
+    and without the force tiles, the Gram is the oracle's -- with row weights, without a rhs column, with a sample count that fills no whole
+    block, accumulated over two calls, with a base-wrench-only row mask and as a submission; the info call says which pass a batch takes
+    and what it executes."""
+    import torch
+
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    t = load_topo(name)
+    om = OracleModel(t, floating=floating)
+    rng = np.random.default_rng(61)
+    S = 64 * 9 + 37
+    st = random_states(t, S, rng, floating, use_limits=True)
+    Y = om.regressor(st)
+    tau = rng.standard_normal((Y.shape[0], 1))
+    w = 0.5 + rng.random(Y.shape[0])
+    A = np.hstack([Y, tau])
+    base = {"reduce_min_work": 0 if mode == "reduced" else 1e30}
+    got = {}
+    for key, opts in (("lane", {}), ("no_force_tiles", {"gram_force_tiles": 0}), ("images", {"gram_lane": 0})):
+        eng = Engine(t, floating=floating, options=dict(base, **opts))
+        info = eng.gram_lane_info(1, S)
+        # (all 480 columns of WALK-MAN need a tile program in two parts: the pass over per-sample images whatever the switch says)
+        inside = not (name == "walkman_apriori" and mode == "direct")
+        assert info["active"] == (key != "images" and inside)
+        if key == "lane" and inside:
+            assert (info["force_tiles"] >= 1) == floating and info["stages"] >= 1 and info["block_image_bytes"] == 8192 * info["tile_rows"]
+            assert info["balanced_pair_levels"] <= info["busiest_wave_pair_levels"] <= info["balanced_pair_levels"] + info["levels"]
+            lane_mfma = info["mfma_per_block"]
+        if key == "no_force_tiles" and inside:
+            assert info["force_tiles"] == 0 and (info["mfma_per_block"] > lane_mfma) == floating
+        G = eng.gram(st, rhs=tau)
+        assert _rel(G, A.T @ A) <= 1e-12 and np.array_equal(G, G.T) and np.array_equal(G, eng.gram(st, rhs=tau))
+        Gw = eng.gram(st, rhs=tau, w=w)
+        assert _rel(Gw, (A * w[:, None]).T @ (A * w[:, None])) <= 1e-12
+        G0 = eng.gram(st)
+        assert _rel(G0, Y.T @ Y) <= 1e-12
+        h = 64 * 4 + 5
+        first = {k: v[:h] for k, v in st.items()}
+        second = {k: v[h:] for k, v in st.items()}
+        G2 = eng.gram(second, rhs=tau[h * om.rows:], out=eng.gram(first, rhs=tau[: h * om.rows]), accumulate=True)
+        assert _rel(G2, A.T @ A) <= 1e-12
+        if floating:   # base-wrench-only identification: every joint row switched off
+            wb = np.zeros((S, om.rows))
+            wb[:, :6] = 1.0 + rng.random((S, 6))
+            wb = wb.reshape(-1)
+            Gb = eng.gram(st, rhs=tau, w=wb)
+            assert _rel(Gb, (A * wb[:, None]).T @ (A * wb[:, None])) <= 1e-12
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in st.items()}
+        out = torch.zeros((om.P + 1, om.P + 1), dtype=torch.float64, device="cuda")
+        eng.wait(eng.gram_submit(dev, out, rhs=torch.from_numpy(tau).cuda()))
+        assert np.array_equal(out.cpu().numpy(), G)
+        got[key] = G
+        eng.close()
+    assert _rel(got["lane"], got["images"]) <= 1e-13 and _rel(got["no_force_tiles"], got["images"]) <= 1e-13
+
+
+@pytest.mark.parametrize("name", ["walkman_apriori", "walkman_left_arm"])
+def test_tsqr_force_group_is_a_switch_not_a_result(name):
+    """The force rows of a floating base as a row group of their own (option tsqr_force_group): the same sign-normalised factor with and
+    without it, fewer MFMAs with it -- also for a column subset and with row weights."""
+    import scipy.linalg as sla
+
+    from flobaroid_amd._lib import Engine
+    from oracle.oracle import OracleModel
+
+    t = load_topo(name)
+    om = OracleModel(t, floating=True)
+    rng = np.random.default_rng(62)
+    S = 1200
+    st = random_states(t, S, rng, True, use_limits=True)
+    Y = om.regressor(st)
+    tau = rng.standard_normal((Y.shape[0], 1))
+    w = 0.5 + rng.random(Y.shape[0])
+    Go = np.hstack([Y, tau]).T @ np.hstack([Y, tau])
+    rank = int(np.linalg.matrix_rank(Go[: om.P, : om.P]))
+    cols = np.sort(sla.qr(Go[: om.P, : om.P], pivoting=True, mode="r")[1][: rank - 3]).astype(np.int32)
+    norm = lambda R: R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
+    res = {}
+    for fg in (1, 0):
+        eng = Engine(t, floating=True, options={"tsqr_group_min_samples": 1, "tsqr_force_group": fg})
+        R = eng.tsqr(st, rhs=tau)
+        assert np.all(np.tril(R, -1) == 0) and _rel(R.T @ R, Go) <= 1e-11
+        Aw = np.hstack([Y[:, cols], tau]) * w[:, None]
+        Rc = eng.tsqr(st, rhs=tau, w=w, cols=cols)
+        assert _rel(Rc.T @ Rc, Aw.T @ Aw) <= 1e-11
+        res[fg] = (norm(Rc), eng.tsqr_work_info(1000000, k=1)["flop"])
+        eng.close()
+    assert _rel(res[1][0], res[0][0]) <= 1e-9 and res[1][1] < res[0][1]
