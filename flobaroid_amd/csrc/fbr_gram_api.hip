@@ -315,7 +315,10 @@ static int get_gram64(fbr_model *m, GramHolder *h)
 
 // One call of the fused pass through fbr_kinimg_kernel / fbr_gram64_kernel (device-resident inputs, one group, k <= 1); everything on the
 // model's stream.  G has been cleared / holds the running sum.
-static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const double *drhs, const double *dw, int k, double *G, bool base_only)
+// h2d_chunked: d / drhs / dw are PINNED HOST pointers: every chunk is copied into one of two staging buffers on the copy stream while the
+// kernels of the chunk before run (the rate including the transfer of the states).
+static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const double *drhs, const double *dw, int k, double *G, bool base_only,
+                       bool h2d_chunked)
 {
     const FbrHostModel &hm = m->hm;
     FbrGram64 &g = h->g64;
@@ -375,9 +378,63 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
     HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     int launches = 0, first_wgs = 0;
+    const size_t stage_per = (size_t)3 * hm.n + (hm.floating ? 15 : 0) + (size_t)hm.rows * k + (dw ? hm.rows : 0);  // doubles per staged sample
+    if (h2d_chunked) {
+        for (int b = 0; b < 2; b++)
+            if ((rc = m->st_chunk[b].ensure(std::max<size_t>(1, (size_t)chb * 64 * stage_per) * sizeof(double)))) return rc;
+        if (!m->copy) {  // (a priority level of its own: see the per-sample-image pass below)
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, greatest));
+        }
+        HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+    }
+    // the states of chunk c in device memory: the caller's arrays, or staging buffer (c & 1) filled on the copy stream
+    struct Staged {
+        DevStates dc;
+        long o;
+        const double *rhs, *w;
+    };
+    auto stage = [&](long c, Staged &out) -> int {
+        const long s0 = c * chb * 64, cs = std::min(chb * 64, S - s0);
+        const int b = (int)(c & 1);
+        out.dc = d;
+        out.o = s0;
+        out.rhs = drhs;
+        out.w = dw;
+        if (!h2d_chunked) return FBR_OK;
+        // the buffer's last reader is the producer launch of the chunk two before (or of an earlier call: the event is simply complete then)
+        HIPCHK(hipStreamWaitEvent(m->copy, m->ev_pack_rec[b] ? m->ev_pack[b] : m->ev_fork, 0));
+        ProfScope ps(m, FBR_PROF_H2D, m->copy);
+        double *p = m->st_chunk[b].as<double>();
+        auto put = [&](const double *src, size_t per, const double **dst) -> int {
+            *dst = nullptr;
+            if (!src || per == 0) return FBR_OK;
+            HIPCHK(hipMemcpyAsync(p, src + (size_t)s0 * per, (size_t)cs * per * sizeof(double), hipMemcpyHostToDevice, m->copy));
+            *dst = p;
+            p += (size_t)cs * per;
+            return FBR_OK;
+        };
+        int r3;
+        if ((r3 = put(d.q, hm.n, &out.dc.q)) || (r3 = put(d.dq, hm.n, &out.dc.dq)) || (r3 = put(d.ddq, hm.n, &out.dc.ddq)) ||
+            (r3 = put(d.bv, 6, &out.dc.bv)) || (r3 = put(d.ba, 6, &out.dc.ba)) || (r3 = put(d.rpy, 3, &out.dc.rpy)) ||
+            (r3 = put(drhs, (size_t)hm.rows * k, &out.rhs)) || (r3 = put(dw, hm.rows, &out.w)))
+            return r3;
+        out.o = 0;
+        HIPCHK(hipEventRecord(m->ev_h2d[b], m->copy));
+        return FBR_OK;
+    };
+    Staged cur, nxt;
+    if (S > 0 && (rc = stage(0, nxt))) return rc;
     for (long b0 = 0; b0 * 64 < S; b0 += chb, launches++) {
         const long s0 = b0 * 64, cs = std::min(chb * 64, S - s0), nb = (cs + 63) / 64;
         const int b = launches & 1;
+        cur = nxt;
+        if ((b0 + chb) * 64 < S && (rc = stage(launches + 1, nxt))) return rc;  // the copy of the next chunk is enqueued before this chunk's kernels
+        if (h2d_chunked) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_h2d[b], 0));
+        const DevStates &dc = cur.dc;
+        const long so = cur.o;
+        const double *crhs = cur.rhs, *cw = cur.w;
         DevKinWrite kw;
         kw.lcol10 = h->d64_lcol;
         kw.colrec = nullptr;
@@ -401,9 +458,9 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     do {                                                                                                                                         \
         HIPCHK(hipFuncSetAttribute((const void *)fbr_kinimg_kernel<D, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                 \
         hipLaunchKernelGGL((fbr_kinimg_kernel<D, W>), dim3(pblocks), dim3(64 * h->g64p.nparts), plds, m->stream, m->dm, kp, kw, cs, g.blk_doubles,       \
-                           d.q + s0 * hm.n, d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,    \
-                           d.rpy ? d.rpy + s0 * 3 : nullptr, drhs ? drhs + (size_t)s0 * hm.rows * k : nullptr,                                    \
-                           dw ? dw + (size_t)s0 * hm.rows : nullptr, h->scr64.as<double>(), k ? h->mom64.as<double>() : nullptr);                 \
+                           dc.q + so * hm.n, dc.dq + so * hm.n, dc.ddq + so * hm.n, dc.bv ? dc.bv + so * 6 : nullptr, dc.ba ? dc.ba + so * 6 : nullptr, \
+                           dc.rpy ? dc.rpy + so * 3 : nullptr, crhs ? crhs + (size_t)so * hm.rows * k : nullptr,                                   \
+                           cw ? cw + (size_t)so * hm.rows : nullptr, h->scr64.as<double>(), k ? h->mom64.as<double>() : nullptr);                  \
     } while (0)
 #define FBR_KINIMG_LAUNCH(D)            \
     do {                                \
@@ -425,6 +482,10 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
 #undef FBR_KINIMG_LAUNCH2
 #undef FBR_KINIMG_LAUNCH
             HIPCHK(hipGetLastError());
+            if (h2d_chunked) {  // (the staging buffer may be refilled once this launch is through)
+                HIPCHK(hipEventRecord(m->ev_pack[b], m->stream));
+                m->ev_pack_rec[b] = true;
+            }
         }
         // the accumulators are carried from chunk to chunk by workgroup index: every chunk but a shorter last one starts the same grid
         const int wgs = (int)std::min<long>(nb, (long)gwgs);
@@ -560,13 +621,14 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
     if (!accumulate) HIPCHK(hipMemsetAsync(G, 0, gcount * sizeof(double), m->stream));
     // the pass over sample-contiguous images (fbr_gram64.h) where the call allows it
     bool lane_pass = false;
-    if (S > 0 && m->opt.gram_lane != 0 && ngroups == 1 && !h2d_chunked && !m->opt.gram_timing && !m->opt.gram_serial &&
+    if (S > 0 && m->opt.gram_lane != 0 && ngroups == 1 && !m->opt.gram_timing && !m->opt.gram_serial &&
         k <= 1 && (k == 0 || moments) && !hm.fric && d.q) {
         if ((rc = get_gram64(m, h))) return rc;
         lane_pass = h->g64_state == 1;
     }
     if (lane_pass) {
-        if ((rc = gram64_pass(m, h, d, drhs, dw, k, G, base_only && h->g64.base_stages > 0))) return rc;
+        if ((rc = gram64_pass(m, h, d, drhs, dw, k, G, base_only && h->g64.base_stages > 0, h2d_chunked))) return rc;
+        if (!async && h2d_chunked && m->copy) HIPCHK(hipStreamSynchronize(m->copy));
     } else if (S > 0) {
         const int T = h->prog.T;
         const bool two_per_cu = h->prog.cfg == FBR_CFG_TWO_PER_CU;
