@@ -1260,6 +1260,12 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
         Gg = eng4.gram_grouped(sub, ng)
         G1 = eng4.gram(sub)
         t_gg = timed(lambda: eng4.gram_grouped(sub, ng, out=Gg), reps=10)  # (out=: no 118 MB allocation inside the timed calls)
+        eng4.profile_enable(True)
+        eng4.profile_get()
+        eng4.gram_grouped(sub, ng, out=Gg)
+        torch.cuda.synchronize()
+        prof_gg = {k_: round(v_[0], 3) for k_, v_ in eng4.profile_get().items() if v_[1]}
+        eng4.profile_enable(False)
         eng4.set_option("reduce_grouped_min_samples", 1e18)  # (no group is that long: the grouped pass over all columns)
         try:
             t_gg_all = timed(lambda: eng4.gram_grouped(sub, ng, out=Gg), reps=10)
@@ -1267,7 +1273,7 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
             eng4.set_option("reduce_grouped_min_samples", 512)
         res["walkman_64_candidates_x_2000_grouped_gram"] = {
             "groups": ng, "samples_per_group": per, "grouped_gram_ms": t_gg * 1e3, "samples_per_s": ng * per / t_gg,
-            "grouped_gram_ms_over_all_columns": t_gg_all * 1e3,
+            "grouped_gram_ms_over_all_columns": t_gg_all * 1e3, "kernel_ms_per_call": prof_gg,
             "relerr_sum_of_groups_vs_one_batch": float(torch.linalg.norm(Gg.sum(dim=0) - G1) / torch.linalg.norm(G1))}
     return res
 

@@ -13,12 +13,14 @@
 //     EQUAL to the global one (one contiguous 4 KB DMA per slab);
 //   * producer fbr_kinimg_kernel: one lane per sample, kinematics fused in, the tree cut into parts for the waves of a workgroup
 //     (fbr_kinid.h); every value of a (column, row) goes out as two 256-byte runs per wave;  tau's products with the columns (k <= 1) are
-//     accumulated on the way: per column one dot product per joint row it already holds, a wave reduction per block;
+//     accumulated on the way: one six-term dot product per column against the link's t_base + sum_j S_j t_j, added to the lane's own running
+//     sum in HBM (no-return atomics, one adder per address: deterministic);
 //   * consumer fbr_gram64_kernel: one workgroup of 8 waves per CU, the accumulators of the tile pairs in registers for the whole pass;
-//     a stage = (a few consecutive row levels, 32 samples): the slabs of the tiles that have the levels arrive by LDS-DMA into one of two buffers while the
-//     MFMAs of the stage before run; a pair takes part in the levels below its common depth; 8 MFMAs per pair and stage;
+//     a stage = (a few consecutive row levels, 32 samples): the slabs of the tiles that have the levels arrive by LDS-DMA into one of two
+//     buffers while the MFMAs of the stage before run; a pair takes part in the levels of its range; 8 MFMAs per pair, level and half block;
 //   * the force rows of the base wrench (levels 0 .. 2) run on tiles of their own that hold the columns with a force only (fbr_gram64_build).
-// Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), one part, device-resident inputs, one group.
+// Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), a tile program in one part, one sample group.
+// Inputs resident in HBM or pinned host memory (staged chunk by chunk); row weights; a base-wrench-only row mask runs the base stages only.
 #pragma once
 // the swizzle of column slot c inside its 32-sample run (see the image layout above)
 #define FBR_G64_SWZ(c) (2 * ((c) & 15))

@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256) void fbr_expand_gram_kernel(int cols, int k, i
                                                                int accumulate)
 {
     const int Pa = cols + k;
+    Gred += (long)blockIdx.y * Pra * Pa;  // blockIdx.y: sample group (fbr_gram_grouped: one Gram and one W per group)
+    G += (long)blockIdx.y * Pa * Pa;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pa * Pa; e += (long)gridDim.x * blockDim.x) {
         const int i = (int)(e / Pa), j = (int)(e - (long)i * Pa);
         if (i > j) continue;  // the upper triangle is computed, the lower one mirrored: G is symmetric to the bit, like the fused Gram's
@@ -51,6 +53,8 @@ __global__ __launch_bounds__(256) void fbr_expand_rows_kernel(int cols, int k, i
                                                                const double *__restrict__ Ev, const double *__restrict__ Rred, double *__restrict__ dst,
                                                                int ldd, const int *__restrict__ colmap, int Pout)
 {
+    Rred += (long)blockIdx.y * Pra * Pra;  // blockIdx.y: sample group (a dense [Pra x ldd] block of dst per group)
+    dst += (long)blockIdx.y * Pra * ldd;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)Pra * Pout; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / Pout), jj = (int)(e - (long)r * Pout);
         const int j = colmap ? colmap[jj] : jj;
@@ -912,12 +916,15 @@ static int gram_via_red(fbr_model *m, int which, const fbr_states *st, const dou
         G = m->g_tmp.as<double>();
         if (accumulate) HIPCHK(hipMemcpyAsync(G, G_out, cnt * sizeof(double), hipMemcpyHostToDevice, m->stream));
     }
-    if ((rc = m->red_w.ensure((size_t)Pra * Pa * sizeof(double)))) return rc;
-    for (int g = 0; g < ngroups; g++) {
-        hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(512), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
-                           m->E_val[which], Gred + (size_t)g * Pra * Pra, m->red_w.as<double>(), Pa, (const int *)nullptr, Pa);
-        hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(1024), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
-                           m->E_val[which], m->red_w.as<double>(), G + (size_t)g * Pa * Pa, accumulate ? 1 : 0);
+    // all groups in two launches (one W = G_red E per group): 128 dependent launches for 64 candidate trajectories were up to two thirds of the
+    // grouped call (bench.py other_configs: 12.7 ms on a run whose stream-to-queue mapping made a launch 68 us, 5.2 ms on the next)
+    if ((rc = m->red_w.ensure((size_t)Pra * Pa * ngroups * sizeof(double)))) return rc;
+    for (int g0 = 0; g0 < ngroups; g0 += 32768) {
+        const int ng = std::min(32768, ngroups - g0);
+        hipLaunchKernelGGL(fbr_expand_rows_kernel, dim3(ng > 1 ? 64 : 512, ng), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
+                           m->E_val[which], Gred + (size_t)g0 * Pra * Pra, m->red_w.as<double>() + (size_t)g0 * Pra * Pa, Pa, (const int *)nullptr, Pa);
+        hipLaunchKernelGGL(fbr_expand_gram_kernel, dim3(ng > 1 ? 128 : 1024, ng), dim3(256), 0, m->stream, m->hm.cols, k, Pra, m->E_beg[which], m->E_row[which],
+                           m->E_val[which], m->red_w.as<double>() + (size_t)g0 * Pra * Pa, G + (size_t)g0 * Pa * Pa, accumulate ? 1 : 0);
     }
     HIPCHK(hipGetLastError());
     if (async) {
