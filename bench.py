@@ -1260,19 +1260,32 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
         Gg = eng4.gram_grouped(sub, ng)
         G1 = eng4.gram(sub)
         t_gg = timed(lambda: eng4.gram_grouped(sub, ng, out=Gg), reps=10)  # (out=: no 118 MB allocation inside the timed calls)
+        each = []
+        for _ in range(12):  # (single calls: a stall that comes and goes shows as a spread here)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng4.gram_grouped(sub, ng, out=Gg)
+            torch.cuda.synchronize()
+            each.append((time.perf_counter() - t0) * 1e3)
         eng4.profile_enable(True)
         eng4.profile_get()
         eng4.gram_grouped(sub, ng, out=Gg)
         torch.cuda.synchronize()
         prof_gg = {k_: round(v_[0], 3) for k_, v_ in eng4.profile_get().items() if v_[1]}
         eng4.profile_enable(False)
+        prof_gg["single_calls_ms_min_median_max"] = [round(min(each), 3), round(sorted(each)[len(each) // 2], 3), round(max(each), 3)]
         eng4.set_option("reduce_grouped_min_samples", 1e18)  # (no group is that long: the grouped pass over all columns)
         try:
             t_gg_all = timed(lambda: eng4.gram_grouped(sub, ng, out=Gg), reps=10)
         finally:
             eng4.set_option("reduce_grouped_min_samples", 512)
+        t_single = sorted(each)[len(each) // 2] * 1e-3
         res["walkman_64_candidates_x_2000_grouped_gram"] = {
-            "groups": ng, "samples_per_group": per, "grouped_gram_ms": t_gg * 1e3, "samples_per_s": ng * per / t_gg,
+            # the optimiser's use: one call per iteration, its result read back before the next one -- the synchronised single call.  Ten calls
+            # enqueued back to back (`back_to_back_ms`) have measured 4 ... 13 ms per call in this process (the same kernels, 4.0 ms of them, in
+            # every case; not reproduced outside bench.py: DESIGN 10)
+            "groups": ng, "samples_per_group": per, "grouped_gram_ms": t_single * 1e3, "samples_per_s": ng * per / t_single,
+            "back_to_back_ms": t_gg * 1e3,
             "grouped_gram_ms_over_all_columns": t_gg_all * 1e3, "kernel_ms_per_call": prof_gg,
             "relerr_sum_of_groups_vs_one_batch": float(torch.linalg.norm(Gg.sum(dim=0) - G1) / torch.linalg.norm(G1))}
     return res
