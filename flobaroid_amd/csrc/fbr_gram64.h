@@ -381,12 +381,15 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void f
     double *st = sw + (HASW ? 64 * ldw : 0);                                             // st [64][ldw] w^2 tau (k == 1)
     double *scr = scratch + ((long)blockIdx.x * wr.nparts + part) * p.nslots * FBR_LINK_REC * 64 + lane;
     double *mo = mom ? mom + (long)blockIdx.x * (wr.cols + 1) * 64 : nullptr;  // [cols + 1][64 lanes]
-    const long nblk = (S + 63) >> 6;
+    // sample groups (fbr_gram_grouped): every group starts a block -- block b = (group b / bpg, block b % bpg of the group)
+    const long Sg = wr.group_samples > 0 ? wr.group_samples : S, bpg = (Sg + 63) >> 6;
+    const long nblk = (S / Sg) * bpg;
     const fbr_clong_ptr cdst = (fbr_clong_ptr)(unsigned long)wr.dst;
     const fbr_cint_ptr ccol = (fbr_cint_ptr)(unsigned long)(wr.lcol10 + (long)part * 10 * m.L);
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const long base = blk << 6;
-        const int valid = (int)min(64L, S - base);
+        const long grp = blk / bpg, lb = blk - grp * bpg;
+        const long base = grp * Sg + (lb << 6);
+        const int valid = (int)min(64L, Sg - (lb << 6));
         __syncthreads();
         {
             const long off = base * n;
@@ -572,6 +575,18 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void f
     }
 }
 
+// The positions of sample slots valid .. 63 of the LAST block of every group (blockIdx.y; bpg blocks per group): groups whose sample count is
+// no multiple of 64 end in a block the producer fills partly, and an image buffer is reused from call to call.
+__global__ __launch_bounds__(256) void fbr_gram64_tail_zero_kernel(double *__restrict__ img, long blk_doubles, long bpg, int ntr, int valid)
+{
+    double *blk = img + ((long)blockIdx.y * bpg + bpg - 1) * blk_doubles;
+    const int per = 16 * (64 - valid);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)ntr * per; e += (long)gridDim.x * blockDim.x) {
+        const int tr = (int)(e / per), r = (int)(e - (long)tr * per), c = r / (64 - valid), sl = valid + r % (64 - valid);
+        blk[(long)tr * 1024 + (sl >> 5) * 512 + c * 32 + ((sl & 31) ^ FBR_G64_SWZ(c))] = 0.0;
+    }
+}
+
 // rhs moments of a call -> G (k == 1): one workgroup per column sums the per-lane running sums of the producer's workgroups in a fixed order
 __global__ __launch_bounds__(256) void fbr_gram64_mom_reduce_kernel(int P, int nwg, const double *__restrict__ mom, double *__restrict__ G)
 {
@@ -621,7 +636,8 @@ __global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr
     for (int i = tid; i < FBR_WPB * MW; i += FBR_WPB * 64) wm[i] = g.wmeta[i];
     for (int i = tid; i <= g.nstage; i += FBR_WPB * 64) stl[i] = g.stage_lev[i];
     fbr_d4 acc[NPW];
-    double *pp = partial + (((long)blockIdx.x * FBR_WPB + wave) * NPW) * 256;
+    img += (long)blockIdx.y * nblk * g.blk_doubles;  // blockIdx.y: sample group (nblk blocks each, fbr_gram_grouped)
+    double *pp = partial + ((((long)blockIdx.y * gridDim.x + blockIdx.x) * FBR_WPB + wave) * NPW) * 256;
     if (carry) {
 #pragma unroll
         for (int q = 0; q < NPW; q++) acc[q] = (fbr_d4){pp[q * 256 + lane], pp[q * 256 + 64 + lane], pp[q * 256 + 128 + lane], pp[q * 256 + 192 + lane]};

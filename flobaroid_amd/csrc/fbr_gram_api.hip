@@ -317,6 +317,40 @@ static int get_gram64(fbr_model *m, GramHolder *h)
     return FBR_OK;
 }
 
+// [0, workgroups]: the one-part workgroup table fbr_gram_reduce_kernel reads, uploaded once per grid size a holder has used
+static int gram64_wg_table(GramHolder *h, int wgs, const int **out)
+{
+    auto it = h->d64_wb.find(wgs);
+    if (it == h->d64_wb.end()) {
+        std::vector<int> wb{0, wgs};
+        const int *dwb = nullptr;
+        if (int rc = upload(h->pool, wb, &dwb)) return rc;
+        it = h->d64_wb.emplace(wgs, dwb).first;
+    }
+    *out = it->second;
+    return FBR_OK;
+}
+
+// the two image buffers of a holder for chunks of chb blocks, and the producer's destination words inside them
+static int gram64_ensure_images(fbr_model *m, GramHolder *h, long chb)
+{
+    const FbrGram64 &g = h->g64;
+    int rc;
+    if (chb <= h->img64_blocks) return FBR_OK;
+    for (int b = 0; b < 2; b++) {
+        if ((rc = h->img64[b].ensure((size_t)chb * g.blk_doubles * sizeof(double)))) return rc;
+        HIPCHK(hipMemsetAsync(h->img64[b].p, 0, h->img64[b].bytes, m->stream));  // structural zeros and padding slots are never written
+        std::vector<long long> dst(h->g64p.rel.size(), 0);
+        for (size_t i = 0; i < dst.size(); i++)
+            if (h->g64p.rel[i]) dst[i] = (long long)(uintptr_t)h->img64[b].p + (h->g64p.rel[i] & ~(1LL << 62));
+        if ((rc = h->dst64[b].ensure(dst.size() * sizeof(long long)))) return rc;
+        HIPCHK(hipMemcpyAsync(h->dst64[b].p, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));  // (dst is a local)
+    }
+    h->img64_blocks = chb;
+    return FBR_OK;
+}
+
 // One call of the fused pass through fbr_kinimg_kernel / fbr_gram64_kernel (device-resident inputs, one group, k <= 1); everything on the
 // model's stream.  G has been cleared / holds the running sum.
 // h2d_chunked: d / drhs / dw are PINNED HOST pointers: every chunk is copied into one of two staging buffers on the copy stream while the
@@ -332,19 +366,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     const long ch = 64L * std::max(1L, std::min<long>(((long)chunk_size(m, S) + 63) / 64, (long)((size_t)3 * 1024 * 1024 * 1024 / ((size_t)g.blk_doubles * 8))));
     long chb = std::min((S + 63) / 64, ch / 64);  // blocks per chunk: whole rounds of the chip (both kernels walk blocks workgroup by workgroup)
     if (chb > m->num_cus) chb = chb / m->num_cus * m->num_cus;
-    if (chb > h->img64_blocks) {
-        for (int b = 0; b < 2; b++) {
-            if ((rc = h->img64[b].ensure((size_t)chb * g.blk_doubles * sizeof(double)))) return rc;
-            HIPCHK(hipMemsetAsync(h->img64[b].p, 0, h->img64[b].bytes, m->stream));  // structural zeros and padding slots are never written
-            std::vector<long long> dst(h->g64p.rel.size(), 0);
-            for (size_t i = 0; i < dst.size(); i++)
-                if (h->g64p.rel[i]) dst[i] = (long long)(uintptr_t)h->img64[b].p + (h->g64p.rel[i] & ~(1LL << 62));
-            if ((rc = h->dst64[b].ensure(dst.size() * sizeof(long long)))) return rc;
-            HIPCHK(hipMemcpyAsync(h->dst64[b].p, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice, m->stream));
-            HIPCHK(hipStreamSynchronize(m->stream));  // (dst is a local)
-        }
-        h->img64_blocks = chb;
-    }
+    if ((rc = gram64_ensure_images(m, h, chb))) return rc;
     const int ldn = std::max(hm.n, 1) | 1, ldw = hm.rows | 1;
     const size_t plds = ((size_t)3 * 64 * ldn + (dw ? (size_t)64 * ldw : 0) + (k ? (size_t)64 * ldw : 0)) * sizeof(double);
     // producer grid: two workgroups per CU where the kernel instance fits 256 registers (fbr_kinimg_kernel's launch bounds)
@@ -449,6 +471,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         kw.has_w = dw ? 1 : 0;
         kw.flev = g.flev;
         kw.base_only = base_only ? 1 : 0;
+        kw.group_samples = 0;
         kw.nparts = h->g64p.nparts;
         for (int pq = 0; pq < FBR_KINWRITE_PARTS; pq++) {
             kw.part_nsteps[pq] = h->g64p.nsteps[pq];
@@ -510,14 +533,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         dr.wpg = first_wgs;
         dr.npw = npw;
         dr.slot_tiles = h->d64_slot_tiles;
-        if (h->d64_wgbegin == nullptr || h->g64_wb_wgs != first_wgs) {  // [0, workgroups]: uploaded when the grid of a call differs from the last one's
-            std::vector<int> wb{0, first_wgs};
-            const int *dwb = nullptr;
-            if ((rc = upload(h->pool, wb, &dwb))) return rc;
-            h->d64_wgbegin = dwb;
-            h->g64_wb_wgs = first_wgs;
-        }
-        dr.wg_begin = h->d64_wgbegin;
+        if ((rc = gram64_wg_table(h, first_wgs, &dr.wg_begin))) return rc;
         dr.tilecol = h->d64_tilecol;
         hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
         HIPCHK(hipGetLastError());
@@ -532,6 +548,133 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         }
     }
     (void)Pa;
+    return FBR_OK;
+}
+
+// blocks a chunk of the sample-contiguous pass may hold (two image buffers of at most 3 GB)
+static long gram64_chunk_blocks(const FbrGram64 &g) { return std::max<long>(1, (long)((size_t)3 * 1024 * 1024 * 1024 / ((size_t)g.blk_doubles * 8))); }
+
+// fbr_gram_grouped through the sample-contiguous pass (k = 0, device-resident inputs): every group starts a block of 64 samples, a group's
+// blocks are shared by wpg workgroups whose partial sums one reduction per group adds up; groups are taken a chunk of whole groups at a time.
+// G: [ngroups][Pa][Pa], cleared.
+static int gram64_grouped_pass(fbr_model *m, GramHolder *h, const DevStates &d, const double *dw, double *G, int ngroups)
+{
+    const FbrHostModel &hm = m->hm;
+    FbrGram64 &g = h->g64;
+    const long S = d.S, Sg = S / ngroups, bpg = (Sg + 63) / 64;
+    const int Pa = hm.cols, npw = g.npw;
+    int rc;
+    const int gpc = (int)std::min<long>(ngroups, std::max<long>(1, gram64_chunk_blocks(g) / bpg));  // groups per chunk
+    if ((rc = gram64_ensure_images(m, h, (long)gpc * bpg))) return rc;
+    const int wpg = (int)std::max<long>(1, std::min<long>(bpg, (long)m->num_cus / std::min(gpc, ngroups)));
+    const int ldn = std::max(hm.n, 1) | 1, ldw = hm.rows | 1;
+    const size_t plds = ((size_t)3 * 64 * ldn + (dw ? (size_t)64 * ldw : 0)) * sizeof(double);
+    const int pgrid_max = (m->kinid.maxlvl <= 10 ? 2 : 1) * m->num_cus;
+    if ((rc = h->scr64.ensure((size_t)pgrid_max * h->g64p.nparts * std::max(h->g64p.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
+    if ((rc = m->partial.ensure((size_t)gpc * wpg * FBR_WPB * npw * 256 * sizeof(double)))) return rc;
+    const size_t glds = (size_t)2 * g.maxact * 512 * sizeof(double) + ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int);
+    DevKinId kp;
+    kp.nsteps = 0;
+    kp.maxlvl = m->kinid.maxlvl;
+    kp.nslots = h->g64p.nslots;
+    kp.ldn = ldn;
+    kp.steps = h->d64_steps;
+    kp.endflush = m->kinid_endflush;
+    DevGram64 dg;
+    dg.NT = g.NT + g.NF;
+    dg.nlev = g.nlev;
+    dg.maxact = g.maxact;
+    dg.npieces = (int)g.pieces.size() / 2;
+    dg.blk_doubles = g.blk_doubles;
+    dg.slab = h->d64_slab;
+    dg.lev_begin = h->d64_levb;
+    dg.pieces = h->d64_pieces;
+    dg.wmeta = h->d64_wmeta;
+    dg.nstage = g.nstage;
+    dg.stage_lev = h->d64_stagelev;
+    typedef void (*g64_fn)(DevGram64, long, const double *, double *, int);
+    const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
+    HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    const int *wgb = nullptr;
+    if ((rc = gram64_wg_table(h, wpg, &wgb))) return rc;
+    int launches = 0;
+    for (int g0 = 0; g0 < ngroups; g0 += gpc, launches++) {
+        const int ng = std::min(gpc, ngroups - g0), b = launches & 1;
+        const long s0 = (long)g0 * Sg, cs = (long)ng * Sg, nb = (long)ng * bpg;
+        DevKinWrite kw;
+        kw.lcol10 = h->d64_lcol;
+        kw.colrec = nullptr;
+        kw.dst = (const long *)h->dst64[b].p;
+        kw.ninert = hm.ninert;
+        kw.cols = hm.cols;
+        kw.k = 0;
+        kw.has_w = dw ? 1 : 0;
+        kw.flev = g.flev;
+        kw.base_only = 0;
+        kw.group_samples = Sg;
+        kw.nparts = h->g64p.nparts;
+        for (int pq = 0; pq < FBR_KINWRITE_PARTS; pq++) {
+            kw.part_nsteps[pq] = h->g64p.nsteps[pq];
+            kw.part_step0[pq] = h->g64p.step0[pq];
+        }
+        const int pblocks = (int)std::min<long>(nb, (long)pgrid_max);
+        if (Sg & 63) {  // every group ends in a block the producer fills partly: what its idle lanes would have written
+            hipLaunchKernelGGL(fbr_gram64_tail_zero_kernel, dim3(16, ng), dim3(256), 0, m->stream, h->img64[b].as<double>(), g.blk_doubles, bpg, g.ntr, (int)(Sg & 63));
+            HIPCHK(hipGetLastError());
+        }
+        {
+            ProfScope ps(m, FBR_PROF_PACK);
+#define FBR_KINIMG_GLAUNCH2(D, W)                                                                                                                 \
+    do {                                                                                                                                         \
+        HIPCHK(hipFuncSetAttribute((const void *)fbr_kinimg_kernel<D, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                 \
+        hipLaunchKernelGGL((fbr_kinimg_kernel<D, W>), dim3(pblocks), dim3(64 * h->g64p.nparts), plds, m->stream, m->dm, kp, kw, cs, g.blk_doubles, \
+                           d.q + s0 * hm.n, d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,    \
+                           d.rpy ? d.rpy + s0 * 3 : nullptr, (const double *)nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,                    \
+                           h->scr64.as<double>(), (double *)nullptr);                                                                            \
+    } while (0)
+#define FBR_KINIMG_GLAUNCH(D)             \
+    do {                                  \
+        if (dw)                           \
+            FBR_KINIMG_GLAUNCH2(D, true); \
+        else                              \
+            FBR_KINIMG_GLAUNCH2(D, false); \
+    } while (0)
+            if (kp.maxlvl <= 4)
+                FBR_KINIMG_GLAUNCH(4);
+            else if (kp.maxlvl <= 8)
+                FBR_KINIMG_GLAUNCH(8);
+            else if (kp.maxlvl <= 10)
+                FBR_KINIMG_GLAUNCH(10);
+            else if (kp.maxlvl <= 12)
+                FBR_KINIMG_GLAUNCH(12);
+            else
+                FBR_KINIMG_GLAUNCH(FBR_KINID_MAXD);
+#undef FBR_KINIMG_GLAUNCH2
+#undef FBR_KINIMG_GLAUNCH
+            HIPCHK(hipGetLastError());
+        }
+        {
+            ProfScope ps(m, FBR_PROF_GRAM);
+            hipLaunchKernelGGL(gk, dim3(wpg, ng), dim3(FBR_WPB * 64), glds, m->stream, dg, bpg, h->img64[b].as<double>(), m->partial.as<double>(), 0);
+            HIPCHK(hipGetLastError());
+        }
+        {
+            ProfScope ps(m, FBR_PROF_REDUCE);
+            DevGram dr = h->dev;
+            dr.wpg = wpg;
+            dr.npw = npw;
+            dr.slot_tiles = h->d64_slot_tiles;
+            dr.wg_begin = wgb;
+            dr.tilecol = h->d64_tilecol;
+            double *Gc = G + (size_t)g0 * Pa * Pa;
+            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, ng), dim3(256), 0, m->stream, dr, m->partial.as<double>(), Gc);
+            if (g.NF > 0) {
+                dr.slot_tiles = h->d64_slot_tiles + (size_t)FBR_WPB * npw * 2;
+                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, ng), dim3(256), 0, m->stream, dr, m->partial.as<double>(), Gc);
+            }
+            HIPCHK(hipGetLastError());
+        }
+    }
     return FBR_OK;
 }
 
@@ -630,7 +773,15 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
         if ((rc = get_gram64(m, h))) return rc;
         lane_pass = h->g64_state == 1;
     }
-    if (lane_pass) {
+    bool lane_grouped = false;
+    if (!lane_pass && S > 0 && m->opt.gram_lane != 0 && ngroups > 1 && k == 0 && !h2d_chunked && !base_only && !m->opt.gram_timing &&
+        !m->opt.gram_serial && !hm.fric && d.q) {
+        if ((rc = get_gram64(m, h))) return rc;
+        lane_grouped = h->g64_state == 1 && (S / ngroups + 63) / 64 <= gram64_chunk_blocks(h->g64);
+    }
+    if (lane_grouped) {
+        if ((rc = gram64_grouped_pass(m, h, d, dw, G, ngroups))) return rc;
+    } else if (lane_pass) {
         if ((rc = gram64_pass(m, h, d, drhs, dw, k, G, base_only && h->g64.base_stages > 0, h2d_chunked))) return rc;
         if (!async && h2d_chunked && m->copy) HIPCHK(hipStreamSynchronize(m->copy));
     } else if (S > 0) {

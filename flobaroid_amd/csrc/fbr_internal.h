@@ -108,10 +108,10 @@ struct GramHolder {
     FbrGram64 g64;
     FbrGram64Producer g64p;   // producer tables (parts, destination words relative to an image buffer)
     const int *d64_slab = nullptr, *d64_levb = nullptr, *d64_pieces = nullptr, *d64_wmeta = nullptr, *d64_lcol = nullptr,
-              *d64_steps = nullptr, *d64_slot_tiles = nullptr, *d64_wgbegin = nullptr, *d64_tilecol = nullptr, *d64_stagelev = nullptr;
+              *d64_steps = nullptr, *d64_slot_tiles = nullptr, *d64_tilecol = nullptr, *d64_stagelev = nullptr;
     DevBuf img64[2], dst64[2], mom64, scr64;
     long img64_blocks = 0;    // capacity of the image buffers in blocks of 64 samples
-    int g64_wb_wgs = -1;      // the grid d64_wgbegin was uploaded for
+    std::map<int, const int *> d64_wb;  // [0, workgroups] tables of the reduction, one per grid a call has used
     struct Deal { const int2 *tab; const int *begin; };
     std::map<int, Deal> deals;  // workgroups per sample group -> device tables of fbr_gram_deal (at most one per count)
 };

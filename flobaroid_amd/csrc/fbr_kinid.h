@@ -256,6 +256,7 @@ struct DevKinWrite {
     int ninert, cols, k, has_w;
     int flev;  // (fbr_kinimg_kernel) base rows below this level go through the force-tile words
     int base_only;  // (fbr_kinimg_kernel) the joint rows carry weight 0 in every sample: not produced
+    long group_samples;  // (fbr_kinimg_kernel) samples per group of a grouped pass (every group starts a block), 0: one group
     int nparts, part_nsteps[FBR_KINWRITE_PARTS], part_step0[FBR_KINWRITE_PARTS];  // wave w of a workgroup walks steps [step0, step0 + nsteps) of p.steps
 };
 #endif

@@ -141,6 +141,16 @@ def test_gram_lane_and_force_tiles_are_switches_not_results(name, floating, mode
             wb = wb.reshape(-1)
             Gb = eng.gram(st, rhs=tau, w=wb)
             assert _rel(Gb, (A * wb[:, None]).T @ (A * wb[:, None])) <= 1e-12
+        # one Gram per group of samples (fbr_gram_grouped): groups that fill no whole block, with row weights
+        ngr = 7
+        Sg = S // ngr
+        stg = {k: v[: ngr * Sg] for k, v in st.items()}
+        wg = w[: ngr * Sg * om.rows]
+        Gg = eng.gram_grouped(stg, ngr, w=wg)
+        for gi in range(ngr):
+            Yg = Y[gi * Sg * om.rows:(gi + 1) * Sg * om.rows] * wg[gi * Sg * om.rows:(gi + 1) * Sg * om.rows, None]
+            assert _rel(Gg[gi], Yg.T @ Yg) <= 1e-12
+        got[key + "_grouped"] = Gg
         dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in st.items()}
         out = torch.zeros((om.P + 1, om.P + 1), dtype=torch.float64, device="cuda")
         eng.wait(eng.gram_submit(dev, out, rhs=torch.from_numpy(tau).cuda()))
@@ -148,6 +158,7 @@ def test_gram_lane_and_force_tiles_are_switches_not_results(name, floating, mode
         got[key] = G
         eng.close()
     assert _rel(got["lane"], got["images"]) <= 1e-13 and _rel(got["no_force_tiles"], got["images"]) <= 1e-13
+    assert _rel(got["lane_grouped"], got["images_grouped"]) <= 1e-13
 
 
 @pytest.mark.parametrize("name", ["walkman_apriori", "walkman_left_arm"])
