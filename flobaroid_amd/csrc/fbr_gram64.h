@@ -19,7 +19,8 @@
 //     a stage = (a few consecutive row levels, 32 samples): the slabs of the tiles that have the levels arrive by LDS-DMA into one of two
 //     buffers while the MFMAs of the stage before run; a pair takes part in the levels of its range; 8 MFMAs per pair, level and half block;
 //   * the force rows of the base wrench (levels 0 .. 2) run on tiles of their own that hold the columns with a force only (fbr_gram64_build).
-// Conditions (else the first pass runs): no friction columns, k <= 1 rhs column (or none), a tile program in one part, one sample group.
+// Conditions (else the first pass runs): k <= 1 rhs column (or none), a tile program in one part; sample groups (fbr_gram_grouped) for k = 0.
+// Friction columns are tiles whose levels are the rows of their own joints.
 // Inputs resident in HBM or pinned host memory (staged chunk by chunk); row weights; a base-wrench-only row mask runs the base stages only.
 #pragma once
 // the swizzle of column slot c inside its 32-sample run (see the image layout above)
@@ -45,6 +46,7 @@ struct FbrGram64 {  // host program
     std::vector<int> slot_tiles; // [2][8 * npw * 2] for the two reductions: main pairs, force pairs (the other kind's slots are -1)
     std::vector<int> tilecol;    // [NT + NF][16] column of each tile slot, -1 = padding
     std::vector<int> fcol_tile, fcol_slot;  // per column: its force tile / slot there, or -1
+    std::vector<int> tile_lo;    // [NT] first level of every main / friction tile
     long mfma_per_block = 0;
     long busiest = 0, balanced = 0;  // sum over the stages of the busiest wave's pair-levels / of ceil(all pair-levels / 8)
 };
@@ -59,15 +61,32 @@ struct FbrGram64 {  // host program
 // force columns is the sum of its two blocks (two reductions, one after the other).  Used when the extra pairs fit the accumulator slots.
 static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram &gp, FbrGram64 &g, bool force_tiles = true)
 {
-    if (gp.T != 1 || hm.fric || (gp.k > 0 && gp.rhs_tiles)) return false;
+    if (gp.T != 1 || (gp.k > 0 && gp.rhs_tiles)) return false;
     const int W = FBR_WPB;
     g.NT = gp.NT;
     g.fb = hm.fb;
     g.npw = gp.cfg.segw * gp.cfg.nseg;
     g.nlev = 0;
-    for (const FbrTile &t : gp.tiles) {
-        if (t.type != 0 || t.friction) return false;
-        g.nlev = std::max(g.nlev, hm.fb + (int)t.tpath.size());
+    // levels of a tile: a main tile has the base-wrench rows and the joints of its path; a FRICTION tile (its columns are non-zero on the row
+    // of their own joint only) just the levels of its own columns' joints -- a contiguous stretch of its path
+    std::vector<int> tlo(gp.NT, 0), thi(gp.NT, 0);
+    for (int t = 0; t < gp.NT; t++) {
+        const FbrTile &tl = gp.tiles[t];
+        if (tl.type != 0) return false;
+        thi[t] = hm.fb + (int)tl.tpath.size();
+        if (tl.friction) {
+            int jmin = (int)tl.tpath.size(), jmax = -1;
+            for (int sl = 0; sl < FBR_TILE; sl++) {
+                if (tl.col[sl] < 0) continue;
+                const int jnt = hm.coldesc[tl.col[sl]].joint;
+                for (int j = 0; j < (int)tl.tpath.size(); j++)
+                    if (tl.tpath[j] == jnt) jmin = std::min(jmin, j), jmax = std::max(jmax, j);
+            }
+            if (jmax < 0) return false;
+            tlo[t] = hm.fb + jmin;
+            thi[t] = hm.fb + jmax + 1;
+        }
+        g.nlev = std::max(g.nlev, thi[t]);
     }
     if (g.nlev == 0 || g.nlev > 255) return false;
     // the tile pairs of the program: unordered, with their common depth cp = fb + joints both tiles' columns have rows on
@@ -81,7 +100,7 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
         const FbrPair &p = gp.pairs[pi];
         if (p.mode != 0) return false;
         const int cp = hm.fb + FbrGramProgram::common_prefix(gp.tiles[p.I].tpath, gp.tiles[p.J].tpath);
-        prs.push_back({p.I, p.J, 0, std::min(cp, g.nlev)});
+        prs.push_back({p.I, p.J, std::max(tlo[p.I], tlo[p.J]), std::min(cp, std::min(thi[p.I], thi[p.J]))});
     }
     // force columns and their tiles
     g.fcol_tile.assign(hm.cols, -1);
@@ -119,7 +138,10 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
     g.tilecol.resize((size_t)NTT * FBR_TILE, -1);
     for (int c = 0; c < hm.cols; c++)
         if (g.fcol_tile[c] >= 0) g.tilecol[(size_t)g.fcol_tile[c] * FBR_TILE + g.fcol_slot[c]] = c;
-    for (Pr &p : prs) p.lo = g.flev;
+    for (int t = 0; t < g.NT; t++)
+        if (!gp.tiles[t].friction) tlo[t] = g.flev;  // (the main tiles start behind the force levels)
+    for (Pr &p : prs) p.lo = std::max(p.lo, std::max(tlo[p.a], tlo[p.b]));
+    prs.erase(std::remove_if(prs.begin(), prs.end(), [](const Pr &p) { return p.lo >= p.hi; }), prs.end());
     for (int f = 0; f < g.NF; f++)
         for (int f2 = f; f2 < g.NF; f2++) prs.push_back({g.NT + f, g.NT + f2, 0, g.flev});
     // tile rows: the force tiles' first (so that "level 0" of a main tile, flev rows in front of its first row, is inside the image), then the
@@ -129,8 +151,11 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
     g.ntr = 0;
     for (int f = 0; f < g.NF; f++)
         for (int lv = 0; lv < g.flev; lv++) g.trow[(size_t)(g.NT + f) * g.nlev + lv] = g.ntr++;
-    for (int t = 0; t < g.NT; t++)
-        for (int lv = g.flev; lv < hm.fb + (int)gp.tiles[t].tpath.size(); lv++) g.trow[(size_t)t * g.nlev + lv] = g.ntr++;
+    for (int t = 0; t < g.NT; t++) {
+        g.ntr = std::max(g.ntr, tlo[t]);  // ("level 0" of the tile, tlo rows in front of its first one, must not fall in front of the image)
+        for (int lv = tlo[t]; lv < thi[t]; lv++) g.trow[(size_t)t * g.nlev + lv] = g.ntr++;
+    }
+    g.tile_lo = tlo;
     g.blk_doubles = (long)g.ntr * 1024;
     // Stages: consecutive levels whose slabs fit one LDS buffer together share a stage --
     // one barrier and one round of LDS-DMA for the three force levels, or for the deep levels only a few tiles reach.
@@ -294,11 +319,12 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
 // rows, column slot, sample 0) -- a multiple of 256 -- with the slot's swizzle (FBR_G64_SWZ) in its low byte and bit 62 set (0: the part does not write that
 // column).  Level lv of the column is 8192 bytes x lv further on (the tile rows of a tile are consecutive; with force tiles "level 0" of a
 // main tile is three rows in front of its first row, rows 0 .. 2 of a force column go through its force word).
-#define FBR_G64_WORDS 14
+#define FBR_G64_WORDS 18  // 10 parameters, the force-tile words of parameters 0 .. 3, up to 4 friction columns of the link's joint
+#define FBR_G64_FRIC 4
 struct FbrGram64Producer {
     int nparts = 1, nslots = 1, step0[FBR_KINWRITE_PARTS] = {0, 0, 0, 0}, nsteps[FBR_KINWRITE_PARTS] = {0, 0, 0, 0};
     std::vector<long long> rel;  // [nparts][L][14]
-    std::vector<int> lcol;       // [nparts][10 L] the column (for the rhs moments) or -1
+    std::vector<int> lcol;       // [nparts][10 L] the column (for the rhs moments) or -1, then [nparts][4 L] the friction columns of the link's joint
     std::vector<int> steps;      // the parts' step programs, one after the other
 };
 
@@ -323,13 +349,15 @@ static inline bool fbr_gram64_build_producer(const FbrHostModel &hm, const FbrGr
     }
     pr.nparts = (int)progs.size();
     pr.rel.assign((size_t)pr.nparts * FBR_G64_WORDS * hm.L, 0);
-    pr.lcol.assign((size_t)pr.nparts * 10 * hm.L, -1);
+    pr.lcol.assign((size_t)pr.nparts * (10 + FBR_G64_FRIC) * hm.L, -1);
+    const int nfric = hm.n > 0 ? (hm.cols - hm.ninert) / hm.n : 0;
+    if (nfric > FBR_G64_FRIC) return false;
     auto word = [](long long tile_row, int sl) { return ((tile_row * 1024 + sl * 32) * 8) | (long long)FBR_G64_SWZ(sl) | (1LL << 62); };
     for (int c = 0; c < hm.ninert; c++) {
         const int t = tile_of[c], sl = slot_of[c], l = hm.coldesc[c].link, pidx = hm.coldesc[c].pidx;
         if (t < 0) continue;  // (a column without a tile: structurally zero, e.g. the base link of a fixed base)
         if (hm.path[l].size() > gp.tiles[t].tpath.size()) return false;  // (cannot happen: the tile's path contains the link's)
-        const long long tr0 = (long long)g.trow[(size_t)t * g.nlev + g.flev] - g.flev;
+        const long long tr0 = (long long)g.trow[(size_t)t * g.nlev + g.tile_lo[t]] - g.tile_lo[t];
         if (tr0 < 0) return false;  // (cannot happen: the force tiles' rows come first)
         for (int pq = 0; pq < pr.nparts; pq++)
             if (own[pq][l]) {
@@ -340,6 +368,24 @@ static inline bool fbr_gram64_build_producer(const FbrHostModel &hm, const FbrGr
                     w14[10 + pidx] = word(g.trow[(size_t)g.fcol_tile[c] * g.nlev], g.fcol_slot[c]);
                 }
                 pr.lcol[((size_t)pq * hm.L + l) * 10 + pidx] = c;
+            }
+    }
+    // friction columns: the part that owns the joint's link writes them, on the row of that joint (level fb + position of the joint on the path)
+    for (int c = hm.ninert; c < hm.cols; c++) {
+        const int t = tile_of[c], sl = slot_of[c], d = hm.coldesc[c].joint, p = (c - hm.ninert) / std::max(hm.n, 1);
+        if (t < 0) continue;
+        int l = -1;
+        for (int x = 0; x < hm.L; x++)
+            if (hm.dof[x] == d) l = x;
+        if (l < 0 || p >= FBR_G64_FRIC || hm.path[l].empty() || hm.path[l].back() != d) return false;
+        const int lv = hm.fb + (int)hm.path[l].size() - 1;
+        if (lv < g.tile_lo[t] || g.trow[(size_t)t * g.nlev + lv] < 0) return false;
+        const long long tr0 = (long long)g.trow[(size_t)t * g.nlev + g.tile_lo[t]] - g.tile_lo[t];
+        if (tr0 < 0) return false;
+        for (int pq = 0; pq < pr.nparts; pq++)
+            if (own[pq][l]) {
+                pr.rel[((size_t)pq * hm.L + l) * FBR_G64_WORDS + 14 + p] = word(tr0, sl);
+                pr.lcol[(size_t)pr.nparts * 10 * hm.L + ((size_t)pq * hm.L + l) * FBR_G64_FRIC + p] = c;
             }
     }
     pr.steps.clear();
@@ -372,7 +418,8 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void f
                                                                               const double *__restrict__ ddq, const double *__restrict__ bv,
                                                                               const double *__restrict__ ba, const double *__restrict__ rpy,
                                                                               const double *__restrict__ rhs, const double *__restrict__ wts,
-                                                                              double *__restrict__ scratch, double *__restrict__ mom)
+                                                                              double *__restrict__ scratch, double *__restrict__ mom,
+                                                                              const double *__restrict__ sign)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nth = blockDim.x, tid = threadIdx.x;
@@ -556,6 +603,22 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void f
             } else {
                 full_group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
                 moment_group(integral_constant<int, 0>{}, integral_constant<int, 6>{});
+            }
+            // friction columns of the link's own joint: one value each, on the row of that joint (the last level of the link's path)
+            const int nfr = wr.cols > wr.ninert ? (wr.cols - wr.ninert) / n : 0;
+            const int dj = nfr ? m.dof[l] : -1;
+            if (dj >= 0 && depth > 0) {
+                const fbr_cint_ptr cfr = (fbr_cint_ptr)(unsigned long)(wr.lcol10 + (long)wr.nparts * 10 * m.L + ((long)part * m.L + l) * FBR_G64_FRIC);
+#pragma unroll
+                for (int pf = 0; pf < FBR_G64_FRIC; pf++)
+                    if (pf < nfr) {
+                        const long dfw = cdst[((long)part * m.L + l) * FBR_G64_WORDS + 14 + pf];
+                        if (dfw == 0) continue;
+                        const int c = cfr[pf];
+                        const double fv = fbr_friction_value(m.coldesc[c].z, mysdq[dj], sign ? sign[s * n + dj] : 0.0, m.stribeck);
+                        store(dfw, m.fb + depth - 1, HASW ? fv * myw[m.fb + dj] : fv);
+                        if (wr.k) unsafeAtomicAdd(mo + (long)c * 64 + lane, fv * myt[m.fb + dj]);
+                    }
             }
         };
         auto emit = [&](int, double) {};

@@ -237,7 +237,7 @@ extern "C" int fbr_gram_lane_info(const fbr_model *mc, int32_t k, int64_t num_sa
     GramHolder *h = nullptr;
     int rc = get_gram(m, k, &h, moments);
     if (rc) return rc;
-    if (!m->opt.gram_lane || k > 1 || (k == 1 && !moments) || m->hm.fric) return FBR_OK;
+    if (!m->opt.gram_lane || k > 1 || (k == 1 && !moments)) return FBR_OK;
     if ((rc = get_gram64(m, h))) return rc;
     if (h->g64_state != 1) return FBR_OK;
     const FbrGram64 &g = h->g64;
@@ -404,7 +404,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
     HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     int launches = 0, first_wgs = 0;
-    const size_t stage_per = (size_t)3 * hm.n + (hm.floating ? 15 : 0) + (size_t)hm.rows * k + (dw ? hm.rows : 0);  // doubles per staged sample
+    const size_t stage_per = (size_t)3 * hm.n + (hm.floating ? 15 : 0) + (d.sign ? hm.n : 0) + (size_t)hm.rows * k + (dw ? hm.rows : 0);  // doubles per staged sample
     if (h2d_chunked) {
         for (int b = 0; b < 2; b++)
             if ((rc = m->st_chunk[b].ensure(std::max<size_t>(1, (size_t)chb * 64 * stage_per) * sizeof(double)))) return rc;
@@ -444,7 +444,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         int r3;
         if ((r3 = put(d.q, hm.n, &out.dc.q)) || (r3 = put(d.dq, hm.n, &out.dc.dq)) || (r3 = put(d.ddq, hm.n, &out.dc.ddq)) ||
             (r3 = put(d.bv, 6, &out.dc.bv)) || (r3 = put(d.ba, 6, &out.dc.ba)) || (r3 = put(d.rpy, 3, &out.dc.rpy)) ||
-            (r3 = put(drhs, (size_t)hm.rows * k, &out.rhs)) || (r3 = put(dw, hm.rows, &out.w)))
+            (r3 = put(d.sign, hm.n, &out.dc.sign)) || (r3 = put(drhs, (size_t)hm.rows * k, &out.rhs)) || (r3 = put(dw, hm.rows, &out.w)))
             return r3;
         out.o = 0;
         HIPCHK(hipEventRecord(m->ev_h2d[b], m->copy));
@@ -487,7 +487,8 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         hipLaunchKernelGGL((fbr_kinimg_kernel<D, W>), dim3(pblocks), dim3(64 * h->g64p.nparts), plds, m->stream, m->dm, kp, kw, cs, g.blk_doubles,       \
                            dc.q + so * hm.n, dc.dq + so * hm.n, dc.ddq + so * hm.n, dc.bv ? dc.bv + so * 6 : nullptr, dc.ba ? dc.ba + so * 6 : nullptr, \
                            dc.rpy ? dc.rpy + so * 3 : nullptr, crhs ? crhs + (size_t)so * hm.rows * k : nullptr,                                   \
-                           cw ? cw + (size_t)so * hm.rows : nullptr, h->scr64.as<double>(), k ? h->mom64.as<double>() : nullptr);                  \
+                           cw ? cw + (size_t)so * hm.rows : nullptr, h->scr64.as<double>(), k ? h->mom64.as<double>() : nullptr,                   \
+                           dc.sign ? dc.sign + so * hm.n : nullptr);                                                                              \
     } while (0)
 #define FBR_KINIMG_LAUNCH(D)            \
     do {                                \
@@ -630,7 +631,7 @@ static int gram64_grouped_pass(fbr_model *m, GramHolder *h, const DevStates &d, 
         hipLaunchKernelGGL((fbr_kinimg_kernel<D, W>), dim3(pblocks), dim3(64 * h->g64p.nparts), plds, m->stream, m->dm, kp, kw, cs, g.blk_doubles, \
                            d.q + s0 * hm.n, d.dq + s0 * hm.n, d.ddq + s0 * hm.n, d.bv ? d.bv + s0 * 6 : nullptr, d.ba ? d.ba + s0 * 6 : nullptr,    \
                            d.rpy ? d.rpy + s0 * 3 : nullptr, (const double *)nullptr, dw ? dw + (size_t)s0 * hm.rows : nullptr,                    \
-                           h->scr64.as<double>(), (double *)nullptr);                                                                            \
+                           h->scr64.as<double>(), (double *)nullptr, d.sign ? d.sign + s0 * hm.n : nullptr);                                      \
     } while (0)
 #define FBR_KINIMG_GLAUNCH(D)             \
     do {                                  \
@@ -769,13 +770,13 @@ static int gram_impl_inner(fbr_model *m, const fbr_states *st, const double *rhs
     // the pass over sample-contiguous images (fbr_gram64.h) where the call allows it
     bool lane_pass = false;
     if (S > 0 && m->opt.gram_lane != 0 && ngroups == 1 && !m->opt.gram_timing && !m->opt.gram_serial &&
-        k <= 1 && (k == 0 || moments) && !hm.fric && d.q) {
+        k <= 1 && (k == 0 || moments) && d.q) {
         if ((rc = get_gram64(m, h))) return rc;
         lane_pass = h->g64_state == 1;
     }
     bool lane_grouped = false;
     if (!lane_pass && S > 0 && m->opt.gram_lane != 0 && ngroups > 1 && k == 0 && !h2d_chunked && !base_only && !m->opt.gram_timing &&
-        !m->opt.gram_serial && !hm.fric && d.q) {
+        !m->opt.gram_serial && d.q) {
         if ((rc = get_gram64(m, h))) return rc;
         lane_grouped = h->g64_state == 1 && (S / ngroups + 63) / 64 <= gram64_chunk_blocks(h->g64);
     }

@@ -311,8 +311,8 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "fused_id"                   1     fbr_predict / fbr_inverse_dynamics_batch run kinematics and torques in ONE kernel, the link records
  *                                      stay in registers (0: kinematics kernel + torque kernel with the records staged through HBM)
  *   "gram_lane"                  1     fused Gram over SAMPLE-contiguous images (MFMA k-steps over four samples of one regressor row) with a
- *                                      one-lane-per-sample producer, where the model allows: no friction columns, at most one rhs column,
- *                                      a tile program in one part; inputs resident in HBM, pageable or pinned (staged chunk by chunk);
+ *                                      one-lane-per-sample producer, where the call allows: at most one rhs column, a tile program in one part
+ *                                      (friction columns included); inputs resident in HBM, pageable or pinned (staged chunk by chunk);
  *                                      fbr_gram_grouped without rhs columns (0: always the per-sample images of the kinematics + packer kernels)
  *   "gram_force_tiles"           1     gram_lane: the three force rows of the base wrench run on tiles of their own that hold only the columns
  *                                      with a force (mass, first moments), when the extra tile pairs fit the accumulators (0: every tile pair

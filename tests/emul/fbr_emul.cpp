@@ -525,7 +525,7 @@ int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
 static int g_force_tiles = 1;
 void emul_set_force_tiles(int on) { g_force_tiles = on; }
 int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
-                const double *rpy, const double *rhs, int k, const double *wts, double *G, long *stats)
+                const double *rpy, const double *sign, const double *rhs, int k, const double *wts, double *G, long *stats)
 {
     FbrHostModel hm;
     make(t, hm);
@@ -594,6 +594,23 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
                             j++;
                         }
                         if (k && live) mom[(size_t)c * 64 + lane] += mc;
+                    }
+            // friction columns: written by the part that owns the joint's link, on the row of that joint (the last level of the link's path)
+            for (int pq = 0; pq < pr.nparts; pq++)
+                for (int l = 0; l < hm.L; l++)
+                    for (int pf = 0; pf < FBR_G64_FRIC; pf++) {
+                        const long long dw = pr.rel[((size_t)pq * hm.L + l) * FBR_G64_WORDS + 14 + pf];
+                        if (!dw) continue;
+                        const int c = pr.lcol[(size_t)pr.nparts * 10 * hm.L + ((size_t)pq * hm.L + l) * FBR_G64_FRIC + pf];
+                        if (c < hm.ninert || c >= hm.cols || hm.dof[l] != hm.coldesc[c].joint) return -12;
+                        const int d = hm.dof[l], lv = hm.fb + (int)hm.path[l].size() - 1, r = hm.fb + d;
+                        const double fv = fbr_friction_value(hm.coldesc[c].pidx, dq[s * hm.n + d], sign ? sign[s * hm.n + d] : 0.0, hm.stribeck);
+                        const long base = (long)((dw & ~(1LL << 62) & ~0xffLL) / 8);
+                        const long at = base + (long)lv * 1024 + (lane >> 5) * 512 + ((lane & 31) ^ (int)(dw & 0xff));
+                        if (at < 0 || at >= g.blk_doubles) return -3;
+                        img[at] = live ? fv * (ws ? ws[r] : 1.0) : 0.0;
+                        written[at]++;
+                        if (k && live) mom[(size_t)c * 64 + lane] += fv * tv(r);
                     }
             if (k && live) {
                 double tt = 0.0;

@@ -163,7 +163,7 @@ class Emul:
         return dict(NT=NT.value, npairs=npairs.value, mfma=mfma.value, T=T.value, part_image_max=img.value,
                     dma_doubles=items.value, mfma_uniform=uni.value)
 
-    def gram64(self, st, rhs=None, w=None):
+    def gram64(self, st, rhs=None, w=None, sign=None):
         """(G, stats) of the pass over sample-contiguous images (csrc/fbr_gram64.h), or None when the model is outside it."""
         S, q, dq, ddq, bv, ba, rpy = self._st(st)
         k = 0
@@ -173,8 +173,9 @@ class Emul:
         w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
         G = np.zeros((self.cols + k, self.cols + k))
         stats = (ctypes.c_long * 10)()
-        rc = lib().emul_gram64(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(rhs), int(k), _d(w),
-                               _d(G), stats)
+        sign = None if sign is None else np.ascontiguousarray(sign, dtype=np.float64)
+        rc = lib().emul_gram64(ctypes.byref(self.t), ctypes.c_long(S), _d(q), _d(dq), _d(ddq), _d(bv), _d(ba), _d(rpy), _d(sign), _d(rhs), int(k),
+                               _d(w), _d(G), stats)
         if rc == -1:
             return None
         assert rc == 0, rc

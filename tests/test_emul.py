@@ -396,3 +396,51 @@ def test_gram_over_sample_contiguous_images(case, which):
     assert np.linalg.norm(E.T @ G0 @ E - Y.T @ Y) <= 1e-12 * np.linalg.norm(Y.T @ Y)
     assert stats0["mfma_per_block"] == stats["mfma_per_block"] and 1 <= stats["parts"] <= 4
     assert stats["balanced_pair_levels"] <= stats["busiest_wave_pair_levels"] <= stats["balanced_pair_levels"] + stats["levels"] and 1 <= stats["stages"] <= stats["levels"]
+
+
+@pytest.mark.parametrize("case,floating,sym", [("kuka_lwr4", False, True), ("kuka_lwr4", False, False), ("walkman_left_arm", True, True),
+                                               ("random2", False, True), ("random3", True, False), ("random4", True, True)])
+@pytest.mark.parametrize("which", [-1, 1], ids=["all_columns", "regrouped"])
+def test_gram_over_sample_contiguous_images_with_friction_columns(case, floating, sym, which):
+    """Friction columns in the pass of csrc/fbr_gram64.h (the reference's identifyFrictionSimultaneously option sets: kuka_lwr4.yaml,
+    walkman_left_arm.yaml): a friction tile holds the levels of its own columns' joints only, its pairs run where both tiles have rows, the
+    part that owns a joint's link writes the joint's friction values (one per column, on the joint's row) and their rhs moments -- against
+    the oracle's [Y | tau] Gram, with the sign series, row weights and a block that is not full."""
+    import emul_lib
+
+    rng = np.random.default_rng(93)
+    if case.startswith("random"):
+        seed = int(case[-1])
+        rng = np.random.default_rng(700 + seed)
+        t = random_topology(rng, 6 + 4 * (seed % 3), p_fixed=0.3, branchiness=0.5)
+    else:
+        t = load_topo(case)
+    if t.num_dofs == 0:
+        pytest.skip("no joints")
+    om = OracleModel(t, floating=floating, fric=True, fric_sym=sym)
+    em = emul_lib.Emul(t, floating=floating, fric=True, fric_sym=sym)
+    E = np.eye(om.P)
+    if which >= 0:
+        red = em.reduction(which)
+        if red is None:
+            pytest.skip("nothing to reduce")
+        em, E = red
+    S = 70
+    st = random_states(t, S, rng, floating)
+    sign = np.tanh(st["dq"] / 0.02)
+    Y = om.regressor(st, sign)
+    tau = rng.standard_normal((Y.shape[0], 1))
+    w = rng.random(Y.shape[0]) + 0.5
+    got = em.gram64(st, tau, w, sign)
+    if got is None:
+        assert case.startswith("random")  # (the shipped robots with friction columns are inside the pass)
+        pytest.skip("model outside the sample-contiguous pass")
+    Gr, stats = got
+    Ea = np.zeros((em.cols + 1, om.P + 1))
+    Ea[: em.cols, : om.P] = E
+    Ea[-1, -1] = 1.0
+    A = np.hstack([Y, tau]) * w[:, None]
+    assert np.linalg.norm(Ea.T @ Gr @ Ea - A.T @ A) <= 1e-12 * np.linalg.norm(A.T @ A)
+    assert np.array_equal(Gr, Gr.T)
+    G0, _ = em.gram64(st, sign=sign)
+    assert np.linalg.norm(E.T @ G0 @ E - Y.T @ Y) <= 1e-12 * np.linalg.norm(Y.T @ Y)
