@@ -317,6 +317,9 @@ static int get_gram64(fbr_model *m, GramHolder *h)
     return FBR_OK;
 }
 
+// blocks a chunk of the sample-contiguous pass may hold (two image buffers of at most 3 GB)
+static long gram64_chunk_blocks(const FbrGram64 &g) { return std::max<long>(1, (long)((size_t)3 * 1024 * 1024 * 1024 / ((size_t)g.blk_doubles * 8))); }
+
 // [0, workgroups]: the one-part workgroup table fbr_gram_reduce_kernel reads, uploaded once per grid size a holder has used
 static int gram64_wg_table(GramHolder *h, int wgs, const int **out)
 {
@@ -363,9 +366,16 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     const long S = d.S;
     const int Pa = hm.cols + k;
     int rc;
-    const long ch = 64L * std::max(1L, std::min<long>(((long)chunk_size(m, S) + 63) / 64, (long)((size_t)3 * 1024 * 1024 * 1024 / ((size_t)g.blk_doubles * 8))));
-    long chb = std::min((S + 63) / 64, ch / 64);  // blocks per chunk: whole rounds of the chip (both kernels walk blocks workgroup by workgroup)
-    if (chb > m->num_cus) chb = chb / m->num_cus * m->num_cus;
+    // blocks per chunk: what the image buffers hold (a call that fits is ONE chunk: a 125 k-sample shard ran 1792 + 162 blocks before);
+    // several chunks: whole rounds of the chip (both kernels walk blocks workgroup by workgroup).  Pinned inputs: chunks of seven rounds
+    // (measured: 20.7 ms per 1 M-sample step against 21.2 with chunks of four -- with two submissions in flight the first copy of a step
+    // hides behind the last kernels of the step before, and fewer chunks mean fewer launches)
+    const long nblocks = (S + 63) / 64;
+    long chb = gram64_chunk_blocks(g);
+    if (h2d_chunked) chb = std::min<long>(chb, 7L * m->num_cus);
+    if (m->opt.chunk_samples >= 1) chb = std::max<long>(1, ((long)m->opt.chunk_samples + 63) / 64);  // (tests: the multi-chunk paths at small sizes)
+    chb = std::min(nblocks, chb);
+    if (chb < nblocks && chb > m->num_cus) chb = chb / m->num_cus * m->num_cus;
     if ((rc = gram64_ensure_images(m, h, chb))) return rc;
     const int ldn = std::max(hm.n, 1) | 1, ldw = hm.rows | 1;
     const size_t plds = ((size_t)3 * 64 * ldn + (dw ? (size_t)64 * ldw : 0) + (k ? (size_t)64 * ldw : 0)) * sizeof(double);
@@ -551,9 +561,6 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     (void)Pa;
     return FBR_OK;
 }
-
-// blocks a chunk of the sample-contiguous pass may hold (two image buffers of at most 3 GB)
-static long gram64_chunk_blocks(const FbrGram64 &g) { return std::max<long>(1, (long)((size_t)3 * 1024 * 1024 * 1024 / ((size_t)g.blk_doubles * 8))); }
 
 // fbr_gram_grouped through the sample-contiguous pass (k = 0, device-resident inputs): every group starts a block of 64 samples, a group's
 // blocks are shared by wpg workgroups whose partial sums one reduction per group adds up; groups are taken a chunk of whole groups at a time.
