@@ -29,7 +29,14 @@ import subprocess
 import sys
 import time
 
-import numpy as np
+# Worker threads of OpenMP / OpenBLAS teams (the CPU baseline legs, NumPy / SciPy in the parity legs) spin after a parallel region by
+# default.  On a box whose cgroup grants 16 CPUs they eat the quota the thread that drives the GPU needs: blocking calls of the later legs
+# then measured 2 ... 13 ms for 2 ms of device work, run to run.  Passive waiting, set before the runtimes load; a caller's own
+# settings win.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -1267,12 +1274,20 @@ def other_configs(args, dev, eng4, topo4, st4, rhs4):
             eng4.gram_grouped(sub, ng, out=Gg)
             torch.cuda.synchronize()
             each.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+        host = []
+        for _ in range(6):  # (back to back: how long each call keeps the HOST)
+            t0 = time.perf_counter()
+            eng4.gram_grouped(sub, ng, out=Gg)
+            host.append(round((time.perf_counter() - t0) * 1e3, 3))
+        torch.cuda.synchronize()
         eng4.profile_enable(True)
         eng4.profile_get()
         eng4.gram_grouped(sub, ng, out=Gg)
         torch.cuda.synchronize()
         prof_gg = {k_: round(v_[0], 3) for k_, v_ in eng4.profile_get().items() if v_[1]}
         eng4.profile_enable(False)
+        prof_gg["host_ms_of_back_to_back_calls"] = host
         prof_gg["single_calls_ms_min_median_max"] = [round(min(each), 3), round(sorted(each)[len(each) // 2], 3), round(max(each), 3)]
         eng4.set_option("reduce_grouped_min_samples", 1e18)  # (no group is that long: the grouped pass over all columns)
         try:
