@@ -34,7 +34,7 @@
 struct FbrGram64 {  // host program
     int NT = 0;      // column tiles of the tile program ("main" tiles)
     int NF = 0;      // force tiles (below); tiles are numbered main 0 .. NT-1, force NT .. NT+NF-1
-    int nlev = 0, fb = 0, flev = 0, ntr = 0, maxact = 0, npw = 0;
+    int nlev = 0, fb = 0, flev = 0, ntr = 0, maxact = 0, npw = 0, wpb = 8;  // npw accumulators per wave, wpb waves per workgroup (8 or 16)
     long blk_doubles = 0;
     std::vector<int> trow;       // [NT + NF][nlev] tile-row index or -1
     std::vector<int> slab;       // [nlev][NT + NF] slab index inside the level's stage or -1
@@ -42,8 +42,9 @@ struct FbrGram64 {  // host program
     std::vector<int> stage_lev;  // [nstage + 1] first level of each stage
     std::vector<int> lev_begin;  // [nlev + 1] into pieces
     std::vector<int> pieces;     // pairs: global offset (doubles, inside the block image, half 0), LDS offset (doubles, inside a stage buffer)
-    std::vector<int> wmeta;      // [8 waves][npw][3]: tile I (-1: empty slot), tile J, first level | (one past the last level) << 8
-    std::vector<int> slot_tiles; // [2][8 * npw * 2] for the two reductions: main pairs, force pairs (the other kind's slots are -1)
+    std::vector<int> wmeta;      // [wpb waves][npw][3]: tile I (-1: empty slot), tile J, first level | (one past the last level) << 8
+    std::vector<int> slot_tiles; // [2][wpb * npw * 2] for the two reductions: main pairs, force pairs (the other kind's slots are -1), in the
+                                 // partial-sum order fbr_gram_reduce_kernel walks: [wave & 7][wave >> 3][slot] (16 waves = 8 rows of twice the slots)
     std::vector<int> tilecol;    // [NT + NF][16] column of each tile slot, -1 = padding
     std::vector<int> fcol_tile, fcol_slot;  // per column: its force tile / slot there, or -1
     std::vector<int> tile_lo;    // [NT] first level of every main / friction tile
@@ -59,13 +60,21 @@ struct FbrGram64 {  // host program
 // force rows get tiles of their own: the columns that have a force, 16 to a tile in column order (base rows are common to all columns:
 // no path condition), every pair of force tiles runs levels 0 .. 2, and the program's tiles start at level 3.  An entry G_ab with two
 // force columns is the sum of its two blocks (two reductions, one after the other).  Used when the extra pairs fit the accumulator slots.
-static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram &gp, FbrGram64 &g, bool force_tiles = true)
+// wide16 (option gram_lane_waves = 16): models of the one-workgroup-per-CU shape (18 accumulators per wave of an 8-wave workgroup) run 16
+// waves of 10 accumulators instead -- four waves per SIMD at 128 registers.  Measured: the Gram kernel 9.70 instead of 9.32 ms per 1 M
+// WALK-MAN samples (operand reads in half groups, more A reloads, less reuse per wave): not the default.
+static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram &gp, FbrGram64 &g, bool force_tiles = true, bool wide16 = false)
 {
     if (gp.T != 1 || (gp.k > 0 && gp.rhs_tiles)) return false;
-    const int W = FBR_WPB;
+    g.npw = gp.cfg.segw * gp.cfg.nseg;
+    g.wpb = FBR_WPB;
+    if (wide16 && g.npw > 10) {
+        g.wpb = 2 * FBR_WPB;
+        g.npw = 10;
+    }
+    const int W = g.wpb;
     g.NT = gp.NT;
     g.fb = hm.fb;
-    g.npw = gp.cfg.segw * gp.cfg.nseg;
     g.nlev = 0;
     // levels of a tile: a main tile has the base-wrench rows and the joints of its path; a FRICTION tile (its columns are non-zero on the row
     // of their own joint only) just the levels of its own columns' joints -- a contiguous stretch of its path
@@ -297,13 +306,14 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
             for (int i : mine) {
                 if (done[i] || (prs[i].a != T && prs[i].b != T)) continue;
                 const int J = prs[i].a == T ? prs[i].b : prs[i].a;
-                const size_t s = (size_t)w * g.npw + q;
+                const size_t s = (size_t)w * g.npw + q;                                                  // wmeta: wave-major
+                const size_t sr = ((size_t)(w & 7) * (W / 8) + (size_t)(w >> 3)) * g.npw + q;             // the reduction's order
                 g.wmeta[3 * s] = T;
                 g.wmeta[3 * s + 1] = J;
                 g.wmeta[3 * s + 2] = prs[i].lo | (prs[i].hi << 8);
                 const int kind = T >= g.NT ? 1 : 0;
-                g.slot_tiles[((size_t)kind * W * g.npw + s) * 2] = T;
-                g.slot_tiles[((size_t)kind * W * g.npw + s) * 2 + 1] = J;
+                g.slot_tiles[((size_t)kind * W * g.npw + sr) * 2] = T;
+                g.slot_tiles[((size_t)kind * W * g.npw + sr) * 2 + 1] = J;
                 g.mfma_per_block += 16L * (prs[i].hi - prs[i].lo);  // 8 MFMAs per level and half
                 done[i] = 1;
                 q++;
@@ -677,11 +687,11 @@ __global__ __launch_bounds__(256) void fbr_gram64_mom_reduce_kernel(int P, int n
 // Consumer.  One workgroup (8 waves) per CU walks blocks blockIdx.x, + gridDim.x, ...; stage = (block, half, level).  partial:
 // [workgroup][wave][slot][4][64] (the layout fbr_gram_reduce_kernel sums); carry: start from it.
 // ------------------------------------------------------------------------------------------------
-template <int SEGW, int NSEG>
-__global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr_gram64_kernel(DevGram64 g, long nblk, const double *__restrict__ img,
-                                                                                              double *__restrict__ partial, int carry)
+template <int NPW, int WPB>
+__global__ __launch_bounds__(WPB * 64, (NPW <= 10) ? 4 : 2) void fbr_gram64_kernel(DevGram64 g, long nblk, const double *__restrict__ img,
+                                                                                  double *__restrict__ partial, int carry)
 {
-    constexpr int NPW = SEGW * NSEG, MW = 3 * NPW;
+    constexpr int MW = 3 * NPW;
     static_assert(MW <= 64, "a wave's slot table is fetched with one load");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int bufd = g.maxact * 512;
@@ -690,17 +700,18 @@ __global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr
     int *levb = slab + g.nlev * g.NT;          // [nlev + 1]
     int *pcs = levb + g.nlev + 1;              // [npieces][2]
     int *wm = pcs + 2 * g.npieces;             // [8][NPW][3]
-    int *stl = wm + FBR_WPB * MW;              // [nstage + 1]
+    int *stl = wm + WPB * MW;              // [nstage + 1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < g.nlev * g.NT; i += FBR_WPB * 64) slab[i] = g.slab[i];
-    for (int i = tid; i <= g.nlev; i += FBR_WPB * 64) levb[i] = g.lev_begin[i];
-    for (int i = tid; i < 2 * g.npieces; i += FBR_WPB * 64) pcs[i] = g.pieces[i];
-    for (int i = tid; i < FBR_WPB * MW; i += FBR_WPB * 64) wm[i] = g.wmeta[i];
-    for (int i = tid; i <= g.nstage; i += FBR_WPB * 64) stl[i] = g.stage_lev[i];
+    for (int i = tid; i < g.nlev * g.NT; i += WPB * 64) slab[i] = g.slab[i];
+    for (int i = tid; i <= g.nlev; i += WPB * 64) levb[i] = g.lev_begin[i];
+    for (int i = tid; i < 2 * g.npieces; i += WPB * 64) pcs[i] = g.pieces[i];
+    for (int i = tid; i < WPB * MW; i += WPB * 64) wm[i] = g.wmeta[i];
+    for (int i = tid; i <= g.nstage; i += WPB * 64) stl[i] = g.stage_lev[i];
     fbr_d4 acc[NPW];
     img += (long)blockIdx.y * nblk * g.blk_doubles;  // blockIdx.y: sample group (nblk blocks each, fbr_gram_grouped)
-    double *pp = partial + ((((long)blockIdx.y * gridDim.x + blockIdx.x) * FBR_WPB + wave) * NPW) * 256;
+    // partial sums in the order of fbr_gram_reduce_kernel (8 rows per workgroup): wave w is row w & 7, slots (w >> 3) NPW ...
+    double *pp = partial + (((((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (wave & 7)) * (WPB / 8) + (wave >> 3)) * NPW) * 256;
     if (carry) {
 #pragma unroll
         for (int q = 0; q < NPW; q++) acc[q] = (fbr_d4){pp[q * 256 + lane], pp[q * 256 + 64 + lane], pp[q * 256 + 128 + lane], pp[q * 256 + 192 + lane]};
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(FBR_WPB * 64, (SEGW * NSEG <= 10) ? 4 : 2) void fbr
         const long blk = (long)blockIdx.x + (bh >> 1) * gridDim.x;
         const double *src = img + blk * g.blk_doubles + (bh & 1) * 512 + 2 * lane;
         double *buf = (st & 1) ? buf1 : buf0;
-        for (int i = levb[stl[sg]] + wave; i < levb[stl[sg + 1]]; i += FBR_WPB) {
+        for (int i = levb[stl[sg]] + wave; i < levb[stl[sg + 1]]; i += WPB) {
             const int gx = __builtin_amdgcn_readfirstlane(pcs[2 * i]), lx = __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]);
             __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + lx), 16, 0, 0);
         }

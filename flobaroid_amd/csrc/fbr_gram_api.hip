@@ -299,7 +299,7 @@ static int get_gram64(fbr_model *m, GramHolder *h)
     if (h->g64_state) return FBR_OK;
     h->g64_state = -1;
     const FbrHostModel &hm = m->hm;
-    if (m->kinid.nsteps <= 0 || !fbr_gram64_build(hm, h->prog, h->g64, m->opt.gram_force_tiles != 0)) return FBR_OK;
+    if (m->kinid.nsteps <= 0 || !fbr_gram64_build(hm, h->prog, h->g64, m->opt.gram_force_tiles != 0, m->opt.gram_lane_waves >= 16)) return FBR_OK;
     FbrGram64 &g = h->g64;
     const size_t lds = (size_t)2 * g.maxact * 512 * sizeof(double) +
                        ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int);
@@ -389,7 +389,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         HIPCHK(hipMemsetAsync(h->mom64.p, 0, (size_t)pblocks * (hm.cols + 1) * 64 * sizeof(double), m->stream));  // (the producer grid of this call)
     }
     const int npw = g.npw;
-    if ((rc = m->partial.ensure((size_t)m->num_cus * FBR_WPB * npw * 256 * sizeof(double)))) return rc;
+    if ((rc = m->partial.ensure((size_t)m->num_cus * g.wpb * npw * 256 * sizeof(double)))) return rc;
     const size_t glds = (size_t)2 * g.maxact * 512 * sizeof(double) + ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int);
     DevKinId kp;
     kp.nsteps = 0;
@@ -411,7 +411,8 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
     dg.nstage = base_only ? g.base_stages : g.nstage;  // (base-wrench-only row masks: the joint levels' stages are not run)
     dg.stage_lev = h->d64_stagelev;
     typedef void (*g64_fn)(DevGram64, long, const double *, double *, int);
-    const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
+    const g64_fn gk = g.wpb == 16 ? fbr_gram64_kernel<10, 16> : (g.npw == 10 ? fbr_gram64_kernel<10, 8> : fbr_gram64_kernel<FBR_ONE_SEGW * FBR_ONE_NSEG, 8>);
+    const int vnpw = g.npw * (g.wpb / 8);  // accumulator slots per ROW of the partial sums (fbr_gram_reduce_kernel walks 8 rows per workgroup)
     HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     int launches = 0, first_wgs = 0;
     const size_t stage_per = (size_t)3 * hm.n + (hm.floating ? 15 : 0) + (d.sign ? hm.n : 0) + (size_t)hm.rows * k + (dw ? hm.rows : 0);  // doubles per staged sample
@@ -534,7 +535,7 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         }
         {
             ProfScope ps(m, FBR_PROF_GRAM);
-            hipLaunchKernelGGL(gk, dim3(first_wgs), dim3(FBR_WPB * 64), glds, m->stream, dg, nb, h->img64[b].as<double>(), m->partial.as<double>(), launches > 0 ? 1 : 0);
+            hipLaunchKernelGGL(gk, dim3(first_wgs), dim3(g.wpb * 64), glds, m->stream, dg, nb, h->img64[b].as<double>(), m->partial.as<double>(), launches > 0 ? 1 : 0);
             HIPCHK(hipGetLastError());
         }
     }
@@ -542,15 +543,15 @@ static int gram64_pass(fbr_model *m, GramHolder *h, const DevStates &d, const do
         ProfScope ps(m, FBR_PROF_REDUCE);
         DevGram dr = h->dev;  // the reduction of fbr_gram_reduce_kernel: one part of first_wgs workgroups
         dr.wpg = first_wgs;
-        dr.npw = npw;
+        dr.npw = vnpw;
         dr.slot_tiles = h->d64_slot_tiles;
         if ((rc = gram64_wg_table(h, first_wgs, &dr.wg_begin))) return rc;
         dr.tilecol = h->d64_tilecol;
-        hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
+        hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * vnpw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
         HIPCHK(hipGetLastError());
         if (g.NF > 0) {  // the blocks of the force tiles: entries the main blocks have written too, hence a launch of their own
-            dr.slot_tiles = h->d64_slot_tiles + (size_t)FBR_WPB * npw * 2;
-            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
+            dr.slot_tiles = h->d64_slot_tiles + (size_t)FBR_WPB * vnpw * 2;
+            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * vnpw, 1), dim3(256), 0, m->stream, dr, m->partial.as<double>(), G);
             HIPCHK(hipGetLastError());
         }
         if (k) {
@@ -579,7 +580,7 @@ static int gram64_grouped_pass(fbr_model *m, GramHolder *h, const DevStates &d, 
     const size_t plds = ((size_t)3 * 64 * ldn + (dw ? (size_t)64 * ldw : 0)) * sizeof(double);
     const int pgrid_max = (m->kinid.maxlvl <= 10 ? 2 : 1) * m->num_cus;
     if ((rc = h->scr64.ensure((size_t)pgrid_max * h->g64p.nparts * std::max(h->g64p.nslots, 1) * FBR_LINK_REC * 64 * sizeof(double)))) return rc;
-    if ((rc = m->partial.ensure((size_t)gpc * wpg * FBR_WPB * npw * 256 * sizeof(double)))) return rc;
+    if ((rc = m->partial.ensure((size_t)gpc * wpg * g.wpb * npw * 256 * sizeof(double)))) return rc;
     const size_t glds = (size_t)2 * g.maxact * 512 * sizeof(double) + ((size_t)g.nlev * (g.NT + g.NF) + g.nlev + 1 + g.pieces.size() + g.wmeta.size() + g.stage_lev.size()) * sizeof(int);
     DevKinId kp;
     kp.nsteps = 0;
@@ -601,7 +602,8 @@ static int gram64_grouped_pass(fbr_model *m, GramHolder *h, const DevStates &d, 
     dg.nstage = g.nstage;
     dg.stage_lev = h->d64_stagelev;
     typedef void (*g64_fn)(DevGram64, long, const double *, double *, int);
-    const g64_fn gk = (g.npw == 10) ? fbr_gram64_kernel<5, 2> : fbr_gram64_kernel<FBR_ONE_SEGW, FBR_ONE_NSEG>;
+    const g64_fn gk = g.wpb == 16 ? fbr_gram64_kernel<10, 16> : (g.npw == 10 ? fbr_gram64_kernel<10, 8> : fbr_gram64_kernel<FBR_ONE_SEGW * FBR_ONE_NSEG, 8>);
+    const int vnpw = g.npw * (g.wpb / 8);  // accumulator slots per ROW of the partial sums (fbr_gram_reduce_kernel walks 8 rows per workgroup)
     HIPCHK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const int *wgb = nullptr;
     if ((rc = gram64_wg_table(h, wpg, &wgb))) return rc;
@@ -663,22 +665,22 @@ static int gram64_grouped_pass(fbr_model *m, GramHolder *h, const DevStates &d, 
         }
         {
             ProfScope ps(m, FBR_PROF_GRAM);
-            hipLaunchKernelGGL(gk, dim3(wpg, ng), dim3(FBR_WPB * 64), glds, m->stream, dg, bpg, h->img64[b].as<double>(), m->partial.as<double>(), 0);
+            hipLaunchKernelGGL(gk, dim3(wpg, ng), dim3(g.wpb * 64), glds, m->stream, dg, bpg, h->img64[b].as<double>(), m->partial.as<double>(), 0);
             HIPCHK(hipGetLastError());
         }
         {
             ProfScope ps(m, FBR_PROF_REDUCE);
             DevGram dr = h->dev;
             dr.wpg = wpg;
-            dr.npw = npw;
+            dr.npw = vnpw;
             dr.slot_tiles = h->d64_slot_tiles;
             dr.wg_begin = wgb;
             dr.tilecol = h->d64_tilecol;
             double *Gc = G + (size_t)g0 * Pa * Pa;
-            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, ng), dim3(256), 0, m->stream, dr, m->partial.as<double>(), Gc);
+            hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * vnpw, ng), dim3(256), 0, m->stream, dr, m->partial.as<double>(), Gc);
             if (g.NF > 0) {
-                dr.slot_tiles = h->d64_slot_tiles + (size_t)FBR_WPB * npw * 2;
-                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * npw, ng), dim3(256), 0, m->stream, dr, m->partial.as<double>(), Gc);
+                dr.slot_tiles = h->d64_slot_tiles + (size_t)FBR_WPB * vnpw * 2;
+                hipLaunchKernelGGL(fbr_gram_reduce_kernel, dim3(FBR_WPB * vnpw, ng), dim3(256), 0, m->stream, dr, m->partial.as<double>(), Gc);
             }
             HIPCHK(hipGetLastError());
         }

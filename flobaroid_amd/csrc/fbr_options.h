@@ -17,6 +17,7 @@ struct FbrOptions {
     // ---- per-sample entry points
     double fused_id = 1;                    // fbr_predict / fbr_inverse_dynamics_batch: kinematics + torques in one kernel, no records in HBM (0: two kernels)
     // ---- fused Gram program
+    double gram_lane_waves = 8;             // gram_lane, models of the one-workgroup-per-CU shape: 8 waves of 18 accumulators (16: 16 waves of 10; measured slower)
     double gram_force_tiles = 1;            // gram_lane: the force rows of the base wrench run on tiles of the columns that have a force (fbr_gram64.h)
     double gram_lane = 1;                   // fused Gram over sample-contiguous images with the one-lane-per-sample producer where the model allows (fbr_gram64.h)
     double gram_shape = 0;                  // 0: by model, 1: one workgroup per CU (18 accumulators), 2: two per CU (10)
@@ -58,6 +59,7 @@ static inline const FbrOptionKey *fbr_option_keys(int *count)
         {"fused_id", &FbrOptions::fused_id, false},
         {"gram_lane", &FbrOptions::gram_lane, false},
         {"gram_force_tiles", &FbrOptions::gram_force_tiles, false},
+        {"gram_lane_waves", &FbrOptions::gram_lane_waves, false},
         {"gram_shape", &FbrOptions::gram_shape, true},
         {"gram_rhs_tile", &FbrOptions::gram_rhs_tile, true},
         {"gram_orient", &FbrOptions::gram_orient, true},

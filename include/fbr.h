@@ -314,6 +314,9 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *                                      one-lane-per-sample producer, where the call allows: at most one rhs column, a tile program in one part
  *                                      (friction columns included); inputs resident in HBM, pageable or pinned (staged chunk by chunk);
  *                                      fbr_gram_grouped without rhs columns (0: always the per-sample images of the kinematics + packer kernels)
+ *   "gram_lane_waves"            8     gram_lane, models whose tile pairs need the one-workgroup-per-CU shape: workgroups of 8 waves with 18
+ *                                      accumulators each (two waves per SIMD); 16: 16 waves with 10 accumulators (four per SIMD at 128
+ *                                      registers: measured 4 % slower on WALK-MAN)
  *   "gram_force_tiles"           1     gram_lane: the three force rows of the base wrench run on tiles of their own that hold only the columns
  *                                      with a force (mass, first moments), when the extra tile pairs fit the accumulators (0: every tile pair
  *                                      pays the three levels)

@@ -522,8 +522,9 @@ int emul_part_stats(const EmulTopo *t, int k, int *out, int cap)
 // segments below their common depth; rhs moments as per-lane running sums.  Returns < 0 when the model is outside that pass.
 // stats (10 longs, optional): tile rows, MFMAs per block, levels, widest stage, sum over levels of the busiest wave's active pairs,
 // sum over levels of ceil(active pairs / waves), parts, pairs, force tiles, stages.
-static int g_force_tiles = 1;
+static int g_force_tiles = 1, g_wide16 = 0;
 void emul_set_force_tiles(int on) { g_force_tiles = on; }
+void emul_set_wide16(int on) { g_wide16 = on; }
 int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, const double *ddq, const double *bv, const double *ba,
                 const double *rpy, const double *sign, const double *rhs, int k, const double *wts, double *G, long *stats)
 {
@@ -533,8 +534,8 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
     fbr_gram_build_best(gp, hm, k, g_shape, !fbr_gram_rhs_moments(hm, k));
     FbrGram64 g;
     FbrGram64Producer pr;
-    if (k > 1 || !fbr_gram64_build(hm, gp, g, g_force_tiles != 0) || !fbr_gram64_build_producer(hm, gp, g, pr)) return -1;
-    const int W = FBR_WPB, npw = g.npw, NTT = g.NT + g.NF;
+    if (k > 1 || !fbr_gram64_build(hm, gp, g, g_force_tiles != 0, g_wide16 != 0) || !fbr_gram64_build_producer(hm, gp, g, pr)) return -1;
+    const int W = g.wpb, npw = g.npw, NTT = g.NT + g.NF;
     if (stats) {
         long npairs = 0;
         for (size_t i = 0; i < g.wmeta.size(); i += 3) npairs += g.wmeta[i] >= 0;
@@ -666,7 +667,8 @@ int emul_gram64(const EmulTopo *t, long S, const double *q, const double *dq, co
     for (int kind = 0; kind < 2; kind++)  // the two reductions: main blocks, force blocks
     for (int w = 0; w < W; w++)
         for (int sl = 0; sl < npw; sl++) {
-            const int tI = g.slot_tiles[2 * ((size_t)kind * W * npw + (size_t)w * npw + sl)], tJ = g.slot_tiles[2 * ((size_t)kind * W * npw + (size_t)w * npw + sl) + 1];
+            const size_t sr = ((size_t)(w & 7) * (W / 8) + (size_t)(w >> 3)) * npw + sl;  // (the reduction's slot order)
+            const int tI = g.slot_tiles[2 * ((size_t)kind * W * npw + sr)], tJ = g.slot_tiles[2 * ((size_t)kind * W * npw + sr) + 1];
             if (tI < 0) continue;
             const double *a4 = &acc[((size_t)w * npw + sl) * 256];
             for (int lane = 0; lane < 64; lane++)

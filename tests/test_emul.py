@@ -386,6 +386,13 @@ def test_gram_over_sample_contiguous_images(case, which):
         assert not case.startswith("walkman")
     else:
         assert stats["force_tiles"] == 0 and stats["mfma_per_block"] == stats_n["mfma_per_block"]
+    # sixteen waves of ten accumulators (option gram_lane_waves = 16): the same Gram through the other slot layout of the reduction
+    emul_lib.lib().emul_set_wide16(1)
+    try:
+        Gw16, _ = em.gram64(st, tau, w)
+    finally:
+        emul_lib.lib().emul_set_wide16(0)
+    assert np.linalg.norm(Gw16 - Gr) <= 1e-13 * np.linalg.norm(Gr)
     Ea = np.zeros((em.cols + 1, om.P + 1))
     Ea[: em.cols, : om.P] = E
     Ea[-1, -1] = 1.0
