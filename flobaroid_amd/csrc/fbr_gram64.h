@@ -729,8 +729,14 @@ __global__ __launch_bounds__(WPB * 64, (NPW <= 10) ? 4 : 2) void fbr_gram64_kern
         const long blk = (long)blockIdx.x + (bh >> 1) * gridDim.x;
         const double *src = img + blk * g.blk_doubles + (bh & 1) * 512 + 2 * lane;
         double *buf = (st & 1) ? buf1 : buf0;
-        for (int i = levb[stl[sg]] + wave; i < levb[stl[sg + 1]]; i += WPB) {
-            const int gx = __builtin_amdgcn_readfirstlane(pcs[2 * i]), lx = __builtin_amdgcn_readfirstlane(pcs[2 * i + 1]);
+        // (the wave's pieces i0, i0 + WPB, ... of the stage: their table entries are fetched by the lanes in parallel -- one LDS round trip
+        // instead of one per piece in front of every stage's first MFMA)
+        const int i0 = __builtin_amdgcn_readfirstlane(levb[stl[sg]]) + wave, i1 = __builtin_amdgcn_readfirstlane(levb[stl[sg + 1]]);
+        const int mine = i0 < i1 ? (i1 - i0 + WPB - 1) / WPB : 0;
+        const int il = i0 + (lane < mine ? lane : 0) * WPB;
+        const int gxv = mine > 0 ? pcs[2 * il] : 0, lxv = mine > 0 ? pcs[2 * il + 1] : 0;
+        for (int j = 0; j < mine; j++) {
+            const int gx = __builtin_amdgcn_readlane(gxv, j), lx = __builtin_amdgcn_readlane(lxv, j);
             __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + lx), 16, 0, 0);
         }
     };
