@@ -186,6 +186,7 @@ static inline bool fbr_gram64_build(const FbrHostModel &hm, const FbrGramProgram
     }
     g.stage_lev.push_back(g.nlev);
     g.nstage = (int)g.stage_lev.size() - 1;
+    if (g.nstage > 62) return false;  // (the kernel keeps the stages' constants one per lane)
     g.base_stages = 0;  // stages of the base-wrench rows alone: all a call runs whose row weights switch every joint row off
     while (g.base_stages < g.nstage && g.stage_lev[g.base_stages + 1] <= hm.fb) g.base_stages++;
     g.slab.assign((size_t)g.nlev * NTT, -1);
@@ -722,16 +723,17 @@ __global__ __launch_bounds__(WPB * 64, (NPW <= 10) ? 4 : 2) void fbr_gram64_kern
     __syncthreads();
     const int nmine = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
     const long nst = (long)(nmine > 0 ? nmine : 0) * 2 * g.nstage;
-    // LDS-DMA of step st = (block, half, stage) into buffer (st & 1): wave w issues pieces w, w + 8, ... of the stage's levels
-    auto dma = [&](long st) {
-        const int sg = (int)(st % g.nstage);
-        const long bh = st / g.nstage;
+    // per-stage constants in registers (lane s: stage s; lane nstage: the end): first level and first DMA piece -- read with a lane select
+    // instead of chained LDS look-ups in front of every stage
+    const int svl = stl[lane <= g.nstage ? lane : 0], svp = levb[svl];
+    // LDS-DMA of step (block-half bh, stage sg) into buffer par: wave w issues pieces w, w + WPB, ... of the stage's levels
+    auto dma = [&](int sg, long bh, int par) {
         const long blk = (long)blockIdx.x + (bh >> 1) * gridDim.x;
         const double *src = img + blk * g.blk_doubles + (bh & 1) * 512 + 2 * lane;
-        double *buf = (st & 1) ? buf1 : buf0;
+        double *buf = par ? buf1 : buf0;
         // (the wave's pieces i0, i0 + WPB, ... of the stage: their table entries are fetched by the lanes in parallel -- one LDS round trip
         // instead of one per piece in front of every stage's first MFMA)
-        const int i0 = __builtin_amdgcn_readfirstlane(levb[stl[sg]]) + wave, i1 = __builtin_amdgcn_readfirstlane(levb[stl[sg + 1]]);
+        const int i0 = __builtin_amdgcn_readlane(svp, sg) + wave, i1 = __builtin_amdgcn_readlane(svp, sg + 1);
         const int mine = i0 < i1 ? (i1 - i0 + WPB - 1) / WPB : 0;
         const int il = i0 + (lane < mine ? lane : 0) * WPB;
         const int gxv = mine > 0 ? pcs[2 * il] : 0, lxv = mine > 0 ? pcs[2 * il + 1] : 0;
@@ -740,21 +742,26 @@ __global__ __launch_bounds__(WPB * 64, (NPW <= 10) ? 4 : 2) void fbr_gram64_kern
             __builtin_amdgcn_global_load_lds((fbr_glb_ptr)(src + gx), (fbr_lds_ptr)(buf + lx), 16, 0, 0);
         }
     };
-    if (nst > 0) dma(0);
+    if (nst > 0) dma(0, 0, 0);
     const int li = lane & 15, kk = lane >> 4;
     const int lofs = li * 32, sx = FBR_G64_SWZ(li);
     const int mv = wm[wave * MW + (lane < MW ? lane : 0)];  // this wave's slots: (tile I, tile J, first level | end level << 8)
     const int idxv = (lane < MW && (lane % 3) != 2 && mv >= 0) ? mv : 0;  // the tile this lane looks up per level (lanes 3q, 3q + 1)
     // this lane's operand position inside a slab (doubles) at k-step ks: column li, sample (4 ks + kk) ^ sx = p0 ^ (4 ks)
     const int p0c = lofs | (sx ^ kk);
+    int sg = 0;   // stage of step st
+    long bh = 0;  // its block-half (of this workgroup's blocks)
     for (long st = 0; st < nst; st++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step st have landed
         __syncthreads();                                  // everyone's have; the other buffer is free
-        if (st + 1 < nst) dma(st + 1);
-        const int sg = (int)(st % g.nstage);
+        const int sgn = sg + 1 == g.nstage ? 0 : sg + 1;
+        const long bhn = sgn ? bh : bh + 1;
+        if (st + 1 < nst) dma(sgn, bhn, (int)((st + 1) & 1));
         const double *buf = (st & 1) ? buf1 : buf0;
-        const int lv1 = __builtin_amdgcn_readfirstlane(stl[sg + 1]);
-        for (int lv = __builtin_amdgcn_readfirstlane(stl[sg]); lv < lv1; lv++) {
+        const int lv0 = __builtin_amdgcn_readlane(svl, sg), lv1 = __builtin_amdgcn_readlane(svl, sg + 1);
+        sg = sgn;
+        bh = bhn;
+        for (int lv = lv0; lv < lv1; lv++) {
             const int offv = slab[lv * g.NT + idxv] * 512;  // the slab offsets of all slots of the wave at this level: one LDS read
             int curI = -1;  // the tile whose operand the registers a[] hold (of this level)
             double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
