@@ -504,11 +504,13 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void f
         };
         auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
         auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
-        auto consts = [&](int l, double *rR, double *rp, double *ax) {
-            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {  // (l is wave-uniform: scalar loads through the constant address space)
+            const fbr_cdouble_ptr cR = (fbr_cdouble_ptr)(unsigned long)m.restR, cp = (fbr_cdouble_ptr)(unsigned long)m.restp,
+                                  ca = (fbr_cdouble_ptr)(unsigned long)m.axis;
+            for (int i = 0; i < 9; i++) rR[i] = cR[9 * l + i];
             for (int i = 0; i < 3; i++) {
-                rp[i] = m.restp[3 * l + i];
-                ax[i] = m.axis[3 * l + i];
+                rp[i] = cp[3 * l + i];
+                ax[i] = ca[3 * l + i];
             }
         };
         // byte offset of this lane's sample inside a (tile row, column) run, before the column's swizzle: block, half, sample

@@ -30,6 +30,13 @@
 
 #define FBR_KINWRITE_PARTS 4  // waves of a lane-WRITER workgroup = parts the tree is cut into (fbr_kinid_build_parts)
 
+#if defined(__HIPCC__)
+// tables every lane of a wave reads at the same index: through the constant address space they are scalar loads
+typedef const __attribute__((address_space(4))) long *fbr_clong_ptr;
+typedef const __attribute__((address_space(4))) int *fbr_cint_ptr;
+typedef const __attribute__((address_space(4))) double *fbr_cdouble_ptr;
+#endif
+
 struct FbrKinIdProgram {
     int nsteps = 0, maxlvl = 0, nslots = 0;
     std::vector<int> steps;     // [nsteps][FBR_KINID_STEP]
@@ -156,7 +163,11 @@ FBR_HD void fbr_kinid_lane(int nsteps, int maxlvl, const int *steps, const int *
         for (int i = 0; i < 6; i++) Sst[j][i] = 0.0;
     }
     for (int k = 0; k < nsteps; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const fbr_cint_ptr st = (fbr_cint_ptr)(unsigned long)(steps + k * FBR_KINID_STEP);  // (the step program: scalar loads)
+#else
         const int *st = steps + k * FBR_KINID_STEP;
+#endif
         const int l = FBR_UNI(st[0]), psrc = FBR_UNI(st[1]), psave = FBR_UNI(st[2]), jt = FBR_UNI(st[3]), d = FBR_UNI(st[4]), lvl = FBR_UNI(st[5]),
                   depth = FBR_UNI(st[6]), fd = FBR_UNI(st[7]);
         double out[FBR_LINK_REC], Sv[6] = {0, 0, 0, 0, 0, 0};
@@ -244,8 +255,6 @@ struct DevKinId {
     const int *steps, *endflush;
 };
 // tables of the lane WRITERS (fbr_kinwrite_kernel below, fbr_kinimg_kernel in fbr_gram64.h)
-typedef const __attribute__((address_space(4))) long *fbr_clong_ptr;
-typedef const __attribute__((address_space(4))) int *fbr_cint_ptr;
 // destinations arrive as integers: a pointer made from one is GENERIC (flat_store: counted by lgkmcnt as well, so that every wait for a scalar load
 // or an LDS read would also wait for the stores in flight) unless it is given the global address space explicitly
 typedef __attribute__((address_space(1))) char *fbr_gchar_ptr;
@@ -348,11 +357,13 @@ __global__ __launch_bounds__(64) void fbr_kinid_kernel(DevModel m, DevKinId p, l
             }
             fbr_link_wrench(rec, pi, F);
         };
-        auto consts = [&](int l, double *rR, double *rp, double *ax) {
-            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {  // (l is wave-uniform: scalar loads through the constant address space)
+            const fbr_cdouble_ptr cR = (fbr_cdouble_ptr)(unsigned long)m.restR, cp = (fbr_cdouble_ptr)(unsigned long)m.restp,
+                                  ca = (fbr_cdouble_ptr)(unsigned long)m.axis;
+            for (int i = 0; i < 9; i++) rR[i] = cR[9 * l + i];
             for (int i = 0; i < 3; i++) {
-                rp[i] = m.restp[3 * l + i];
-                ax[i] = m.axis[3 * l + i];
+                rp[i] = cp[3 * l + i];
+                ax[i] = ca[3 * l + i];
             }
         };
         auto emit = [&](int r, double v) {
@@ -420,11 +431,13 @@ __global__ __launch_bounds__(64) void fbr_kinfd_kernel(DevModel m, DevKinId p, l
         };
         auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
         auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
-        auto consts = [&](int l, double *rR, double *rp, double *ax) {
-            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {  // (l is wave-uniform: scalar loads through the constant address space)
+            const fbr_cdouble_ptr cR = (fbr_cdouble_ptr)(unsigned long)m.restR, cp = (fbr_cdouble_ptr)(unsigned long)m.restp,
+                                  ca = (fbr_cdouble_ptr)(unsigned long)m.axis;
+            for (int i = 0; i < 9; i++) rR[i] = cR[9 * l + i];
             for (int i = 0; i < 3; i++) {
-                rp[i] = m.restp[3 * l + i];
-                ax[i] = m.axis[3 * l + i];
+                rp[i] = cp[3 * l + i];
+                ax[i] = ca[3 * l + i];
             }
         };
         auto Wr = [&](int r, int c) { return Ws[(long)r * m.cols + c]; };
@@ -530,11 +543,13 @@ __global__ __launch_bounds__(64 * FBR_KINWRITE_PARTS, MAXD <= 10 ? 2 : 1) void f
         };
         auto save = [&](int b, int i, double v) { scr[(b * FBR_LINK_REC + i) * 64] = v; };
         auto load = [&](int b, int i) { return scr[(b * FBR_LINK_REC + i) * 64]; };
-        auto consts = [&](int l, double *rR, double *rp, double *ax) {
-            for (int i = 0; i < 9; i++) rR[i] = m.restR[9 * l + i];
+        auto consts = [&](int l, double *rR, double *rp, double *ax) {  // (l is wave-uniform: scalar loads through the constant address space)
+            const fbr_cdouble_ptr cR = (fbr_cdouble_ptr)(unsigned long)m.restR, cp = (fbr_cdouble_ptr)(unsigned long)m.restp,
+                                  ca = (fbr_cdouble_ptr)(unsigned long)m.axis;
+            for (int i = 0; i < 9; i++) rR[i] = cR[9 * l + i];
             for (int i = 0; i < 3; i++) {
-                rp[i] = m.restp[3 * l + i];
-                ax[i] = m.axis[3 * l + i];
+                rp[i] = cp[3 * l + i];
+                ax[i] = ca[3 * l + i];
             }
         };
         const fbr_clong_ptr cdst = (fbr_clong_ptr)(unsigned long)wr.dst;
