@@ -668,9 +668,16 @@ __global__ __launch_bounds__(256) void fbr_gram64_mom_reduce_kernel(int P, int n
 {
     __shared__ double part[256];
     const int c = blockIdx.x, t = threadIdx.x;
-    double s = 0.0;
-    for (int i = t; i < nwg * 64; i += 256) s += mom[((long)(i >> 6) * (P + 1) + c) * 64 + (i & 63)];
-    part[t] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // (independent running sums: the loads are far apart)
+    int i = t;
+    for (; i + 768 < nwg * 64; i += 1024) {
+        s0 += mom[((long)(i >> 6) * (P + 1) + c) * 64 + (i & 63)];
+        s1 += mom[((long)((i + 256) >> 6) * (P + 1) + c) * 64 + ((i + 256) & 63)];
+        s2 += mom[((long)((i + 512) >> 6) * (P + 1) + c) * 64 + ((i + 512) & 63)];
+        s3 += mom[((long)((i + 768) >> 6) * (P + 1) + c) * 64 + ((i + 768) & 63)];
+    }
+    for (; i < nwg * 64; i += 256) s0 += mom[((long)(i >> 6) * (P + 1) + c) * 64 + (i & 63)];
+    part[t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (t < o) part[t] += part[t + o];

@@ -1295,8 +1295,18 @@ __global__ __launch_bounds__(256) void fbr_gram_reduce_kernel(DevGram g, const d
     const int per_wg = FBR_WPB * g.npw;
     const int part = slot / per_wg, rem = slot - part * per_wg;
     const long w0 = (long)blockIdx.y * g.wpg + g.wg_begin[part], w1 = (long)blockIdx.y * g.wpg + g.wg_begin[part + 1];
-    double v = 0.0;
-    for (long w = w0; w < w1; w++) v += partial[((w * per_wg + rem) << 8) + t];
+    // four independent running sums (the loads of a thread are 8 bytes at a 2 KB x slots stride: with one sum the loop is one memory latency
+    // per workgroup of the pass), added in a fixed order
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    long w = w0;
+    for (; w + 3 < w1; w += 4) {
+        v0 += partial[((w * per_wg + rem) << 8) + t];
+        v1 += partial[(((w + 1) * per_wg + rem) << 8) + t];
+        v2 += partial[(((w + 2) * per_wg + rem) << 8) + t];
+        v3 += partial[(((w + 3) * per_wg + rem) << 8) + t];
+    }
+    for (; w < w1; w++) v0 += partial[((w * per_wg + rem) << 8) + t];
+    const double v = (v0 + v1) + (v2 + v3);
     const int row = (lane >> 4) + 4 * reg, col = lane & 15;
     const int ci = g.tilecol[I * FBR_TILE + row], cj = g.tilecol[J * FBR_TILE + col];
     if (ci < 0 || cj < 0) return;
