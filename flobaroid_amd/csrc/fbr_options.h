@@ -35,6 +35,7 @@ struct FbrOptions {
     double tsqr_force_group = 1;            // row-group TSQR: the force rows of a floating base as a group of their own over the columns that have a force
     double tsqr_lane_writer = 1;            // regressor writer of the TSQR: one lane per sample, kinematics fused, column-major chunks (0: kinematics kernel + workgroup-per-sample writers)
     double tsqr_writer = 0;                 // grouped regressor writer: 0 by work-item count; 8 / 16: store width forced; 32: rows staged in the LDS
+    double tsqr_side_trees_beside = 0;      // the side groups' merge trees start beside the main group's last fold (1) or behind it (0)
     double tsqr_prologue_overlap = 1;       // a submission's kinematics / first writer beside the trees of the one before
     double tsqr_timing = 0;                 // diagnostic: per-phase cycle counters of the wide level-0 kernel
     double tsqr_short_call_factors = 1;     // fewer private factors (shallower merge trees) for calls too short to amortise them
@@ -74,6 +75,7 @@ static inline const FbrOptionKey *fbr_option_keys(int *count)
         {"tsqr_lane_writer", &FbrOptions::tsqr_lane_writer, false},
         {"tsqr_force_group", &FbrOptions::tsqr_force_group, false},
         {"tsqr_writer", &FbrOptions::tsqr_writer, false},
+        {"tsqr_side_trees_beside", &FbrOptions::tsqr_side_trees_beside, false},
         {"tsqr_prologue_overlap", &FbrOptions::tsqr_prologue_overlap, false},
         {"tsqr_timing", &FbrOptions::tsqr_timing, false},
         {"tsqr_short_call_factors", &FbrOptions::tsqr_short_call_factors, false},

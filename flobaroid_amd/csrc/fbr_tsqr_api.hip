@@ -721,7 +721,10 @@ static int tsqr_groups_impl(fbr_model *m, const DevStates &d, const TsqrGroupPla
         };
         for (int g = 0; g < G; g++)
             if (g != gp.main && (rc = fold_group(g))) return rc;
-        if (s0 + ch >= S && gp.main >= 0 && (rc = launch_side_trees())) return rc;  // (last chunk: the side trees beside the main group's fold)
+        // (last chunk: option tsqr_side_trees_beside = 1 starts the side groups' trees beside the main group's fold.  That paid while the main
+        // group folded all six base-wrench rows; with the force rows in a group of their own its fold is half as long, and the trees' first
+        // levels only keep its workgroups off their CUs: 125 k samples 7.3 ... 7.45 ms beside, 6.9 ... 7.0 behind; 1 M samples the same)
+        if (s0 + ch >= S && gp.main >= 0 && m->opt.tsqr_side_trees_beside != 0 && (rc = launch_side_trees())) return rc;
         if (gp.main >= 0 && (rc = fold_group(gp.main))) return rc;
     }
     if (!side_trees_launched && (rc = launch_side_trees())) return rc;

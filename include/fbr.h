@@ -337,6 +337,9 @@ int fbr_model_link_merge_info(const fbr_model *m, int64_t num_samples, int32_t *
  *   "tsqr_writer"                0     grouped regressor writer: 0 by work-item count; 8 / 16: one thread per column / column pair, stores of that
  *                                      width; 32: rows staged in the LDS and streamed out in 16-byte pieces (measured: no faster)
  *   "tsqr_tree_one_wg"           0     merges by one workgroup instead of pipelined across workgroups (bit-identical, slower)
+ *   "tsqr_side_trees_beside"     0     row-group TSQR: 1 starts the side groups' merge trees beside the main group's last level-0 fold (the
+ *                                      default of rounds 3 - 5); 0 behind it (round 6: with the force rows in a group of their own the main
+ *                                      fold is half as long and a 125 k-sample call is 0.45 ms shorter this way)
  *   "tsqr_prologue_overlap"      1     a submission's kinematics / first writer beside the merge trees of the one before
  *   "tsqr_short_call_factors"    1     fewer private factors (shallower merge trees) for calls too short to amortise them
  *   "gram_serial", "gram_timing", "tsqr_timing"  0   diagnostics (producer on the main stream; cycle counters printed to stderr)
